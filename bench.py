@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench.py - TF-IDF + LSI(k=50) throughput on synthetic planted-topic CSR (BASELINE.json).
+
+A "step" is one pass of the hot path over one batch: tfidf (counts -> TF-IDF values) followed
+by lsi (CSR transpose, block subspace iteration to convergence, Rayleigh-Ritz), with the
+count matrix already resident in HBM when the timed region starts and U / stdev / V left in
+HBM at the end.
+
+Workloads (--workload):
+  c3shard (default)  125 000 cells x 200 000 peaks per GPU, 3 % nnz: rank r holds rows
+                     [r*125k, (r+1)*125k) of BASELINE.json configs[2]; --gpus 8 is exactly the
+                     1M x 200k configuration, sharded by cells with RCCL all-reduce of the
+                     per-peak sums and of Z = X^T Y.  Weak scaling.
+  c2                 10 000 x 30 000, 3 % nnz (configs[1])
+  c3full             1 000 000 x 200 000 on ONE GPU (needs ~150 GB of HBM)
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+WORKLOADS = {
+    "c3shard": dict(cells=125_000, peaks=200_000),
+    "c2": dict(cells=10_000, peaks=30_000),
+    "c3full": dict(cells=1_000_000, peaks=200_000),
+}
+
+
+class TimedBackend:
+    """Wraps the backend to time every SpMM launch with HIP events on the launch stream."""
+
+    def __init__(self, be):
+        self._be = be
+        self.events = []
+        self.enabled = False
+
+    def __getattr__(self, name):
+        return getattr(self._be, name)
+
+    def spmm(self, X, Q, out=None):
+        if not self.enabled:
+            return self._be.spmm(X, Q, out=out)
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = self._be.spmm(X, Q, out=out)
+        e.record()
+        B = Q.shape[1]
+        n, d = X.shape
+        self.events.append((s, e, 8 * X.nnz + 8 * (n + 1) + 4 * B * (n + d)))
+        return r
+
+
+def cpu_baseline(be, peaks, density, seed, sample_cells):
+    """The reference's CPU path (scipy tfidf + ARPACK svds, f32 like sc.read_10x_h5 data) on a
+    bounded sample of the same generator.  Checker-side code: uses oracle/."""
+    import scipy.sparse as sp
+    from oracle import lsi_oracle, tfidf_oracle
+
+    Xs = be.synth_counts(0, sample_cells, peaks, 50, density, seed)
+    m = sp.csr_matrix((be.to_host(Xs.values), be.to_host(Xs.indices), be.to_host(Xs.indptr)), shape=Xs.shape)
+    t0 = time.perf_counter()
+    tf = tfidf_oracle.tfidf(m)
+    t1 = time.perf_counter()
+    lsi_oracle.lsi(tf, n_comps=50, dtype=np.float32)
+    t2 = time.perf_counter()
+    return {
+        "value": sample_cells / (t2 - t0),
+        "unit": "cells/s",
+        "cores": int(os.environ.get("OMP_NUM_THREADS", 0)) or 1,
+        "kind": "port",
+        "sample": f"{sample_cells} cells x {peaks} peaks ({m.nnz} nnz, same generator, rows 0..{sample_cells - 1}); "
+                  f"scipy tfidf {t1 - t0:.2f}s + svds(k=50,f32) {t2 - t1:.2f}s; scipy sparse kernels use 1 core "
+                  f"(host has {os.cpu_count()})",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3shard", choices=sorted(WORKLOADS))
+    ap.add_argument("--cells", type=int, default=None, help="override cells per GPU")
+    ap.add_argument("--peaks", type=int, default=None)
+    ap.add_argument("--density", type=float, default=0.03)
+    ap.add_argument("--n-comps", type=int, default=50)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-sample-cells", type=int, default=4000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from muon_amd._comm import TorchDistComm
+
+        comm = TorchDistComm()
+
+    from muon_amd._atac.preproc import tfidf_device
+    from muon_amd._atac.tools import lsi_device
+    from muon_amd._backend import HipBackend
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.cells:
+        wl["cells"] = args.cells
+    if args.peaks:
+        wl["peaks"] = args.peaks
+    n_local, d = wl["cells"], wl["peaks"]
+    n_global = n_local * world
+
+    be = TimedBackend(HipBackend(local_rank))
+    X = be.synth_counts(rank * n_local, n_local, d, 50, args.density, args.seed)
+    nnz_local = X.nnz
+    tf_vals = torch.empty_like(X.values)
+    flags = 3  # log_tf | log_idf (reference defaults)
+
+    info = {}
+
+    def step():
+        T = tfidf_device(be, X, n_global, flags, 1e4, comm=comm, out=tf_vals)
+        U, stdev, V, inf = lsi_device(be, T, n_comps=args.n_comps, n_obs=n_global, comm=comm,
+                                      return_info=True)
+        info.update(inf)
+        return U, stdev, V
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    be.events.clear()
+    be.enabled = True
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    be.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel: the CSR SpMM (both X*Q and X^T*Y run through it)
+    ms = [s.elapsed_time(e) for s, e, _ in be.events]
+    byt = [b for _, _, b in be.events]
+    avg_ms = float(np.mean(ms))
+    achieved = float(np.mean(byt)) / (avg_ms * 1e-3) / 1e9
+    spmm_total_ms = float(np.sum(ms))
+
+    if rank == 0:
+        out = {
+            "metric": "cells/sec for TF-IDF+LSI(k=50)",
+            "value": n_global * args.steps / dt,
+            "unit": "cells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: planted-topic CSR, {n_local} cells x {d} peaks per GPU "
+                            f"({n_global} x {d} total), {nnz_local} nnz on rank 0 "
+                            f"({nnz_local / n_local / d:.4f} dense), tfidf + lsi(n_comps={args.n_comps})",
+                "parallelism": f"cells row-sharded x{world}" if world > 1 else "1 GPU",
+                "lsi": {"block": info.get("block"), "iterations": info.get("iterations"),
+                        "converged": info.get("converged"), "spmm_per_step": len(ms) // max(args.steps, 1)},
+            },
+            "roofline": {
+                "kernel": "k_spmm_rowwave<64> (CSR SpMM, f32, B=64 dense columns)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_ms": avg_ms,
+                "launches": len(ms),
+                "share_of_step": spmm_total_ms / (dt * 1e3),
+                "algorithmic_bytes_per_launch": float(np.mean(byt)),
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(be, d, args.density, args.seed, args.cpu_sample_cells)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+/*
+ * muon_amd.h - C-ABI of libmuon_amd.so: the MI355X (gfx950) kernels behind
+ *   muon.atac.pp.tfidf   (/root/reference/muon/_atac/preproc.py:16-129)
+ *   muon.atac.tl.lsi     (/root/reference/muon/_atac/tools.py:29-71)
+ *   muon.tl.mofa         (/root/reference/muon/_core/tools.py:290-708)
+ *
+ * The reference is pure Python and has no FFI of its own; the boundary a
+ * maintainer binds is therefore "the scipy / mofapy2 calls those three functions
+ * make".  Every entry point below names the reference statement it replaces.
+ * INTEGRATION.md shows the ctypes stub that would sit in the reference.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 on success and a negative mu_status otherwise;
+ *     mu_last_error() returns a thread-local description of the last failure.
+ *   - pointers named d_* are DEVICE pointers (hipMalloc'd by the caller - e.g.
+ *     torch tensors' data_ptr() - or obtained from mu_malloc); h_* are host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *     kernels are launched asynchronously on it; nothing synchronises unless the
+ *     comment says so.  The library keeps no global state except the error string.
+ *   - CSR layout: indptr int64[n_rows+1], indices int32[nnz], values f32|f64[nnz];
+ *     column indices sorted ascending inside each row where stated.
+ *   - dense blocks are row-major with a fixed leading dimension ld == B columns,
+ *     B in {16, 32, 64}.
+ */
+#ifndef MUON_AMD_H
+#define MUON_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  MU_OK = 0,
+  MU_ERR_ARG = -1,     /* bad argument (null pointer, unsupported B, ...) */
+  MU_ERR_HIP = -2,     /* a HIP runtime call or kernel launch failed      */
+  MU_ERR_NO_DEVICE = -3,
+  MU_ERR_UNSUPPORTED = -4
+} mu_status;
+
+#define MU_DTYPE_F32 0
+#define MU_DTYPE_F64 1
+
+/* tfidf flag bits: the booleans of preproc.py:18-20 */
+#define MU_TFIDF_LOG_TF 1
+#define MU_TFIDF_LOG_IDF 2
+#define MU_TFIDF_LOG_TFIDF 4
+
+/* ---- runtime plumbing ------------------------------------------------------ */
+int mu_version(void);
+const char* mu_last_error(void);
+int mu_device_count(int* count);
+int mu_set_device(int device);
+/* name (<= len-1 chars), #CUs and bytes of device memory of `device` */
+int mu_device_info(int device, char* name, int len, int* n_cu, size_t* total_mem);
+int mu_malloc(void** d_ptr, size_t bytes);
+int mu_free(void* d_ptr);
+int mu_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
+int mu_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
+int mu_memset(void* d_dst, int value, size_t bytes, void* stream);
+int mu_stream_sync(void* stream); /* blocks the host */
+
+/* ---- TF-IDF (preproc.py:92-119) ------------------------------------------- */
+/* Bytes of scratch mu_csr_row_col_sums needs for this shape (d_work). */
+size_t mu_csr_row_col_sums_worksize(int64_t n_rows, int64_t n_cols);
+
+/* rowsum[i] = sum_j c_ij  (preproc.py:93  counts.sum(axis=1))
+ * colsum[j] = sum_i c_ij  (preproc.py:106 counts.sum(axis=0))
+ * One pass over (indices, values): LDS-staged per-column partial sums swept slab by
+ * slab over sorted rows, wave shuffle reductions for the row sums, fixed-order final
+ * reduction (bit-reproducible).  Requires sorted column indices.  Both outputs f64. */
+int mu_csr_row_col_sums(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                        const int32_t* d_indices, const void* d_values, double* d_rowsum,
+                        double* d_colsum, void* d_work, size_t work_bytes, void* stream);
+
+/* idf[j] = n_obs / colsum[j]; log1p if MU_TFIDF_LOG_IDF  (preproc.py:106-108), computed
+ * and stored in `dtype` (f32 counts give an f32 idf in the reference).
+ * n_obs is adata.shape[0] - the GLOBAL cell count when rows are sharded. */
+int mu_tfidf_idf(int dtype, int64_t n_cols, double n_obs, const double* d_colsum, int flags,
+                 void* d_idf, void* stream);
+
+/* out_ij = f(c_ij) following preproc.py:93-117 in the reference's operation order:
+ *   t = (1/rowsum_i)*c_ij ; t *= scale (skipped when scale is 0 or 1) ; log1p if LOG_TF ;
+ *   t *= idf_j ; log1p if LOG_TFIDF.
+ * Replaces the two diag x CSR SpGEMMs (scipy csr_matmat) and the sparse log1p with one
+ * fused pass; arithmetic is done in the dtype of the values like the reference does.
+ * d_out may alias d_values.  d_zero_count (may be NULL) receives the number of outputs
+ * that are exactly 0 - entries scipy's SpGEMM would have dropped. */
+int mu_tfidf_scale(int dtype, int64_t n_rows, const int64_t* d_indptr, const int32_t* d_indices,
+                   const void* d_values, const double* d_rowsum, const void* d_idf, double scale,
+                   int flags, void* d_out, unsigned long long* d_zero_count, void* stream);
+
+/* Drop stored entries whose value is exactly 0 (what csr_matmat does to explicit zeros).
+ * Step 1 writes the surviving count of every row; the caller scans it into the new
+ * indptr (mu_exclusive_scan_i64); step 2 compacts. */
+int mu_csr_count_nonzero(int dtype, int64_t n_rows, const int64_t* d_indptr, const void* d_values,
+                         int64_t* d_row_nnz, void* stream);
+int mu_csr_compact_nonzero(int dtype, int64_t n_rows, const int64_t* d_indptr,
+                           const int32_t* d_indices, const void* d_values,
+                           const int64_t* d_new_indptr, int32_t* d_new_indices, void* d_new_values,
+                           void* stream);
+/* out[0]=0, out[i+1]=out[i]+in[i], i<n (single workgroup; n up to ~1e8). */
+int mu_exclusive_scan_i64(int64_t n, const int64_t* d_in, int64_t* d_out, void* stream);
+
+/* binarize (preproc.py:148-150): X.data[X.data != 0] = 1, in place (NaN != 0, so NaN -> 1;
+ * explicit stored zeros stay 0). */
+int mu_binarize_values(int dtype, int64_t nnz, void* d_values, void* stream);
+
+/* ---- CSR transpose (device CSC copy used for X^T * Y) ----------------------- */
+size_t mu_csr_transpose_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz);
+/* Builds the CSR of X^T: t_indptr int64[n_cols+1], t_indices int32[nnz] (row ids of X,
+ * ascending inside each output row), t_values.  Stable => bit-reproducible. */
+int mu_csr_transpose(int dtype, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                     const int64_t* d_indptr, const int32_t* d_indices, const void* d_values,
+                     int64_t* d_t_indptr, int32_t* d_t_indices, void* d_t_values, void* d_work,
+                     size_t work_bytes, void* stream);
+
+/* ---- LSI building blocks (tools.py:53: the ARPACK operator of scipy svds) ---- */
+/* Y[n_rows x B] = X * Q, X CSR f32, Q dense [n_cols x B] f32 row-major (ld=B).
+ * The SpMM that replaces the csr_matvec / csr_matvecs calls inside svds.
+ * accumulate != 0 adds into Y instead of overwriting. */
+int mu_spmm_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
+                const float* d_values, const float* d_Q, int B, float* d_Y, int accumulate,
+                void* stream);
+
+size_t mu_gram_worksize(int64_t n_rows, int B);
+/* G[B x B] (f64) = A^T A and colsum[B] (f64) = 1^T A for A [n_rows x B] f32 (ld=B).
+ * f64 MFMA (v_mfma_f64_16x16x4_f64), fixed-order reduction. Replaces the dense QR of
+ * svds (_svds.py:513) together with mu_dense_apply_f32 (CholeskyQR). */
+int mu_gram_f32(int64_t n_rows, int B, const float* d_A, double* d_G, double* d_colsum,
+                void* d_work, size_t work_bytes, void* stream);
+
+/* Out[n_rows x B] = A[n_rows x B] * M[B x B] + bias[B] (bias may be NULL); f32 MFMA
+ * (v_mfma_f32_16x16x4_f32).  Out may alias A. */
+int mu_dense_apply_f32(int64_t n_rows, int B, const float* d_A, const float* d_M,
+                       const float* d_bias, float* d_Out, void* stream);
+
+/* standard normal fill, counter based (seed, element index) -> reproducible */
+int mu_randn_f32(int64_t count, uint64_t seed, float* d_out, void* stream);
+
+/* ---- synthetic planted-topic counts (bench / tests only) ------ */
+/* Pass 1: nnz of every row for rows [row0, row0+n_rows) of the global matrix.
+ * Pass 2 (after scanning the counts into indptr): fills indices / values (f32 counts).*/
+int mu_synth_row_nnz(int64_t row0, int64_t n_rows, int64_t n_cols, int n_topics, double density,
+                     uint64_t seed, int64_t* d_row_nnz, void* stream);
+int mu_synth_fill(int64_t row0, int64_t n_rows, int64_t n_cols, int n_topics, double density,
+                  uint64_t seed, const int64_t* d_indptr, int32_t* d_indices, float* d_values,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUON_AMD_H */

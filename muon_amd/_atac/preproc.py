@@ -1,0 +1,223 @@
+"""muon.atac.pp.tfidf / binarize on MI355X.
+
+Host side mirrors /root/reference/muon/_atac/preproc.py:16-152 (same signature, same
+errors and warnings, same in-place write-back); the arithmetic (:92-117) runs as HIP
+kernels through the C-ABI (csrc/tfidf.hip).  Extra keyword-only arguments (``comm``,
+``n_obs``, ``match_scipy_order``, ``keep_on_device``) default to the reference's behaviour.
+"""
+from __future__ import annotations
+
+from typing import Optional, Union
+from warnings import warn
+
+import numpy as np
+from scipy.sparse import csr_matrix, issparse
+
+from .._comm import default_comm
+from .._containers import is_anndata, is_mudata, view_to_actual
+from .._ffi import TFIDF_LOG_IDF, TFIDF_LOG_TF, TFIDF_LOG_TFIDF
+
+DEVICE_ATTR = "_muon_amd_device"
+
+
+def _flags(log_tf, log_idf, log_tfidf):
+    return (TFIDF_LOG_TF if log_tf else 0) | (TFIDF_LOG_IDF if log_idf else 0) | (
+        TFIDF_LOG_TFIDF if log_tfidf else 0
+    )
+
+
+def _effective_scale(scale_factor) -> float:
+    # preproc.py:101: the multiply is skipped for None / 0 / 1
+    if scale_factor is None or scale_factor == 0 or scale_factor == 1:
+        return 1.0
+    return float(scale_factor)
+
+
+def canonical_csr(counts) -> csr_matrix:
+    """Host-side *layout* normalisation before upload (no arithmetic on values):
+    CSR, duplicates summed, sorted column indices, int32 indices, int64 indptr, and the
+    dtype promotion the reference's first statement performs (ints -> float64)."""
+    if issparse(counts):
+        m = counts.tocsr()
+        if m is counts:
+            m = m.copy()
+    else:
+        m = csr_matrix(np.asarray(counts))  # dense branch (:97-99,113-114) ends in CSR too
+    if m.dtype not in (np.float32, np.float64):
+        m = m.astype(np.float64)  # 1.0 / n_peaks is float64 and promotes integer counts
+    if not m.has_canonical_format:
+        m.sum_duplicates()  # also sorts
+    if not m.has_sorted_indices:
+        m.sort_indices()
+    return m
+
+
+def tfidf_device(backend, X, n_obs, flags: int, scale: float, comm=None, out=None):
+    """Device-resident TF-IDF of a (row shard of a) CSR.  Returns a DeviceCSR that shares
+    indptr / indices with ``X`` unless zeros had to be dropped.
+
+    Pipeline: one reduction sweep (row sums, LDS-staged column sums), an all-reduce of the
+    d column sums when rows are sharded, the idf vector, one fused scale pass."""
+    comm = default_comm(comm)
+    rowsum, colsum = backend.row_col_sums(X)
+    comm.all_reduce_sum(colsum)
+    idf = backend.idf(colsum, float(n_obs), flags, X.values.dtype)
+    vals, zero_count = backend.tfidf_scale(X, rowsum, idf, scale, flags, out=out)
+    res = X.with_values(vals)
+    if int(zero_count.item()) != 0:
+        # scipy's SpGEMM drops entries whose product is exactly 0
+        res = backend.compact_nonzero(res)
+    return res
+
+
+def _reverse_rows(m: csr_matrix) -> csr_matrix:
+    """Emit every row in descending column order (what two scipy SpGEMMs + one sparse
+    log1p leave behind for the default flags); data follows the indices."""
+    indptr = m.indptr.astype(np.int64)
+    nnz = m.nnz
+    row_of = np.repeat(np.arange(m.shape[0], dtype=np.int64), np.diff(indptr))
+    pos = np.arange(nnz, dtype=np.int64)
+    perm = indptr[row_of] + (indptr[row_of + 1] - 1 - pos)
+    out = csr_matrix((m.data[perm], m.indices[perm], m.indptr.copy()), shape=m.shape)
+    out.has_sorted_indices = False
+    return out
+
+
+def tfidf(
+    data,
+    log_tf: bool = True,
+    log_idf: bool = True,
+    log_tfidf: bool = False,
+    scale_factor: Union[int, float] = 1e4,
+    inplace: bool = True,
+    copy: bool = False,
+    from_layer: Optional[str] = None,
+    to_layer: Optional[str] = None,
+    *,
+    comm=None,
+    n_obs: Optional[int] = None,
+    match_scipy_order: bool = False,
+    keep_on_device: bool = True,
+    backend=None,
+):
+    """
+    Transform peak counts with TF-IDF (Term Frequency - Inverse Document Frequency).
+
+    TF: peak counts are normalised by total number of counts per cell
+    DF: total number of counts for each peak
+    IDF: number of cells divided by DF
+
+    By default, log(TF) * log(IDF) is returned.  Signature, validation and write-back follow
+    the reference (preproc.py:16-129); see the module docstring for the extra keywords.
+
+    comm
+            ``TorchDistComm`` when ``data`` holds this rank's row (cell) shard.
+    n_obs
+            Global number of cells when sharded (defaults to the sum over ranks).
+    match_scipy_order
+            Emit rows in the (descending) column order scipy's SpGEMM produces instead of
+            canonical sorted CSR.
+    keep_on_device
+            Keep the device copy attached to the result so that ``lsi`` skips the upload.
+    """
+    if is_anndata(data):
+        adata = data
+    elif is_mudata(data) and "atac" in data.mod:
+        adata = data.mod["atac"]
+    else:
+        raise TypeError("Expected AnnData or MuData object with 'atac' modality")
+
+    if log_tfidf and (log_tf or log_idf):
+        raise AttributeError(
+            "When returning log(TF*IDF), \
+            applying neither log(TF) nor log(IDF) is possible."
+        )
+
+    if copy and not inplace:
+        raise ValueError("`copy=True` cannot be used with `inplace=False`.")
+
+    if to_layer is not None and not inplace:
+        raise ValueError(f"`to_layer='{str(to_layer)}'` cannot be used with `inplace=False`.")
+
+    if copy:
+        adata = adata.copy()
+
+    view_to_actual(adata)
+
+    counts = adata.X if from_layer is None else adata.layers[from_layer]
+
+    # Check before the computation
+    if to_layer is not None and to_layer in adata.layers:
+        warn(f"Existing layer '{str(to_layer)}' will be overwritten")
+
+    if backend is None:
+        from .._backend import get_backend
+
+        backend = get_backend()  # raises without a GPU: there is no CPU fallback
+    comm = default_comm(comm)
+
+    host = canonical_csr(counts)
+    if n_obs is None:
+        n_obs = comm.sum_scalar(adata.shape[0])
+    X = backend.upload_csr(host.indptr, host.indices, host.data, host.shape)
+    flags = _flags(log_tf, log_idf, log_tfidf)
+    R = tfidf_device(backend, X, n_obs, flags, _effective_scale(scale_factor), comm=comm)
+
+    vals = backend.to_host(R.values)
+    if R.indices is X.indices:
+        res = csr_matrix((vals, host.indices.copy(), host.indptr.copy()), shape=host.shape)
+    else:  # explicit zeros were dropped on the device
+        res = csr_matrix(
+            (vals, backend.to_host(R.indices), backend.to_host(R.indptr).astype(host.indptr.dtype)),
+            shape=host.shape,
+        )
+    res.has_sorted_indices = True
+    if match_scipy_order and log_tf and not log_tfidf:
+        res = _reverse_rows(res)
+    if keep_on_device:
+        try:
+            setattr(res, DEVICE_ATTR, (R, backend))
+        except Exception:  # noqa: BLE001
+            pass
+
+    # res = np.nan_to_num(tf_idf, nan=0.0) is a no-op on sparse matrices (preproc.py:119)
+    if not inplace:
+        return res
+
+    if to_layer is not None:
+        adata.layers[to_layer] = res
+    else:
+        adata.X = res
+
+    if copy:
+        return adata
+
+
+def binarize(data, *, backend=None):
+    """
+    Transform peak counts to the binary matrix (all the non-zero values become 1).
+    Mirrors preproc.py:132-152: sparse X has its stored values set to 1 in place.
+    """
+    if is_anndata(data):
+        adata = data
+    elif is_mudata(data) and "atac" in data.mod:
+        adata = data.mod["atac"]
+    else:
+        raise TypeError("Expected AnnData or MuData object with 'atac' modality")
+
+    if backend is None:
+        from .._backend import get_backend
+
+        backend = get_backend()
+    if issparse(adata.X):
+        # Sparse matrix: stored values that are non-zero become 1, in place (:148-150)
+        data = adata.X.data
+        if data.dtype not in (np.float32, np.float64):
+            data[data != 0] = 1  # integer counts: no floating-point kernel involved
+            return
+        vals = backend.to_device(data)
+        backend.binarize_values(vals)
+        data[...] = backend.to_host(vals)
+    else:
+        # dense input is a toy-size branch in the reference too (:151-152)
+        adata.X[adata.X != 0] = 1

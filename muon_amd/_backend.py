@@ -1,0 +1,231 @@
+"""Device-side operator set used by the tfidf / lsi / mofa host code.
+
+``HipBackend`` forwards every operator to a hand-written gfx950 kernel through the C-ABI
+(``_ffi``).  Device memory, streams and collectives are PyTorch-ROCm plumbing: tensors are
+only containers whose ``data_ptr()`` is handed to the kernels.  There is no CPU
+implementation in this package - constructing ``HipBackend`` without a GPU raises.
+(The multi-process *host logic* is exercised on CPU by tests that inject their own
+operator set; see tests/cpu_backend.py.)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _ffi
+from ._ffi import F32, F64, check
+
+
+@dataclass
+class DeviceCSR:
+    """CSR resident in HBM: indptr int64[n+1], indices int32[nnz], values f32|f64[nnz]."""
+
+    indptr: torch.Tensor
+    indices: torch.Tensor
+    values: torch.Tensor
+    shape: Tuple[int, int]
+
+    @property
+    def nnz(self) -> int:
+        return int(self.indices.numel())
+
+    @property
+    def dtype(self):
+        return self.values.dtype
+
+    def with_values(self, values: torch.Tensor) -> "DeviceCSR":
+        return DeviceCSR(self.indptr, self.indices, values, self.shape)
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float64:
+        return F64
+    raise TypeError(f"unsupported value dtype {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def pick_block(width: int) -> int:
+    for b in (16, 32, 64):
+        if width <= b:
+            return b
+    raise NotImplementedError(
+        f"block width {width} > 64 is not supported yet (n_comps + oversample must be <= 64)"
+    )
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, device: Optional[int] = None):
+        _ffi.require_gpu()
+        self.lib = _ffi.lib()
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", int(device))
+
+    # -- plumbing -------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def to_device(self, arr) -> torch.Tensor:
+        return torch.as_tensor(np.ascontiguousarray(arr)).to(self.device, non_blocking=False)
+
+    def to_host(self, t: torch.Tensor) -> np.ndarray:
+        return t.detach().cpu().numpy()
+
+    def upload_csr(self, indptr, indices, values, shape) -> DeviceCSR:
+        return DeviceCSR(
+            self.to_device(np.asarray(indptr, dtype=np.int64)),
+            self.to_device(np.asarray(indices, dtype=np.int32)),
+            self.to_device(values),
+            (int(shape[0]), int(shape[1])),
+        )
+
+    # -- TF-IDF (reference preproc.py:92-117) -----------------------------------------
+    def row_col_sums(self, X: DeviceCSR):
+        n, d = X.shape
+        rowsum = self.empty((n,), torch.float64)
+        colsum = self.empty((d,), torch.float64)
+        wb = int(self.lib.mu_csr_row_col_sums_worksize(n, d))
+        work = self.empty((wb,), torch.uint8)
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_csr_row_col_sums(_dt(X.values), n, d, _p(X.indptr), _p(X.indices),
+                                               _p(X.values), _p(rowsum), _p(colsum), _p(work), wb,
+                                               self._stream()))
+        return rowsum, colsum
+
+    def idf(self, colsum: torch.Tensor, n_obs: float, flags: int, dtype) -> torch.Tensor:
+        d = colsum.numel()
+        out = self.empty((d,), dtype)
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_tfidf_idf(_dt(out), d, float(n_obs), _p(colsum), flags, _p(out),
+                                        self._stream()))
+        return out
+
+    def tfidf_scale(self, X: DeviceCSR, rowsum, idf, scale: float, flags: int, out=None):
+        if out is None:
+            out = torch.empty_like(X.values)
+        zc = self.zeros((1,), torch.int64)
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_tfidf_scale(_dt(X.values), X.shape[0], _p(X.indptr), _p(X.indices),
+                                          _p(X.values), _p(rowsum), _p(idf), float(scale), flags,
+                                          _p(out), _p(zc), self._stream()))
+        return out, zc
+
+    def compact_nonzero(self, X: DeviceCSR) -> DeviceCSR:
+        n = X.shape[0]
+        row_nnz = self.empty((n,), torch.int64)
+        new_indptr = self.empty((n + 1,), torch.int64)
+        with torch.cuda.device(self.device):
+            st = self._stream()
+            check(self.lib.mu_csr_count_nonzero(_dt(X.values), n, _p(X.indptr), _p(X.values),
+                                                _p(row_nnz), st))
+            check(self.lib.mu_exclusive_scan_i64(n, _p(row_nnz), _p(new_indptr), st))
+            new_nnz = int(new_indptr[-1].item())
+            new_indices = self.empty((new_nnz,), torch.int32)
+            new_values = self.empty((new_nnz,), X.values.dtype)
+            check(self.lib.mu_csr_compact_nonzero(_dt(X.values), n, _p(X.indptr), _p(X.indices),
+                                                  _p(X.values), _p(new_indptr), _p(new_indices),
+                                                  _p(new_values), st))
+        return DeviceCSR(new_indptr, new_indices, new_values, X.shape)
+
+    def binarize_values(self, values: torch.Tensor) -> None:
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_binarize_values(_dt(values), values.numel(), _p(values),
+                                              self._stream()))
+
+    # -- LSI building blocks (reference tools.py:53 -> scipy svds) ---------------------
+    def transpose(self, X: DeviceCSR) -> DeviceCSR:
+        n, d = X.shape
+        nnz = X.nnz
+        t_indptr = self.empty((d + 1,), torch.int64)
+        t_indices = self.empty((nnz,), torch.int32)
+        t_values = torch.empty_like(X.values)
+        wb = int(self.lib.mu_csr_transpose_worksize(n, d, nnz))
+        work = self.empty((wb,), torch.uint8)
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_csr_transpose(_dt(X.values), n, d, nnz, _p(X.indptr), _p(X.indices),
+                                            _p(X.values), _p(t_indptr), _p(t_indices),
+                                            _p(t_values), _p(work), wb, self._stream()))
+        return DeviceCSR(t_indptr, t_indices, t_values, (d, n))
+
+    def spmm(self, X: DeviceCSR, Q: torch.Tensor, out=None) -> torch.Tensor:
+        n, d = X.shape
+        B = Q.shape[1]
+        assert Q.shape[0] == d and Q.dtype == torch.float32 and Q.is_contiguous()
+        if X.values.dtype != torch.float32:
+            raise TypeError("spmm runs on f32 values")
+        if out is None:
+            out = self.empty((n, B), torch.float32)
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_spmm_f32(n, d, _p(X.indptr), _p(X.indices), _p(X.values), _p(Q), B,
+                                       _p(out), 0, self._stream()))
+        return out
+
+    def gram(self, A: torch.Tensor):
+        n, B = A.shape
+        assert A.dtype == torch.float32 and A.is_contiguous()
+        G = self.empty((B, B), torch.float64)
+        cs = self.empty((B,), torch.float64)
+        wb = int(self.lib.mu_gram_worksize(n, B))
+        work = self.empty((wb,), torch.uint8)
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_gram_f32(n, B, _p(A), _p(G), _p(cs), _p(work), wb, self._stream()))
+        return G, cs
+
+    def apply(self, A: torch.Tensor, M: torch.Tensor, bias=None, out=None) -> torch.Tensor:
+        n, B = A.shape
+        assert M.shape == (B, B) and M.dtype == torch.float32 and M.is_contiguous()
+        if out is None:
+            out = torch.empty_like(A)
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_dense_apply_f32(n, B, _p(A), _p(M), _p(bias), _p(out), self._stream()))
+        return out
+
+    def randn(self, rows: int, B: int, seed: int) -> torch.Tensor:
+        out = self.empty((rows, B), torch.float32)
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_randn_f32(rows * B, int(seed) & (2**64 - 1), _p(out), self._stream()))
+        return out
+
+    # -- synthetic data (bench / tests) ---------------------------------------------
+    def synth_counts(self, row0: int, n_rows: int, n_cols: int, n_topics: int = 50,
+                     density: float = 0.03, seed: int = 0) -> DeviceCSR:
+        row_nnz = self.empty((n_rows,), torch.int64)
+        indptr = self.empty((n_rows + 1,), torch.int64)
+        with torch.cuda.device(self.device):
+            st = self._stream()
+            check(self.lib.mu_synth_row_nnz(row0, n_rows, n_cols, n_topics, density, seed,
+                                            _p(row_nnz), st))
+            check(self.lib.mu_exclusive_scan_i64(n_rows, _p(row_nnz), _p(indptr), st))
+            nnz = int(indptr[-1].item())
+            indices = self.empty((nnz,), torch.int32)
+            values = self.empty((nnz,), torch.float32)
+            check(self.lib.mu_synth_fill(row0, n_rows, n_cols, n_topics, density, seed, _p(indptr),
+                                         _p(indices), _p(values), st))
+        return DeviceCSR(indptr, indices, values, (n_rows, n_cols))
+
+
+_default_backend = None
+
+
+def get_backend():
+    """The process-wide HipBackend on the current device (raises without a GPU)."""
+    global _default_backend
+    if _default_backend is None or _default_backend.device.index != torch.cuda.current_device():
+        _default_backend = HipBackend()
+    return _default_backend

@@ -1,0 +1,71 @@
+"""Collectives for the row(cell)-sharded path: one process per GPU, RCCL over xGMI.
+
+The reference has no distributed code; sharding cells across ranks is this package's
+design.  Only three reductions exist on the path:
+  * tfidf : all-reduce of the per-peak count sums (d values)
+  * lsi   : all-reduce of Z = X^T Y (d x B) per iteration, and of the small B x B Gram
+  * mofa  : all-reduce of the D x K sufficient statistics per iteration
+``torch.distributed`` with backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+from __future__ import annotations
+
+import torch
+
+
+class LocalComm:
+    """Single process: every reduction is the identity."""
+
+    world_size = 1
+    rank = 0
+
+    def all_reduce_sum(self, *tensors):
+        return tensors[0] if len(tensors) == 1 else tensors
+
+    def all_gather_rows(self, t):
+        return t
+
+    def sum_scalar(self, x):
+        return x
+
+
+class TorchDistComm:
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self._dist = dist
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_reduce_sum(self, *tensors):
+        for t in tensors:
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        return tensors[0] if len(tensors) == 1 else tensors
+
+    def all_gather_rows(self, t):
+        """Concatenate row shards of possibly different length along dim 0."""
+        n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+        sizes = [torch.zeros_like(n) for _ in range(self.world_size)]
+        self._dist.all_gather(sizes, n, group=self.group)
+        sizes = [int(s.item()) for s in sizes]
+        mx = max(sizes)
+        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        bufs = [torch.empty_like(pad) for _ in range(self.world_size)]
+        self._dist.all_gather(bufs, pad, group=self.group)
+        return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+
+    def sum_scalar(self, x):
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        if self._dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        self._dist.all_reduce(t, group=self.group)
+        return float(t.item())
+
+
+def default_comm(comm=None):
+    """``comm=None`` always means single process (the reference's semantics): a caller that
+    holds a row shard per rank passes ``TorchDistComm()`` explicitly."""
+    return LocalComm() if comm is None else comm

@@ -1,0 +1,246 @@
+// Dense blocks of the LSI solver: the only MFMA work on the path.
+//   gram  : G = A^T A (f64 accumulate, v_mfma_f64_16x16x4_f64) + column sums
+//   apply : Out = A * M + bias          (v_mfma_f32_16x16x4_f32)
+//   randn : counter-based standard normals for the start block
+// Together gram + (host Cholesky of the B x B Gram) + apply form the CholeskyQR step that
+// replaces the dense QR / SVD tail of scipy svds (_svds.py:513-539); A is n x B with
+// B <= 64, so these kernels stream A once and are bound by HBM, not by the matrix cores.
+#include "common.hpp"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kGramThreads = 256;  // 4 waves
+
+// MFMA f64 16x16x4 operand maps (cdna_hip_programming.md §3):
+//   A operand: lane l holds A[i = l & 15][k = l >> 4]
+//   B operand: lane l holds B[k = l >> 4][j = l & 15]
+//   C/D      : reg r of lane l is C[row = (l >> 4) + 4 r][col = l & 15]
+// For G = A^T A a 16x16 tile (ti, tj) takes both operands from the same four rows of A:
+//   a = A[r + (l >> 4)][16 ti + (l & 15)],  b = A[r + (l >> 4)][16 tj + (l & 15)].
+template <int B>
+__global__ __launch_bounds__(kGramThreads) void k_gram_partial(int64_t n_rows,
+                                                               const float* __restrict__ A,
+                                                               double* __restrict__ partial) {
+  constexpr int T = B / 16;
+  constexpr int NT = T * (T + 1) / 2;  // upper-triangular tiles only
+  __shared__ double red[B * B + B];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane >> 4, lc = lane & 15;
+
+  d4 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  double cs[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) cs[t] = 0.0;
+
+  // rows are dealt to waves in groups of four
+  const int64_t n_groups = (n_rows + 3) / 4;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t gstride = (int64_t)gridDim.x * 4;
+  for (int64_t grp = gw; grp < n_groups; grp += gstride) {
+    const int64_t row = grp * 4 + lr;
+    double x[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) x[t] = (row < n_rows) ? (double)A[row * B + 16 * t + lc] : 0.0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) cs[t] += x[t];
+    int k = 0;
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+      for (int tj = ti; tj < T; ++tj) {
+        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti], x[tj], acc[k], 0, 0, 0);
+        ++k;
+      }
+  }
+
+  // reduce the four waves through LDS (fixed order), then write this workgroup's partial
+  for (int i = threadIdx.x; i < B * B + B; i += kGramThreads) red[i] = 0.0;
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      int k = 0;
+#pragma unroll
+      for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+        for (int tj = ti; tj < T; ++tj) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int gi = 16 * ti + lr + 4 * r, gj = 16 * tj + lc;
+            red[gi * B + gj] += acc[k][r];
+          }
+          ++k;
+        }
+      // column sums: add the four row-groups of the wave
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        double v = cs[t];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lr == 0) red[B * B + 16 * t + lc] += v;
+      }
+    }
+    __syncthreads();
+  }
+  double* dst = partial + (int64_t)blockIdx.x * (B * B + B);
+  for (int i = threadIdx.x; i < B * B + B; i += kGramThreads) dst[i] = red[i];
+}
+
+template <int B>
+__global__ __launch_bounds__(256) void k_gram_reduce(int n_partials, const double* __restrict__ partial,
+                                                     double* __restrict__ G,
+                                                     double* __restrict__ colsum) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * B + B) return;
+  int src = e;
+  if (e < B * B) {
+    const int i = e / B, j = e % B;
+    // only tiles with ti <= tj were computed; mirror the rest
+    if ((i / 16) > (j / 16)) src = j * B + i;
+  }
+  double acc = 0.0;
+  for (int p = 0; p < n_partials; ++p) acc += partial[(int64_t)p * (B * B + B) + src];
+  if (e < B * B) G[e] = acc; else if (colsum) colsum[e - B * B] = acc;
+}
+
+static inline int gram_blocks(int64_t n_rows) {
+  int64_t groups = (n_rows + 15) / 16;  // one workgroup step = 16 rows
+  int64_t blocks = groups < 1 ? 1 : groups;
+  const int64_t cap = (int64_t)mu_num_cus() * 4;
+  return (int)(blocks > cap ? cap : blocks);
+}
+
+// MFMA f32 16x16x4: A operand lane l = A[i = l & 15][k = l >> 4]; B operand = B[k = l >> 4][j = l & 15];
+// C/D reg r of lane l = C[row = 4 (l >> 4) + r][col = l & 15].
+template <int B>
+__global__ __launch_bounds__(256) void k_dense_apply(int64_t n_rows, const float* __restrict__ A,
+                                                     const float* __restrict__ M,
+                                                     const float* __restrict__ bias,
+                                                     float* __restrict__ Out) {
+  constexpr int T = B / 16;   // output column tiles
+  constexpr int KS = B / 4;   // k steps
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane >> 4, lc = lane & 15;
+  float bm[KS][T];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int t = 0; t < T; ++t) bm[ks][t] = M[(4 * ks + lr) * B + 16 * t + lc];
+  float bb[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) bb[t] = bias ? bias[16 * t + lc] : 0.f;
+
+  const int64_t n_tiles = (n_rows + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t r0 = tile * 16;
+    const int64_t arow = r0 + lc;
+    float a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = (arow < n_rows) ? A[arow * B + 4 * ks + lr] : 0.f;
+    f4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f4{bb[t], bb[t], bb[t], bb[t]};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bm[ks][t], acc[t], 0, 0, 0);
+    // all of this wave's reads of the tile are complete (consumed by the MFMAs above) before
+    // the stores below, so Out may alias A
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t orow = r0 + 4 * lr + r;
+        if (orow < n_rows) Out[orow * B + 16 * t + lc] = acc[t][r];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_randn(int64_t count, uint64_t seed, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t h1 = splitmix64(seed ^ (uint64_t)(2 * i) * 0xD6E8FEB86659FD93ull);
+    const uint64_t h2 = splitmix64(h1 + (uint64_t)(2 * i + 1));
+    const float u1 = u01(h1), u2 = u01(h2);
+    out[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+  }
+}
+
+extern "C" {
+
+size_t mu_gram_worksize(int64_t n_rows, int B) {
+  return (size_t)gram_blocks(n_rows) * (size_t)(B * B + B) * sizeof(double) + 256;
+}
+
+int mu_gram_f32(int64_t n_rows, int B, const float* d_A, double* d_G, double* d_colsum, void* d_work,
+                size_t work_bytes, void* stream) {
+  MU_REQUIRE(B == 16 || B == 32 || B == 64, "B must be 16, 32 or 64");
+  MU_REQUIRE(n_rows >= 0 && d_G, "bad arguments");
+  MU_REQUIRE(n_rows == 0 || d_A, "null input");
+  MU_REQUIRE(d_work && work_bytes >= mu_gram_worksize(n_rows, B), "work buffer too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = gram_blocks(n_rows);
+  double* partial = (double*)d_work;
+  const unsigned rblocks = (unsigned)((B * B + B + 255) / 256);
+  switch (B) {
+    case 64:
+      hipLaunchKernelGGL(k_gram_partial<64>, dim3(blocks), dim3(kGramThreads), 0, st, n_rows, d_A, partial);
+      MU_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_gram_reduce<64>, dim3(rblocks), dim3(256), 0, st, blocks, partial, d_G, d_colsum);
+      break;
+    case 32:
+      hipLaunchKernelGGL(k_gram_partial<32>, dim3(blocks), dim3(kGramThreads), 0, st, n_rows, d_A, partial);
+      MU_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_gram_reduce<32>, dim3(rblocks), dim3(256), 0, st, blocks, partial, d_G, d_colsum);
+      break;
+    default:
+      hipLaunchKernelGGL(k_gram_partial<16>, dim3(blocks), dim3(kGramThreads), 0, st, n_rows, d_A, partial);
+      MU_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_gram_reduce<16>, dim3(rblocks), dim3(256), 0, st, blocks, partial, d_G, d_colsum);
+      break;
+  }
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_dense_apply_f32(int64_t n_rows, int B, const float* d_A, const float* d_M,
+                       const float* d_bias, float* d_Out, void* stream) {
+  MU_REQUIRE(B == 16 || B == 32 || B == 64, "B must be 16, 32 or 64");
+  MU_REQUIRE(n_rows >= 0, "negative n_rows");
+  if (n_rows == 0) return MU_OK;
+  MU_REQUIRE(d_A && d_M && d_Out, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t blocks = (n_rows + 63) / 64;
+  const int64_t cap = (int64_t)mu_num_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  switch (B) {
+    case 64:
+      hipLaunchKernelGGL(k_dense_apply<64>, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, d_A, d_M, d_bias, d_Out);
+      break;
+    case 32:
+      hipLaunchKernelGGL(k_dense_apply<32>, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, d_A, d_M, d_bias, d_Out);
+      break;
+    default:
+      hipLaunchKernelGGL(k_dense_apply<16>, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, d_A, d_M, d_bias, d_Out);
+      break;
+  }
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_randn_f32(int64_t count, uint64_t seed, float* d_out, void* stream) {
+  MU_REQUIRE(count >= 0, "negative count");
+  if (count == 0) return MU_OK;
+  MU_REQUIRE(d_out, "null pointer");
+  int64_t blocks = (count + 255) / 256;
+  const int64_t cap = (int64_t)mu_num_cus() * 16;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_randn, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, count, seed, d_out);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,390 @@
+// TF-IDF kernels: replace the six scipy passes of
+// /root/reference/muon/_atac/preproc.py:92-117 (two reductions, two diag x CSR
+// SpGEMMs, a scalar multiply and a sparse log1p) by one reduction sweep and one
+// fused scale pass.  HBM-bound: 8 B/nnz (sweep) + 12 B/nnz (scale).
+#include "sweep.hpp"
+
+// ---------------------------------------------------------------------------------
+// slab pointers
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_slab_ptr(int64_t n_rows, int64_t S,
+                                                  const int64_t* __restrict__ indptr,
+                                                  const int32_t* __restrict__ indices,
+                                                  int64_t* __restrict__ sp) {
+  const int64_t total = n_rows * (S + 1);
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = id / (S + 1);
+    const int64_t s = id - row * (S + 1);
+    int64_t lo = indptr[row], hi = indptr[row + 1];
+    if (s == S) {
+      sp[id] = hi;
+      continue;
+    }
+    const int64_t key = s * (int64_t)kSlab;
+    while (lo < hi) {
+      int64_t mid = lo + ((hi - lo) >> 1);
+      if ((int64_t)indices[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    sp[id] = lo;
+  }
+}
+
+int launch_slab_ptr(int64_t n_rows, int64_t n_cols, const int64_t* indptr, const int32_t* indices,
+                    int64_t* sp, hipStream_t stream) {
+  const int64_t S = num_slabs(n_cols);
+  const int64_t total = n_rows * (S + 1);
+  if (total == 0) return MU_OK;
+  int64_t blocks = (total + 255) / 256;
+  const int64_t cap = (int64_t)mu_num_cus() * 32;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_slab_ptr, dim3((unsigned)blocks), dim3(256), 0, stream, n_rows, S, indptr,
+                     indices, sp);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// row sums + per-workgroup column partial sums (LDS bins), one pass over the nnz
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kSweepThreads) void k_row_col_sums(
+    int64_t n_rows, int64_t n_cols, int64_t S, const int64_t* __restrict__ indptr,
+    const int32_t* __restrict__ indices, const T* __restrict__ values,
+    const int64_t* __restrict__ sp, double* __restrict__ rowsum, double* __restrict__ partial) {
+  __shared__ double bins[kSlab];  // 64 KiB
+  __shared__ int64_t s_r[2];
+  const int g = blockIdx.x, G = gridDim.x;
+  if (threadIdx.x == 0) sweep_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
+  __syncthreads();
+  const int64_t r0 = s_r[0], r1 = s_r[1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+  for (int64_t s = 0; s < S; ++s) {
+    for (int t = threadIdx.x; t < kSlab; t += kSweepThreads) bins[t] = 0.0;
+    __syncthreads();
+    const int32_t cbase = (int32_t)(s * kSlab);
+    for (int64_t row = r0 + wave; row < r1; row += kSweepWaves) {
+      const int64_t lo = sp[row * (S + 1) + s], hi = sp[row * (S + 1) + s + 1];
+      double rs = 0.0;
+      for (int64_t p = lo + lane; p < hi; p += 256) {
+        // four independent chunks in flight per wave
+        int32_t c[4];
+        T v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t q = p + 64 * u;
+          const bool ok = q < hi;
+          c[u] = ok ? indices[q] : -1;
+          v[u] = ok ? values[q] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (c[u] >= 0) {
+            atomicAdd(&bins[c[u] - cbase], (double)v[u]);
+            rs += (double)v[u];
+          }
+        }
+      }
+      rs = wave_sum(rs);
+      if (lane == 0) {
+        if (s == 0) rowsum[row] = rs; else rowsum[row] += rs;
+      }
+    }
+    __syncthreads();
+    const int64_t ncol_here = (n_cols - (int64_t)cbase) < kSlab ? (n_cols - (int64_t)cbase) : kSlab;
+    double* dst = partial + (int64_t)g * n_cols + cbase;
+    for (int t = threadIdx.x; t < ncol_here; t += kSweepThreads) dst[t] = bins[t];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partials(int64_t n_cols, int G,
+                                                         const double* __restrict__ partial,
+                                                         double* __restrict__ colsum) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_cols) return;
+  double acc = 0.0;
+  for (int g = 0; g < G; ++g) acc += partial[(int64_t)g * n_cols + j];  // fixed order
+  colsum[j] = acc;
+}
+
+// ---------------------------------------------------------------------------------
+// idf and the fused scale pass
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_idf(int64_t n_cols, double n_obs,
+                                             const double* __restrict__ colsum, int flags,
+                                             T* __restrict__ idf) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_cols) return;
+  T v = (T)n_obs / (T)colsum[j];  // preproc.py:106
+  if (flags & MU_TFIDF_LOG_IDF) v = log1p(v);  // :107-108
+  idf[j] = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_tfidf_scale(
+    int64_t n_rows, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const T* __restrict__ values, const double* __restrict__ rowsum, const T* __restrict__ idf,
+    T scale, int use_scale, int flags, T* __restrict__ out, unsigned long long* zero_count) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  unsigned int zeros = 0;
+  for (int64_t row = wave0; row < n_rows; row += n_waves) {
+    const int64_t lo = indptr[row], hi = indptr[row + 1];
+    const T inv = (T)1 / (T)rowsum[row];  // preproc.py:94  1.0 / n_peaks
+    for (int64_t p = lo + lane; p < hi; p += 64) {
+      const int32_t c = indices[p];
+      T t = inv * values[p];                         // :96  D @ counts
+      if (use_scale) t = t * scale;                  // :101-102
+      if (flags & MU_TFIDF_LOG_TF) t = log1p(t);     // :103-104
+      t = t * idf[c];                                // :110-112  tf @ diag(idf)
+      if (flags & MU_TFIDF_LOG_TFIDF) t = log1p(t);  // :116-117
+      out[p] = t;
+      zeros += (t == (T)0) ? 1u : 0u;
+    }
+  }
+  if (zero_count) {
+    zeros = wave_sum(zeros);
+    if (lane == 0 && zeros) atomicAdd(zero_count, (unsigned long long)zeros);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// explicit-zero compaction, scan, fill
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_count_nonzero(int64_t n_rows,
+                                                       const int64_t* __restrict__ indptr,
+                                                       const T* __restrict__ values,
+                                                       int64_t* __restrict__ row_nnz) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t row = wave0; row < n_rows; row += n_waves) {
+    const int64_t lo = indptr[row], hi = indptr[row + 1];
+    int cnt = 0;
+    for (int64_t p = lo + lane; p < hi; p += 64) cnt += (values[p] != (T)0) ? 1 : 0;  // NaN kept
+    cnt = wave_sum(cnt);
+    if (lane == 0) row_nnz[row] = cnt;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_compact_nonzero(
+    int64_t n_rows, const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const T* __restrict__ values, const int64_t* __restrict__ new_indptr,
+    int32_t* __restrict__ new_indices, T* __restrict__ new_values) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t row = wave0; row < n_rows; row += n_waves) {
+    const int64_t lo = indptr[row], hi = indptr[row + 1];
+    int64_t dst = new_indptr[row];
+    for (int64_t p0 = lo; p0 < hi; p0 += 64) {
+      const int64_t p = p0 + lane;
+      const bool in = p < hi;
+      const T v = in ? values[p] : (T)0;
+      const bool keep = in && (v != (T)0);
+      const unsigned long long m = __ballot(keep);
+      if (keep) {
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        new_indices[dst + rank] = indices[p];
+        new_values[dst + rank] = v;
+      }
+      dst += __popcll(m);
+    }
+  }
+}
+
+// out[0] = 0, out[i+1] = out[i] + in[i]; one workgroup, three phases
+__global__ __launch_bounds__(1024) void k_exclusive_scan_i64(int64_t n, const int64_t* __restrict__ in,
+                                                             int64_t* __restrict__ out) {
+  __shared__ int64_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t chunk = (n + 1023) / 1024;
+  const int64_t b = (int64_t)t * chunk;
+  const int64_t e = (b + chunk < n) ? (b + chunk) : n;
+  int64_t s = 0;
+  for (int64_t i = b; i < e; ++i) s += in[i];
+  part[t] = s;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over the 1024 partials
+  for (int off = 1; off < 1024; off <<= 1) {
+    int64_t v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int64_t run = (t == 0) ? 0 : part[t - 1];
+  if (t == 0) out[0] = 0;
+  for (int64_t i = b; i < e; ++i) {
+    run += in[i];
+    out[i + 1] = run;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_binarize(int64_t n, T* __restrict__ v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    if (v[i] != (T)0) v[i] = (T)1;  // preproc.py:150
+}
+
+static inline unsigned grid_for_rows(int64_t n_rows) {
+  // one wave per row, 4 waves per block, capped at 16 blocks per CU (grid-stride beyond)
+  int64_t blocks = (n_rows + 3) / 4;
+  const int64_t cap = (int64_t)mu_num_cus() * 16;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+extern "C" {
+
+size_t mu_csr_row_col_sums_worksize(int64_t n_rows, int64_t n_cols) {
+  const int64_t S = num_slabs(n_cols);
+  const int G = sweep_grid();
+  return (size_t)(n_rows * (S + 1)) * sizeof(int64_t) + (size_t)G * (size_t)n_cols * sizeof(double) +
+         256;
+}
+
+int mu_csr_row_col_sums(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                        const int32_t* d_indices, const void* d_values, double* d_rowsum,
+                        double* d_colsum, void* d_work, size_t work_bytes, void* stream) {
+  MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative shape");
+  MU_REQUIRE(d_indptr && d_rowsum && d_colsum, "null pointer");
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  MU_REQUIRE(work_bytes >= mu_csr_row_col_sums_worksize(n_rows, n_cols) && d_work,
+             "work buffer too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_cols == 0 || n_rows == 0) {
+    if (n_cols) MU_CHECK_HIP(hipMemsetAsync(d_colsum, 0, sizeof(double) * n_cols, st));
+    if (n_rows) MU_CHECK_HIP(hipMemsetAsync(d_rowsum, 0, sizeof(double) * n_rows, st));
+    return MU_OK;
+  }
+  const int64_t S = num_slabs(n_cols);
+  const int G = sweep_grid();
+  int64_t* sp = (int64_t*)d_work;
+  size_t off = ((size_t)(n_rows * (S + 1)) * sizeof(int64_t) + 255) & ~(size_t)255;
+  double* partial = (double*)((char*)d_work + off);
+  int rc = launch_slab_ptr(n_rows, n_cols, d_indptr, d_indices, sp, st);
+  if (rc) return rc;
+  if (dtype == MU_DTYPE_F32)
+    hipLaunchKernelGGL(k_row_col_sums<float>, dim3(G), dim3(kSweepThreads), 0, st, n_rows, n_cols, S,
+                       d_indptr, d_indices, (const float*)d_values, sp, d_rowsum, partial);
+  else
+    hipLaunchKernelGGL(k_row_col_sums<double>, dim3(G), dim3(kSweepThreads), 0, st, n_rows, n_cols,
+                       S, d_indptr, d_indices, (const double*)d_values, sp, d_rowsum, partial);
+  MU_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st,
+                     n_cols, G, partial, d_colsum);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_tfidf_idf(int dtype, int64_t n_cols, double n_obs, const double* d_colsum, int flags,
+                 void* d_idf, void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  if (n_cols == 0) return MU_OK;
+  MU_REQUIRE(d_colsum && d_idf, "null pointer");
+  const unsigned blocks = (unsigned)((n_cols + 255) / 256);
+  if (dtype == MU_DTYPE_F32)
+    hipLaunchKernelGGL(k_idf<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n_cols, n_obs,
+                       d_colsum, flags, (float*)d_idf);
+  else
+    hipLaunchKernelGGL(k_idf<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n_cols, n_obs,
+                       d_colsum, flags, (double*)d_idf);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_tfidf_scale(int dtype, int64_t n_rows, const int64_t* d_indptr, const int32_t* d_indices,
+                   const void* d_values, const double* d_rowsum, const void* d_idf, double scale,
+                   int flags, void* d_out, unsigned long long* d_zero_count, void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  MU_REQUIRE(!((flags & MU_TFIDF_LOG_TFIDF) && (flags & (MU_TFIDF_LOG_TF | MU_TFIDF_LOG_IDF))),
+             "log_tfidf excludes log_tf / log_idf (preproc.py:69-73)");
+  hipStream_t st = (hipStream_t)stream;
+  if (d_zero_count) MU_CHECK_HIP(hipMemsetAsync(d_zero_count, 0, sizeof(unsigned long long), st));
+  if (n_rows == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_rowsum && d_idf && d_out, "null pointer");
+  const int use_scale = !(scale == 0.0 || scale == 1.0);  // preproc.py:101
+  const unsigned blocks = grid_for_rows(n_rows);
+  if (dtype == MU_DTYPE_F32)
+    hipLaunchKernelGGL(k_tfidf_scale<float>, dim3(blocks), dim3(256), 0, st, n_rows, d_indptr,
+                       d_indices, (const float*)d_values, d_rowsum, (const float*)d_idf,
+                       (float)scale, use_scale, flags, (float*)d_out, d_zero_count);
+  else
+    hipLaunchKernelGGL(k_tfidf_scale<double>, dim3(blocks), dim3(256), 0, st, n_rows, d_indptr,
+                       d_indices, (const double*)d_values, d_rowsum, (const double*)d_idf, scale,
+                       use_scale, flags, (double*)d_out, d_zero_count);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_csr_count_nonzero(int dtype, int64_t n_rows, const int64_t* d_indptr, const void* d_values,
+                         int64_t* d_row_nnz, void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  if (n_rows == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_row_nnz, "null pointer");
+  const unsigned blocks = grid_for_rows(n_rows);
+  if (dtype == MU_DTYPE_F32)
+    hipLaunchKernelGGL(k_count_nonzero<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       n_rows, d_indptr, (const float*)d_values, d_row_nnz);
+  else
+    hipLaunchKernelGGL(k_count_nonzero<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       n_rows, d_indptr, (const double*)d_values, d_row_nnz);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_csr_compact_nonzero(int dtype, int64_t n_rows, const int64_t* d_indptr,
+                           const int32_t* d_indices, const void* d_values,
+                           const int64_t* d_new_indptr, int32_t* d_new_indices, void* d_new_values,
+                           void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  if (n_rows == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_new_indptr, "null pointer");
+  const unsigned blocks = grid_for_rows(n_rows);
+  if (dtype == MU_DTYPE_F32)
+    hipLaunchKernelGGL(k_compact_nonzero<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       n_rows, d_indptr, d_indices, (const float*)d_values, d_new_indptr,
+                       d_new_indices, (float*)d_new_values);
+  else
+    hipLaunchKernelGGL(k_compact_nonzero<double>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       n_rows, d_indptr, d_indices, (const double*)d_values, d_new_indptr,
+                       d_new_indices, (double*)d_new_values);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_exclusive_scan_i64(int64_t n, const int64_t* d_in, int64_t* d_out, void* stream) {
+  MU_REQUIRE(n >= 0 && d_out, "bad arguments");
+  MU_REQUIRE(n == 0 || d_in, "null input");
+  hipLaunchKernelGGL(k_exclusive_scan_i64, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, d_in,
+                     d_out);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_binarize_values(int dtype, int64_t nnz, void* d_values, void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  if (nnz == 0) return MU_OK;
+  MU_REQUIRE(d_values, "null pointer");
+  int64_t blocks = (nnz + 255) / 256;
+  const int64_t cap = (int64_t)mu_num_cus() * 16;
+  if (blocks > cap) blocks = cap;
+  if (dtype == MU_DTYPE_F32)
+    hipLaunchKernelGGL(k_binarize<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       nnz, (float*)d_values);
+  else
+    hipLaunchKernelGGL(k_binarize<double>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       nnz, (double*)d_values);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+}  // extern "C"

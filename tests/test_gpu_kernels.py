@@ -1,0 +1,161 @@
+"""Kernel-level parity: every C-ABI kernel against a scipy / numpy f64 restatement of the
+same operation on seeded inputs (bit-exact for index work, f32-roundoff for sums)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from tests.synth import planted_topics_csr, unstructured_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _up(hip, m):
+    m = m.tocsr()
+    m.sort_indices()
+    return hip.upload_csr(m.indptr, m.indices, m.data, m.shape)
+
+
+def _down(hip, X):
+    return sp.csr_matrix((hip.to_host(X.values), hip.to_host(X.indices), hip.to_host(X.indptr)), shape=X.shape)
+
+
+SHAPES = [(1, 1, 1.0), (7, 5, 0.5), (100, 10, 0.2), (257, 131, 0.08), (300, 9000, 0.01),
+          (2000, 20000, 0.004), (5000, 700, 0.03)]
+
+
+@pytest.mark.parametrize("n,d,dens", SHAPES)
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_row_col_sums(hip, n, d, dens, dt):
+    rng = np.random.default_rng(n * 31 + d)
+    m = sp.random(n, d, density=dens, format="csr", random_state=rng, dtype=np.float64)
+    m.data = (1 + rng.poisson(0.7, size=m.nnz)).astype(dt)
+    if n > 6:
+        m = m.tolil(); m[3, :] = 0; m = m.tocsr(); m.eliminate_zeros()
+    X = _up(hip, m)
+    rs, cs = hip.row_col_sums(X)
+    # integer-valued counts: both reductions are exact
+    assert np.array_equal(hip.to_host(rs), np.asarray(m.sum(axis=1)).reshape(-1).astype(np.float64))
+    assert np.array_equal(hip.to_host(cs), np.asarray(m.sum(axis=0)).reshape(-1).astype(np.float64))
+
+
+def test_row_col_sums_float_values_and_reproducible(hip):
+    rng = np.random.default_rng(3)
+    m = sp.random(4000, 30000, density=0.01, format="csr", random_state=rng, dtype=np.float64)
+    X = _up(hip, m)
+    rs, cs = hip.row_col_sums(X)
+    np.testing.assert_allclose(hip.to_host(rs), np.asarray(m.sum(axis=1)).reshape(-1), rtol=1e-12)
+    np.testing.assert_allclose(hip.to_host(cs), np.asarray(m.sum(axis=0)).reshape(-1), rtol=1e-12)
+    rs2, cs2 = hip.row_col_sums(X)
+    assert torch.equal(rs, rs2)
+
+
+@pytest.mark.parametrize("n,d,dens", SHAPES)
+def test_transpose_is_bit_exact_and_sorted(hip, n, d, dens):
+    rng = np.random.default_rng(n + d)
+    m = sp.random(n, d, density=dens, format="csr", random_state=rng, dtype=np.float32)
+    X = _up(hip, m)
+    T = _down(hip, hip.transpose(X))
+    ref = m.T.tocsr()
+    ref.sort_indices()
+    assert np.array_equal(T.indptr, ref.indptr.astype(np.int64))
+    assert np.array_equal(T.indices, ref.indices)  # ascending row ids => stable
+    assert np.array_equal(T.data, ref.data)
+
+
+def test_transpose_empty_and_float64(hip):
+    m = sp.csr_matrix((5, 7), dtype=np.float64)
+    T = _down(hip, hip.transpose(_up(hip, m)))
+    assert T.shape == (7, 5) and T.nnz == 0 and np.all(T.indptr == 0)
+    m = sp.random(50, 20000, density=0.02, format="csr", random_state=1, dtype=np.float64)
+    T = _down(hip, hip.transpose(_up(hip, m)))
+    ref = m.T.tocsr(); ref.sort_indices()
+    assert (T != ref).nnz == 0 and np.array_equal(T.indices, ref.indices)
+
+
+@pytest.mark.parametrize("B", [16, 32, 64])
+@pytest.mark.parametrize("n,d,dens", [(1, 3, 1.0), (100, 10, 0.2), (513, 700, 0.05), (3000, 20000, 0.01)])
+def test_spmm(hip, B, n, d, dens):
+    rng = np.random.default_rng(B + n)
+    m = sp.random(n, d, density=dens, format="csr", random_state=rng, dtype=np.float32)
+    Q = rng.standard_normal((d, B)).astype(np.float32)
+    Y = hip.to_host(hip.spmm(_up(hip, m), hip.to_device(Q)))
+    ref = m.astype(np.float64) @ Q.astype(np.float64)
+    scale = np.abs(m).astype(np.float64) @ np.abs(Q).astype(np.float64) + 1e-30
+    assert np.max(np.abs(Y - ref) / scale) < 2e-6  # f32 accumulation
+    # rows without entries give exact zeros
+    empty = np.diff(m.indptr) == 0
+    assert np.all(Y[empty] == 0)
+
+
+@pytest.mark.parametrize("B", [16, 32, 64])
+@pytest.mark.parametrize("n", [1, 3, 64, 1000, 40001])
+def test_gram_and_colsum(hip, B, n):
+    rng = np.random.default_rng(n)
+    A = (rng.standard_normal((n, B)) * (1 + np.arange(B))).astype(np.float32)  # asymmetric columns
+    G, cs = hip.gram(hip.to_device(A))
+    A64 = A.astype(np.float64)
+    np.testing.assert_allclose(hip.to_host(G), A64.T @ A64, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(hip.to_host(cs), A64.sum(axis=0), rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("B", [16, 32, 64])
+@pytest.mark.parametrize("n", [1, 17, 1000, 40001])
+def test_dense_apply(hip, B, n):
+    rng = np.random.default_rng(n + B)
+    A = rng.standard_normal((n, B)).astype(np.float32)
+    M = rng.standard_normal((B, B)).astype(np.float32)  # not symmetric: catches transposes
+    b = rng.standard_normal(B).astype(np.float32)
+    ref = A.astype(np.float64) @ M.astype(np.float64)
+    out = hip.to_host(hip.apply(hip.to_device(A), hip.to_device(M)))
+    assert np.max(np.abs(out - ref)) < 1e-4 * np.sqrt(B)
+    out = hip.to_host(hip.apply(hip.to_device(A), hip.to_device(M), bias=hip.to_device(b)))
+    assert np.max(np.abs(out - (ref + b))) < 1e-4 * np.sqrt(B)
+    # in place
+    Ad = hip.to_device(A)
+    hip.apply(Ad, hip.to_device(M), out=Ad)
+    assert np.max(np.abs(hip.to_host(Ad) - ref)) < 1e-4 * np.sqrt(B)
+
+
+def test_scan_and_compact(hip):
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 5, 1023, 1024, 1025, 100003):
+        v = rng.integers(0, 1000, size=n).astype(np.int64)
+        vin = hip.to_device(v) if n else hip.empty((0,), torch.int64)
+        out = hip.empty((n + 1,), torch.int64)
+        from muon_amd._ffi import check
+        check(hip.lib.mu_exclusive_scan_i64(n, vin.data_ptr() if n else None, out.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(hip.to_host(out), np.concatenate([[0], np.cumsum(v)]))
+    m = sp.random(300, 200, density=0.1, format="csr", random_state=2, dtype=np.float32)
+    m.data[::7] = 0
+    m.data[5] = np.nan
+    C = _down(hip, hip.compact_nonzero(_up(hip, m)))
+    keep = m.data != 0
+    ref = m.copy(); ref.eliminate_zeros()  # scipy keeps NaN as well
+    assert np.array_equal(C.indptr, ref.indptr) and np.array_equal(C.indices, ref.indices)
+    assert np.array_equal(C.data, m.data[keep], equal_nan=True)
+
+
+def test_randn_moments_and_reproducible(hip):
+    a = hip.randn(200000, 64, 1)
+    b = hip.randn(200000, 64, 1)
+    c = hip.randn(200000, 64, 2)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(a.mean().item()) < 2e-3 and abs(a.std().item() - 1) < 2e-3
+    cc = torch.corrcoef(a[:, :8].T)
+    assert (cc - torch.eye(8, device=cc.device)).abs().max().item() < 0.02
+
+
+def test_synth_counts_structure(hip):
+    X = hip.synth_counts(0, 2000, 30000, n_topics=50, density=0.03, seed=0)
+    m = _down(hip, X)
+    assert m.has_canonical_format or (np.all(np.diff(m.indices)[np.diff(m.indices) <= 0].size >= 0))
+    m2 = m.copy(); m2.sort_indices()
+    assert np.array_equal(m2.indices, m.indices)  # columns come out sorted
+    dens = m.nnz / (2000 * 30000)
+    assert 0.02 < dens < 0.045
+    assert m.data.min() >= 1 and m.data.max() <= 4 and np.all(m.data == np.round(m.data))
+    # a shard generated elsewhere equals the same rows of the full matrix
+    S = _down(hip, hip.synth_counts(500, 300, 30000, n_topics=50, density=0.03, seed=0))
+    assert (S != m[500:800]).nnz == 0

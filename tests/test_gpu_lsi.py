@@ -1,0 +1,66 @@
+"""muon_amd.atac.tl.lsi on the GPU against the reference executed here (golden fixture)
+and the f64 ARPACK oracle on seeded planted-topic matrices.
+Bar (BASELINE.json north_star): largest principal angle between the spans of the top-k
+right singular vectors < 1e-4 rad; singular values within 1e-5 relative."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from muon_amd import AnnData
+from muon_amd import atac as ac
+from oracle import lsi_oracle
+from tests.synth import planted_topics_csr
+
+pytestmark = pytest.mark.gpu
+ANGLE = 1e-4
+
+
+def test_against_reference_fixture(golden_dir):
+    g = np.load(f"{golden_dir}/lsi_golden.npz")
+    X = sp.csr_matrix((g["tfidf_data"], g["tfidf_indices"], g["tfidf_indptr"]), shape=tuple(g["tfidf_shape"]))
+    for tag, scale in (("scaled", True), ("raw", False)):
+        ad = AnnData(X.copy())
+        ac.tl.lsi(ad, scale_embeddings=scale, n_comps=12)
+        assert lsi_oracle.max_subspace_angle(ad.varm["LSI"], g[f"LSI_{tag}"]) < ANGLE
+        assert lsi_oracle.max_subspace_angle(ad.obsm["X_lsi"], g[f"X_lsi_{tag}"]) < 5 * ANGLE
+        np.testing.assert_allclose(ad.uns["lsi"]["stdev"], g[f"stdev_{tag}"], rtol=1e-5)
+        assert ad.obsm["X_lsi"].dtype == X.dtype
+
+
+def test_pipeline_tfidf_then_lsi_against_oracle():
+    X = planted_topics_csr(6000, 9000, n_topics=50, density=0.03, seed=2, dtype=np.float32)
+    ad = AnnData(X.copy())
+    ac.pp.tfidf(ad)
+    ref = lsi_oracle.lsi(ad.X, n_comps=50)
+    ac.tl.lsi(ad, n_comps=50)  # re-uses the device copy left by tfidf
+    assert lsi_oracle.max_subspace_angle(ad.varm["LSI"], ref["LSI"]) < ANGLE
+    np.testing.assert_allclose(ad.uns["lsi"]["stdev"], ref["stdev"], rtol=1e-5)
+    # the leading component is isolated: compare it vector-wise (sign aligned)
+    u = lsi_oracle.sign_align(ad.obsm["X_lsi"][:, :1], ref["X_lsi"][:, :1])
+    np.testing.assert_allclose(u, ref["X_lsi"][:, :1], atol=2e-3)
+    np.testing.assert_allclose(ad.obsm["X_lsi"].mean(axis=0), 0, atol=1e-3)
+    np.testing.assert_allclose(ad.obsm["X_lsi"].std(axis=0), 1, rtol=1e-3)
+
+
+def test_small_widths_and_errors():
+    X = planted_topics_csr(300, 200, n_topics=5, density=0.1, seed=4, dtype=np.float64)
+    ad = AnnData(X.copy())
+    ac.pp.tfidf(ad)
+    ref = lsi_oracle.lsi(ad.X, n_comps=5)
+    ac.tl.lsi(ad, n_comps=5)
+    assert ad.obsm["X_lsi"].dtype == np.float64
+    assert lsi_oracle.max_subspace_angle(ad.varm["LSI"], ref["LSI"]) < ANGLE
+    with pytest.raises(ValueError):
+        ac.tl.lsi(AnnData(sp.random(10, 60, density=0.5, format="csr")), n_comps=50)
+    with pytest.raises(TypeError):
+        ac.tl.lsi(np.ones((3, 3)))
+
+
+def test_run_to_run_bit_reproducible():
+    X = planted_topics_csr(1500, 2500, n_topics=10, density=0.05, seed=8, dtype=np.float32)
+    a, b = AnnData(X.copy()), AnnData(X.copy())
+    for ad in (a, b):
+        ac.pp.tfidf(ad)
+        ac.tl.lsi(ad, n_comps=10)
+    assert np.array_equal(a.obsm["X_lsi"], b.obsm["X_lsi"])
+    assert np.array_equal(a.varm["LSI"], b.varm["LSI"])

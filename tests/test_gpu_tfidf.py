@@ -1,0 +1,147 @@
+"""muon_amd.atac.pp.tfidf on the GPU against (a) the reference's own golden values,
+(b) fixtures produced by executing the reference source, (c) the CPU oracle on seeded
+matrices, (d) size-independent properties at a size the oracle cannot reach quickly.
+Bar: identical nnz pattern / indices (canonical order), values within 1e-5 relative."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from muon_amd import AnnData, MuData
+from muon_amd import atac as ac
+from oracle import tfidf_oracle
+from tests.synth import planted_topics_csr, unstructured_csr
+from tests.test_tfidf_oracle import SWEEPS, _csr
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def _same(res, ref, rtol=RTOL):
+    ref = tfidf_oracle.canonical(ref)
+    assert res.shape == ref.shape
+    assert np.array_equal(res.indptr, ref.indptr), "indptr differs"
+    assert np.array_equal(res.indices, ref.indices), "indices differ"
+    assert res.dtype == ref.dtype
+    fin = np.isfinite(ref.data)
+    assert np.array_equal(np.isnan(res.data), np.isnan(ref.data))
+    np.testing.assert_allclose(res.data[fin], ref.data[fin], rtol=rtol, atol=0)
+
+
+def test_reference_golden_dense():
+    # /root/reference/tests/test_atac_preproc.py:11-52
+    np.random.seed(2020)
+    x = np.abs(np.random.normal(size=(4, 5)))
+    adata = AnnData(x.copy())
+    ac.pp.tfidf(adata, log_tf=True, log_idf=True)
+    assert "%.3f" % adata.X[0, 0] == "4.659"
+    assert "%.3f" % adata.X[3, 0] == "4.770"
+    view = AnnData(x.copy())[:, :]
+    ac.pp.tfidf(view, log_tf=True, log_idf=True)
+    assert "%.3f" % view.X[0, 0] == "4.659"
+    a = AnnData(x.copy())
+    cp = ac.pp.tfidf(a, copy=True)
+    assert a.X[0, 0] == x[0, 0] and "%.3f" % cp.X[0, 0] == "4.659"
+    res = ac.pp.tfidf(a, inplace=False)
+    assert a.X[0, 0] == x[0, 0] and "%.3f" % res[0, 0] == "4.659"
+    ac.pp.tfidf(a, to_layer="new")
+    assert "%.3f" % a.layers["new"][0, 0] == "4.659"
+    a = AnnData(x.copy())
+    a.layers["counts"] = a.X.copy() + 1
+    a.X = None
+    ac.pp.tfidf(a, from_layer="counts")
+    assert "%.3f" % a.X[0, 0] == "2.856"
+    m = MuData({"atac": AnnData(x.copy())})
+    ac.pp.tfidf(m)
+    assert "%.3f" % m.mod["atac"].X[0, 0] == "4.659"
+
+
+def test_reference_golden_sparse():
+    # /root/reference/tests/test_atac_preproc.py:57-64
+    np.random.seed(2020)
+    x = sp.rand(100, 10, density=0.2, format="csr")
+    adata = AnnData(x)
+    ac.pp.tfidf(adata, log_tf=True, log_idf=True)
+    assert "%.3f" % adata.X[10, 9] == "18.749"
+    assert "%.3f" % adata.X[50, 5] == "0.000"
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(f"{golden_dir}/tfidf_golden.npz")
+
+
+def test_fixture_dense_and_sparse(gold):
+    _same(ac.pp.tfidf(AnnData(gold["dense_in"]), inplace=False), _csr(gold, "dense_out"))
+    _same(ac.pp.tfidf(AnnData(_csr(gold, "sparse_in")), inplace=False), _csr(gold, "sparse_out"))
+    raw = ac.pp.tfidf(AnnData(_csr(gold, "sparse_in")), inplace=False, match_scipy_order=True)
+    assert np.array_equal(raw.indices, gold["sparse_out_indices"])
+    np.testing.assert_allclose(raw.data, gold["sparse_out_data"], rtol=RTOL)
+
+
+@pytest.mark.parametrize("name", sorted(SWEEPS))
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_fixture_option_sweep(gold, name, dt):
+    cnt = _csr(gold, "sweep_in").astype(dt)  # has an empty row and an empty column
+    res = ac.pp.tfidf(AnnData(cnt), inplace=False, **SWEEPS[name])
+    _same(res, _csr(gold, f"sweep_{name}_{dt}"))
+
+
+def test_fixture_explicit_zeros_are_dropped_and_ints_promoted(gold):
+    res = ac.pp.tfidf(AnnData(_csr(gold, "ezero_in")), inplace=False)
+    _same(res, _csr(gold, "ezero_out"))
+    assert res.nnz < _csr(gold, "ezero_in").nnz
+    res = ac.pp.tfidf(AnnData(_csr(gold, "sweep_in").astype(np.int32)), inplace=False)
+    assert res.dtype == np.float64
+    _same(res, _csr(gold, "sweep_int32"))
+
+
+@pytest.mark.parametrize("gen", ["planted", "unstructured"])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_against_oracle_seeded(gen, dt):
+    if gen == "planted":
+        X = planted_topics_csr(3000, 20000, n_topics=30, density=0.02, seed=11, dtype=dt)
+    else:
+        X = unstructured_csr(2500, 17000, density=0.02, seed=12, dtype=dt)
+    for kw in (dict(), dict(log_tf=False, log_idf=False, log_tfidf=True), dict(scale_factor=None)):
+        _same(ac.pp.tfidf(AnnData(X.copy()), inplace=False, **kw), tfidf_oracle.tfidf(X, **kw))
+
+
+def test_unsorted_and_duplicate_input_is_canonicalised():
+    rng = np.random.default_rng(5)
+    r = rng.integers(0, 50, 4000); c = rng.integers(0, 80, 4000)
+    coo = sp.coo_matrix((np.ones(4000, np.float32), (r, c)), shape=(50, 80))
+    raw = sp.csr_matrix((coo.data, coo.col, np.concatenate([[0], np.cumsum(np.bincount(coo.row, minlength=50))])), shape=(50, 80))
+    # raw has duplicates and is unsorted; scipy's SpGEMM sums duplicates too
+    order = np.argsort(coo.row, kind="stable")
+    raw = sp.csr_matrix((coo.data[order], coo.col[order], raw.indptr), shape=(50, 80))
+    _same(ac.pp.tfidf(AnnData(raw.copy()), inplace=False), tfidf_oracle.tfidf(raw))
+
+
+def test_properties_at_scale(hip):
+    """200k x 30k device-generated counts (~1.8e8 nnz): size-independent checks."""
+    from muon_amd._atac.preproc import tfidf_device
+    import torch
+    X = hip.synth_counts(0, 200000, 30000, n_topics=50, density=0.03, seed=0)
+    rs, cs = hip.row_col_sums(X)
+    tot = float(X.values.double().sum().item())
+    assert float(rs.sum().item()) == tot and float(cs.sum().item()) == tot  # checksum of checksums
+    # reference (torch scatter) for the column sums
+    ref_cs = torch.zeros(30000, dtype=torch.float64, device=X.values.device)
+    ref_cs.index_add_(0, X.indices.long(), X.values.double())
+    assert torch.equal(ref_cs, cs)
+    R = tfidf_device(hip, X, 200000, 3, 1e4)
+    assert R.indices is X.indices  # pattern untouched
+    # spot-check 3 rows against the oracle formula
+    rsh, csh = hip.to_host(rs), hip.to_host(cs)
+    ip = hip.to_host(X.indptr)
+    for row in (0, 77777, 199999):
+        lo, hi = ip[row], ip[row + 1]
+        c = hip.to_host(X.values[lo:hi]).astype(np.float32)
+        j = hip.to_host(X.indices[lo:hi])
+        exp = np.log1p((np.float32(1.0) / np.float32(rsh[row])) * c * np.float32(1e4)) * np.log1p(np.float32(200000) / csh[j].astype(np.float32))
+        np.testing.assert_allclose(hip.to_host(R.values[lo:hi]), exp, rtol=RTOL)
+    # scale invariance of tf: tfidf(2*counts) == tfidf(counts) up to the idf shift
+    X2 = X.with_values(X.values * 2)
+    R2 = tfidf_device(hip, X2, 400000, 1, 1e4)  # log_tf only, n_obs doubled keeps idf equal
+    R1 = tfidf_device(hip, X, 200000, 1, 1e4)
+    torch.testing.assert_close(R2.values, R1.values, rtol=1e-6, atol=0)

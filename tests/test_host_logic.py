@@ -1,0 +1,129 @@
+"""Host logic of tfidf / lsi without a GPU: argument validation and write-back semantics of
+the reference (/root/reference/tests/test_atac_preproc.py), driven through the CPU test
+operator set, plus the rule that the product path has no CPU fallback."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import muon_amd
+from muon_amd import AnnData, MuData
+from muon_amd import atac as ac
+from oracle import lsi_oracle, tfidf_oracle
+from tests.cpu_backend import CpuTestBackend
+from tests.synth import planted_topics_csr
+
+BE = CpuTestBackend()
+
+
+def _dense_adata():
+    np.random.seed(2020)
+    return AnnData(np.abs(np.random.normal(size=(4, 5))))
+
+
+def test_namespaces_match_reference():
+    assert callable(muon_amd.atac.pp.tfidf)
+    assert callable(muon_amd.atac.pp.binarize)
+    assert callable(muon_amd.atac.tl.lsi)
+    assert callable(muon_amd.tl.mofa)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    from muon_amd._ffi import MuonAmdError
+
+    with pytest.raises(MuonAmdError):
+        ac.pp.tfidf(_dense_adata())
+    with pytest.raises(MuonAmdError):
+        ac.tl.lsi(AnnData(sp.random(30, 20, density=0.3, format="csr")))
+
+
+def test_tfidf_validation_errors():
+    a = _dense_adata()
+    with pytest.raises(TypeError):
+        ac.pp.tfidf(np.ones((3, 3)), backend=BE)
+    with pytest.raises(TypeError):
+        ac.pp.tfidf(MuData({"rna": a}), backend=BE)
+    with pytest.raises(AttributeError):
+        ac.pp.tfidf(a, log_tfidf=True, backend=BE)
+    with pytest.raises(ValueError):
+        ac.pp.tfidf(a, copy=True, inplace=False, backend=BE)
+    with pytest.raises(ValueError):
+        ac.pp.tfidf(a, to_layer="x", inplace=False, backend=BE)
+
+
+def test_tfidf_writeback_semantics():
+    # mirrors test_atac_preproc.py:16-52 (values themselves are GPU-checked in test_gpu_*)
+    adata = _dense_adata()
+    ac.pp.tfidf(adata, log_tf=True, log_idf=True, backend=BE)
+    assert "%.3f" % adata.X[0, 0] == "4.659"
+    assert "%.3f" % adata.X[3, 0] == "4.770"
+    assert sp.issparse(adata.X)  # preproc.py:114: the result is CSR even for dense input
+
+    base = _dense_adata()
+    view = base[:, :]
+    assert view.is_view
+    ac.pp.tfidf(view, backend=BE)
+    assert not view.is_view and "%.3f" % view.X[0, 0] == "4.659"
+
+    adata = _dense_adata()
+    orig = adata.X[0, 0]
+    cp = ac.pp.tfidf(adata, copy=True, backend=BE)
+    assert adata.X[0, 0] == orig and "%.3f" % cp.X[0, 0] == "4.659"
+
+    res = ac.pp.tfidf(adata, inplace=False, backend=BE)
+    assert adata.X[0, 0] == orig and "%.3f" % res[0, 0] == "4.659"
+
+    ac.pp.tfidf(adata, to_layer="new", backend=BE)
+    assert adata.X[0, 0] == orig and "%.3f" % adata.layers["new"][0, 0] == "4.659"
+    with pytest.warns(UserWarning, match="will be overwritten"):
+        ac.pp.tfidf(adata, to_layer="new", backend=BE)
+
+    adata = _dense_adata()
+    adata.layers["counts"] = adata.X.copy() + 1
+    adata.X = None
+    ac.pp.tfidf(adata, from_layer="counts", backend=BE)
+    assert "%.3f" % adata.X[0, 0] == "2.856"
+
+    m = MuData({"atac": _dense_adata()})
+    ac.pp.tfidf(m, backend=BE)
+    assert "%.3f" % m.mod["atac"].X[0, 0] == "4.659"
+
+
+def test_match_scipy_order_reproduces_reference_layout(golden_dir):
+    g = np.load(f"{golden_dir}/tfidf_golden.npz")
+    x = sp.csr_matrix((g["sparse_in_data"], g["sparse_in_indices"], g["sparse_in_indptr"]), shape=(100, 10))
+    res = ac.pp.tfidf(AnnData(x), inplace=False, match_scipy_order=True, backend=BE)
+    assert np.array_equal(res.indices, g["sparse_out_indices"])
+    assert np.array_equal(res.indptr, g["sparse_out_indptr"])
+    np.testing.assert_allclose(res.data, g["sparse_out_data"], rtol=1e-12)
+
+
+def test_lsi_writeback_and_parity_cpu_host_logic():
+    X = planted_topics_csr(500, 300, n_topics=8, density=0.08, seed=5, dtype=np.float32)
+    ad = AnnData(X)
+    ac.pp.tfidf(ad, backend=BE)
+    ref = lsi_oracle.lsi(ad.X, n_comps=8)
+    ac.tl.lsi(ad, n_comps=8, backend=BE)
+    assert ad.obsm["X_lsi"].shape == (500, 8) and ad.varm["LSI"].shape == (300, 8)
+    assert ad.uns["lsi"]["stdev"].shape == (8,)
+    assert lsi_oracle.max_subspace_angle(ad.varm["LSI"], ref["LSI"]) < 1e-4
+    np.testing.assert_allclose(ad.uns["lsi"]["stdev"], ref["stdev"], rtol=1e-5)
+    # scaled embeddings: zero mean / unit variance per component (tools.py:60-63)
+    np.testing.assert_allclose(ad.obsm["X_lsi"].mean(axis=0), 0, atol=1e-3)
+    np.testing.assert_allclose(ad.obsm["X_lsi"].std(axis=0), 1, rtol=1e-3)
+    with pytest.raises(TypeError):
+        ac.tl.lsi(np.ones((3, 3)), backend=BE)
+    with pytest.raises(ValueError):
+        ac.tl.lsi(AnnData(sp.random(10, 60, density=0.5, format="csr")), n_comps=50, backend=BE)
+
+
+def test_binarize():
+    x = sp.random(20, 10, density=0.3, format="csr", dtype=np.float32, random_state=1)
+    x.data[:] = np.arange(1, x.nnz + 1)
+    x.data[3] = 0
+    ad = AnnData(x)
+    ac.pp.binarize(ad, backend=BE)
+    exp = np.ones(x.nnz, dtype=np.float32)
+    exp[3] = 0
+    assert np.array_equal(ad.X.data, exp)
