@@ -196,7 +196,7 @@ def main():
                         "converged": info.get("converged"), "spmm_per_step": len(ms) // max(args.steps, 1)},
             },
             "roofline": {
-                "kernel": "k_spmm_rowwave<64> (CSR SpMM, f32, B=64 dense columns)",
+                "kernel": "k_spmm_lds64 (CSR SpMM, f32, B=64: Q column slabs in LDS, DPP broadcast)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

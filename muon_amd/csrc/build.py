@@ -31,7 +31,7 @@ def _digest(paths):
     for p in paths:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(f for f in FLAGS if not f.startswith("-I")).encode())  # paths differ per box
     return h.hexdigest()
 
 
