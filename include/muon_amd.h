@@ -126,6 +126,11 @@ int mu_spmm_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const i
                 const float* d_values, const float* d_Q, int B, float* d_Y, int accumulate,
                 void* stream);
 
+/* Same product in f64 (MOFA runs in float64 unless use_float32=True, tools.py:308). */
+int mu_spmm_f64(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
+                const double* d_values, const double* d_Q, int B, double* d_Y, int accumulate,
+                void* stream);
+
 size_t mu_gram_worksize(int64_t n_rows, int B);
 /* G[B x B] (f64) = A^T A and colsum[B] (f64) = 1^T A for A [n_rows x B] f32 (ld=B).
  * f64 MFMA (v_mfma_f64_16x16x4_f64), fixed-order reduction. Replaces the dense QR of
@@ -140,6 +145,24 @@ int mu_dense_apply_f32(int64_t n_rows, int B, const float* d_A, const float* d_M
 
 /* standard normal fill, counter based (seed, element index) -> reproducible */
 int mu_randn_f32(int64_t count, uint64_t seed, float* d_out, void* stream);
+
+/* ---- MOFA+ coordinate updates (tools.py:585 ent.run(): mofapy2's W and Z node updates) ---- */
+/* Spike-and-slab + ARD update of the weights of ONE view, one thread per feature, Gauss-Seidel
+ * over the K factors.  Inputs are the sufficient statistics of the current factors:
+ *   B[G][D][K] = Y_g^T <Z_g>, tau[G][D], Gz[G][K][K] = <Z_g>^T <Z_g>, Z2[G][K] = sum_n <z_nk^2>,
+ *   alpha[K] = <alpha_k>, lth[K] = <ln theta_k>, l1mth[K] = <ln(1-theta_k)>.
+ * In/out EW[D][K]; out EW2 = <w^2>, gamma = q(s=1), EWh2 = <w_hat^2>, sig2 = slab variance. */
+int mu_mofa_update_w(int dtype, int64_t D, int K, int G, const void* d_B, const void* d_tau,
+                     const void* d_Gz, const void* d_Z2, const void* d_alpha, const void* d_lth,
+                     const void* d_l1mth, int spikeslab, void* d_EW, void* d_EW2, void* d_gamma,
+                     void* d_EWh2, void* d_sig2, void* stream);
+/* Update of the factors, one thread per sample.  A[M][N][K] = Y_m (tau_g o <W_m>) (row n uses its
+ * own group's tau), pres[M][N] in {0,1} (sample observed in view m), grp[N] group id,
+ * Gw[M][G][K][K] = <W>^T diag(tau_g) <W>, dw2[M][G][K] = sum_d tau_gd <w_dk^2>, alphaz[G][K].
+ * In/out EZ[N][K]; out EZ2 = <z^2>, sig2 = posterior variance. */
+int mu_mofa_update_z(int dtype, int64_t N, int K, int M, int G, const void* d_A, const void* d_pres,
+                     const int32_t* d_grp, const void* d_Gw, const void* d_dw2, const void* d_alphaz,
+                     void* d_EZ, void* d_EZ2, void* d_sig2, void* stream);
 
 /* ---- synthetic planted-topic counts (bench / tests only) ------ */
 /* Pass 1: nnz of every row for rows [row0, row0+n_rows) of the global matrix.

@@ -166,14 +166,15 @@ class HipBackend:
     def spmm(self, X: DeviceCSR, Q: torch.Tensor, out=None) -> torch.Tensor:
         n, d = X.shape
         B = Q.shape[1]
-        assert Q.shape[0] == d and Q.dtype == torch.float32 and Q.is_contiguous()
-        if X.values.dtype != torch.float32:
-            raise TypeError("spmm runs on f32 values")
+        assert Q.shape[0] == d and Q.dtype in (torch.float32, torch.float64) and Q.is_contiguous()
+        if X.values.dtype != Q.dtype:
+            raise TypeError("spmm needs values and dense block of one dtype")
         if out is None:
-            out = self.empty((n, B), torch.float32)
+            out = self.empty((n, B), Q.dtype)
+        fn = self.lib.mu_spmm_f32 if Q.dtype == torch.float32 else self.lib.mu_spmm_f64
         with torch.cuda.device(self.device):
-            check(self.lib.mu_spmm_f32(n, d, _p(X.indptr), _p(X.indices), _p(X.values), _p(Q), B,
-                                       _p(out), 0, self._stream()))
+            check(fn(n, d, _p(X.indptr), _p(X.indices), _p(X.values), _p(Q), B, _p(out), 0,
+                     self._stream()))
         return out
 
     def gram(self, A: torch.Tensor):
@@ -201,6 +202,23 @@ class HipBackend:
         with torch.cuda.device(self.device):
             check(self.lib.mu_randn_f32(rows * B, int(seed) & (2**64 - 1), _p(out), self._stream()))
         return out
+
+    # -- MOFA+ coordinate updates (reference tools.py:585 -> mofapy2 node updates) -----------
+    def mofa_update_w(self, B, tau, Gz, Z2, alpha, lth, l1mth, spikeslab, EW, EW2, gamma, EWh2, sig2):
+        G, D, K = B.shape
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_mofa_update_w(_dt(EW), D, K, G, _p(B), _p(tau), _p(Gz), _p(Z2),
+                                            _p(alpha), _p(lth), _p(l1mth), int(bool(spikeslab)),
+                                            _p(EW), _p(EW2), _p(gamma), _p(EWh2), _p(sig2),
+                                            self._stream()))
+
+    def mofa_update_z(self, A, pres, grp, Gw, dw2, alphaz, EZ, EZ2, sig2):
+        M, N, K = A.shape
+        G = alphaz.shape[0]
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_mofa_update_z(_dt(EZ), N, K, M, G, _p(A), _p(pres), _p(grp), _p(Gw),
+                                            _p(dw2), _p(alphaz), _p(EZ), _p(EZ2), _p(sig2),
+                                            self._stream()))
 
     # -- synthetic data (bench / tests) ---------------------------------------------
     def synth_counts(self, row0: int, n_rows: int, n_cols: int, n_topics: int = 50,

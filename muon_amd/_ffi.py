@@ -55,10 +55,13 @@ SIGNATURES = {
     "mu_csr_transpose_worksize": (_sz, [_i64, _i64, _i64]),
     "mu_csr_transpose": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
+    "mu_spmm_f64": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "mu_gram_worksize": (_sz, [_i64, _i32]),
     "mu_gram_f32": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_dense_apply_f32": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mu_randn_f32": (C.c_int, [_i64, _u64, _vp, _vp]),
+    "mu_mofa_update_w": (C.c_int, [_i32, _i64, _i32, _i32] + [_vp] * 7 + [_i32] + [_vp] * 6),
+    "mu_mofa_update_z": (C.c_int, [_i32, _i64, _i32, _i32, _i32] + [_vp] * 10),
     "mu_synth_row_nnz": (C.c_int, [_i64, _i64, _i64, _i32, _dbl, _u64, _vp, _vp]),
     "mu_synth_fill": (C.c_int, [_i64, _i64, _i64, _i32, _dbl, _u64, _vp, _vp, _vp, _vp]),
 }

@@ -88,7 +88,8 @@ class CpuTestBackend:
                          torch.from_numpy(t.data.copy()), (X.shape[1], X.shape[0]))
 
     def spmm(self, X, Q, out=None):
-        y = torch.from_numpy((self._sp(X).astype(np.float32) @ Q.numpy()).astype(np.float32))
+        dt = Q.numpy().dtype
+        y = torch.from_numpy((self._sp(X).astype(dt) @ Q.numpy()).astype(dt))
         if out is not None:
             out.copy_(y)
             return out
@@ -110,3 +111,42 @@ class CpuTestBackend:
     def randn(self, rows, B, seed):
         g = torch.Generator().manual_seed(int(seed))
         return torch.randn((rows, B), generator=g, dtype=torch.float32)
+
+    # MOFA+ sweeps: same arithmetic as csrc/mofa.hip, vectorised over rows with torch
+    def mofa_update_w(self, B, tau, Gz, Z2, alpha, lth, l1mth, spikeslab, EW, EW2, gamma, EWh2, sig2):
+        G, D, K = B.shape
+        for k in range(K):
+            t = torch.zeros(D, dtype=EW.dtype)
+            q = torch.zeros(D, dtype=EW.dtype)
+            for g in range(G):
+                cross = EW @ Gz[g][:, k] - EW[:, k] * Gz[g][k, k]
+                t += tau[g] * (B[g][:, k] - cross)
+                q += tau[g] * Z2[g][k]
+            prec = q + alpha[k]
+            s2 = 1.0 / prec
+            mu = t * s2
+            if spikeslab:
+                lam = lth[k] - l1mth[k] + 0.5 * torch.log(alpha[k]) - 0.5 * torch.log(prec) + 0.5 * t * t * s2
+                gam = torch.sigmoid(lam)
+            else:
+                gam = torch.ones(D, dtype=EW.dtype)
+            EW[:, k] = gam * mu
+            EW2[:, k] = gam * (mu * mu + s2)
+            gamma[:, k] = gam
+            EWh2[:, k] = gam * (mu * mu + s2) + (1 - gam) / alpha[k]
+            sig2[:, k] = s2
+
+    def mofa_update_z(self, A, pres, grp, Gw, dw2, alphaz, EZ, EZ2, sig2):
+        M, N, K = A.shape
+        g = grp.long()
+        for k in range(K):
+            num = torch.zeros(N, dtype=EZ.dtype)
+            prec = alphaz[g, k].clone()
+            for m in range(M):
+                gw = Gw[m][g]  # N x K x K
+                cross = (EZ * gw[:, :, k]).sum(dim=1) - EZ[:, k] * gw[:, k, k]
+                num += pres[m] * (A[m][:, k] - cross)
+                prec += pres[m] * dw2[m][g, k]
+            EZ[:, k] = num / prec
+            EZ2[:, k] = EZ[:, k] ** 2 + 1.0 / prec
+            sig2[:, k] = 1.0 / prec

@@ -1,0 +1,167 @@
+"""MOFA without a GPU: (a) the oracle against what the reference's tests pin at the mofapy2
+boundary (tests/test_muon_tools.py:25-44 structure; monotone ELBO), (b) the engine's host
+logic (statistics, implicit centring, groups, missing samples) against the oracle through the
+CPU test operator set, (c) the wrapper's signature, validation and write-back."""
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+
+import muon_amd as mu
+from muon_amd import AnnData, MuData
+from muon_amd._core.mofa_engine import MofaEngine
+from oracle import mofa_oracle
+from tests.cpu_backend import CpuTestBackend
+
+BE = CpuTestBackend()
+
+
+def simple_views():
+    # /root/reference/tests/test_muon_tools.py:15-23
+    np.random.seed(1000)
+    z = np.random.normal(size=(100, 5))
+    w1 = np.random.normal(size=(90, 5))
+    w2 = np.random.normal(size=(50, 5))
+    e1 = np.random.normal(size=(100, 90))
+    e2 = np.random.normal(size=(100, 50))
+    return np.dot(z, w1.T) + e1, np.dot(z, w2.T) + e2
+
+
+def r2_per_factor(y, Z, W):
+    return [1 - np.sum((y - Z[:, [i]] @ W[:, [i]].T) ** 2) / np.sum(y ** 2) for i in range(Z.shape[1])]
+
+
+def test_oracle_structure_and_monotone_elbo():
+    y1, y2 = simple_views()
+    r = mofa_oracle.run([y1, y2], n_factors=10, n_iterations=1000)
+    e = np.array(r["elbo"])
+    assert np.all(np.diff(e) > -1e-8 * abs(e[0])), "ELBO must not decrease"
+    y = np.concatenate([y1, y2], axis=1)
+    r2 = sorted(r2_per_factor(y, r["Z"], np.concatenate(r["W"])), reverse=True)
+    assert all(v > 0.1 for v in r2[:5]) and not any(v > 0.1 for v in r2[5:])
+
+
+@pytest.mark.parametrize("case", ["dense", "groups", "sparse_missing", "noard_nospike"])
+def test_engine_matches_oracle_iteration_by_iteration(case):
+    y1, y2 = simple_views()
+    rng = np.random.default_rng(0)
+    groups = None
+    views = [y1, y2]
+    kw = {}
+    if case == "groups":
+        groups = rng.integers(0, 3, 100)
+    if case == "sparse_missing":
+        groups = rng.integers(0, 2, 100)
+        y1 = y1.copy(); y1[85:] = np.nan
+        y2 = y2.copy(); y2[np.abs(y2) < 1.0] = 0
+        views = [y1, sp.csr_matrix(y2)]
+    if case == "noard_nospike":
+        kw = dict(ard_weights=False, ard_factors=False, spikeslab_weights=False)
+    dense = [v.toarray() if sp.issparse(v) else v for v in views]
+    ref = mofa_oracle.run(dense, groups=groups, n_factors=8, n_iterations=25, convergence_mode="slow", **kw)
+    eng = MofaEngine(BE, views, np.zeros(100, dtype=int) if groups is None else groups, 8, seed=1, **kw)
+    eng.run(25, "slow")
+    res = eng.results(sort_factors=False)
+    n = min(len(ref["elbo"]), len(res["elbo"]))
+    np.testing.assert_allclose(res["elbo"][:n], ref["elbo"][:n], rtol=1e-10)
+    np.testing.assert_allclose(res["Z"], ref["Z"], atol=1e-9)
+    for a, b in zip(res["W"], ref["W"]):
+        np.testing.assert_allclose(a, b, atol=1e-9)
+    np.testing.assert_allclose(res["r2"], ref["r2"], atol=1e-7)
+
+
+def test_scaling_options_match_oracle():
+    y1, y2 = simple_views()
+    y2 = y2 * 7.0
+    groups = np.random.default_rng(1).integers(0, 2, 100)
+    for kw in (dict(scale_views=True), dict(scale_groups=True), dict(center_groups=False)):
+        ref = mofa_oracle.run([y1, y2], groups=groups, n_factors=6, n_iterations=10, convergence_mode="slow", **kw)
+        eng = MofaEngine(BE, [y1, sp.csr_matrix(y2)], groups, 6, seed=1, **kw)
+        eng.run(10, "slow")
+        np.testing.assert_allclose(eng.elbo, ref["elbo"], rtol=1e-9)
+
+
+class TestWrapperLikeReference:
+    """Mirrors /root/reference/tests/test_muon_tools.py:12-87 on the duck containers."""
+
+    def setup_method(self):
+        y1, y2 = simple_views()
+        self.mdata = MuData({"y1": AnnData(y1), "y2": AnnData(y2)})
+
+    def test_mofa_nfactors(self, tmp_path):
+        n_factors = 10
+        mu.tl.mofa(self.mdata, n_factors=n_factors, quiet=True, verbose=False,
+                   outfile=str(tmp_path / "m.hdf5"), backend=BE)
+        y = np.concatenate([self.mdata.mod["y1"].X, self.mdata.mod["y2"].X], axis=1)
+        r2 = r2_per_factor(y, self.mdata.obsm["X_mofa"], self.mdata.varm["LFs"])
+        # Only first 5 factors should have high R2
+        assert all(i > 0.1 for i in r2[:5])
+        assert not any(i > 0.1 for i in r2[5:])
+        assert (tmp_path / "m.hdf5").exists()
+        u = self.mdata.uns["mofa"]
+        assert u["params"]["model"]["n_factors"] == 10 and set(u["variance"]) == {"y1", "y2"}
+        assert u["variance"]["y1"].shape == (10,)
+
+    def test_mofa_anndata(self):
+        a = self.mdata["y1"]
+        mu.tl.mofa(a, n_factors=10, quiet=True, verbose=False, backend=BE)
+        assert "X_mofa" in a.obsm and "LFs" in a.varm
+        assert a.obsm["X_mofa"].shape == (100, 10) and a.varm["LFs"].shape == (90, 10)
+
+    def test_mofa_anndata_groups_cat(self):
+        adata = self.mdata["y1"].copy()
+        np.random.seed(3)
+        adata.obs["ab"] = np.random.choice(["a", "b"], adata.n_obs)
+        adata.obs["ab"] = adata.obs.ab.astype("category")
+        mu.tl.mofa(adata, groups_label="ab", n_factors=10, quiet=True, verbose=False, backend=BE)
+        assert "X_mofa" in adata.obsm and "LFs" in adata.varm
+        assert set(adata.uns["mofa"]["variance"]["data"]) == {"a", "b"}
+
+    def test_mofa_obs_union(self):
+        y1 = self.mdata["y1"]
+        y2 = self.mdata["y2"]
+        for sparsity in (0, 1, 2):
+            if sparsity == 0 or sparsity == 2:
+                y1.X = sp.csr_matrix(y1.X)
+            if sparsity == 1 or sparsity == 2:
+                y2.X = sp.csr_matrix(y2.X)
+            a, b = y1[:-10], y2[10:]
+            a._init_as_actual(); b._init_as_actual()
+            mdata = MuData({"y1": a, "y2": b})
+            mu.tl.mofa(mdata, n_factors=10, quiet=True, verbose=False, use_obs="union",
+                       likelihoods="gaussian", backend=BE)
+            assert mdata.obsm["X_mofa"].shape == (100, 10) and mdata.varm["LFs"].shape == (140, 10)
+            assert np.all(np.isfinite(mdata.obsm["X_mofa"]))
+
+    def test_mofa_obs_intersection_and_errors(self):
+        a, b = self.mdata["y1"][:-10], self.mdata["y2"][10:]
+        a._init_as_actual(); b._init_as_actual()
+        mdata = MuData({"y1": a, "y2": b})
+        with pytest.raises(IndexError):
+            mu.tl.mofa(mdata, backend=BE)
+        with pytest.raises(ValueError):
+            mu.tl.mofa(mdata, use_obs="bogus", backend=BE)
+        mu.tl.mofa(mdata, use_obs="intersection", n_factors=5, backend=BE)
+        xm = mdata.obsm["X_mofa"]
+        assert xm.shape == (100, 5) and np.isnan(xm[:10]).all() and np.isnan(xm[90:]).all()
+        assert np.isfinite(xm[10:90]).all()
+        with pytest.raises(TypeError):
+            mu.tl.mofa(np.ones((3, 3)), backend=BE)
+        with pytest.raises(ValueError):
+            mu.tl.mofa(self.mdata, groups_label="nope", backend=BE)
+        with pytest.raises(NotImplementedError):
+            mu.tl.mofa(self.mdata, svi_mode=True, backend=BE)
+        with pytest.raises(NotImplementedError):
+            mu.tl.mofa(MuData({"c": AnnData(np.random.poisson(2, size=(30, 8)).astype(float))}), backend=BE)
+
+    def test_use_var_subset_zero_fills(self):
+        self.mdata.mod["y1"].var["highly_variable"] = np.arange(90) % 2 == 0
+        self.mdata.mod["y2"].var["highly_variable"] = np.arange(50) % 5 != 0
+        self.mdata.update()
+        cp = mu.tl.mofa(self.mdata, n_factors=4, copy=True, backend=BE)
+        assert "X_mofa" not in self.mdata.obsm and cp.obsm["X_mofa"].shape == (100, 4)
+        lf = cp.varm["LFs"]
+        sel = np.concatenate([np.arange(90) % 2 == 0, np.arange(50) % 5 != 0])
+        assert lf.shape == (140, 4) and np.all(lf[~sel] == 0) and np.any(lf[sel] != 0)
+        with pytest.warns(UserWarning, match="There is no column"):
+            mu.tl.mofa(self.mdata, n_factors=3, use_var="absent", backend=BE)
