@@ -78,6 +78,7 @@ class MofaEngine:
         self.views = [self._prepare_view(v, center_groups, scale_views, scale_groups) for v in views]
         self.Ds = [v.D for v in self.views]
         self._init_state(seed, row_offset, n_total)
+        self._stats = {}
         self.elbo = []
 
     # -- helpers -------------------------------------------------------------------------
@@ -109,7 +110,20 @@ class MofaEngine:
         V = _View()
         N = self.N
         V.D = D = v.shape[1]
-        if issparse(v):
+        from .._backend import DeviceCSR
+
+        if isinstance(v, (DeviceCSR, torch.Tensor)):
+            # device-resident view (bench / pipelines): rows must already be in group order
+            if not np.array_equal(self.perm, np.arange(N)):
+                raise NotImplementedError("device-resident views need samples sorted by group")
+            pres = np.ones(N, dtype=bool)
+            if isinstance(v, DeviceCSR):
+                V.kind = "sparse"
+                V.X = v.with_values(v.values.to(T))
+            else:
+                V.kind = "dense"
+                V.Y = v.to(T)
+        elif issparse(v):
             m = v.tocsr()[self.perm]
             m.sort_indices()
             V.kind = "sparse"
@@ -210,6 +224,16 @@ class MofaEngine:
 
     # -- sufficient statistics --------------------------------------------------------------
     def _zstats(self, m):
+        # B computed after the Z update serves tau / ELBO of this iteration AND the W update of
+        # the next one (Z does not change in between): two passes over Y per iteration, not three
+        cached = self._stats.get(m)
+        if cached is not None:
+            return cached
+        st = self._zstats_compute(m)
+        self._stats[m] = st
+        return st
+
+    def _zstats_compute(self, m):
         V, K, G = self.views[m], self.K, self.G
         Gz = torch.zeros((G, K, K), dtype=self.T, device=self.EZ.device)
         Z2 = torch.zeros((G, K), dtype=self.T, device=self.EZ.device)
@@ -269,6 +293,7 @@ class MofaEngine:
         az = self.alpha_z if self.opts["ard_factors"] else torch.ones_like(self.alpha_z)
         self.be.mofa_update_z(A.contiguous(), pres, self.grp, Gw.contiguous(), dw2.contiguous(),
                               az.contiguous(), self.EZ, self.EZ2, self.sig2z)
+        self._stats = {}  # <Z> changed: statistics are stale
 
     def _gamma_kl(self, a0, b0, a, b, ex, elx):
         lp = a0 * math.log(b0) - math.lgamma(a0) + (a0 - 1.0) * elx - b0 * ex
@@ -281,7 +306,6 @@ class MofaEngine:
         elbo = torch.zeros((), dtype=torch.float64, device=self.EZ.device)
         for m, (V, Wm) in enumerate(zip(self.views, self.W)):
             Gz, Z2, B = self._zstats(m)
-            self._B_cache = None
             EW, EW2 = Wm.EW, Wm.EW2
             Ngm = V.Ngm.to(EW.device).to(self.T)
             for g in range(G):

@@ -1,0 +1,120 @@
+"""The row(cell)-sharded path with world_size 2 on CPU (gloo): two processes each hold half of
+the cells, exchange the per-peak sums (tfidf), Z = X^T Y and the Gram (lsi) and the MOFA
+statistics through TorchDistComm, and must reproduce the single-process result.  Kernels are
+replaced by the CPU test operator set (tests/cpu_backend.py); the collectives, sharding and
+host algebra are the product code."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from muon_amd._atac.preproc import canonical_csr, tfidf_device
+        from muon_amd._atac.tools import lsi_device
+        from muon_amd._comm import TorchDistComm
+        from muon_amd._core.mofa_engine import MofaEngine
+        from tests.cpu_backend import CpuTestBackend
+        from tests.synth import planted_topics_csr
+
+        be = CpuTestBackend()
+        comm = TorchDistComm()
+        X = planted_topics_csr(600, 400, n_topics=8, density=0.08, seed=5, dtype=np.float32)
+        n = X.shape[0]
+        lo, hi = (0, 290) if rank == 0 else (290, n)  # uneven shards
+        Xs = canonical_csr(X[lo:hi])
+        Xd = be.upload_csr(Xs.indptr, Xs.indices, Xs.data, Xs.shape)
+        T = tfidf_device(be, Xd, n, 3, 1e4, comm=comm)
+        U, stdev, V, info = lsi_device(be, T, n_comps=8, n_obs=n, comm=comm, return_info=True)
+        Uall = comm.all_gather_rows(U.contiguous())
+
+        # MOFA: samples sharded, two views (one sparse), two groups
+        rng = np.random.default_rng(0)
+        Z = rng.standard_normal((120, 4))
+        y1 = Z @ rng.standard_normal((30, 4)).T + rng.standard_normal((120, 30))
+        y2 = Z @ rng.standard_normal((50, 4)).T + rng.standard_normal((120, 50))
+        y2[np.abs(y2) < 0.8] = 0
+        groups = rng.integers(0, 2, 120)
+        a, b = (0, 55) if rank == 0 else (55, 120)
+        eng = MofaEngine(be, [y1[a:b], sp.csr_matrix(y2[a:b])], groups[a:b], 6, seed=1, comm=comm,
+                         row_offset=a, n_total=120)
+        eng.run(12, "slow")
+        res = eng.results(sort_factors=False)
+        Zall = comm.all_gather_rows(torch.from_numpy(res["Z"]))
+        if rank == 0:
+            q.put({"tfidf": T.values.numpy(), "U": Uall.numpy(), "stdev": stdev, "V": V.numpy(),
+                   "elbo": res["elbo"], "Z": Zall.numpy(), "W": res["W"], "iters": info["iterations"]})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world_size_2_matches_single_process():
+    sys.path.insert(0, ROOT)
+    from muon_amd._atac.preproc import canonical_csr, tfidf_device
+    from muon_amd._atac.tools import lsi_device
+    from muon_amd._core.mofa_engine import MofaEngine
+    from oracle import lsi_oracle
+    from tests.cpu_backend import CpuTestBackend
+    from tests.synth import planted_topics_csr
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    be = CpuTestBackend()
+    X = planted_topics_csr(600, 400, n_topics=8, density=0.08, seed=5, dtype=np.float32)
+    Xs = canonical_csr(X)
+    Xd = be.upload_csr(Xs.indptr, Xs.indices, Xs.data, Xs.shape)
+    T = tfidf_device(be, Xd, 600, 3, 1e4)
+    # rank 0 held rows 0..289: its TF-IDF values equal the first rows of the global result
+    n0 = int(Xs.indptr[290])
+    np.testing.assert_allclose(got["tfidf"], T.values.numpy()[:n0], rtol=1e-6)
+    U, stdev, V = lsi_device(be, T, n_comps=8, n_obs=600)
+    np.testing.assert_allclose(got["stdev"], stdev, rtol=1e-5)
+    assert lsi_oracle.max_subspace_angle(got["V"], V.numpy()) < 1e-4
+    assert got["U"].shape == (600, 8)
+    assert lsi_oracle.max_subspace_angle(got["U"], U.numpy()) < 5e-4
+
+    rng = np.random.default_rng(0)
+    Z = rng.standard_normal((120, 4))
+    y1 = Z @ rng.standard_normal((30, 4)).T + rng.standard_normal((120, 30))
+    y2 = Z @ rng.standard_normal((50, 4)).T + rng.standard_normal((120, 50))
+    y2[np.abs(y2) < 0.8] = 0
+    groups = rng.integers(0, 2, 120)
+    eng = MofaEngine(be, [y1, sp.csr_matrix(y2)], groups, 6, seed=1)
+    eng.run(12, "slow")
+    res = eng.results(sort_factors=False)
+    np.testing.assert_allclose(got["elbo"], res["elbo"], rtol=1e-9)
+    np.testing.assert_allclose(got["Z"], res["Z"], atol=1e-8)
+    for a, b in zip(got["W"], res["W"]):
+        np.testing.assert_allclose(a, b, atol=1e-8)
