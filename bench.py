@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-sample-cells", type=int, default=4000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pack", action="store_true",
+                    help="ablation: run the SpMM on plain CSR (k_spmm_lds64) instead of the packed copy")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,7 +143,7 @@ def main():
     def step():
         T = tfidf_device(be, X, n_global, flags, 1e4, comm=comm, out=tf_vals)
         U, stdev, V, inf = lsi_device(be, T, n_comps=args.n_comps, n_obs=n_global, comm=comm,
-                                      return_info=True)
+                                      return_info=True, pack=False if args.no_pack else None)
         info.update(inf)
         return U, stdev, V
 
@@ -196,7 +198,10 @@ def main():
                         "converged": info.get("converged"), "spmm_per_step": len(ms) // max(args.steps, 1)},
             },
             "roofline": {
-                "kernel": "k_spmm_lds64 (CSR SpMM, f32, B=64: Q column slabs in LDS, DPP broadcast)",
+                "kernel": ("k_spmm_lds64 (CSR SpMM, f32, B=64: Q column slabs in LDS, DPP broadcast)"
+                           if args.no_pack else
+                           "k_spmm_pcr64 (packed chunked-row SpMM, f32, B=64: Q column slabs in LDS via "
+                           "LDS-DMA, counted-vmcnt chunk stream, DPP broadcast)"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

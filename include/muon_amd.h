@@ -126,6 +126,30 @@ int mu_spmm_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const i
                 const float* d_values, const float* d_Q, int B, float* d_Y, int accumulate,
                 void* stream);
 
+/* Packed chunked-row copy of a CSR for the B = 64 SpMM ("PCR16"): every row is cut into
+ * chunks of 16 (column int32, value f32) pairs = one aligned 128-byte line each, the tail is
+ * padded with (INT32_MAX, 0) and one all-padding chunk closes every row.  Built once per
+ * lsi() call for X and for X^T; the subspace iteration then streams every line exactly once
+ * per product.
+ *   1. mu_csr_pack_count: row_chunks[i] = ceil(nnz_i / 16) + 1
+ *   2. caller scans row_chunks into cptr int64[n_rows + 1] (mu_exclusive_scan_i64) and
+ *      allocates ent: 128 bytes x cptr[n_rows]
+ *   3. mu_csr_pack_fill
+ * Requires sorted column indices inside rows (canonical CSR). */
+int mu_csr_pack_count(int64_t n_rows, const int64_t* d_indptr, int64_t* d_row_chunks, void* stream);
+int mu_csr_pack_fill(int64_t n_rows, const int64_t* d_indptr, const int32_t* d_indices,
+                     const float* d_values, const int64_t* d_cptr, void* d_ent, void* stream);
+/* Y[n_rows x 64] = X * Q on the packed copy (B must be 64, n_cols <= 2^22).  Same result as
+ * mu_spmm_f32 up to f32 summation order (entries of a row are accumulated in column order,
+ * fmaf chain per dense column; bit-reproducible run to run). */
+int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, const void* d_ent,
+                       const float* d_Q, int B, float* d_Y, void* stream);
+
+/* Tuning / ablation knobs (tests and bench only; defaults are what ships):
+ *   "spmm_k"  rows-sets per wave of the packed SpMM, 1..8 (0 = automatic). */
+int mu_tune_set(const char* key, int value);
+int mu_tune_get(const char* key);
+
 /* Same product in f64 (MOFA runs in float64 unless use_float32=True, tools.py:308). */
 int mu_spmm_f64(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
                 const double* d_values, const double* d_Q, int B, double* d_Y, int accumulate,

@@ -85,6 +85,7 @@ def lsi_device(
     seed: int = 1,
     Xt=None,
     return_info: bool = False,
+    pack: Optional[bool] = None,
 ):
     """Truncated SVD of a device-resident CSR (row shard) by block subspace iteration.
 
@@ -105,6 +106,14 @@ def lsi_device(
         X = X.with_values(X.values.to(torch.float32))
     if Xt is None:
         Xt = backend.transpose(X)
+    # B = 64: both operands of the iteration are streamed from their packed chunked-row copies
+    # (DESIGN.md §4); the CSR of X^T is only needed to build its copy.
+    if pack is None:
+        pack = (hasattr(backend, "can_pack") and backend.can_pack(X, B)
+                and backend.can_pack(Xt, B))
+    if pack:
+        Xt = backend.pack(Xt)
+        X = backend.pack(X)
 
     Q = backend.randn(d, B, seed)
     if w < B:

@@ -40,6 +40,17 @@ class DeviceCSR:
         return DeviceCSR(self.indptr, self.indices, values, self.shape)
 
 
+@dataclass
+class DevicePackedCSR:
+    """Packed chunked-row copy of a CSR ("PCR16", include/muon_amd.h): cptr int64[n+1] chunk
+    offsets, ent uint8[128 * n_chunks] (16 (column, value) pairs per chunk).  SpMM-only."""
+
+    cptr: torch.Tensor
+    ent: torch.Tensor
+    shape: Tuple[int, int]
+    nnz: int
+
+
 def _dt(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
         return F32
@@ -163,10 +174,42 @@ class HipBackend:
                                             _p(t_values), _p(work), wb, self._stream()))
         return DeviceCSR(t_indptr, t_indices, t_values, (d, n))
 
-    def spmm(self, X: DeviceCSR, Q: torch.Tensor, out=None) -> torch.Tensor:
+    def can_pack(self, X: DeviceCSR, B: int) -> bool:
+        """The packed SpMM exists for f32 values, B = 64 and at most 2^22 columns."""
+        return X.values.dtype == torch.float32 and B == 64 and 0 < X.shape[1] <= (1 << 22)
+
+    def pack(self, X: DeviceCSR) -> DevicePackedCSR:
+        """Build the packed chunked-row copy used by the B = 64 SpMM (once per lsi call)."""
+        n, d = X.shape
+        assert X.values.dtype == torch.float32
+        row_chunks = self.empty((max(n, 1),), torch.int64)
+        cptr = self.zeros((n + 1,), torch.int64)
+        with torch.cuda.device(self.device):
+            st = self._stream()
+            check(self.lib.mu_csr_pack_count(n, _p(X.indptr), _p(row_chunks), st))
+            check(self.lib.mu_exclusive_scan_i64(n, _p(row_chunks), _p(cptr), st))
+            n_chunks = int(cptr[-1].item()) if n > 0 else 0
+            ent = self.empty((max(n_chunks, 1) * 128,), torch.uint8)
+            check(self.lib.mu_csr_pack_fill(n, _p(X.indptr), _p(X.indices), _p(X.values), _p(cptr),
+                                            _p(ent), st))
+        return DevicePackedCSR(cptr, ent, (n, d), X.nnz)
+
+    def tune(self, key: str, value: int) -> None:
+        check(self.lib.mu_tune_set(key.encode(), int(value)))
+
+    def spmm(self, X, Q: torch.Tensor, out=None) -> torch.Tensor:
         n, d = X.shape
         B = Q.shape[1]
         assert Q.shape[0] == d and Q.dtype in (torch.float32, torch.float64) and Q.is_contiguous()
+        if isinstance(X, DevicePackedCSR):
+            if Q.dtype != torch.float32 or B != 64:
+                raise TypeError("the packed SpMM needs an f32 dense block of width 64")
+            if out is None:
+                out = self.empty((n, B), Q.dtype)
+            with torch.cuda.device(self.device):
+                check(self.lib.mu_spmm_packed_f32(n, d, _p(X.cptr), _p(X.ent), _p(Q), B, _p(out),
+                                                  self._stream()))
+            return out
         if X.values.dtype != Q.dtype:
             raise TypeError("spmm needs values and dense block of one dtype")
         if out is None:

@@ -27,9 +27,29 @@ int mu_num_cus() {
   return cached[dev];
 }
 
+static int g_tune_spmm_k = 0;
+
+int mu_tune_spmm_k() { return g_tune_spmm_k; }
+
 extern "C" {
 
-int mu_version(void) { return 100; }
+int mu_version(void) { return 101; }
+
+int mu_tune_set(const char* key, int value) {
+  MU_REQUIRE(key, "null key");
+  if (strcmp(key, "spmm_k") == 0) {
+    MU_REQUIRE(value >= 0 && value <= 8, "spmm_k must be 0..8");
+    g_tune_spmm_k = value;
+    return MU_OK;
+  }
+  mu_set_error("mu_tune_set: unknown key %s", key);
+  return MU_ERR_ARG;
+}
+
+int mu_tune_get(const char* key) {
+  if (key && strcmp(key, "spmm_k") == 0) return g_tune_spmm_k;
+  return -1;
+}
 
 const char* mu_last_error(void) { return g_err; }
 

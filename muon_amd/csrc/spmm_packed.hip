@@ -1,0 +1,397 @@
+// SpMM on the packed chunked-row copy of a CSR (B = 64, f32):  Y[n x 64] = X[n x d] * Q[d x 64].
+//
+// This is the kernel the block subspace iteration of muon_amd.atac.tl.lsi spends its time in; it
+// stands where ARPACK's reverse-communication loop calls csr_matvec / csr_matvecs through
+// scipy.sparse.linalg.svds (/root/reference/muon/_atac/tools.py:53, scipy _svds.py:441-466,516).
+//
+// Layout ("PCR16", built once per lsi() call by mu_csr_pack_*):
+//   * every row is cut into chunks of 16 (column, value) pairs, 8 bytes per pair, so a chunk is
+//     exactly one aligned 128-byte line; the last chunk is padded with (0x7fffffff, 0) and one
+//     all-padding chunk closes every row (so "the next chunk" always exists);
+//   * cptr int64[n+1] are chunk offsets.
+// A 16-lane group streams one row: it holds the current and the next chunk in registers, one
+// pair per lane, and every line of the matrix is fetched exactly once, a full slab sweep ahead
+// of its use.
+//
+// Kernel structure (one 1024-thread workgroup = 64*K rows, K <= 8, per CU):
+//   * the columns of X are swept in slabs of 256; the slab's 256 Q rows (64 KiB) are copied to
+//     LDS by LDS-DMA, double buffered;
+//   * a wave is four 16-lane groups, group g walks row 4k+g of row-set k and keeps its K float4
+//     accumulators in registers; lane `sub` owns dense columns 4 sub .. 4 sub + 3;
+//   * per (row-set, slab) the 16-slot window starting at the row's cursor is cut out of
+//     (current chunk ++ next chunk) with a select and a ds_bpermute rotation, the entries that
+//     fall into the slab are a prefix of it (sorted rows), and entry e's (LDS address, value) is
+//     broadcast inside the group with DPP row_newbcast, so one ds_read_b128 serves four rows;
+//   * a group that used up its current chunk promotes the next one and requests the chunk after
+//     it with an EXEC-masked global_load_dwordx2 (inline asm: exactly one VMEM instruction per
+//     row-set and slab, so completion is tracked with counted s_waitcnt vmcnt(K-1) instead of
+//     the vmcnt(0) the compiler has to fall back to for conditionally issued loads).
+//
+// All VMEM traffic of the main loop is issued from inline asm (hipcc neither counts nor waits for
+// it): the LDS-DMA pieces and the chunk requests.  In-order completion makes the counted waits
+// safe however many extra (overflow-pass) requests are interleaved.
+#include <cstdlib>
+#include "common.hpp"
+
+namespace {
+
+constexpr int kSlabCols = 256;                   // Q rows per slab: 256 x 256 B = 64 KiB
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+constexpr int kKMax = 8;
+constexpr int kDmaPieces = (kSlabCols * 256) / (kWaves * 1024);  // 1 KiB pieces per wave (= 4)
+constexpr int kPadCol = 0x7fffffff;
+
+template <int E>
+__device__ __forceinline__ int bcast_i(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, 0x150 + E, 0xf, 0xf, true);  // row_newbcast:E
+}
+template <int E>
+__device__ __forceinline__ float bcast_f(float x) {
+  return __builtin_bit_cast(float, bcast_i<E>(__builtin_bit_cast(int, x)));
+}
+
+// Entries E..E+3 of every group's window: four independent ds_read_b128 per call.  `base` is the
+// LDS byte address of the slab buffer plus this lane's 16-byte column offset; slots a group does
+// not use carry a = 0, v = 0 (a broadcast read of slab row 0 and FMAs with zero).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const f32x4* lds_f4p;
+template <int E>
+__device__ __forceinline__ void lds_quad(unsigned base, int a, float v, float4& acc) {
+  const unsigned a0 = (unsigned)bcast_i<E>(a) + base, a1 = (unsigned)bcast_i<E + 1>(a) + base;
+  const unsigned a2 = (unsigned)bcast_i<E + 2>(a) + base, a3 = (unsigned)bcast_i<E + 3>(a) + base;
+  const f32x4 q0 = *(lds_f4p)(a0);
+  const f32x4 q1 = *(lds_f4p)(a1);
+  const f32x4 q2 = *(lds_f4p)(a2);
+  const f32x4 q3 = *(lds_f4p)(a3);
+  const float v0 = bcast_f<E>(v), v1 = bcast_f<E + 1>(v);
+  const float v2 = bcast_f<E + 2>(v), v3 = bcast_f<E + 3>(v);
+  acc.x = fmaf(v0, q0.x, acc.x); acc.y = fmaf(v0, q0.y, acc.y);
+  acc.z = fmaf(v0, q0.z, acc.z); acc.w = fmaf(v0, q0.w, acc.w);
+  acc.x = fmaf(v1, q1.x, acc.x); acc.y = fmaf(v1, q1.y, acc.y);
+  acc.z = fmaf(v1, q1.z, acc.z); acc.w = fmaf(v1, q1.w, acc.w);
+  acc.x = fmaf(v2, q2.x, acc.x); acc.y = fmaf(v2, q2.y, acc.y);
+  acc.z = fmaf(v2, q2.z, acc.z); acc.w = fmaf(v2, q2.w, acc.w);
+  acc.x = fmaf(v3, q3.x, acc.x); acc.y = fmaf(v3, q3.y, acc.y);
+  acc.z = fmaf(v3, q3.z, acc.z); acc.w = fmaf(v3, q3.w, acc.w);
+}
+
+// one LDS-DMA piece: 64 lanes x 16 B land contiguously at the wave-uniform LDS byte address
+__device__ __forceinline__ void dma_piece(const float4* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+// The next chunk of every (row-set, group) lives in v[kNx + 2k], v[kNx + 2k + 1] (column, value
+// bits); v[kNx + 16] is a sink.  These registers are written by the asm chunk requests while the
+// wave keeps running, so they must never be visible to hipcc as values: a compiler-made copy of
+// a register whose load is still in flight reads stale data (it did happen with "+v" operands).
+// The kernel is compiled with amdgpu_num_vgpr(kNx / 2) - on the unified gfx950 register file
+// that caps hipcc's own allocation at v[0 .. kNx-1] - and the asm statements name the registers
+// above literally; the clobber lists make the kernel descriptor allocate them (hipcc warns that
+// they are "reserved", which is the point).
+constexpr int kNx = 104;
+#pragma clang diagnostic ignored "-Winline-asm"
+#define MU_NX_CLOBBERS                                                                         \
+  "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",      \
+      "v115", "v116", "v117", "v118", "v119", "v120"
+
+// EXEC-masked chunk request: lanes of `mask` overwrite their pair, the others keep it.  Exactly
+// ONE VMEM instruction is issued with a non-empty EXEC whatever the mask is (an empty mask turns
+// into a one-lane load into the sink), so the counted s_waitcnt never depends on how the
+// hardware treats a VMEM instruction whose EXEC is zero.
+template <int k>
+__device__ __forceinline__ void request_chunk(unsigned byte_off, const void* base,
+                                              unsigned long long mask) {
+  unsigned long long save;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\t"
+      "s_and_b64 exec, exec, %3\n\t"
+      "s_cbranch_scc1 1f\n\t"
+      "s_mov_b64 exec, 1\n\t"
+      "global_load_dword v120, %1, %2\n\t"
+      "s_branch 2f\n"
+      "1:\n\t"
+      "global_load_dwordx2 v[%c4:%c5], %1, %2\n"
+      "2:\n\t"
+      "s_mov_b64 exec, %0"
+      : "=&s"(save)
+      : "v"(byte_off), "s"(base), "s"(mask), "i"(kNx + 2 * k), "i"(kNx + 2 * k + 1)
+      : MU_NX_CLOBBERS);
+}
+
+// wait until at most N VMEM operations are outstanding, then read the next chunk of row-set k
+template <int k, int N>
+__device__ __forceinline__ void wait_next_chunk(int& col, int& valbits) {
+  asm volatile(
+      "s_waitcnt vmcnt(%c2)\n\t"
+      "v_mov_b32 %0, v%c3\n\t"
+      "v_mov_b32 %1, v%c4"
+      : "=v"(col), "=v"(valbits)
+      : "i"(N), "i"(kNx + 2 * k), "i"(kNx + 2 * k + 1)
+      : MU_NX_CLOBBERS);
+}
+
+template <int k>
+__device__ __forceinline__ void set_next_chunk(int col, int valbits) {
+  asm volatile(
+      "v_mov_b32 v%c2, %0\n\t"
+      "v_mov_b32 v%c3, %1"
+      :
+      : "v"(col), "v"(valbits), "i"(kNx + 2 * k), "i"(kNx + 2 * k + 1)
+      : MU_NX_CLOBBERS);
+}
+
+struct RowState {
+  int posv;   // lane 16 g + k: consumed entries of the current chunk of (row-set k, group g)
+  int cidv;   // lane 16 g + k: chunk to request next (relative to the workgroup's first chunk)
+  int lastv;  // lane 16 g + k: the row's closing (all padding) chunk
+};
+
+template <int K>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_vgpr(kNx / 2))) void k_spmm_pcr64(
+    int64_t n_rows, int64_t n_cols, const int64_t* __restrict__ cptr,
+    const unsigned long long* __restrict__ ent, const float* __restrict__ Q, float* __restrict__ Y) {
+  __shared__ float4 qs[2][kSlabCols * 16];  // 2 x 64 KiB; Q row c of a slab at [16 c .. 16 c + 15]
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform32(threadIdx.x >> 6);
+  const int sub = lane & 15, g = lane >> 4;
+  const int sub16 = sub * 16;
+  const int rot_base = (lane & 48) << 2;  // ds_bpermute byte address of the group's lane 0
+  const int64_t rb0 = (int64_t)blockIdx.x * (64 * K);
+  const int64_t rb1 = (rb0 + 64 * K) < n_rows ? (rb0 + 64 * K) : n_rows;
+  const int64_t cbase = uniform64(cptr[rb0]);
+  const unsigned long long* __restrict__ entb = ent + cbase * 16;  // wave-uniform
+  const float4* __restrict__ Q4 = reinterpret_cast<const float4*>(Q);
+  const int64_t q4_total = n_cols * 16;
+  const int ncols32 = (int)n_cols;
+  const unsigned qs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&qs[0][0]);
+
+  float4 acc[K];
+  int cc[K], cv[K];            // current chunk: column / value bits of entry `sub`
+  RowState st;                 // (the next chunk lives in v[kNx + 2k .. +1], see above)
+  int hasv;                    // lane 16 g + k: row exists
+  {
+    const int64_t row = rb0 + ((int64_t)wave * K + sub) * 4 + g;
+    const bool ok = (sub < K) && (row < rb1);
+    const int c0 = ok ? (int)(cptr[row] - cbase) : 0;
+    const int c1 = ok ? (int)(cptr[row + 1] - cbase) : 1;
+    st.posv = 0;
+    st.lastv = c1 - 1;
+    st.cidv = (c0 + 2) < (c1 - 1) ? (c0 + 2) : (c1 - 1);
+    hasv = ok ? c0 : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = float4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: chunk 0 and chunk min(1, last) of every row (plain loads, hipcc waits for them)
+#define MU_INIT(k)                                                                     \
+  if constexpr (k < K) {                                                               \
+    const int c0_ = bcast_i<k>(hasv);                                                  \
+    const int l_ = bcast_i<k>(st.lastv);                                               \
+    const bool has_ = c0_ >= 0;                                                        \
+    const int a_ = has_ ? c0_ : 0;                                                     \
+    const int b_ = has_ ? ((c0_ + 1) < l_ ? (c0_ + 1) : l_) : 0;                       \
+    const unsigned long long e0_ = entb[(int64_t)a_ * 16 + sub];                       \
+    const unsigned long long e1_ = entb[(int64_t)b_ * 16 + sub];                       \
+    cc[k] = has_ ? (int)(unsigned)e0_ : kPadCol;                                       \
+    cv[k] = (int)(unsigned)(e0_ >> 32);                                                \
+    set_next_chunk<k>(has_ ? (int)(unsigned)e1_ : kPadCol, (int)(unsigned)(e1_ >> 32)); \
+  }
+  MU_INIT(0) MU_INIT(1) MU_INIT(2) MU_INIT(3) MU_INIT(4) MU_INIT(5) MU_INIT(6) MU_INIT(7)
+#undef MU_INIT
+
+  auto slab_dma = [&](int64_t s0, int buf) {
+#pragma unroll
+    for (int u = 0; u < kDmaPieces; ++u) {
+      const int piece = wave * kDmaPieces + u;       // 1 KiB piece of the 64 KiB slab
+      int64_t i = s0 * 16 + piece * 64 + lane;       // float4 index into Q
+      if (i >= q4_total) i = q4_total - 1;           // tail slab: clamp (never consumed)
+      dma_piece(Q4 + i, qs_lds + (unsigned)buf * (kSlabCols * 256u) + (unsigned)piece * 1024u);
+    }
+  };
+  slab_dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int buf = 0;
+  for (int64_t s0 = 0; s0 < n_cols; s0 += kSlabCols, buf ^= 1) {
+    if ((s0 + kSlabCols) < n_cols) slab_dma(s0 + kSlabCols, buf ^ 1);  // lands while this slab is consumed
+    const int s_lo = (int)s0;
+    const int s_hi = (s_lo + kSlabCols) < ncols32 ? (s_lo + kSlabCols) : ncols32;
+    const unsigned qbase = qs_lds + (unsigned)buf * (kSlabCols * 256u) + (unsigned)sub16;
+    unsigned again = 0;
+
+    // SLOW = overflow pass (a row had more than 16 entries in this slab): its request was issued
+    // just now, so drain everything; the main pass only needs the request of the previous slab.
+#define MU_PASS(k, SLOW)                                                                      \
+  {                                                                                           \
+    int ncol, nval;                                                                           \
+    if (SLOW) wait_next_chunk<k, 0>(ncol, nval); else wait_next_chunk<k, K - 1>(ncol, nval);  \
+    const int p = bcast_i<k>(st.posv);                                                        \
+    const bool from_cur = sub >= p;                                                           \
+    const int mc = from_cur ? cc[k] : ncol;                                                   \
+    const int mv = from_cur ? cv[k] : nval;                                                   \
+    const int src = rot_base + (((sub + p) & 15) << 2);                                       \
+    const int wc = __builtin_amdgcn_ds_bpermute(src, mc);                                     \
+    const int wv = __builtin_amdgcn_ds_bpermute(src, mv);                                     \
+    const bool valid = wc < s_hi; /* sorted rows: the slab's entries are a prefix */          \
+    const unsigned long long m = __ballot(valid);                                             \
+    const int cnt = __popc((unsigned)(m >> (16 * g)) & 0xffffu);                              \
+    const unsigned mm = (unsigned)m | (unsigned)(m >> 32);                                    \
+    const unsigned any16 = (mm | (mm >> 16)) & 0xffffu; /* bit e: some group has entry e */   \
+    const int a = valid ? ((wc - s_lo) << 8) : 0;                                             \
+    const float vv = valid ? __builtin_bit_cast(float, wv) : 0.f;                             \
+    const int np = p + cnt;                                                                   \
+    const bool shift = np >= 16;                                                              \
+    const unsigned long long smask = __ballot(shift);                                         \
+    cc[k] = shift ? ncol : cc[k];                                                             \
+    cv[k] = shift ? nval : cv[k];                                                             \
+    const int cid = bcast_i<k>(st.cidv);                                                      \
+    request_chunk<k>(((unsigned)cid << 7) | ((unsigned)sub << 3), entb, smask);               \
+    if (sub == k) {                                                                           \
+      st.posv = np & 15;                                                                      \
+      st.cidv = shift ? (st.cidv < st.lastv ? st.cidv + 1 : st.lastv) : st.cidv;              \
+    }                                                                                         \
+    lds_quad<0>(qbase, a, vv, acc[k]);                                                \
+    if (any16 & 0x00f0u) lds_quad<4>(qbase, a, vv, acc[k]);                           \
+    if (any16 & 0x0f00u) lds_quad<8>(qbase, a, vv, acc[k]);                           \
+    if (any16 & 0xf000u) lds_quad<12>(qbase, a, vv, acc[k]);                          \
+    if (__ballot(cnt == 16)) again |= 1u << k; /* window used up: maybe more in this slab */  \
+  }
+#define MU_MAIN(k) if constexpr (k < K) MU_PASS(k, false)
+    MU_MAIN(0) MU_MAIN(1) MU_MAIN(2) MU_MAIN(3) MU_MAIN(4) MU_MAIN(5) MU_MAIN(6) MU_MAIN(7)
+#undef MU_MAIN
+    if (again) {
+      do {
+        const unsigned pend = again;
+        again = 0;
+#define MU_OVER(k) if constexpr (k < K) { if (pend & (1u << k)) MU_PASS(k, true) }
+        MU_OVER(0) MU_OVER(1) MU_OVER(2) MU_OVER(3) MU_OVER(4) MU_OVER(5) MU_OVER(6) MU_OVER(7)
+#undef MU_OVER
+      } while (again);
+      // an overflow request of row-set k is younger than the main-pass requests the next slab's
+      // vmcnt(K-1) is counted against: drain, so that the count only ever guards main-pass requests
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef MU_PASS
+    // The DMA pieces of the next slab were issued before this slab's >= K requests: allowing K
+    // outstanding VMEM operations proves they landed without draining the requests.
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(K) : "memory");
+    __syncthreads();  // next slab visible; everyone finished reading this one
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // requests still in flight target v[kNx ..]
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int64_t row = rb0 + ((int64_t)wave * K + k) * 4 + g;
+    if (row < rb1) *reinterpret_cast<float4*>(Y + row * 64 + sub * 4) = acc[k];
+  }
+}
+
+// ---- packing -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_count(int64_t n_rows, const int64_t* __restrict__ indptr,
+                                                    int64_t* __restrict__ row_chunks) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_rows) row_chunks[r] = ((indptr[r + 1] - indptr[r] + 15) >> 4) + 1;
+}
+
+// one 16-lane group per chunk would waste the closing chunks; a wave per row streams instead
+__global__ __launch_bounds__(256) void k_pack_fill(int64_t n_rows, const int64_t* __restrict__ indptr,
+                                                   const int32_t* __restrict__ indices,
+                                                   const float* __restrict__ values,
+                                                   const int64_t* __restrict__ cptr,
+                                                   unsigned long long* __restrict__ ent) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = uniform64(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t row = wave0; row < n_rows; row += n_waves) {
+    const int64_t lo = uniform64(indptr[row]), hi = uniform64(indptr[row + 1]);
+    const int64_t o0 = uniform64(cptr[row]) * 16, o1 = uniform64(cptr[row + 1]) * 16;
+    for (int64_t j = lane; j < o1 - o0; j += 64) {
+      const int64_t p = lo + j;
+      unsigned long long e = (unsigned long long)(unsigned)kPadCol;
+      if (p < hi)
+        e = (unsigned long long)(unsigned)indices[p] |
+            ((unsigned long long)__builtin_bit_cast(unsigned, values[p]) << 32);
+      ent[o0 + j] = e;
+    }
+  }
+}
+
+template <int K>
+int launch_pcr(int64_t n_rows, int64_t n_cols, const int64_t* cptr, const unsigned long long* ent,
+               const float* Q, float* Y, hipStream_t st) {
+  const int64_t wgs = (n_rows + 64 * K - 1) / (64 * K);
+  hipLaunchKernelGGL(k_spmm_pcr64<K>, dim3((unsigned)wgs), dim3(kThreads), 0, st, n_rows, n_cols, cptr,
+                     ent, Q, Y);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mu_csr_pack_count(int64_t n_rows, const int64_t* d_indptr, int64_t* d_row_chunks, void* stream) {
+  MU_REQUIRE(n_rows >= 0, "negative size");
+  if (n_rows == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_row_chunks, "null pointer");
+  hipLaunchKernelGGL(k_pack_count, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, n_rows, d_indptr, d_row_chunks);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_csr_pack_fill(int64_t n_rows, const int64_t* d_indptr, const int32_t* d_indices,
+                     const float* d_values, const int64_t* d_cptr, void* d_ent, void* stream) {
+  MU_REQUIRE(n_rows >= 0, "negative size");
+  if (n_rows == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_cptr && d_ent, "null pointer");
+  int64_t blocks = (n_rows + 3) / 4;
+  const int64_t cap = (int64_t)mu_num_cus() * 32;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_pack_fill, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_rows,
+                     d_indptr, d_indices, d_values, d_cptr, (unsigned long long*)d_ent);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, const void* d_ent,
+                       const float* d_Q, int B, float* d_Y, void* stream) {
+  MU_REQUIRE(B == 64, "the packed SpMM is built for B = 64");
+  MU_REQUIRE(n_rows >= 0 && n_cols > 0 && n_cols <= ((int64_t)1 << 22), "shape out of range");
+  if (n_rows == 0) return MU_OK;
+  MU_REQUIRE(d_cptr && d_ent && d_Q && d_Y, "null pointer");
+  // K row-sets per wave: the smallest number of full-chip rounds R whose 64*K-row blocks fit
+  // the register budget (K <= 8); one workgroup per CU (128 KiB of LDS).
+  const int64_t cus = mu_num_cus();
+  int K = kKMax;
+  for (int64_t R = 1; R <= 1024; ++R) {
+    const int64_t k = (n_rows + 64 * cus * R - 1) / (64 * cus * R);
+    if (k <= kKMax) { K = (int)(k < 1 ? 1 : k); break; }
+  }
+  const int force_k = mu_tune_spmm_k();  // tests / tuning only
+  if (force_k >= 1 && force_k <= kKMax) K = force_k;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned long long* ent = (const unsigned long long*)d_ent;
+  switch (K) {
+    case 1: return launch_pcr<1>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
+    case 2: return launch_pcr<2>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
+    case 3: return launch_pcr<3>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
+    case 4: return launch_pcr<4>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
+    case 5: return launch_pcr<5>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
+    case 6: return launch_pcr<6>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
+    case 7: return launch_pcr<7>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
+    default: return launch_pcr<8>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
+  }
+}
+
+}  // extern "C"

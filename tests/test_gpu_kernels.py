@@ -159,3 +159,102 @@ def test_synth_counts_structure(hip):
     # a shard generated elsewhere equals the same rows of the full matrix
     S = _down(hip, hip.synth_counts(500, 300, 30000, n_topics=50, density=0.03, seed=0))
     assert (S != m[500:800]).nnz == 0
+
+
+# ---- packed chunked-row SpMM (B = 64) ---------------------------------------------------
+def _pack_ref(m):
+    """numpy restatement of the PCR16 layout (include/muon_amd.h): 16-pair chunks, padded with
+    (INT32_MAX, 0), one closing all-padding chunk per row."""
+    n = m.shape[0]
+    lens = np.diff(m.indptr)
+    chunks = (lens + 15) // 16 + 1
+    cptr = np.concatenate([[0], np.cumsum(chunks)]).astype(np.int64)
+    col = np.full(cptr[-1] * 16, 0x7FFFFFFF, dtype=np.uint32)
+    val = np.zeros(cptr[-1] * 16, dtype=np.float32)
+    for r in range(n):
+        lo, hi = m.indptr[r], m.indptr[r + 1]
+        o = cptr[r] * 16
+        col[o:o + hi - lo] = m.indices[lo:hi]
+        val[o:o + hi - lo] = m.data[lo:hi]
+    ent = np.empty(cptr[-1] * 16, dtype=np.uint64)
+    ent[:] = col.astype(np.uint64) | (val.view(np.uint32).astype(np.uint64) << np.uint64(32))
+    return cptr, ent
+
+
+def _heavy_rows_csr(n, d, dens, rng, bursts=True):
+    m = sp.random(n, d, density=dens, format="lil", random_state=rng, dtype=np.float32)
+    if bursts and n > 8 and d > 40:
+        w = min(d, 700)
+        m[1, :w] = rng.standard_normal(w).astype(np.float32)           # > 32 entries per slab: overflow passes
+        m[5, d - min(d, 300):] = 1.5                                      # dense tail incl. the ragged last slab
+        m[n - 1, ::2] = 0.25                                              # every second column of every slab
+        m[2, :] = 0                                                       # empty row
+    m = m.tocsr()
+    m.eliminate_zeros()
+    m.sort_indices()
+    return m.astype(np.float32)
+
+
+def test_pack_layout_bit_exact(hip):
+    rng = np.random.default_rng(11)
+    m = _heavy_rows_csr(203, 1000, 0.03, rng)
+    P = hip.pack(_up(hip, m))
+    cptr, ent = _pack_ref(m)
+    assert np.array_equal(hip.to_host(P.cptr), cptr)
+    got = hip.to_host(P.ent).view(np.uint64)[: ent.size]
+    assert np.array_equal(got, ent)
+
+
+@pytest.mark.parametrize("n,d,dens", [(1, 3, 1.0), (5, 255, 0.3), (64, 256, 0.1), (100, 257, 0.2),
+                                      (513, 700, 0.05), (1000, 5000, 0.03), (3000, 20000, 0.01),
+                                      (4097, 1031, 0.04)])
+def test_spmm_packed_matches_f64_and_csr_kernel(hip, n, d, dens):
+    rng = np.random.default_rng(n * 7 + d)
+    m = _heavy_rows_csr(n, d, dens, rng)
+    Q = rng.standard_normal((d, 64)).astype(np.float32)
+    X = _up(hip, m)
+    Qd = hip.to_device(Q)
+    hip.tune("spmm_k", 0)
+    Y = hip.to_host(hip.spmm(hip.pack(X), Qd))
+    ref = m.astype(np.float64) @ Q.astype(np.float64)
+    scale = np.abs(m).astype(np.float64) @ np.abs(Q).astype(np.float64) + 1e-30
+    assert np.max(np.abs(Y - ref) / scale) < 2e-6  # f32 accumulation
+    assert np.all(Y[np.diff(m.indptr) == 0] == 0)
+    Yc = hip.to_host(hip.spmm(X, Qd))
+    assert np.max(np.abs(Y - Yc) / scale) < 2e-6
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_spmm_packed_every_rowset_count_is_bit_identical(hip, K):
+    """K (row-sets per wave) only changes which wave owns a row: results must not depend on it."""
+    rng = np.random.default_rng(5)
+    m = _heavy_rows_csr(2500, 3000, 0.02, rng)
+    Q = rng.standard_normal((3000, 64)).astype(np.float32)
+    P = hip.pack(_up(hip, m))
+    Qd = hip.to_device(Q)
+    try:
+        hip.tune("spmm_k", K)
+        Y = hip.spmm(P, Qd)
+        Y2 = hip.spmm(P, Qd)
+        hip.tune("spmm_k", 0)
+        Y0 = hip.spmm(P, Qd)
+    finally:
+        hip.tune("spmm_k", 0)
+    assert torch.equal(Y, Y2) and torch.equal(Y, Y0)
+    ref = m.astype(np.float64) @ Q.astype(np.float64)
+    scale = np.abs(m).astype(np.float64) @ np.abs(Q).astype(np.float64) + 1e-30
+    assert np.max(np.abs(hip.to_host(Y) - ref) / scale) < 2e-6
+
+
+def test_spmm_packed_transpose_round_trip_property(hip):
+    """<X q, y> == <q, X^T y> through the two packed operands of the subspace iteration
+    (size-independent adjoint property; planted-topic counts with the real row-length spread)."""
+    m = planted_topics_csr(6000, 9000, n_topics=20, density=0.03, seed=3, dtype=np.float32)
+    X = _up(hip, m)
+    Xt = hip.transpose(X)
+    Xp, Xtp = hip.pack(X), hip.pack(Xt)
+    q = hip.randn(9000, 64, 7)
+    y = hip.randn(6000, 64, 8)
+    lhs = (hip.spmm(Xp, q).double() * y.double()).sum(dim=0)
+    rhs = (q.double() * hip.spmm(Xtp, y).double()).sum(dim=0)
+    assert torch.allclose(lhs, rhs, rtol=1e-5, atol=1e-3 * float(lhs.abs().max()))
