@@ -145,8 +145,10 @@ int mu_csr_pack_fill(int64_t n_rows, const int64_t* d_indptr, const int32_t* d_i
 int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, const void* d_ent,
                        const float* d_Q, int B, float* d_Y, void* stream);
 
-/* Tuning / ablation knobs (tests and bench only; defaults are what ships):
- *   "spmm_k"  rows-sets per wave of the packed SpMM, 1..8 (0 = automatic). */
+/* Tuning / ablation knobs (tests and bench only; all default to 0 = what ships):
+ *   "spmm_k"    row-sets per wave of the packed SpMM, 1..8 (0 = automatic)
+ *   "spmm_fma"  reserved (the v_fmac_f32_dpp formulation measured slower; kept in the source)
+ *   "spmm_mode" timing ablations of the packed SpMM (bit mask; results are then WRONG) */
 int mu_tune_set(const char* key, int value);
 int mu_tune_get(const char* key);
 

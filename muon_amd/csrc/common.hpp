@@ -30,8 +30,6 @@ constexpr int kWave = 64;
 
 // number of CUs of the current device (cached per device id)
 int mu_num_cus();
-// tuning knob "spmm_k" (mu_tune_set); 0 = automatic
-int mu_tune_spmm_k();
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

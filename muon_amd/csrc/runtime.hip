@@ -27,9 +27,9 @@ int mu_num_cus() {
   return cached[dev];
 }
 
-static int g_tune_spmm_k = 0;
-
-int mu_tune_spmm_k() { return g_tune_spmm_k; }
+// tuning / ablation knobs (tests and bench only)
+static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "spmm_fma"};
+static int g_tune[3] = {0, 0, 0};
 
 extern "C" {
 
@@ -37,17 +37,21 @@ int mu_version(void) { return 101; }
 
 int mu_tune_set(const char* key, int value) {
   MU_REQUIRE(key, "null key");
-  if (strcmp(key, "spmm_k") == 0) {
-    MU_REQUIRE(value >= 0 && value <= 8, "spmm_k must be 0..8");
-    g_tune_spmm_k = value;
-    return MU_OK;
-  }
+  for (int i = 0; i < 3; ++i)
+    if (strcmp(key, kTuneKeys[i]) == 0) {
+      MU_REQUIRE(value >= 0, "negative value");
+      MU_REQUIRE(i != 0 || value <= 8, "spmm_k must be 0..8");
+      g_tune[i] = value;
+      return MU_OK;
+    }
   mu_set_error("mu_tune_set: unknown key %s", key);
   return MU_ERR_ARG;
 }
 
 int mu_tune_get(const char* key) {
-  if (key && strcmp(key, "spmm_k") == 0) return g_tune_spmm_k;
+  if (key)
+    for (int i = 0; i < 3; ++i)
+      if (strcmp(key, kTuneKeys[i]) == 0) return g_tune[i];
   return -1;
 }
 

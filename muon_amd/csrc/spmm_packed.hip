@@ -56,7 +56,18 @@ __device__ __forceinline__ float bcast_f(float x) {
 // not use carry a = 0, v = 0 (a broadcast read of slab row 0 and FMAs with zero).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const f32x4* lds_f4p;
+
+// acc += bcast(v, lane E of the row) * q, one v_fmac_f32 with the DPP broadcast folded in
 template <int E>
+__device__ __forceinline__ void fmac_bcast(float& acc, float v, float q) {
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%c3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "+v"(acc)
+      : "v"(v), "v"(q), "i"(E));
+}
+
+// FMA = 0: value broadcast with v_mov_dpp + fmaf (hipcc packs pairs into v_pk_fma_f32);
+// FMA = 1: v_fmac_f32_dpp (no separate broadcast, no packed math).
+template <int E, int FMA>
 __device__ __forceinline__ void lds_quad(unsigned base, int a, float v, float4& acc) {
   const unsigned a0 = (unsigned)bcast_i<E>(a) + base, a1 = (unsigned)bcast_i<E + 1>(a) + base;
   const unsigned a2 = (unsigned)bcast_i<E + 2>(a) + base, a3 = (unsigned)bcast_i<E + 3>(a) + base;
@@ -64,16 +75,27 @@ __device__ __forceinline__ void lds_quad(unsigned base, int a, float v, float4& 
   const f32x4 q1 = *(lds_f4p)(a1);
   const f32x4 q2 = *(lds_f4p)(a2);
   const f32x4 q3 = *(lds_f4p)(a3);
-  const float v0 = bcast_f<E>(v), v1 = bcast_f<E + 1>(v);
-  const float v2 = bcast_f<E + 2>(v), v3 = bcast_f<E + 3>(v);
-  acc.x = fmaf(v0, q0.x, acc.x); acc.y = fmaf(v0, q0.y, acc.y);
-  acc.z = fmaf(v0, q0.z, acc.z); acc.w = fmaf(v0, q0.w, acc.w);
-  acc.x = fmaf(v1, q1.x, acc.x); acc.y = fmaf(v1, q1.y, acc.y);
-  acc.z = fmaf(v1, q1.z, acc.z); acc.w = fmaf(v1, q1.w, acc.w);
-  acc.x = fmaf(v2, q2.x, acc.x); acc.y = fmaf(v2, q2.y, acc.y);
-  acc.z = fmaf(v2, q2.z, acc.z); acc.w = fmaf(v2, q2.w, acc.w);
-  acc.x = fmaf(v3, q3.x, acc.x); acc.y = fmaf(v3, q3.y, acc.y);
-  acc.z = fmaf(v3, q3.z, acc.z); acc.w = fmaf(v3, q3.w, acc.w);
+  if constexpr (FMA == 0) {
+    const float v0 = bcast_f<E>(v), v1 = bcast_f<E + 1>(v);
+    const float v2 = bcast_f<E + 2>(v), v3 = bcast_f<E + 3>(v);
+    acc.x = fmaf(v0, q0.x, acc.x); acc.y = fmaf(v0, q0.y, acc.y);
+    acc.z = fmaf(v0, q0.z, acc.z); acc.w = fmaf(v0, q0.w, acc.w);
+    acc.x = fmaf(v1, q1.x, acc.x); acc.y = fmaf(v1, q1.y, acc.y);
+    acc.z = fmaf(v1, q1.z, acc.z); acc.w = fmaf(v1, q1.w, acc.w);
+    acc.x = fmaf(v2, q2.x, acc.x); acc.y = fmaf(v2, q2.y, acc.y);
+    acc.z = fmaf(v2, q2.z, acc.z); acc.w = fmaf(v2, q2.w, acc.w);
+    acc.x = fmaf(v3, q3.x, acc.x); acc.y = fmaf(v3, q3.y, acc.y);
+    acc.z = fmaf(v3, q3.z, acc.z); acc.w = fmaf(v3, q3.w, acc.w);
+  } else {
+    fmac_bcast<E>(acc.x, v, q0.x); fmac_bcast<E>(acc.y, v, q0.y);
+    fmac_bcast<E>(acc.z, v, q0.z); fmac_bcast<E>(acc.w, v, q0.w);
+    fmac_bcast<E + 1>(acc.x, v, q1.x); fmac_bcast<E + 1>(acc.y, v, q1.y);
+    fmac_bcast<E + 1>(acc.z, v, q1.z); fmac_bcast<E + 1>(acc.w, v, q1.w);
+    fmac_bcast<E + 2>(acc.x, v, q2.x); fmac_bcast<E + 2>(acc.y, v, q2.y);
+    fmac_bcast<E + 2>(acc.z, v, q2.z); fmac_bcast<E + 2>(acc.w, v, q2.w);
+    fmac_bcast<E + 3>(acc.x, v, q3.x); fmac_bcast<E + 3>(acc.y, v, q3.y);
+    fmac_bcast<E + 3>(acc.z, v, q3.z); fmac_bcast<E + 3>(acc.w, v, q3.w);
+  }
 }
 
 // one LDS-DMA piece: 64 lanes x 16 B land contiguously at the wave-uniform LDS byte address
@@ -91,41 +113,54 @@ __device__ __forceinline__ void dma_piece(const float4* gsrc, unsigned lds_dst) 
 }
 
 // The next chunk of every (row-set, group) lives in v[kNx + 2k], v[kNx + 2k + 1] (column, value
-// bits); v[kNx + 16] is a sink.  These registers are written by the asm chunk requests while the
+// bits); v[kNx + 16] is a sink (kNx = 110: v110 .. v126).  These registers are written by the asm chunk requests while the
 // wave keeps running, so they must never be visible to hipcc as values: a compiler-made copy of
 // a register whose load is still in flight reads stale data (it did happen with "+v" operands).
 // The kernel is compiled with amdgpu_num_vgpr(kNx / 2) - on the unified gfx950 register file
 // that caps hipcc's own allocation at v[0 .. kNx-1] - and the asm statements name the registers
 // above literally; the clobber lists make the kernel descriptor allocate them (hipcc warns that
 // they are "reserved", which is the point).
-constexpr int kNx = 104;
+constexpr int kNx = 110;
 #pragma clang diagnostic ignored "-Winline-asm"
 #define MU_NX_CLOBBERS                                                                         \
-  "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114",      \
-      "v115", "v116", "v117", "v118", "v119", "v120"
+  "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",      \
+      "v121", "v122", "v123", "v124", "v125", "v126"
 
-// EXEC-masked chunk request: lanes of `mask` overwrite their pair, the others keep it.  Exactly
-// ONE VMEM instruction is issued with a non-empty EXEC whatever the mask is (an empty mask turns
-// into a one-lane load into the sink), so the counted s_waitcnt never depends on how the
-// hardware treats a VMEM instruction whose EXEC is zero.
-template <int k>
+// EXEC-masked chunk request: lanes of `mask` overwrite their pair, the others keep it.
+// SAFE = true issues exactly ONE VMEM instruction with a non-empty EXEC whatever the mask is (an
+// empty mask turns into a one-lane load into the sink), so the counted s_waitcnt does not depend
+// on how the hardware treats a VMEM instruction whose EXEC is zero.  SAFE = false is the
+// branch-free form; scripts/probes/exec0_vmcnt.hip shows on gfx950 whether such an instruction
+// takes part in the in-order vmcnt accounting (it must, for the counted waits to hold).
+template <int k, bool SAFE>
 __device__ __forceinline__ void request_chunk(unsigned byte_off, const void* base,
                                               unsigned long long mask) {
   unsigned long long save;
-  asm volatile(
-      "s_mov_b64 %0, exec\n\t"
-      "s_and_b64 exec, exec, %3\n\t"
-      "s_cbranch_scc1 1f\n\t"
-      "s_mov_b64 exec, 1\n\t"
-      "global_load_dword v120, %1, %2\n\t"
-      "s_branch 2f\n"
-      "1:\n\t"
-      "global_load_dwordx2 v[%c4:%c5], %1, %2\n"
-      "2:\n\t"
-      "s_mov_b64 exec, %0"
-      : "=&s"(save)
-      : "v"(byte_off), "s"(base), "s"(mask), "i"(kNx + 2 * k), "i"(kNx + 2 * k + 1)
-      : MU_NX_CLOBBERS);
+  if constexpr (SAFE) {
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "s_and_b64 exec, exec, %3\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "global_load_dword v126, %1, %2\n\t"
+        "s_branch 2f\n"
+        "1:\n\t"
+        "global_load_dwordx2 v[%c4:%c5], %1, %2\n"
+        "2:\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(save)
+        : "v"(byte_off), "s"(base), "s"(mask), "i"(kNx + 2 * k), "i"(kNx + 2 * k + 1)
+        : MU_NX_CLOBBERS);
+  } else {
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "s_and_b64 exec, exec, %3\n\t"
+        "global_load_dwordx2 v[%c4:%c5], %1, %2\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(save)
+        : "v"(byte_off), "s"(base), "s"(mask), "i"(kNx + 2 * k), "i"(kNx + 2 * k + 1)
+        : MU_NX_CLOBBERS);
+  }
 }
 
 // wait until at most N VMEM operations are outstanding, then read the next chunk of row-set k
@@ -156,10 +191,16 @@ struct RowState {
   int lastv;  // lane 16 g + k: the row's closing (all padding) chunk
 };
 
-template <int K>
+// MODE is 0 in production; the other bits switch parts of the kernel off for timing ablations
+// (results are then wrong on purpose): 1 no LDS gathers / FMAs, 2 no slab DMA, 4 no slab barrier,
+// 8 no chunk requests (and no overflow passes), 16 no window rotation, 32 no wait for the chunk,
+// 64 branch-free chunk request (see request_chunk).
+template <int K, int MODE>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_vgpr(kNx / 2))) void k_spmm_pcr64(
     int64_t n_rows, int64_t n_cols, const int64_t* __restrict__ cptr,
     const unsigned long long* __restrict__ ent, const float* __restrict__ Q, float* __restrict__ Y) {
+  constexpr int mode = MODE;
+  constexpr int FMA = 0;
   __shared__ float4 qs[2][kSlabCols * 16];  // 2 x 64 KiB; Q row c of a slab at [16 c .. 16 c + 15]
   const int lane = threadIdx.x & 63;
   const int wave = uniform32(threadIdx.x >> 6);
@@ -224,7 +265,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_vgpr(kNx / 2)))
 
   int buf = 0;
   for (int64_t s0 = 0; s0 < n_cols; s0 += kSlabCols, buf ^= 1) {
-    if ((s0 + kSlabCols) < n_cols) slab_dma(s0 + kSlabCols, buf ^ 1);  // lands while this slab is consumed
+    if ((s0 + kSlabCols) < n_cols && !(mode & 2)) slab_dma(s0 + kSlabCols, buf ^ 1);  // lands while this slab is consumed
     const int s_lo = (int)s0;
     const int s_hi = (s_lo + kSlabCols) < ncols32 ? (s_lo + kSlabCols) : ncols32;
     const unsigned qbase = qs_lds + (unsigned)buf * (kSlabCols * 256u) + (unsigned)sub16;
@@ -235,14 +276,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_vgpr(kNx / 2)))
 #define MU_PASS(k, SLOW)                                                                      \
   {                                                                                           \
     int ncol, nval;                                                                           \
-    if (SLOW) wait_next_chunk<k, 0>(ncol, nval); else wait_next_chunk<k, K - 1>(ncol, nval);  \
+    if (SLOW) wait_next_chunk<k, 0>(ncol, nval);                                              \
+    else if (mode & 32) wait_next_chunk<k, 63>(ncol, nval);                                   \
+    else wait_next_chunk<k, K - 1>(ncol, nval);                                               \
     const int p = bcast_i<k>(st.posv);                                                        \
     const bool from_cur = sub >= p;                                                           \
     const int mc = from_cur ? cc[k] : ncol;                                                   \
     const int mv = from_cur ? cv[k] : nval;                                                   \
     const int src = rot_base + (((sub + p) & 15) << 2);                                       \
-    const int wc = __builtin_amdgcn_ds_bpermute(src, mc);                                     \
-    const int wv = __builtin_amdgcn_ds_bpermute(src, mv);                                     \
+    const int wc = (mode & 16) ? mc : __builtin_amdgcn_ds_bpermute(src, mc);                  \
+    const int wv = (mode & 16) ? mv : __builtin_amdgcn_ds_bpermute(src, mv);                  \
     const bool valid = wc < s_hi; /* sorted rows: the slab's entries are a prefix */          \
     const unsigned long long m = __ballot(valid);                                             \
     const int cnt = __popc((unsigned)(m >> (16 * g)) & 0xffffu);                              \
@@ -252,20 +295,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_vgpr(kNx / 2)))
     const float vv = valid ? __builtin_bit_cast(float, wv) : 0.f;                             \
     const int np = p + cnt;                                                                   \
     const bool shift = np >= 16;                                                              \
-    const unsigned long long smask = __ballot(shift);                                         \
+    const unsigned long long smask = (mode & 8) ? 0ull : __ballot(shift);                     \
     cc[k] = shift ? ncol : cc[k];                                                             \
     cv[k] = shift ? nval : cv[k];                                                             \
     const int cid = bcast_i<k>(st.cidv);                                                      \
-    request_chunk<k>(((unsigned)cid << 7) | ((unsigned)sub << 3), entb, smask);               \
+    request_chunk<k, !(MODE & 64)>(((unsigned)cid << 7) | ((unsigned)sub << 3), entb, smask); \
     if (sub == k) {                                                                           \
       st.posv = np & 15;                                                                      \
       st.cidv = shift ? (st.cidv < st.lastv ? st.cidv + 1 : st.lastv) : st.cidv;              \
     }                                                                                         \
-    lds_quad<0>(qbase, a, vv, acc[k]);                                                \
-    if (any16 & 0x00f0u) lds_quad<4>(qbase, a, vv, acc[k]);                           \
-    if (any16 & 0x0f00u) lds_quad<8>(qbase, a, vv, acc[k]);                           \
-    if (any16 & 0xf000u) lds_quad<12>(qbase, a, vv, acc[k]);                          \
-    if (__ballot(cnt == 16)) again |= 1u << k; /* window used up: maybe more in this slab */  \
+    if (!(mode & 1)) {                                                                        \
+      lds_quad<0, FMA>(qbase, a, vv, acc[k]);                                                 \
+      if (any16 & 0x00f0u) lds_quad<4, FMA>(qbase, a, vv, acc[k]);                            \
+      if (any16 & 0x0f00u) lds_quad<8, FMA>(qbase, a, vv, acc[k]);                            \
+      if (any16 & 0xf000u) lds_quad<12, FMA>(qbase, a, vv, acc[k]);                           \
+    } else {                                                                                  \
+      acc[k].x += vv + (float)a;                                                              \
+    }                                                                                         \
+    if (__ballot(cnt == 16) && !(mode & 8)) again |= 1u << k; /* window used up: maybe more */ \
   }
 #define MU_MAIN(k) if constexpr (k < K) MU_PASS(k, false)
     MU_MAIN(0) MU_MAIN(1) MU_MAIN(2) MU_MAIN(3) MU_MAIN(4) MU_MAIN(5) MU_MAIN(6) MU_MAIN(7)
@@ -286,7 +333,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_vgpr(kNx / 2)))
     // The DMA pieces of the next slab were issued before this slab's >= K requests: allowing K
     // outstanding VMEM operations proves they landed without draining the requests.
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(K) : "memory");
-    __syncthreads();  // next slab visible; everyone finished reading this one
+    if (!(mode & 4)) __syncthreads();  // next slab visible; everyone finished reading this one
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // requests still in flight target v[kNx ..]
 #pragma unroll
@@ -326,12 +373,32 @@ __global__ __launch_bounds__(256) void k_pack_fill(int64_t n_rows, const int64_t
   }
 }
 
+// ablation instances exist for the two K the bench shapes use; everything else runs MODE 0
 template <int K>
 int launch_pcr(int64_t n_rows, int64_t n_cols, const int64_t* cptr, const unsigned long long* ent,
                const float* Q, float* Y, hipStream_t st) {
   const int64_t wgs = (n_rows + 64 * K - 1) / (64 * K);
-  hipLaunchKernelGGL(k_spmm_pcr64<K>, dim3((unsigned)wgs), dim3(kThreads), 0, st, n_rows, n_cols, cptr,
-                     ent, Q, Y);
+  const int mode = mu_tune_get("spmm_mode");
+#define MU_LAUNCH(M)                                                                             \
+  hipLaunchKernelGGL((k_spmm_pcr64<K, M>), dim3((unsigned)wgs), dim3(kThreads), 0, st, n_rows, n_cols, \
+                     cptr, ent, Q, Y)
+  if constexpr (K >= 7) {
+    switch (mode) {
+      case 0: MU_LAUNCH(0); break;
+      case 1: MU_LAUNCH(1); break;
+      case 3: MU_LAUNCH(3); break;
+      case 9: MU_LAUNCH(9); break;
+      case 11: MU_LAUNCH(11); break;
+      case 27: MU_LAUNCH(27); break;
+      case 64: MU_LAUNCH(64); break;
+      case 65: MU_LAUNCH(65); break;
+      default: mu_set_error("spmm_mode %d has no compiled instance", mode); return MU_ERR_ARG;
+    }
+  } else {
+    MU_REQUIRE(mode == 0, "ablation modes exist for K = 7, 8 only");
+    MU_LAUNCH(0);
+  }
+#undef MU_LAUNCH
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
@@ -378,7 +445,7 @@ int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, co
     const int64_t k = (n_rows + 64 * cus * R - 1) / (64 * cus * R);
     if (k <= kKMax) { K = (int)(k < 1 ? 1 : k); break; }
   }
-  const int force_k = mu_tune_spmm_k();  // tests / tuning only
+  const int force_k = mu_tune_get("spmm_k");  // tests / tuning only
   if (force_k >= 1 && force_k <= kKMax) K = force_k;
   hipStream_t st = (hipStream_t)stream;
   const unsigned long long* ent = (const unsigned long long*)d_ent;
