@@ -139,6 +139,21 @@ int mu_spmm_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const i
 int mu_csr_pack_count(int64_t n_rows, const int64_t* d_indptr, int64_t* d_row_chunks, void* stream);
 int mu_csr_pack_fill(int64_t n_rows, const int64_t* d_indptr, const int32_t* d_indices,
                      const float* d_values, const int64_t* d_cptr, void* d_ent, void* stream);
+/* The packed copy of X^T (n_cols rows, cell ids ascending inside every row) straight from the CSR
+ * of X - what Z = X^T Y of the iteration streams; no CSR of X^T is materialised.
+ *   1. mu_csr_tpack_count: row_chunks[c] = ceil(nnz of column c / 16) + 1 (and keeps its
+ *      per-workgroup column offsets in d_work)
+ *   2. caller scans row_chunks into cptr int64[n_cols + 1] and allocates ent (128 B x cptr[n_cols])
+ *   3. mu_csr_tpack_fill with the SAME d_work
+ * Stable and free of global atomics => bit-reproducible.  n_rows < ~1.04e6 (32-bit slab cursors). */
+size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols);
+int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                       const int32_t* d_indices, int64_t* d_row_chunks, void* d_work,
+                       size_t work_bytes, void* stream);
+int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                      const int32_t* d_indices, const float* d_values, const int64_t* d_cptr,
+                      void* d_ent, void* d_work, size_t work_bytes, void* stream);
+
 /* Y[n_rows x 64] = X * Q on the packed copy (B must be 64, n_cols <= 2^22).  Same result as
  * mu_spmm_f32 up to f32 summation order (entries of a row are accumulated in column order,
  * fmaf chain per dense column; bit-reproducible run to run). */
@@ -146,9 +161,10 @@ int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, co
                        const float* d_Q, int B, float* d_Y, void* stream);
 
 /* Tuning / ablation knobs (tests and bench only; all default to 0 = what ships):
- *   "spmm_k"    row-sets per wave of the packed SpMM, 1..8 (0 = automatic)
- *   "spmm_fma"  reserved (the v_fmac_f32_dpp formulation measured slower; kept in the source)
- *   "spmm_mode" timing ablations of the packed SpMM (bit mask; results are then WRONG) */
+ *   "spmm_k"     row-sets per wave of the packed SpMM (0 = automatic)
+ *   "spmm_waves" waves per workgroup of the packed SpMM: 16 (default), 12, 8
+ *   "spmm_pipe"  software pipelining level of the packed SpMM
+ *   "spmm_mode"  timing ablations of the packed SpMM (bit mask; results are then WRONG) */
 int mu_tune_set(const char* key, int value);
 int mu_tune_get(const char* key);
 

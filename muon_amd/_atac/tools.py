@@ -104,16 +104,16 @@ def lsi_device(
     w = min(B, min(n_obs, d))
     if X.values.dtype != torch.float32:
         X = X.with_values(X.values.to(torch.float32))
-    if Xt is None:
-        Xt = backend.transpose(X)
     # B = 64: both operands of the iteration are streamed from their packed chunked-row copies
-    # (DESIGN.md §4); the CSR of X^T is only needed to build its copy.
+    # (DESIGN.md §4); X^T's is built straight from the CSR of X, no CSR of X^T in between.
     if pack is None:
-        pack = (hasattr(backend, "can_pack") and backend.can_pack(X, B)
-                and backend.can_pack(Xt, B))
+        pack = (Xt is None and hasattr(backend, "can_pack") and backend.can_pack(X, B)
+                and 0 < n_local <= (1 << 20))
     if pack:
-        Xt = backend.pack(Xt)
+        Xt = backend.transpose_pack(X)
         X = backend.pack(X)
+    elif Xt is None:
+        Xt = backend.transpose(X)
 
     Q = backend.randn(d, B, seed)
     if w < B:

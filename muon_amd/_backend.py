@@ -194,6 +194,25 @@ class HipBackend:
                                             _p(ent), st))
         return DevicePackedCSR(cptr, ent, (n, d), X.nnz)
 
+    def transpose_pack(self, X: DeviceCSR) -> DevicePackedCSR:
+        """Packed chunked-row copy of X^T straight from the CSR of X (no CSR of X^T)."""
+        n, d = X.shape
+        assert X.values.dtype == torch.float32
+        row_chunks = self.empty((max(d, 1),), torch.int64)
+        cptr = self.zeros((d + 1,), torch.int64)
+        wb = int(self.lib.mu_csr_tpack_worksize(n, d))
+        work = self.empty((wb,), torch.uint8)
+        with torch.cuda.device(self.device):
+            st = self._stream()
+            check(self.lib.mu_csr_tpack_count(n, d, _p(X.indptr), _p(X.indices), _p(row_chunks),
+                                              _p(work), wb, st))
+            check(self.lib.mu_exclusive_scan_i64(d, _p(row_chunks), _p(cptr), st))
+            n_chunks = int(cptr[-1].item()) if d > 0 else 0
+            ent = self.empty((max(n_chunks, 1) * 128,), torch.uint8)
+            check(self.lib.mu_csr_tpack_fill(n, d, _p(X.indptr), _p(X.indices), _p(X.values),
+                                             _p(cptr), _p(ent), _p(work), wb, st))
+        return DevicePackedCSR(cptr, ent, (d, n), X.nnz)
+
     def tune(self, key: str, value: int) -> None:
         check(self.lib.mu_tune_set(key.encode(), int(value)))
 

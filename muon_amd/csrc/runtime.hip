@@ -28,8 +28,9 @@ int mu_num_cus() {
 }
 
 // tuning / ablation knobs (tests and bench only)
-static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "spmm_fma"};
-static int g_tune[3] = {0, 0, 0};
+static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "spmm_waves", "spmm_pipe"};
+constexpr int kTuneN = 4;
+static int g_tune[kTuneN] = {0, 0, 0, 0};
 
 extern "C" {
 
@@ -37,10 +38,10 @@ int mu_version(void) { return 101; }
 
 int mu_tune_set(const char* key, int value) {
   MU_REQUIRE(key, "null key");
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < kTuneN; ++i)
     if (strcmp(key, kTuneKeys[i]) == 0) {
       MU_REQUIRE(value >= 0, "negative value");
-      MU_REQUIRE(i != 0 || value <= 8, "spmm_k must be 0..8");
+      MU_REQUIRE(i != 0 || value <= 16, "spmm_k must be 0..16");
       g_tune[i] = value;
       return MU_OK;
     }
@@ -50,7 +51,7 @@ int mu_tune_set(const char* key, int value) {
 
 int mu_tune_get(const char* key) {
   if (key)
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < kTuneN; ++i)
       if (strcmp(key, kTuneKeys[i]) == 0) return g_tune[i];
   return -1;
 }

@@ -31,16 +31,24 @@
 // it): the LDS-DMA pieces and the chunk requests.  In-order completion makes the counted waits
 // safe however many extra (overflow-pass) requests are interleaved.
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 #include "common.hpp"
 
 namespace {
 
-constexpr int kSlabCols = 256;                   // Q rows per slab: 256 x 256 B = 64 KiB
-constexpr int kThreads = 1024;
-constexpr int kWaves = kThreads / 64;
-constexpr int kKMax = 8;
-constexpr int kDmaPieces = (kSlabCols * 256) / (kWaves * 1024);  // 1 KiB pieces per wave (= 4)
+constexpr int kSlabCols = 256;   // Q rows per slab: 256 x 256 B = 64 KiB, double buffered
+constexpr int kKMaxAny = 16;
 constexpr int kPadCol = 0x7fffffff;
+
+// Geometry per workgroup size.  A workgroup of W waves owns 4*W*K rows; one workgroup per CU (the
+// two slab buffers take 128 KiB of LDS), so W fixes the register budget per lane: 512 / (W / 4).
+// hipcc is capped at v[0 .. NX-1] by amdgpu_num_vgpr(NX / 2) on the kernel wrappers; the asm
+// statements own v[NX .. NX + 2 KMAX] (see below).
+template <int W> struct Geo;
+template <> struct Geo<16> { static constexpr int NX = 110, KMAX = 8; };   // 128 regs: 110 + 17
+template <> struct Geo<12> { static constexpr int NX = 144, KMAX = 11; };  // 168 regs: 144 + 23
+template <> struct Geo<8> { static constexpr int NX = 200, KMAX = 16; };   // 256 regs: 200 + 33
 
 template <int E>
 __device__ __forceinline__ int bcast_i(int x) {
@@ -51,51 +59,37 @@ __device__ __forceinline__ float bcast_f(float x) {
   return __builtin_bit_cast(float, bcast_i<E>(__builtin_bit_cast(int, x)));
 }
 
-// Entries E..E+3 of every group's window: four independent ds_read_b128 per call.  `base` is the
-// LDS byte address of the slab buffer plus this lane's 16-byte column offset; slots a group does
-// not use carry a = 0, v = 0 (a broadcast read of slab row 0 and FMAs with zero).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const f32x4* lds_f4p;
 
-// acc += bcast(v, lane E of the row) * q, one v_fmac_f32 with the DPP broadcast folded in
-template <int E>
-__device__ __forceinline__ void fmac_bcast(float& acc, float v, float q) {
-  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%c3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-      : "+v"(acc)
-      : "v"(v), "v"(q), "i"(E));
-}
+struct Quad { f32x4 q0, q1, q2, q3; };
 
-// FMA = 0: value broadcast with v_mov_dpp + fmaf (hipcc packs pairs into v_pk_fma_f32);
-// FMA = 1: v_fmac_f32_dpp (no separate broadcast, no packed math).
-template <int E, int FMA>
-__device__ __forceinline__ void lds_quad(unsigned base, int a, float v, float4& acc) {
+// Entries E..E+3 of every group's window: four independent ds_read_b128.  `base` is the LDS byte
+// address of the slab buffer plus this lane's 16-byte column offset; slots a group does not use
+// carry a = 0, v = 0 (a broadcast read of slab row 0 and FMAs with zero).
+template <int E>
+__device__ __forceinline__ Quad quad_read(unsigned base, int a) {
   const unsigned a0 = (unsigned)bcast_i<E>(a) + base, a1 = (unsigned)bcast_i<E + 1>(a) + base;
   const unsigned a2 = (unsigned)bcast_i<E + 2>(a) + base, a3 = (unsigned)bcast_i<E + 3>(a) + base;
-  const f32x4 q0 = *(lds_f4p)(a0);
-  const f32x4 q1 = *(lds_f4p)(a1);
-  const f32x4 q2 = *(lds_f4p)(a2);
-  const f32x4 q3 = *(lds_f4p)(a3);
-  if constexpr (FMA == 0) {
-    const float v0 = bcast_f<E>(v), v1 = bcast_f<E + 1>(v);
-    const float v2 = bcast_f<E + 2>(v), v3 = bcast_f<E + 3>(v);
-    acc.x = fmaf(v0, q0.x, acc.x); acc.y = fmaf(v0, q0.y, acc.y);
-    acc.z = fmaf(v0, q0.z, acc.z); acc.w = fmaf(v0, q0.w, acc.w);
-    acc.x = fmaf(v1, q1.x, acc.x); acc.y = fmaf(v1, q1.y, acc.y);
-    acc.z = fmaf(v1, q1.z, acc.z); acc.w = fmaf(v1, q1.w, acc.w);
-    acc.x = fmaf(v2, q2.x, acc.x); acc.y = fmaf(v2, q2.y, acc.y);
-    acc.z = fmaf(v2, q2.z, acc.z); acc.w = fmaf(v2, q2.w, acc.w);
-    acc.x = fmaf(v3, q3.x, acc.x); acc.y = fmaf(v3, q3.y, acc.y);
-    acc.z = fmaf(v3, q3.z, acc.z); acc.w = fmaf(v3, q3.w, acc.w);
-  } else {
-    fmac_bcast<E>(acc.x, v, q0.x); fmac_bcast<E>(acc.y, v, q0.y);
-    fmac_bcast<E>(acc.z, v, q0.z); fmac_bcast<E>(acc.w, v, q0.w);
-    fmac_bcast<E + 1>(acc.x, v, q1.x); fmac_bcast<E + 1>(acc.y, v, q1.y);
-    fmac_bcast<E + 1>(acc.z, v, q1.z); fmac_bcast<E + 1>(acc.w, v, q1.w);
-    fmac_bcast<E + 2>(acc.x, v, q2.x); fmac_bcast<E + 2>(acc.y, v, q2.y);
-    fmac_bcast<E + 2>(acc.z, v, q2.z); fmac_bcast<E + 2>(acc.w, v, q2.w);
-    fmac_bcast<E + 3>(acc.x, v, q3.x); fmac_bcast<E + 3>(acc.y, v, q3.y);
-    fmac_bcast<E + 3>(acc.z, v, q3.z); fmac_bcast<E + 3>(acc.w, v, q3.w);
-  }
+  Quad r;
+  r.q0 = *(lds_f4p)(a0);
+  r.q1 = *(lds_f4p)(a1);
+  r.q2 = *(lds_f4p)(a2);
+  r.q3 = *(lds_f4p)(a3);
+  return r;
+}
+template <int E>
+__device__ __forceinline__ void quad_fma(const Quad& r, float v, float4& acc) {
+  const float v0 = bcast_f<E>(v), v1 = bcast_f<E + 1>(v);
+  const float v2 = bcast_f<E + 2>(v), v3 = bcast_f<E + 3>(v);
+  acc.x = fmaf(v0, r.q0.x, acc.x); acc.y = fmaf(v0, r.q0.y, acc.y);
+  acc.z = fmaf(v0, r.q0.z, acc.z); acc.w = fmaf(v0, r.q0.w, acc.w);
+  acc.x = fmaf(v1, r.q1.x, acc.x); acc.y = fmaf(v1, r.q1.y, acc.y);
+  acc.z = fmaf(v1, r.q1.z, acc.z); acc.w = fmaf(v1, r.q1.w, acc.w);
+  acc.x = fmaf(v2, r.q2.x, acc.x); acc.y = fmaf(v2, r.q2.y, acc.y);
+  acc.z = fmaf(v2, r.q2.z, acc.z); acc.w = fmaf(v2, r.q2.w, acc.w);
+  acc.x = fmaf(v3, r.q3.x, acc.x); acc.y = fmaf(v3, r.q3.y, acc.y);
+  acc.z = fmaf(v3, r.q3.z, acc.z); acc.w = fmaf(v3, r.q3.w, acc.w);
 }
 
 // one LDS-DMA piece: 64 lanes x 16 B land contiguously at the wave-uniform LDS byte address
@@ -112,103 +106,117 @@ __device__ __forceinline__ void dma_piece(const float4* gsrc, unsigned lds_dst) 
       : "memory");
 }
 
-// The next chunk of every (row-set, group) lives in v[kNx + 2k], v[kNx + 2k + 1] (column, value
-// bits); v[kNx + 16] is a sink (kNx = 110: v110 .. v126).  These registers are written by the asm chunk requests while the
-// wave keeps running, so they must never be visible to hipcc as values: a compiler-made copy of
-// a register whose load is still in flight reads stale data (it did happen with "+v" operands).
-// The kernel is compiled with amdgpu_num_vgpr(kNx / 2) - on the unified gfx950 register file
-// that caps hipcc's own allocation at v[0 .. kNx-1] - and the asm statements name the registers
-// above literally; the clobber lists make the kernel descriptor allocate them (hipcc warns that
-// they are "reserved", which is the point).
-constexpr int kNx = 110;
+// The next chunk of every (row-set, group) lives in v[NX + 2k], v[NX + 2k + 1] (column, value
+// bits).  These registers are written by the asm chunk requests while the wave keeps running, so
+// they must never be visible to hipcc as values: a compiler-made copy of a register whose load
+// is still in flight reads stale data (it did happen with "+v" operands).  The kernel wrappers
+// are compiled with amdgpu_num_vgpr(NX / 2) - on the unified gfx950 register file that caps
+// hipcc's own allocation at v[0 .. NX-1] - and the asm statements name the registers above
+// literally; the clobber lists make the kernel descriptor allocate them (hipcc warns that they
+// are "reserved", which is the point).  tests/test_layout.py audits the generated ISA.
 #pragma clang diagnostic ignored "-Winline-asm"
-#define MU_NX_CLOBBERS                                                                         \
-  "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",      \
-      "v121", "v122", "v123", "v124", "v125", "v126"
+#define MU_CLOB_16                                                                                \
+  "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", \
+      "v122", "v123", "v124", "v125", "v126"
+#define MU_CLOB_12                                                                                \
+  "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", \
+      "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166"
+#define MU_CLOB_8                                                                                 \
+  "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", \
+      "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222",     \
+      "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232"
 
-// EXEC-masked chunk request: lanes of `mask` overwrite their pair, the others keep it.
-// SAFE = true issues exactly ONE VMEM instruction with a non-empty EXEC whatever the mask is (an
-// empty mask turns into a one-lane load into the sink), so the counted s_waitcnt does not depend
-// on how the hardware treats a VMEM instruction whose EXEC is zero.  SAFE = false is the
-// branch-free form; scripts/probes/exec0_vmcnt.hip shows on gfx950 whether such an instruction
-// takes part in the in-order vmcnt accounting (it must, for the counted waits to hold).
-template <int k, bool SAFE>
+// EXEC-masked chunk request: lanes of `mask` overwrite their pair, the others keep it.  Always
+// exactly one VMEM instruction, also when the mask is empty: on gfx950 a VMEM instruction issued
+// with EXEC = 0 still takes part in the in-order vmcnt accounting (scripts/probes/
+// exec0_vmcnt.hip: 524288/524288 lanes read the loaded value behind eight such loads and
+// vmcnt(8), 0/524288 in the control arm), which is what the counted waits below rely on.
+#define MU_REQUEST_ASM(CLOB)                                                          \
+  asm volatile(                                                                       \
+      "s_mov_b64 %0, exec\n\t"                                                        \
+      "s_and_b64 exec, exec, %3\n\t"                                                  \
+      "global_load_dwordx2 v[%c4:%c5], %1, %2\n\t"                                    \
+      "s_mov_b64 exec, %0"                                                            \
+      : "=&s"(save)                                                                   \
+      : "v"(byte_off), "s"(base), "s"(mask), "i"(NX + 2 * k), "i"(NX + 2 * k + 1)     \
+      : CLOB)
+template <int W, int k>
 __device__ __forceinline__ void request_chunk(unsigned byte_off, const void* base,
                                               unsigned long long mask) {
+  constexpr int NX = Geo<W>::NX;
   unsigned long long save;
-  if constexpr (SAFE) {
-    asm volatile(
-        "s_mov_b64 %0, exec\n\t"
-        "s_and_b64 exec, exec, %3\n\t"
-        "s_cbranch_scc1 1f\n\t"
-        "s_mov_b64 exec, 1\n\t"
-        "global_load_dword v126, %1, %2\n\t"
-        "s_branch 2f\n"
-        "1:\n\t"
-        "global_load_dwordx2 v[%c4:%c5], %1, %2\n"
-        "2:\n\t"
-        "s_mov_b64 exec, %0"
-        : "=&s"(save)
-        : "v"(byte_off), "s"(base), "s"(mask), "i"(kNx + 2 * k), "i"(kNx + 2 * k + 1)
-        : MU_NX_CLOBBERS);
-  } else {
-    asm volatile(
-        "s_mov_b64 %0, exec\n\t"
-        "s_and_b64 exec, exec, %3\n\t"
-        "global_load_dwordx2 v[%c4:%c5], %1, %2\n\t"
-        "s_mov_b64 exec, %0"
-        : "=&s"(save)
-        : "v"(byte_off), "s"(base), "s"(mask), "i"(kNx + 2 * k), "i"(kNx + 2 * k + 1)
-        : MU_NX_CLOBBERS);
-  }
+  if constexpr (W == 16) MU_REQUEST_ASM(MU_CLOB_16);
+  else if constexpr (W == 12) MU_REQUEST_ASM(MU_CLOB_12);
+  else MU_REQUEST_ASM(MU_CLOB_8);
 }
 
 // wait until at most N VMEM operations are outstanding, then read the next chunk of row-set k
-template <int k, int N>
+#define MU_WAIT_ASM(CLOB)                                                  \
+  asm volatile(                                                            \
+      "s_waitcnt vmcnt(%c2)\n\t"                                           \
+      "v_mov_b32 %0, v%c3\n\t"                                             \
+      "v_mov_b32 %1, v%c4"                                                 \
+      : "=v"(col), "=v"(valbits)                                           \
+      : "i"(N), "i"(NX + 2 * k), "i"(NX + 2 * k + 1)                       \
+      : CLOB)
+template <int W, int k, int N>
 __device__ __forceinline__ void wait_next_chunk(int& col, int& valbits) {
-  asm volatile(
-      "s_waitcnt vmcnt(%c2)\n\t"
-      "v_mov_b32 %0, v%c3\n\t"
-      "v_mov_b32 %1, v%c4"
-      : "=v"(col), "=v"(valbits)
-      : "i"(N), "i"(kNx + 2 * k), "i"(kNx + 2 * k + 1)
-      : MU_NX_CLOBBERS);
+  constexpr int NX = Geo<W>::NX;
+  if constexpr (W == 16) MU_WAIT_ASM(MU_CLOB_16);
+  else if constexpr (W == 12) MU_WAIT_ASM(MU_CLOB_12);
+  else MU_WAIT_ASM(MU_CLOB_8);
 }
 
-template <int k>
+#define MU_SET_ASM(CLOB)                                                   \
+  asm volatile(                                                            \
+      "v_mov_b32 v%c2, %0\n\t"                                             \
+      "v_mov_b32 v%c3, %1"                                                 \
+      :                                                                    \
+      : "v"(col), "v"(valbits), "i"(NX + 2 * k), "i"(NX + 2 * k + 1)       \
+      : CLOB)
+template <int W, int k>
 __device__ __forceinline__ void set_next_chunk(int col, int valbits) {
-  asm volatile(
-      "v_mov_b32 v%c2, %0\n\t"
-      "v_mov_b32 v%c3, %1"
-      :
-      : "v"(col), "v"(valbits), "i"(kNx + 2 * k), "i"(kNx + 2 * k + 1)
-      : MU_NX_CLOBBERS);
+  constexpr int NX = Geo<W>::NX;
+  if constexpr (W == 16) MU_SET_ASM(MU_CLOB_16);
+  else if constexpr (W == 12) MU_SET_ASM(MU_CLOB_12);
+  else MU_SET_ASM(MU_CLOB_8);
 }
 
-struct RowState {
-  int posv;   // lane 16 g + k: consumed entries of the current chunk of (row-set k, group g)
-  int cidv;   // lane 16 g + k: chunk to request next (relative to the workgroup's first chunk)
-  int lastv;  // lane 16 g + k: the row's closing (all padding) chunk
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+struct Win {      // what stage A of a pass hands to stage B
+  int a;          // lane e of a group: LDS byte offset (inside the slab) of window entry e, 0 if unused
+  float vv;       // lane e: value of window entry e, 0 if unused
+  unsigned any16; // bit e: some group of the wave uses window entry e
 };
 
 // MODE is 0 in production; the other bits switch parts of the kernel off for timing ablations
-// (results are then wrong on purpose): 1 no LDS gathers / FMAs, 2 no slab DMA, 4 no slab barrier,
-// 8 no chunk requests (and no overflow passes), 16 no window rotation, 32 no wait for the chunk,
-// 64 branch-free chunk request (see request_chunk).
-template <int K, int MODE>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_vgpr(kNx / 2))) void k_spmm_pcr64(
-    int64_t n_rows, int64_t n_cols, const int64_t* __restrict__ cptr,
-    const unsigned long long* __restrict__ ent, const float* __restrict__ Q, float* __restrict__ Y) {
-  constexpr int mode = MODE;
-  constexpr int FMA = 0;
+// (results are then wrong on purpose): 1 no LDS gathers / FMAs, 2 no slab DMA, 8 no chunk
+// requests (and no overflow passes), 16 no window rotation.
+// PIPE: 0 = stage A(k) then B(k); 1 = A(k+1) is issued before B(k); 2 = additionally two quads of
+// LDS reads in flight inside B (needs ~28 more registers: W <= 12).
+template <int W, int K, int MODE, int PIPE>
+__device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
+                                                const int64_t* __restrict__ cptr,
+                                                const unsigned long long* __restrict__ ent,
+                                                const float* __restrict__ Q, float* __restrict__ Y) {
+  static_assert(K >= 1 && K <= Geo<W>::KMAX && K <= 16, "K out of range for this workgroup size");
+  constexpr int kPieces = (kSlabCols * 256) / 1024;  // 1 KiB LDS-DMA pieces per slab (= 64)
   __shared__ float4 qs[2][kSlabCols * 16];  // 2 x 64 KiB; Q row c of a slab at [16 c .. 16 c + 15]
   const int lane = threadIdx.x & 63;
   const int wave = uniform32(threadIdx.x >> 6);
   const int sub = lane & 15, g = lane >> 4;
   const int sub16 = sub * 16;
   const int rot_base = (lane & 48) << 2;  // ds_bpermute byte address of the group's lane 0
-  const int64_t rb0 = (int64_t)blockIdx.x * (64 * K);
-  const int64_t rb1 = (rb0 + 64 * K) < n_rows ? (rb0 + 64 * K) : n_rows;
+  const int64_t rb0 = (int64_t)blockIdx.x * (4 * W * K);
+  const int64_t rb1 = (rb0 + 4 * W * K) < n_rows ? (rb0 + 4 * W * K) : n_rows;
   const int64_t cbase = uniform64(cptr[rb0]);
   const unsigned long long* __restrict__ entb = ent + cbase * 16;  // wave-uniform
   const float4* __restrict__ Q4 = reinterpret_cast<const float4*>(Q);
@@ -217,130 +225,185 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_vgpr(kNx / 2)))
   const unsigned qs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&qs[0][0]);
 
   float4 acc[K];
-  int cc[K], cv[K];            // current chunk: column / value bits of entry `sub`
-  RowState st;                 // (the next chunk lives in v[kNx + 2k .. +1], see above)
-  int hasv;                    // lane 16 g + k: row exists
+  int cc[K], cv[K];  // current chunk: column / value bits of entry `sub`
+  int posv;          // lane 16 g + k: consumed entries of the current chunk of (row-set k, group g)
+  int cidv;          // lane 16 g + k: chunk to request next (relative to the workgroup's first chunk)
+  int lastv;         // lane 16 g + k: the row's closing (all padding) chunk
+  int hasv;          // lane 16 g + k: first chunk of the row, -1 if there is no such row
   {
     const int64_t row = rb0 + ((int64_t)wave * K + sub) * 4 + g;
     const bool ok = (sub < K) && (row < rb1);
     const int c0 = ok ? (int)(cptr[row] - cbase) : 0;
     const int c1 = ok ? (int)(cptr[row + 1] - cbase) : 1;
-    st.posv = 0;
-    st.lastv = c1 - 1;
-    st.cidv = (c0 + 2) < (c1 - 1) ? (c0 + 2) : (c1 - 1);
+    posv = 0;
+    lastv = c1 - 1;
+    cidv = (c0 + 2) < (c1 - 1) ? (c0 + 2) : (c1 - 1);
     hasv = ok ? c0 : -1;
   }
-#pragma unroll
-  for (int k = 0; k < K; ++k) acc[k] = float4{0.f, 0.f, 0.f, 0.f};
-
   // prologue: chunk 0 and chunk min(1, last) of every row (plain loads, hipcc waits for them)
-#define MU_INIT(k)                                                                     \
-  if constexpr (k < K) {                                                               \
-    const int c0_ = bcast_i<k>(hasv);                                                  \
-    const int l_ = bcast_i<k>(st.lastv);                                               \
-    const bool has_ = c0_ >= 0;                                                        \
-    const int a_ = has_ ? c0_ : 0;                                                     \
-    const int b_ = has_ ? ((c0_ + 1) < l_ ? (c0_ + 1) : l_) : 0;                       \
-    const unsigned long long e0_ = entb[(int64_t)a_ * 16 + sub];                       \
-    const unsigned long long e1_ = entb[(int64_t)b_ * 16 + sub];                       \
-    cc[k] = has_ ? (int)(unsigned)e0_ : kPadCol;                                       \
-    cv[k] = (int)(unsigned)(e0_ >> 32);                                                \
-    set_next_chunk<k>(has_ ? (int)(unsigned)e1_ : kPadCol, (int)(unsigned)(e1_ >> 32)); \
-  }
-  MU_INIT(0) MU_INIT(1) MU_INIT(2) MU_INIT(3) MU_INIT(4) MU_INIT(5) MU_INIT(6) MU_INIT(7)
-#undef MU_INIT
+  static_for<K>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    acc[k] = float4{0.f, 0.f, 0.f, 0.f};
+    const int c0 = bcast_i<k>(hasv);
+    const int l = bcast_i<k>(lastv);
+    const bool has = c0 >= 0;
+    const int a = has ? c0 : 0;
+    const int b = has ? ((c0 + 1) < l ? (c0 + 1) : l) : 0;
+    const unsigned long long e0 = entb[(int64_t)a * 16 + sub];
+    const unsigned long long e1 = entb[(int64_t)b * 16 + sub];
+    cc[k] = has ? (int)(unsigned)e0 : kPadCol;
+    cv[k] = (int)(unsigned)(e0 >> 32);
+    set_next_chunk<W, k>(has ? (int)(unsigned)e1 : kPadCol, (int)(unsigned)(e1 >> 32));
+  });
 
   auto slab_dma = [&](int64_t s0, int buf) {
-#pragma unroll
-    for (int u = 0; u < kDmaPieces; ++u) {
-      const int piece = wave * kDmaPieces + u;       // 1 KiB piece of the 64 KiB slab
-      int64_t i = s0 * 16 + piece * 64 + lane;       // float4 index into Q
-      if (i >= q4_total) i = q4_total - 1;           // tail slab: clamp (never consumed)
+    for (int piece = wave; piece < kPieces; piece += W) {  // 1 KiB pieces of the 64 KiB slab
+      int64_t i = s0 * 16 + piece * 64 + lane;             // float4 index into Q
+      if (i >= q4_total) i = q4_total - 1;                 // tail slab: clamp (never consumed)
       dma_piece(Q4 + i, qs_lds + (unsigned)buf * (kSlabCols * 256u) + (unsigned)piece * 1024u);
     }
   };
+  constexpr int kMyPiecesMax = (kPieces + W - 1) / W;  // DMA pieces one wave issues per slab
   slab_dma(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   int buf = 0;
   for (int64_t s0 = 0; s0 < n_cols; s0 += kSlabCols, buf ^= 1) {
-    if ((s0 + kSlabCols) < n_cols && !(mode & 2)) slab_dma(s0 + kSlabCols, buf ^ 1);  // lands while this slab is consumed
+    if ((s0 + kSlabCols) < n_cols && !(MODE & 2)) slab_dma(s0 + kSlabCols, buf ^ 1);  // lands while this slab is consumed
     const int s_lo = (int)s0;
     const int s_hi = (s_lo + kSlabCols) < ncols32 ? (s_lo + kSlabCols) : ncols32;
     const unsigned qbase = qs_lds + (unsigned)buf * (kSlabCols * 256u) + (unsigned)sub16;
     unsigned again = 0;
 
-    // SLOW = overflow pass (a row had more than 16 entries in this slab): its request was issued
-    // just now, so drain everything; the main pass only needs the request of the previous slab.
-#define MU_PASS(k, SLOW)                                                                      \
-  {                                                                                           \
-    int ncol, nval;                                                                           \
-    if (SLOW) wait_next_chunk<k, 0>(ncol, nval);                                              \
-    else if (mode & 32) wait_next_chunk<k, 63>(ncol, nval);                                   \
-    else wait_next_chunk<k, K - 1>(ncol, nval);                                               \
-    const int p = bcast_i<k>(st.posv);                                                        \
-    const bool from_cur = sub >= p;                                                           \
-    const int mc = from_cur ? cc[k] : ncol;                                                   \
-    const int mv = from_cur ? cv[k] : nval;                                                   \
-    const int src = rot_base + (((sub + p) & 15) << 2);                                       \
-    const int wc = (mode & 16) ? mc : __builtin_amdgcn_ds_bpermute(src, mc);                  \
-    const int wv = (mode & 16) ? mv : __builtin_amdgcn_ds_bpermute(src, mv);                  \
-    const bool valid = wc < s_hi; /* sorted rows: the slab's entries are a prefix */          \
-    const unsigned long long m = __ballot(valid);                                             \
-    const int cnt = __popc((unsigned)(m >> (16 * g)) & 0xffffu);                              \
-    const unsigned mm = (unsigned)m | (unsigned)(m >> 32);                                    \
-    const unsigned any16 = (mm | (mm >> 16)) & 0xffffu; /* bit e: some group has entry e */   \
-    const int a = valid ? ((wc - s_lo) << 8) : 0;                                             \
-    const float vv = valid ? __builtin_bit_cast(float, wv) : 0.f;                             \
-    const int np = p + cnt;                                                                   \
-    const bool shift = np >= 16;                                                              \
-    const unsigned long long smask = (mode & 8) ? 0ull : __ballot(shift);                     \
-    cc[k] = shift ? ncol : cc[k];                                                             \
-    cv[k] = shift ? nval : cv[k];                                                             \
-    const int cid = bcast_i<k>(st.cidv);                                                      \
-    request_chunk<k, !(MODE & 64)>(((unsigned)cid << 7) | ((unsigned)sub << 3), entb, smask); \
-    if (sub == k) {                                                                           \
-      st.posv = np & 15;                                                                      \
-      st.cidv = shift ? (st.cidv < st.lastv ? st.cidv + 1 : st.lastv) : st.cidv;              \
-    }                                                                                         \
-    if (!(mode & 1)) {                                                                        \
-      lds_quad<0, FMA>(qbase, a, vv, acc[k]);                                                 \
-      if (any16 & 0x00f0u) lds_quad<4, FMA>(qbase, a, vv, acc[k]);                            \
-      if (any16 & 0x0f00u) lds_quad<8, FMA>(qbase, a, vv, acc[k]);                            \
-      if (any16 & 0xf000u) lds_quad<12, FMA>(qbase, a, vv, acc[k]);                           \
-    } else {                                                                                  \
-      acc[k].x += vv + (float)a;                                                              \
-    }                                                                                         \
-    if (__ballot(cnt == 16) && !(mode & 8)) again |= 1u << k; /* window used up: maybe more */ \
-  }
-#define MU_MAIN(k) if constexpr (k < K) MU_PASS(k, false)
-    MU_MAIN(0) MU_MAIN(1) MU_MAIN(2) MU_MAIN(3) MU_MAIN(4) MU_MAIN(5) MU_MAIN(6) MU_MAIN(7)
-#undef MU_MAIN
+    // Stage A of a pass: cut the 16-slot window of (row-set k, every group) out of (current chunk ++
+    // next chunk), find the prefix that belongs to this slab, advance the cursors, request the next
+    // chunk.  SLOW = overflow pass (a row had more than 16 entries in this slab): its request was
+    // issued just now, so drain everything; a main pass only needs the request of the previous slab.
+    auto stage_a = [&](auto kc, auto slowc) -> Win {
+      constexpr int k = decltype(kc)::value;
+      constexpr bool SLOW = decltype(slowc)::value;
+      int ncol, nval;
+      if constexpr (SLOW) wait_next_chunk<W, k, 0>(ncol, nval);
+      else wait_next_chunk<W, k, K - 1>(ncol, nval);
+      const int p = bcast_i<k>(posv);
+      const bool from_cur = sub >= p;
+      const int mc = from_cur ? cc[k] : ncol;
+      const int mv = from_cur ? cv[k] : nval;
+      const int src = rot_base + (((sub + p) & 15) << 2);
+      const int wc = (MODE & 16) ? mc : __builtin_amdgcn_ds_bpermute(src, mc);
+      const int wv = (MODE & 16) ? mv : __builtin_amdgcn_ds_bpermute(src, mv);
+      const bool valid = wc < s_hi;  // sorted rows: the slab's entries are a prefix
+      const unsigned long long m = __ballot(valid);
+      const int cnt = __popc((unsigned)(m >> (16 * g)) & 0xffffu);
+      const unsigned mm = (unsigned)m | (unsigned)(m >> 32);
+      Win w;
+      w.any16 = (mm | (mm >> 16)) & 0xffffu;  // bit e: some group has entry e
+      w.a = valid ? ((wc - s_lo) << 8) : 0;
+      w.vv = valid ? __builtin_bit_cast(float, wv) : 0.f;
+      const int np = p + cnt;
+      const bool shift = np >= 16;
+      const unsigned long long smask = (MODE & 8) ? 0ull : __ballot(shift);
+      cc[k] = shift ? ncol : cc[k];
+      cv[k] = shift ? nval : cv[k];
+      const int cid = bcast_i<k>(cidv);
+      request_chunk<W, k>(((unsigned)cid << 7) | ((unsigned)sub << 3), entb, smask);
+      if (sub == k) {
+        posv = np & 15;
+        cidv = shift ? (cidv < lastv ? cidv + 1 : lastv) : cidv;
+      }
+      if (__ballot(cnt == 16) && !(MODE & 8)) again |= 1u << k;  // window used up: maybe more in this slab
+      return w;
+    };
+    // Stage B: the LDS gathers and FMAs of the window.
+    auto stage_b = [&](auto kc, const Win& w) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (MODE & 1) {
+        acc[k].x += w.vv + (float)w.a;
+      } else if constexpr (PIPE >= 2) {
+        Quad r0 = quad_read<0>(qbase, w.a);
+        Quad r1 = quad_read<4>(qbase, w.a);
+        quad_fma<0>(r0, w.vv, acc[k]);
+        if (w.any16 & 0x0f00u) {
+          r0 = quad_read<8>(qbase, w.a);
+          quad_fma<4>(r1, w.vv, acc[k]);
+          if (w.any16 & 0xf000u) {
+            r1 = quad_read<12>(qbase, w.a);
+            quad_fma<8>(r0, w.vv, acc[k]);
+            quad_fma<12>(r1, w.vv, acc[k]);
+          } else {
+            quad_fma<8>(r0, w.vv, acc[k]);
+          }
+        } else {
+          quad_fma<4>(r1, w.vv, acc[k]);
+        }
+      } else {
+        { const Quad r = quad_read<0>(qbase, w.a); quad_fma<0>(r, w.vv, acc[k]); }
+        if (w.any16 & 0x00f0u) { const Quad r = quad_read<4>(qbase, w.a); quad_fma<4>(r, w.vv, acc[k]); }
+        if (w.any16 & 0x0f00u) { const Quad r = quad_read<8>(qbase, w.a); quad_fma<8>(r, w.vv, acc[k]); }
+        if (w.any16 & 0xf000u) { const Quad r = quad_read<12>(qbase, w.a); quad_fma<12>(r, w.vv, acc[k]); }
+      }
+    };
+
+    if constexpr (PIPE >= 1) {
+      Win w = stage_a(std::integral_constant<int, 0>{}, std::false_type{});
+      static_for<K>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        Win wn = w;
+        if constexpr (k + 1 < K) wn = stage_a(std::integral_constant<int, k + 1>{}, std::false_type{});
+        stage_b(kc, w);
+        w = wn;
+      });
+    } else {
+      static_for<K>([&](auto kc) {
+        const Win w = stage_a(kc, std::false_type{});
+        stage_b(kc, w);
+      });
+    }
     if (again) {
       do {
         const unsigned pend = again;
         again = 0;
-#define MU_OVER(k) if constexpr (k < K) { if (pend & (1u << k)) MU_PASS(k, true) }
-        MU_OVER(0) MU_OVER(1) MU_OVER(2) MU_OVER(3) MU_OVER(4) MU_OVER(5) MU_OVER(6) MU_OVER(7)
-#undef MU_OVER
+        static_for<K>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          if (pend & (1u << k)) {
+            const Win w = stage_a(kc, std::true_type{});
+            stage_b(kc, w);
+          }
+        });
       } while (again);
       // an overflow request of row-set k is younger than the main-pass requests the next slab's
       // vmcnt(K-1) is counted against: drain, so that the count only ever guards main-pass requests
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#undef MU_PASS
-    // The DMA pieces of the next slab were issued before this slab's >= K requests: allowing K
+    // The DMA pieces of the next slab were issued before this slab's K requests: allowing K
     // outstanding VMEM operations proves they landed without draining the requests.
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(K) : "memory");
-    if (!(mode & 4)) __syncthreads();  // next slab visible; everyone finished reading this one
+    __syncthreads();  // next slab visible; everyone finished reading this one
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // requests still in flight target v[kNx ..]
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
+  (void)kMyPiecesMax;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // requests still in flight target v[NX ..]
+  static_for<K>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
     const int64_t row = rb0 + ((int64_t)wave * K + k) * 4 + g;
     if (row < rb1) *reinterpret_cast<float4*>(Y + row * 64 + sub * 4) = acc[k];
-  }
+  });
+}
+
+#define MU_KARGS                                                                          \
+  int64_t n_rows, int64_t n_cols, const int64_t *__restrict__ cptr,                       \
+      const unsigned long long *__restrict__ ent, const float *__restrict__ Q, float *__restrict__ Y
+template <int K, int MODE, int PIPE>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(55))) void k_spmm_pcr64_w16(MU_KARGS) {
+  spmm_pcr64_body<16, K, MODE, PIPE>(n_rows, n_cols, cptr, ent, Q, Y);
+}
+template <int K, int MODE, int PIPE>
+__global__ __launch_bounds__(768) __attribute__((amdgpu_num_vgpr(72))) void k_spmm_pcr64_w12(MU_KARGS) {
+  spmm_pcr64_body<12, K, MODE, PIPE>(n_rows, n_cols, cptr, ent, Q, Y);
+}
+template <int K, int MODE, int PIPE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(100))) void k_spmm_pcr64_w8(MU_KARGS) {
+  spmm_pcr64_body<8, K, MODE, PIPE>(n_rows, n_cols, cptr, ent, Q, Y);
 }
 
 // ---- packing -----------------------------------------------------------------------------
@@ -373,37 +436,29 @@ __global__ __launch_bounds__(256) void k_pack_fill(int64_t n_rows, const int64_t
   }
 }
 
-// ablation instances exist for the two K the bench shapes use; everything else runs MODE 0
-template <int K>
-int launch_pcr(int64_t n_rows, int64_t n_cols, const int64_t* cptr, const unsigned long long* ent,
-               const float* Q, float* Y, hipStream_t st) {
-  const int64_t wgs = (n_rows + 64 * K - 1) / (64 * K);
-  const int mode = mu_tune_get("spmm_mode");
-#define MU_LAUNCH(M)                                                                             \
-  hipLaunchKernelGGL((k_spmm_pcr64<K, M>), dim3((unsigned)wgs), dim3(kThreads), 0, st, n_rows, n_cols, \
-                     cptr, ent, Q, Y)
-  if constexpr (K >= 7) {
-    switch (mode) {
-      case 0: MU_LAUNCH(0); break;
-      case 1: MU_LAUNCH(1); break;
-      case 3: MU_LAUNCH(3); break;
-      case 9: MU_LAUNCH(9); break;
-      case 11: MU_LAUNCH(11); break;
-      case 27: MU_LAUNCH(27); break;
-      case 64: MU_LAUNCH(64); break;
-      case 65: MU_LAUNCH(65); break;
-      default: mu_set_error("spmm_mode %d has no compiled instance", mode); return MU_ERR_ARG;
-    }
-  } else {
-    MU_REQUIRE(mode == 0, "ablation modes exist for K = 7, 8 only");
-    MU_LAUNCH(0);
+// K row-sets per wave: the smallest number of full-chip rounds R whose 4*W*K-row blocks fit the
+// register budget (K <= KMAX); one workgroup per CU (128 KiB of LDS).
+template <int W>
+int pick_k(int64_t n_rows) {
+  const int64_t cus = mu_num_cus();
+  for (int64_t R = 1; R <= 4096; ++R) {
+    const int64_t k = (n_rows + 4 * W * cus * R - 1) / (4 * W * cus * R);
+    if (k <= Geo<W>::KMAX) return (int)(k < 1 ? 1 : k);
   }
-#undef MU_LAUNCH
-  MU_CHECK_LAUNCH();
-  return MU_OK;
+  return Geo<W>::KMAX;
 }
 
+#define MU_GO(KERNEL, W, KK, M, P)                                                              \
+  {                                                                                             \
+    const int64_t wgs = (n_rows + 4 * W * KK - 1) / (4 * W * KK);                               \
+    hipLaunchKernelGGL((KERNEL<KK, M, P>), dim3((unsigned)wgs), dim3(64 * W), 0, st, n_rows, n_cols, \
+                       cptr, ent, Q, Y);                                                        \
+    MU_CHECK_LAUNCH();                                                                          \
+    return MU_OK;                                                                               \
+  }
+
 }  // namespace
+
 
 extern "C" {
 
@@ -437,28 +492,71 @@ int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, co
   MU_REQUIRE(n_rows >= 0 && n_cols > 0 && n_cols <= ((int64_t)1 << 22), "shape out of range");
   if (n_rows == 0) return MU_OK;
   MU_REQUIRE(d_cptr && d_ent && d_Q && d_Y, "null pointer");
-  // K row-sets per wave: the smallest number of full-chip rounds R whose 64*K-row blocks fit
-  // the register budget (K <= 8); one workgroup per CU (128 KiB of LDS).
-  const int64_t cus = mu_num_cus();
-  int K = kKMax;
-  for (int64_t R = 1; R <= 1024; ++R) {
-    const int64_t k = (n_rows + 64 * cus * R - 1) / (64 * cus * R);
-    if (k <= kKMax) { K = (int)(k < 1 ? 1 : k); break; }
-  }
-  const int force_k = mu_tune_get("spmm_k");  // tests / tuning only
-  if (force_k >= 1 && force_k <= kKMax) K = force_k;
   hipStream_t st = (hipStream_t)stream;
+  const int64_t* cptr = d_cptr;
   const unsigned long long* ent = (const unsigned long long*)d_ent;
-  switch (K) {
-    case 1: return launch_pcr<1>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
-    case 2: return launch_pcr<2>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
-    case 3: return launch_pcr<3>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
-    case 4: return launch_pcr<4>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
-    case 5: return launch_pcr<5>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
-    case 6: return launch_pcr<6>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
-    case 7: return launch_pcr<7>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
-    default: return launch_pcr<8>(n_rows, n_cols, d_cptr, ent, d_Q, d_Y, st);
+  const float* Q = d_Q;
+  float* Y = d_Y;
+  // tests / tuning only (mu_tune_set); all 0 in production
+  const int force_k = mu_tune_get("spmm_k");
+  const int mode = mu_tune_get("spmm_mode");
+  const int waves = mu_tune_get("spmm_waves") ? mu_tune_get("spmm_waves") : 16;
+  const int pipe = mu_tune_get("spmm_pipe");
+  if (waves == 16) {
+    int K = pick_k<16>(n_rows);
+    if (force_k >= 1 && force_k <= Geo<16>::KMAX) K = force_k;
+    if (mode != 0) {
+      MU_REQUIRE(pipe == 0 && (K == 7 || K == 8), "ablation modes exist for W = 16, K = 7 / 8, pipe 0 only");
+#define MU_ABL(KK)                                             \
+  switch (mode) {                                              \
+    case 1: MU_GO(k_spmm_pcr64_w16, 16, KK, 1, 0)              \
+    case 9: MU_GO(k_spmm_pcr64_w16, 16, KK, 9, 0)              \
+    case 11: MU_GO(k_spmm_pcr64_w16, 16, KK, 11, 0)            \
+    default: break;                                            \
   }
+      if (K == 7) MU_ABL(7) else MU_ABL(8)
+#undef MU_ABL
+      mu_set_error("spmm_mode %d has no compiled instance", mode);
+      return MU_ERR_ARG;
+    }
+#define MU_W16(KK)                                            \
+  case KK:                                                    \
+    if (pipe == 1) MU_GO(k_spmm_pcr64_w16, 16, KK, 0, 1)      \
+    MU_GO(k_spmm_pcr64_w16, 16, KK, 0, 0)
+    switch (K) {
+      MU_W16(1) MU_W16(2) MU_W16(3) MU_W16(4) MU_W16(5) MU_W16(6) MU_W16(7) MU_W16(8)
+      default: break;
+    }
+#undef MU_W16
+  } else if (waves == 12) {
+    MU_REQUIRE(mode == 0, "ablation modes exist for W = 16 only");
+    int K = pick_k<12>(n_rows);
+    if (force_k >= 1 && force_k <= Geo<12>::KMAX) K = force_k;
+#define MU_W12(KK)                                            \
+  case KK:                                                    \
+    if (pipe == 2) MU_GO(k_spmm_pcr64_w12, 12, KK, 0, 2)      \
+    MU_GO(k_spmm_pcr64_w12, 12, KK, 0, 1)
+    switch (K) {
+      MU_W12(9) MU_W12(11)
+      default: break;
+    }
+#undef MU_W12
+  } else if (waves == 8) {
+    MU_REQUIRE(mode == 0, "ablation modes exist for W = 16 only");
+    int K = pick_k<8>(n_rows);
+    if (force_k >= 1 && force_k <= Geo<8>::KMAX) K = force_k;
+#define MU_W8(KK)                                             \
+  case KK:                                                    \
+    if (pipe == 2) MU_GO(k_spmm_pcr64_w8, 8, KK, 0, 2)        \
+    MU_GO(k_spmm_pcr64_w8, 8, KK, 0, 1)
+    switch (K) {
+      MU_W8(13) MU_W8(16)
+      default: break;
+    }
+#undef MU_W8
+  }
+  mu_set_error("mu_spmm_packed_f32: no compiled instance for waves=%d k=%d pipe=%d", waves, force_k, pipe);
+  return MU_ERR_ARG;
 }
 
 }  // extern "C"

@@ -1,0 +1,300 @@
+// Packed chunked-row copy of X^T built straight from the CSR of X ("transpose-pack").
+//
+// Z = X^T * Y of the block subspace iteration (the rmatvec side of scipy svds, _svds.py:441-466,
+// reached from /root/reference/muon/_atac/tools.py:53) runs through the same packed SpMM as
+// Y = X * Q; this file builds its operand without materialising a CSR of X^T first.
+// Stable (every output row lists the cells in ascending order => canonical rows, and the f32 sums
+// of the SpMM are bit-reproducible), no global atomics.
+//
+//   1. slab pointers: sp[row][s] = first entry of `row` with column >= s * kTSlab
+//   2. count: workgroup g owns a contiguous, nnz-balanced row range and counts the entries of every
+//      column in LDS, slab by slab                                           -> cnt[g][col]
+//   3. base:  per column, exclusive prefix of cnt over g (in place), the column total and its
+//      chunk count ceil(total / 16) + 1                                      -> caller scans -> cptr
+//   4. fill:  same sweep.  Rows are taken in batches of 64 (four per wave).  A batch first ORs one
+//      bit per entry into a 64-bit row mask per column (LDS), then every entry finds its rank
+//      among the batch's entries of its column with a popcount of the lower bits and writes its
+//      (cell, value) pair to  slab_start + pos[col] + rank;  the entry that owns the highest bit
+//      advances pos[col] and clears the mask.  Masks are double buffered, so a batch costs two
+//      workgroup barriers and no global traffic besides the entries themselves.
+//   5. pads:  the tail of the last real chunk and the closing chunk of every output row.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kTSlab = 4096;  // columns per slab: pos 16 KiB + two mask buffers 64 KiB of LDS
+constexpr int kTThreads = 1024;
+constexpr int kTWaves = kTThreads / 64;
+constexpr unsigned kPad = 0x7fffffffu;
+
+inline int64_t t_slabs(int64_t n_cols) { return (n_cols + kTSlab - 1) / kTSlab; }
+inline int t_grid() { return 2 * mu_num_cus(); }  // two 1024-thread workgroups per CU
+
+// rows [r0, r1) owned by workgroup g of G: contiguous, balanced by nnz
+__device__ __forceinline__ void t_row_range(const int64_t* indptr, int64_t n_rows, int g, int G,
+                                            int64_t& r0, int64_t& r1) {
+  const int64_t nnz = indptr[n_rows];
+  auto cut = [&](int k) -> int64_t {
+    if (k <= 0) return 0;
+    if (k >= G) return n_rows;
+    const int64_t key = (nnz / G) * k + ((nnz % G) * k) / G;
+    const int64_t r = lower_bound_i64(indptr, 0, n_rows, key);
+    return r > n_rows ? n_rows : r;
+  };
+  r0 = cut(g);
+  r1 = cut(g + 1);
+}
+
+__global__ __launch_bounds__(256) void k_t_slab_ptr(int64_t n_rows, int64_t S,
+                                                    const int64_t* __restrict__ indptr,
+                                                    const int32_t* __restrict__ indices,
+                                                    int64_t* __restrict__ sp) {
+  const int64_t total = n_rows * (S + 1);
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = id / (S + 1);
+    const int64_t s = id - row * (S + 1);
+    int64_t lo = indptr[row], hi = indptr[row + 1];
+    if (s == S) {
+      sp[id] = hi;
+      continue;
+    }
+    const int64_t key = s * (int64_t)kTSlab;
+    while (lo < hi) {
+      const int64_t mid = lo + ((hi - lo) >> 1);
+      if ((int64_t)indices[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    sp[id] = lo;
+  }
+}
+
+__global__ __launch_bounds__(kTThreads) void k_t_count(int64_t n_rows, int64_t n_cols, int64_t S,
+                                                       const int64_t* __restrict__ indptr,
+                                                       const int32_t* __restrict__ indices,
+                                                       const int64_t* __restrict__ sp,
+                                                       uint32_t* __restrict__ cnt) {
+  __shared__ uint32_t bins[kTSlab];
+  __shared__ int64_t s_r[2];
+  const int g = blockIdx.x, G = gridDim.x;
+  if (threadIdx.x == 0) t_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
+  __syncthreads();
+  const int64_t r0 = s_r[0], r1 = s_r[1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t s = 0; s < S; ++s) {
+    for (int t = threadIdx.x; t < kTSlab; t += kTThreads) bins[t] = 0u;
+    __syncthreads();
+    const int32_t cbase = (int32_t)(s * kTSlab);
+    for (int64_t row = r0 + wave; row < r1; row += kTWaves) {
+      const int64_t lo = sp[row * (S + 1) + s], hi = sp[row * (S + 1) + s + 1];
+      for (int64_t p = lo + lane; p < hi; p += 64) atomicAdd(&bins[indices[p] - cbase], 1u);
+    }
+    __syncthreads();
+    const int64_t here = (n_cols - (int64_t)cbase) < kTSlab ? (n_cols - (int64_t)cbase) : kTSlab;
+    uint32_t* dst = cnt + (int64_t)g * n_cols + cbase;
+    for (int t = threadIdx.x; t < here; t += kTThreads) dst[t] = bins[t];
+    __syncthreads();
+  }
+}
+
+// cnt[g][c] <- sum_{g' < g} cnt[g'][c];  coltot[c] = sum_g cnt[g][c];  chunks[c] = ceil(coltot/16) + 1
+__global__ __launch_bounds__(256) void k_t_base(int64_t n_cols, int G, uint32_t* __restrict__ cnt,
+                                                int64_t* __restrict__ coltot,
+                                                int64_t* __restrict__ chunks) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cols) return;
+  uint32_t run = 0;
+  for (int g = 0; g < G; ++g) {
+    const uint32_t t = cnt[(int64_t)g * n_cols + c];
+    cnt[(int64_t)g * n_cols + c] = run;
+    run += t;
+  }
+  coltot[c] = (int64_t)run;
+  chunks[c] = (((int64_t)run + 15) >> 4) + 1;
+}
+
+__global__ __launch_bounds__(kTThreads) void k_t_fill(int64_t n_rows, int64_t n_cols, int64_t S,
+                                                      const int64_t* __restrict__ indptr,
+                                                      const int32_t* __restrict__ indices,
+                                                      const float* __restrict__ values,
+                                                      const int64_t* __restrict__ sp,
+                                                      const int64_t* __restrict__ cptr,
+                                                      const uint32_t* __restrict__ base,
+                                                      unsigned long long* __restrict__ ent) {
+  __shared__ uint32_t pos[kTSlab];               // next free slot of the column, relative to the slab
+  __shared__ unsigned long long bm[2][kTSlab];   // per column: which rows of the batch hit it
+  __shared__ int64_t s_r[2];
+  const int g = blockIdx.x, G = gridDim.x;
+  if (threadIdx.x == 0) t_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
+  __syncthreads();
+  const int64_t r0 = s_r[0], r1 = s_r[1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t* mybase = base + (int64_t)g * n_cols;
+  const int64_t n_batches = (r1 - r0 + 63) >> 6;
+
+  for (int64_t s = 0; s < S; ++s) {
+    const int32_t cbase = (int32_t)(s * kTSlab);
+    const int64_t chunk0 = cptr[cbase];
+    const int64_t slab_start = chunk0 * 16;
+    for (int t = threadIdx.x; t < kTSlab; t += kTThreads) {
+      const int64_t c = (int64_t)cbase + t;
+      pos[t] = (c < n_cols) ? (uint32_t)((cptr[c] - chunk0) * 16) + mybase[c] : 0u;
+      bm[0][t] = 0ull;
+      bm[1][t] = 0ull;
+    }
+    __syncthreads();
+    for (int64_t b = 0; b <= n_batches; ++b) {
+      // phase X: close batch b-1 (advance cursors, clear its masks), announce batch b
+      if (b > 0) {
+        unsigned long long* m_prev = bm[(b - 1) & 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rl = wave * 4 + j;
+          const int64_t row = r0 + ((b - 1) << 6) + rl;
+          if (row < r1) {
+            const int64_t lo = sp[row * (S + 1) + s], hi = sp[row * (S + 1) + s + 1];
+            for (int64_t p = lo + lane; p < hi; p += 64) {
+              const int c = indices[p] - cbase;
+              const unsigned long long m = m_prev[c];
+              if ((m >> rl) == 1ull) {  // this entry owns the highest bit (0 once cleared)
+                pos[c] += (uint32_t)__popcll(m);
+                m_prev[c] = 0ull;
+              }
+            }
+          }
+        }
+      }
+      if (b < n_batches) {
+        unsigned long long* m_cur = bm[b & 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rl = wave * 4 + j;
+          const int64_t row = r0 + (b << 6) + rl;
+          if (row < r1) {
+            const int64_t lo = sp[row * (S + 1) + s], hi = sp[row * (S + 1) + s + 1];
+            for (int64_t p = lo + lane; p < hi; p += 64)
+              atomicOr(&m_cur[indices[p] - cbase], 1ull << rl);
+          }
+        }
+      }
+      __syncthreads();
+      // phase Y: emit batch b at  slab_start + pos[col] + rank
+      if (b < n_batches) {
+        const unsigned long long* m_cur = bm[b & 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rl = wave * 4 + j;
+          const int64_t row = r0 + (b << 6) + rl;
+          if (row < r1) {
+            const int64_t lo = sp[row * (S + 1) + s], hi = sp[row * (S + 1) + s + 1];
+            for (int64_t p = lo + lane; p < hi; p += 64) {
+              const int c = indices[p] - cbase;
+              const unsigned long long m = m_cur[c];
+              const int rank = __popcll(m & ((1ull << rl) - 1ull));
+              const unsigned long long e =
+                  (unsigned long long)(unsigned)row |
+                  ((unsigned long long)__builtin_bit_cast(unsigned, values[p]) << 32);
+              ent[slab_start + (int64_t)pos[c] + rank] = e;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// tail of the last real chunk + the closing chunk of every output row: at most 31 pads
+__global__ __launch_bounds__(256) void k_t_pads(int64_t n_cols, const int64_t* __restrict__ coltot,
+                                                const int64_t* __restrict__ cptr,
+                                                unsigned long long* __restrict__ ent) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t c = id >> 5;
+  if (c >= n_cols) return;
+  const int64_t o = cptr[c] * 16 + coltot[c] + (id & 31);
+  if (o < cptr[c + 1] * 16) ent[o] = (unsigned long long)kPad;
+}
+
+struct TWork {
+  int64_t* sp;
+  uint32_t* cnt;
+  int64_t* coltot;
+};
+inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+inline TWork carve(void* work, int64_t n_rows, int64_t n_cols) {
+  const int64_t S = t_slabs(n_cols);
+  char* w = (char*)work;
+  TWork t;
+  t.sp = (int64_t*)w;
+  w += al((size_t)(n_rows * (S + 1)) * sizeof(int64_t));
+  t.cnt = (uint32_t*)w;
+  w += al((size_t)t_grid() * (size_t)n_cols * sizeof(uint32_t));
+  t.coltot = (int64_t*)w;
+  return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols) {
+  const int64_t S = t_slabs(n_cols);
+  return al((size_t)(n_rows * (S + 1)) * sizeof(int64_t)) +
+         al((size_t)t_grid() * (size_t)n_cols * sizeof(uint32_t)) +
+         al((size_t)n_cols * sizeof(int64_t)) + 256;
+}
+
+int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                       const int32_t* d_indices, int64_t* d_row_chunks, void* d_work,
+                       size_t work_bytes, void* stream) {
+  MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
+  // cursors inside a slab are 32-bit: a slab (kTSlab output rows, padding included) must stay below 2^32 slots
+  MU_REQUIRE((n_rows + 32) * (int64_t)kTSlab < ((int64_t)1 << 32), "too many rows for 32-bit slab cursors");
+  if (n_cols == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_row_chunks && d_work, "null pointer");
+  MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols), "work buffer too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t S = t_slabs(n_cols);
+  const int G = t_grid();
+  const TWork w = carve(d_work, n_rows, n_cols);
+  MU_CHECK_HIP(hipMemsetAsync(w.cnt, 0, (size_t)G * (size_t)n_cols * sizeof(uint32_t), st));
+  if (n_rows > 0) {
+    const int64_t total = n_rows * (S + 1);
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = (int64_t)mu_num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_t_slab_ptr, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, S, d_indptr,
+                       d_indices, w.sp);
+    MU_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_t_count, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, S, d_indptr,
+                       d_indices, w.sp, w.cnt);
+    MU_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_t_base, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, n_cols, G,
+                     w.cnt, w.coltot, d_row_chunks);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                      const int32_t* d_indices, const float* d_values, const int64_t* d_cptr,
+                      void* d_ent, void* d_work, size_t work_bytes, void* stream) {
+  MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
+  if (n_cols == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_cptr && d_ent && d_work, "null pointer");
+  MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols), "work buffer too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t S = t_slabs(n_cols);
+  const int G = t_grid();
+  const TWork w = carve(d_work, n_rows, n_cols);
+  if (n_rows > 0) {
+    hipLaunchKernelGGL(k_t_fill, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, S, d_indptr,
+                       d_indices, d_values, w.sp, d_cptr, w.cnt, (unsigned long long*)d_ent);
+    MU_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_t_pads, dim3((unsigned)((n_cols * 32 + 255) / 256)), dim3(256), 0, st, n_cols,
+                     w.coltot, d_cptr, (unsigned long long*)d_ent);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+}  // extern "C"

@@ -17,7 +17,8 @@ ap.add_argument("--cells", type=int, default=125000)
 ap.add_argument("--peaks", type=int, default=200000)
 ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--modes", default="0")
-ap.add_argument("--fma", default="0")
+ap.add_argument("--waves", default="0")
+ap.add_argument("--pipe", default="0")
 ap.add_argument("--ks", default="0")
 ap.add_argument("--csr", action="store_true", help="also time the CSR kernel")
 args = ap.parse_args()
@@ -49,18 +50,29 @@ def timeit(M, D):
 ops = [("X*Q ", Tp, Q), ("Xt*Y", Ttp, Y)]
 if args.csr:
     ops += [("X*Q  csr", T, Q), ("Xt*Y csr", Tt, Y)]
-for fma in [int(x) for x in args.fma.split(",")]:
+Zp = be.spmm(Ttp, Y)
+ref = {"X*Q ": Yp.clone(), "Xt*Y": Zp.clone()}
+from muon_amd._ffi import MuonAmdError
+for waves in [int(x) for x in args.waves.split(",")]:
+  for pipe in [int(x) for x in args.pipe.split(",")]:
     for K in [int(x) for x in args.ks.split(",")]:
         for mode in [int(x) for x in args.modes.split(",")]:
-            be.tune("spmm_fma", fma)
+            be.tune("spmm_waves", waves)
+            be.tune("spmm_pipe", pipe)
             be.tune("spmm_k", K)
             be.tune("spmm_mode", mode)
             for name, M, D in ops:
-                ms = timeit(M, D)
+                try:
+                    ms = timeit(M, D)
+                except MuonAmdError as e:
+                    print(f"waves={waves} pipe={pipe} K={K} mode={mode} {name}: {e}")
+                    continue
+                same = ""
+                if mode == 0 and name in ref:
+                    same = " bit-identical" if torch.equal(be.spmm(M, D), ref[name]) else " DIFFERS"
                 n, d = M.shape
                 byt = 8 * M.nnz + 8 * (n + 1) + 4 * 64 * (n + d)
-                print(f"fma={fma} K={K} mode={mode:2d} {name}: {ms:7.3f} ms  {byt / ms / 1e6:6.0f} GB/s alg  "
-                      f"{M.nnz / ms / 1e6:6.1f} Gnnz/s", flush=True)
-be.tune("spmm_mode", 0)
-be.tune("spmm_k", 0)
-be.tune("spmm_fma", 0)
+                print(f"waves={waves:2d} pipe={pipe} K={K:2d} mode={mode:2d} {name}: {ms:7.3f} ms  {byt / ms / 1e6:6.0f} GB/s alg  "
+                      f"{M.nnz / ms / 1e6:6.1f} Gnnz/s{same}", flush=True)
+for k in ("spmm_mode", "spmm_k", "spmm_waves", "spmm_pipe"):
+    be.tune(k, 0)

@@ -258,3 +258,28 @@ def test_spmm_packed_transpose_round_trip_property(hip):
     lhs = (hip.spmm(Xp, q).double() * y.double()).sum(dim=0)
     rhs = (q.double() * hip.spmm(Xtp, y).double()).sum(dim=0)
     assert torch.allclose(lhs, rhs, rtol=1e-5, atol=1e-3 * float(lhs.abs().max()))
+
+
+@pytest.mark.parametrize("n,d,dens", [(1, 1, 1.0), (7, 5, 0.5), (100, 10, 0.2), (257, 131, 0.08),
+                                      (300, 9000, 0.01), (2000, 20000, 0.004), (5000, 700, 0.03),
+                                      (70, 4097, 0.2)])
+def test_transpose_pack_is_bit_exact(hip, n, d, dens):
+    """The packed copy of X^T built straight from X equals the numpy packing of scipy's transpose
+    (cell ids ascending inside every output row, pads and closing chunks included)."""
+    rng = np.random.default_rng(n * 13 + d)
+    m = _heavy_rows_csr(n, d, dens, rng, bursts=(n > 8 and d > 40))
+    P = hip.transpose_pack(_up(hip, m))
+    mt = m.T.tocsr()
+    mt.sort_indices()
+    cptr, ent = _pack_ref(mt)
+    assert P.shape == (d, n)
+    assert np.array_equal(hip.to_host(P.cptr), cptr)
+    got = hip.to_host(P.ent).view(np.uint64)[: ent.size]
+    assert np.array_equal(got, ent)
+
+
+def test_transpose_pack_empty_matrix(hip):
+    m = sp.csr_matrix((5, 7), dtype=np.float32)
+    P = hip.transpose_pack(_up(hip, m))
+    assert np.array_equal(hip.to_host(P.cptr), np.arange(8))
+    assert np.all(hip.to_host(P.ent).view(np.uint64)[: 7 * 16] == 0x7FFFFFFF)
