@@ -105,6 +105,21 @@ __global__ __launch_bounds__(256) void k_gram_reduce(int n_partials, const doubl
   if (e < B * B) G[e] = acc; else if (colsum) colsum[e - B * B] = acc;
 }
 
+// first level of the partial reduction: fold chunk y of the workgroup partials (fixed order)
+constexpr int kGramFold = 32;
+template <int B>
+__global__ __launch_bounds__(256) void k_gram_fold(int n_partials, const double* __restrict__ partial,
+                                                   double* __restrict__ folded) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * B + B) return;
+  const int chunk = (n_partials + kGramFold - 1) / kGramFold;
+  const int p0 = blockIdx.y * chunk;
+  const int p1 = (p0 + chunk) < n_partials ? (p0 + chunk) : n_partials;
+  double acc = 0.0;
+  for (int p = p0; p < p1; ++p) acc += partial[(int64_t)p * (B * B + B) + e];
+  folded[(int64_t)blockIdx.y * (B * B + B) + e] = acc;
+}
+
 static inline int gram_blocks(int64_t n_rows) {
   int64_t groups = (n_rows + 15) / 16;  // one workgroup step = 16 rows
   int64_t blocks = groups < 1 ? 1 : groups;
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(256) void k_randn(int64_t count, uint64_t seed, flo
 extern "C" {
 
 size_t mu_gram_worksize(int64_t n_rows, int B) {
-  return (size_t)gram_blocks(n_rows) * (size_t)(B * B + B) * sizeof(double) + 256;
+  return (size_t)(gram_blocks(n_rows) + kGramFold) * (size_t)(B * B + B) * sizeof(double) + 256;
 }
 
 int mu_gram_f32(int64_t n_rows, int B, const float* d_A, double* d_G, double* d_colsum, void* d_work,
@@ -184,22 +199,29 @@ int mu_gram_f32(int64_t n_rows, int B, const float* d_A, double* d_G, double* d_
   hipStream_t st = (hipStream_t)stream;
   const int blocks = gram_blocks(n_rows);
   double* partial = (double*)d_work;
+  double* folded = partial + (size_t)blocks * (size_t)(B * B + B);
   const unsigned rblocks = (unsigned)((B * B + B + 255) / 256);
   switch (B) {
     case 64:
       hipLaunchKernelGGL(k_gram_partial<64>, dim3(blocks), dim3(kGramThreads), 0, st, n_rows, d_A, partial);
       MU_CHECK_LAUNCH();
-      hipLaunchKernelGGL(k_gram_reduce<64>, dim3(rblocks), dim3(256), 0, st, blocks, partial, d_G, d_colsum);
+      hipLaunchKernelGGL(k_gram_fold<64>, dim3(rblocks, kGramFold), dim3(256), 0, st, blocks, partial, folded);
+      MU_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_gram_reduce<64>, dim3(rblocks), dim3(256), 0, st, kGramFold, folded, d_G, d_colsum);
       break;
     case 32:
       hipLaunchKernelGGL(k_gram_partial<32>, dim3(blocks), dim3(kGramThreads), 0, st, n_rows, d_A, partial);
       MU_CHECK_LAUNCH();
-      hipLaunchKernelGGL(k_gram_reduce<32>, dim3(rblocks), dim3(256), 0, st, blocks, partial, d_G, d_colsum);
+      hipLaunchKernelGGL(k_gram_fold<32>, dim3(rblocks, kGramFold), dim3(256), 0, st, blocks, partial, folded);
+      MU_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_gram_reduce<32>, dim3(rblocks), dim3(256), 0, st, kGramFold, folded, d_G, d_colsum);
       break;
     default:
       hipLaunchKernelGGL(k_gram_partial<16>, dim3(blocks), dim3(kGramThreads), 0, st, n_rows, d_A, partial);
       MU_CHECK_LAUNCH();
-      hipLaunchKernelGGL(k_gram_reduce<16>, dim3(rblocks), dim3(256), 0, st, blocks, partial, d_G, d_colsum);
+      hipLaunchKernelGGL(k_gram_fold<16>, dim3(rblocks, kGramFold), dim3(256), 0, st, blocks, partial, folded);
+      MU_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_gram_reduce<16>, dim3(rblocks), dim3(256), 0, st, kGramFold, folded, d_G, d_colsum);
       break;
   }
   MU_CHECK_LAUNCH();

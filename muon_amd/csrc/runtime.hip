@@ -28,9 +28,9 @@ int mu_num_cus() {
 }
 
 // tuning / ablation knobs (tests and bench only)
-static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "spmm_waves", "spmm_pipe"};
-constexpr int kTuneN = 4;
-static int g_tune[kTuneN] = {0, 0, 0, 0};
+static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "spmm_waves", "spmm_pipe", "tpack_v1"};
+constexpr int kTuneN = 5;
+static int g_tune[kTuneN] = {0, 0, 0, 0, 0};
 
 extern "C" {
 

@@ -201,7 +201,8 @@ struct Win {      // what stage A of a pass hands to stage B
 // (results are then wrong on purpose): 1 no LDS gathers / FMAs, 2 no slab DMA, 8 no chunk
 // requests (and no overflow passes), 16 no window rotation.
 // PIPE: 0 = stage A(k) then B(k); 1 = A(k+1) is issued before B(k); 2 = additionally two quads of
-// LDS reads in flight inside B (needs ~28 more registers: W <= 12).
+// LDS reads in flight inside B (needs ~28 more registers: W <= 12)
+// (the dispatcher uses PIPE 1; tune knob spmm_pipe = 1 selects PIPE 0 for comparison).
 template <int W, int K, int MODE, int PIPE>
 __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
                                                 const int64_t* __restrict__ cptr,
@@ -320,7 +321,7 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
       constexpr int k = decltype(kc)::value;
       if constexpr (MODE & 1) {
         acc[k].x += w.vv + (float)w.a;
-      } else if constexpr (PIPE >= 2) {
+      } else if constexpr (PIPE == 2) {
         Quad r0 = quad_read<0>(qbase, w.a);
         Quad r1 = quad_read<4>(qbase, w.a);
         quad_fma<0>(r0, w.vv, acc[k]);
@@ -345,7 +346,7 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
       }
     };
 
-    if constexpr (PIPE >= 1) {
+    if constexpr (PIPE == 1 || PIPE == 2) {
       Win w = stage_a(std::integral_constant<int, 0>{}, std::false_type{});
       static_for<K>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -521,39 +522,13 @@ int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, co
     }
 #define MU_W16(KK)                                            \
   case KK:                                                    \
-    if (pipe == 1) MU_GO(k_spmm_pcr64_w16, 16, KK, 0, 1)      \
-    MU_GO(k_spmm_pcr64_w16, 16, KK, 0, 0)
+    if (pipe == 1) MU_GO(k_spmm_pcr64_w16, 16, KK, 0, 0)      \
+    MU_GO(k_spmm_pcr64_w16, 16, KK, 0, 1)
     switch (K) {
       MU_W16(1) MU_W16(2) MU_W16(3) MU_W16(4) MU_W16(5) MU_W16(6) MU_W16(7) MU_W16(8)
       default: break;
     }
 #undef MU_W16
-  } else if (waves == 12) {
-    MU_REQUIRE(mode == 0, "ablation modes exist for W = 16 only");
-    int K = pick_k<12>(n_rows);
-    if (force_k >= 1 && force_k <= Geo<12>::KMAX) K = force_k;
-#define MU_W12(KK)                                            \
-  case KK:                                                    \
-    if (pipe == 2) MU_GO(k_spmm_pcr64_w12, 12, KK, 0, 2)      \
-    MU_GO(k_spmm_pcr64_w12, 12, KK, 0, 1)
-    switch (K) {
-      MU_W12(9) MU_W12(11)
-      default: break;
-    }
-#undef MU_W12
-  } else if (waves == 8) {
-    MU_REQUIRE(mode == 0, "ablation modes exist for W = 16 only");
-    int K = pick_k<8>(n_rows);
-    if (force_k >= 1 && force_k <= Geo<8>::KMAX) K = force_k;
-#define MU_W8(KK)                                             \
-  case KK:                                                    \
-    if (pipe == 2) MU_GO(k_spmm_pcr64_w8, 8, KK, 0, 2)        \
-    MU_GO(k_spmm_pcr64_w8, 8, KK, 0, 1)
-    switch (K) {
-      MU_W8(13) MU_W8(16)
-      default: break;
-    }
-#undef MU_W8
   }
   mu_set_error("mu_spmm_packed_f32: no compiled instance for waves=%d k=%d pipe=%d", waves, force_k, pipe);
   return MU_ERR_ARG;

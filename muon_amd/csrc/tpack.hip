@@ -28,7 +28,7 @@ constexpr int kTWaves = kTThreads / 64;
 constexpr unsigned kPad = 0x7fffffffu;
 
 inline int64_t t_slabs(int64_t n_cols) { return (n_cols + kTSlab - 1) / kTSlab; }
-inline int t_grid() { return 2 * mu_num_cus(); }  // two 1024-thread workgroups per CU
+inline int t_grid() { return mu_num_cus(); }  // one 1024-thread workgroup per CU (the staged fill needs 140 KiB of LDS)
 
 // rows [r0, r1) owned by workgroup g of G: contiguous, balanced by nnz
 __device__ __forceinline__ void t_row_range(const int64_t* indptr, int64_t n_rows, int g, int G,
@@ -203,6 +203,180 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill(int64_t n_rows, int64_t n_
   }
 }
 
+// ---- fill, version 2: LDS-staged, run-coalesced stores -----------------------------------------
+// The version above stores every pair on its own: 7.8e8 scattered 8-byte stores, each a 32-byte
+// partial write at the memory side (WRITE_SIZE 7.7x the useful bytes on the old transpose), and the
+// kernel ran at the partial-write rate of the fabric.  Here a workgroup stages the (row block x
+// column slab) tile in LDS, sorted by (column, row), and writes every column's run with
+// consecutive lanes, so the stores of a run are one or two full lines.
+//   * the tile is sorted with a counting sort whose buckets are (column, wave): a wave owns a
+//     contiguous range of the workgroup's rows and walks them IN ORDER, so a plain
+//     read-increment-write of its own bucket cursor gives every pair its stable slot - no
+//     atomics, no per-batch barriers (4 barriers per tile);
+//   * per-row cursors (first entry not yet consumed) live in global memory: no slab pointers;
+//   * a tile that does not fit the staging buffer falls back to direct stores (same slots).
+constexpr int kF2Cols = 768;     // max columns per slab (the host picks C <= kF2Cols from nnz / d)
+constexpr int kF2Cap = 10240;    // staged pairs: 80 KiB
+constexpr int kF2Rows = 8;       // rows a wave has in flight
+
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int l) {
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
+  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+  return ((int64_t)hi << 32) | (int64_t)(uint32_t)lo;
+}
+
+// PHASE 0: count pairs per (wave, column).  PHASE 1: place them (LDS when `staged`, else global).
+template <int PHASE>
+__device__ __forceinline__ void f2_walk(int64_t wrow0, int64_t wrow1, int32_t cbase, int32_t cend,
+                                        const int64_t* __restrict__ indptr,
+                                        const int32_t* __restrict__ indices,
+                                        const float* __restrict__ values, int64_t* __restrict__ curs,
+                                        uint32_t* wbucket, const uint32_t* lpos, const uint32_t* gpos,
+                                        unsigned long long* stage, bool staged, int64_t slab_start,
+                                        unsigned long long* __restrict__ ent) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t rb = wrow0; rb < wrow1; rb += kF2Rows) {  // wave-uniform
+    int64_t cur = 0, end = 0;
+    if (lane < kF2Rows && rb + lane < wrow1) {
+      cur = curs[rb + lane];
+      end = indptr[rb + lane + 1];
+    }
+    int32_t ci[kF2Rows];
+    float cv[kF2Rows];
+#pragma unroll
+    for (int j = 0; j < kF2Rows; ++j) {
+      const int64_t p = readlane_i64(cur, j) + lane;
+      const bool in = p < readlane_i64(end, j);  // rows past wrow1 have cur = end = 0
+      ci[j] = in ? indices[p] : 0x7fffffff;
+      if (PHASE == 1) cv[j] = in ? values[p] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < kF2Rows; ++j) {
+      int64_t c0 = readlane_i64(cur, j);
+      const int64_t e0 = readlane_i64(end, j);
+      int32_t c = ci[j];
+      float v = (PHASE == 1) ? cv[j] : 0.f;
+      while (true) {
+        const bool valid = c < cend;  // sorted rows: a prefix of the 64 loaded entries
+        const int n = __popcll(__ballot(valid));
+        if (valid) {
+          const int cl = c - cbase;
+          if (PHASE == 0) {
+            wbucket[cl] += 1u;  // columns inside one row are distinct: no two lanes share a counter
+          } else {
+            const uint32_t k = wbucket[cl];
+            wbucket[cl] = k + 1u;
+            const unsigned long long e = (unsigned long long)(unsigned)(rb + j) |
+                                         ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32);
+            if (staged) stage[lpos[cl] + k] = e;
+            else ent[slab_start + (int64_t)gpos[cl] + k] = e;
+          }
+        }
+        c0 += n;
+        if (n < 64) break;  // wave-uniform
+        const int64_t p = c0 + lane;  // a row with more than 64 entries in this slab
+        const bool in = p < e0;
+        c = in ? indices[p] : 0x7fffffff;
+        if (PHASE == 1) v = in ? values[p] : 0.f;
+      }
+      if (PHASE == 1 && lane == j) cur = c0;
+    }
+    if (PHASE == 1 && lane < kF2Rows && rb + lane < wrow1) curs[rb + lane] = cur;
+  }
+}
+
+__global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n_cols, int C,
+                                                       const int64_t* __restrict__ indptr,
+                                                       const int32_t* __restrict__ indices,
+                                                       const float* __restrict__ values,
+                                                       int64_t* __restrict__ curs,
+                                                       const int64_t* __restrict__ cptr,
+                                                       const uint32_t* __restrict__ base,
+                                                       const int64_t* __restrict__ coltot,
+                                                       unsigned long long* __restrict__ ent) {
+  __shared__ unsigned long long stage[kF2Cap];     // 80 KiB
+  __shared__ uint32_t bucket[kTWaves][kF2Cols];    // 48 KiB: per (wave, column) count, then cursor
+  __shared__ uint32_t lcount[kF2Cols], lpos[kF2Cols], gpos[kF2Cols];
+  __shared__ uint32_t wsum[kTWaves];
+  __shared__ int64_t s_r[2];
+  const int g = blockIdx.x, G = gridDim.x;
+  if (threadIdx.x == 0) t_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
+  __syncthreads();
+  const int64_t r0 = s_r[0], r1 = s_r[1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t rw = (r1 - r0 + kTWaves - 1) / kTWaves;  // rows per wave
+  const int64_t wrow0 = (r0 + wave * rw) < r1 ? (r0 + wave * rw) : r1;
+  const int64_t wrow1 = (wrow0 + rw) < r1 ? (wrow0 + rw) : r1;
+  const uint32_t* base_g = base + (int64_t)g * n_cols;
+  const uint32_t* base_n = (g + 1 < G) ? base + (int64_t)(g + 1) * n_cols : nullptr;
+
+  for (int64_t cb = 0; cb < n_cols; cb += C) {
+    const int32_t cbase = (int32_t)cb;
+    const int32_t cend = (int32_t)((cb + C) < n_cols ? (cb + C) : n_cols);
+    const int64_t chunk0 = cptr[cbase];
+    const int64_t slab_start = chunk0 * 16;
+    // tile counts per column, their exclusive scan, global run starts; clear the buckets
+    for (int t = threadIdx.x; t < kTWaves * kF2Cols; t += kTThreads) (&bucket[0][0])[t] = 0u;
+    uint32_t mine = 0;
+    if (threadIdx.x < kF2Cols) {
+      const int64_t c = (int64_t)cbase + threadIdx.x;
+      if (c < cend) {
+        const uint32_t b0 = base_g[c];
+        const uint32_t b1 = base_n ? base_n[c] : (uint32_t)coltot[c];
+        mine = b1 - b0;
+        gpos[threadIdx.x] = (uint32_t)((cptr[c] - chunk0) * 16) + b0;
+      }
+      lcount[threadIdx.x] = mine;
+    }
+    // block exclusive scan of lcount (first kF2Cols threads = 12 waves)
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t wpre = 0, total = 0;
+    for (int w = 0; w < kTWaves; ++w) {
+      const uint32_t t = wsum[w];
+      if (w < wave) wpre += t;
+      total += t;
+    }
+    if (threadIdx.x < kF2Cols) lpos[threadIdx.x] = wpre + incl - mine;
+    const bool staged = total <= (uint32_t)kF2Cap;
+    __syncthreads();
+    if (total == 0) continue;  // uniform: nothing of this row block falls into the slab
+
+    f2_walk<0>(wrow0, wrow1, cbase, cend, indptr, indices, values, curs, bucket[wave], lpos, gpos, stage,
+               staged, slab_start, ent);
+    __syncthreads();
+    // per column: exclusive prefix of the wave counts = first slot of every wave inside the run
+    if (threadIdx.x < kF2Cols) {
+      uint32_t run = 0;
+      for (int w = 0; w < kTWaves; ++w) {
+        const uint32_t t = bucket[w][threadIdx.x];
+        bucket[w][threadIdx.x] = run;
+        run += t;
+      }
+    }
+    __syncthreads();
+    f2_walk<1>(wrow0, wrow1, cbase, cend, indptr, indices, values, curs, bucket[wave], lpos, gpos, stage,
+               staged, slab_start, ent);
+    __syncthreads();
+    if (staged) {
+      // write-out: one 16-lane group per column, consecutive lanes = consecutive pairs of the run
+      const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+      for (int cl = grp; cl < cend - cbase; cl += kTThreads / 16) {
+        const uint32_t L = lcount[cl], src = lpos[cl];
+        const int64_t dst = slab_start + (int64_t)gpos[cl];
+        for (uint32_t i = sub; i < L; i += 16) ent[dst + i] = stage[src + i];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // tail of the last real chunk + the closing chunk of every output row: at most 31 pads
 __global__ __launch_bounds__(256) void k_t_pads(int64_t n_cols, const int64_t* __restrict__ coltot,
                                                 const int64_t* __restrict__ cptr,
@@ -218,6 +392,7 @@ struct TWork {
   int64_t* sp;
   uint32_t* cnt;
   int64_t* coltot;
+  int64_t* curs;
 };
 inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 inline TWork carve(void* work, int64_t n_rows, int64_t n_cols) {
@@ -229,6 +404,8 @@ inline TWork carve(void* work, int64_t n_rows, int64_t n_cols) {
   t.cnt = (uint32_t*)w;
   w += al((size_t)t_grid() * (size_t)n_cols * sizeof(uint32_t));
   t.coltot = (int64_t*)w;
+  w += al((size_t)n_cols * sizeof(int64_t));
+  t.curs = (int64_t*)w;
   return t;
 }
 
@@ -240,7 +417,7 @@ size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols) {
   const int64_t S = t_slabs(n_cols);
   return al((size_t)(n_rows * (S + 1)) * sizeof(int64_t)) +
          al((size_t)t_grid() * (size_t)n_cols * sizeof(uint32_t)) +
-         al((size_t)n_cols * sizeof(int64_t)) + 256;
+         al((size_t)n_cols * sizeof(int64_t)) + al((size_t)(n_rows + 1) * sizeof(int64_t)) + 256;
 }
 
 int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
@@ -287,8 +464,25 @@ int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
   const int G = t_grid();
   const TWork w = carve(d_work, n_rows, n_cols);
   if (n_rows > 0) {
-    hipLaunchKernelGGL(k_t_fill, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, S, d_indptr,
-                       d_indices, d_values, w.sp, d_cptr, w.cnt, (unsigned long long*)d_ent);
+    if (mu_tune_get("tpack_v1")) {
+      hipLaunchKernelGGL(k_t_fill, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, S, d_indptr,
+                         d_indices, d_values, w.sp, d_cptr, w.cnt, (unsigned long long*)d_ent);
+    } else {
+      // slab width: the expected tile (nnz / G rows x C columns) fills ~80 % of the staging buffer
+      int64_t nnz = 0;
+      MU_CHECK_HIP(hipMemcpyAsync(&nnz, d_indptr + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+      MU_CHECK_HIP(hipStreamSynchronize(st));
+      const double per_col = (double)nnz / (double)G / (double)n_cols;  // pairs of a tile per column
+      int64_t C = per_col > 0 ? (int64_t)(0.8 * kF2Cap / per_col) : kF2Cols;
+      C = (C / 64) * 64;
+      if (C < 64) C = 64;
+      if (C > kF2Cols) C = kF2Cols;
+      MU_CHECK_HIP(hipMemcpyAsync(w.curs, d_indptr, sizeof(int64_t) * (size_t)n_rows,
+                                  hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(k_t_fill2, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C, d_indptr,
+                         d_indices, d_values, w.curs, d_cptr, w.cnt, w.coltot,
+                         (unsigned long long*)d_ent);
+    }
     MU_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(k_t_pads, dim3((unsigned)((n_cols * 32 + 255) / 256)), dim3(256), 0, st, n_cols,

@@ -21,9 +21,17 @@ ap.add_argument("--waves", default="0")
 ap.add_argument("--pipe", default="0")
 ap.add_argument("--ks", default="0")
 ap.add_argument("--csr", action="store_true", help="also time the CSR kernel")
+ap.add_argument("--calibrate", action="store_true",
+                help="run a 4 GiB device copy first (known HBM byte count for PMC calibration)")
 args = ap.parse_args()
 
 be = HipBackend(0)
+if args.calibrate:
+    src = torch.empty(1 << 30, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)  # reads 4 GiB, writes 4 GiB (far beyond the 256 MiB Infinity Cache)
+    torch.cuda.synchronize()
+    del src, dst
 X = be.synth_counts(0, args.cells, args.peaks, 50, 0.03, 0)
 T = tfidf_device(be, X, args.cells, 3, 1e4)
 Tt = be.transpose(T)

@@ -283,3 +283,26 @@ def test_transpose_pack_empty_matrix(hip):
     P = hip.transpose_pack(_up(hip, m))
     assert np.array_equal(hip.to_host(P.cptr), np.arange(8))
     assert np.all(hip.to_host(P.ent).view(np.uint64)[: 7 * 16] == 0x7FFFFFFF)
+
+
+def test_transpose_pack_tile_overflow_falls_back_and_v1_agree(hip):
+    """A (row block x column slab) tile larger than the staging buffer takes the direct-store path;
+    the staged kernel, the fallback and the first-generation kernel give the same bytes."""
+    rng = np.random.default_rng(21)
+    n, d = 60000, 200
+    dense = sp.random(n, 100, density=0.95, format="csr", random_state=rng, dtype=np.float32)
+    m = sp.hstack([dense, sp.csr_matrix((n, d - 100), dtype=np.float32)], format="csr")
+    m.sort_indices()
+    X = _up(hip, m)
+    P = hip.transpose_pack(X)
+    mt = m.T.tocsr()
+    mt.sort_indices()
+    cptr, ent = _pack_ref(mt)
+    assert np.array_equal(hip.to_host(P.cptr), cptr)
+    assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
+    try:
+        hip.tune("tpack_v1", 1)
+        P1 = hip.transpose_pack(X)
+    finally:
+        hip.tune("tpack_v1", 0)
+    assert torch.equal(P1.cptr, P.cptr) and torch.equal(P1.ent[: ent.size * 8], P.ent[: ent.size * 8])
