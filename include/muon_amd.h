@@ -180,6 +180,11 @@ size_t mu_gram_worksize(int64_t n_rows, int B);
 int mu_gram_f32(int64_t n_rows, int B, const float* d_A, double* d_G, double* d_colsum,
                 void* d_work, size_t work_bytes, void* stream);
 
+/* C[B x B] (f64) = A^T Bm for A, Bm [n_rows x B] f32 (ld = B); same work buffer size as mu_gram_f32.
+ * Feeds the stopping rule of lsi (angle between the Ritz subspaces of consecutive iterations). */
+int mu_gram_cross_f32(int64_t n_rows, int B, const float* d_A, const float* d_Bm, double* d_C,
+                      void* d_work, size_t work_bytes, void* stream);
+
 /* Out[n_rows x B] = A[n_rows x B] * M[B x B] + bias[B] (bias may be NULL); f32 MFMA
  * (v_mfma_f32_16x16x4_f32).  Out may alias A. */
 int mu_dense_apply_f32(int64_t n_rows, int B, const float* d_A, const float* d_M,

@@ -57,6 +57,21 @@ def _chol_inverse(G: np.ndarray, w: int):
     return M
 
 
+def _ritz_subspace_sine(Ga, Cx, Gb, Wa, Wb) -> float:
+    """sin of the largest principal angle between span(Qa Wa) and span(Qb Wb), from the f64 Grams
+    Ga = Qa^T Qa, Cx = Qa^T Qb, Gb = Qb^T Qb (exact for the stored f32 columns, orthonormal or not)."""
+    A = Wa.T @ Ga @ Wa          # (Qa Wa)^T (Qa Wa)
+    Bm = Wb.T @ Gb @ Wb
+    Cm = Wa.T @ Cx @ Wb
+    La = np.linalg.cholesky((A + A.T) / 2)
+    Lb = np.linalg.cholesky((Bm + Bm.T) / 2)
+    M = np.linalg.solve(La, Cm)            # La^-1 Cm
+    M = np.linalg.solve(Lb, M.T).T         # La^-1 Cm Lb^-T: cosines are its singular values
+    # sin^2 = eigenvalues of I - M^T M (symmetric PSD); take the largest
+    S = np.eye(M.shape[1]) - M.T @ M
+    return float(np.sqrt(max(np.linalg.eigvalsh((S + S.T) / 2)[-1], 0.0)))
+
+
 def _orthonormalize(backend, Z: torch.Tensor, w: int, passes: int = 2):
     """CholeskyQR(passes) in place on the replicated d x B block; returns the eigenvalues
     source (first Gram, host f64) for the convergence test."""
@@ -80,6 +95,7 @@ def lsi_device(
     comm=None,
     n_iter: Optional[int] = None,
     tol: float = 1e-7,
+    angle_tol: float = 1e-5,
     max_iter: int = 60,
     oversample: int = DEFAULT_OVERSAMPLE,
     seed: int = 1,
@@ -122,51 +138,73 @@ def lsi_device(
     Z = backend.spmm(Xt, Y)
     comm.all_reduce_sum(Z)
 
-    prev = None
+    # Stopping rule (n_iter=None): after Y = X Q_j the Rayleigh-Ritz step is cheap (Gram of the n x B
+    # block), so every iteration measures s_j = sin of the largest principal angle between the top-k
+    # Ritz subspaces V_{j-1} = Q_{j-1} W_{j-1} and V_j = Q_j W_j.  The angle is computed from f64
+    # Grams of the f32 blocks (Q_{j-1}^T Q_{j-1}, Q_{j-1}^T Q_j, Q_j^T Q_j), which is exact for the
+    # columns actually stored, whatever orthogonality they lost in f32.  With the contraction
+    # rho_j = s_j / s_{j-1} (floored at 0.05, capped at 0.9; 0.5 while unknown) the distance of V_j
+    # from the limit is  err_j ~ s_j rho_j / (1 - rho_j);  we stop when 3 err_j < angle_tol (default
+    # 1e-5, ten times under the 1e-4 parity target) or when s_j stagnates at the f32 noise floor.
+    # Stopping happens AFTER Y = X Q_j, which is exactly what the final Rayleigh-Ritz needs, so no
+    # product is wasted: q iterations cost 2 q + 1 SpMMs.
     it = 0
-    pending = None  # Gram of the previous iteration, evaluated while the GPU runs the next one
     converged = n_iter is not None
     limit = n_iter if n_iter is not None else max_iter
-    history = []
-    deltas = []
+    history = []   # singular value estimates per iteration
+    angles = []    # s_j
+    Qprev = Gprev = Wprev = None
+    have_ritz = False
+    lam = W = csh = None
+    err = None
+
+    def ritz(Yb):
+        G, cs = backend.gram(Yb)
+        comm.all_reduce_sum(G, cs)
+        Gh = G.cpu().numpy()[:w, :w]
+        lam_, W_ = np.linalg.eigh(Gh)
+        order = np.argsort(lam_)[::-1][:k]
+        return np.maximum(lam_[order], 0), W_[:, order], cs.cpu().numpy()[:w]
+
     while True:
-        Z, G1 = _orthonormalize(backend, Z, w, passes=2)
+        Z, _G1 = _orthonormalize(backend, Z, w, passes=2)
         Q = Z
         it += 1
+        Y = backend.spmm(X, Q, out=Y)
         if it >= limit:
             break
-        stop_after = False
-        if n_iter is None and pending is not None:
-            # lagged test: singular values of Z = (X^T X) Q are sigma_i^2 estimates
-            ev = np.linalg.eigvalsh(pending[:w, :w])[::-1][:k]
-            est = np.sqrt(np.sqrt(np.maximum(ev, 0)))
-            history.append(est)
-            if prev is not None:
-                delta = float(np.max(np.abs(est - prev) / np.maximum(est, 1e-300)))
-                deltas.append(delta)
-                if delta < tol:
-                    stop_after = True
-                elif len(deltas) >= 3 and delta < 1e-5 and delta > 0.5 * min(deltas[-3:-1]):
-                    stop_after = True  # stagnated at the f32 noise floor of the estimates
-            prev = est
-        pending = G1
-        if stop_after:
-            converged = True
-            break
-        Y = backend.spmm(X, Q, out=Y)
+        if n_iter is None:
+            lam, W, csh = ritz(Y)
+            have_ritz = True
+            history.append(np.sqrt(lam))
+            Gq = backend.gram(Q)[0].cpu().numpy()[:w, :w]
+            stop = False
+            if Qprev is not None:
+                Cx = backend.gram_cross(Qprev, Q).cpu().numpy()[:w, :w]
+                s_j = _ritz_subspace_sine(Gprev, Cx, Gq, Wprev, W)
+                angles.append(s_j)
+                rho = 0.5 if len(angles) < 2 or angles[-2] <= 0 else min(0.9, max(0.05, s_j / angles[-2]))
+                err = s_j * rho / (1.0 - rho)
+                if 3.0 * err < angle_tol:
+                    stop = True
+                elif len(angles) >= 2 and s_j < 1e-4 and s_j > 0.5 * angles[-2]:
+                    stop = True  # stagnated at the f32 noise floor
+                if len(history) >= 2:
+                    dsv = np.max(np.abs(history[-1] - history[-2]) / np.maximum(history[-1], 1e-300))
+                    if dsv < tol * 1e-3:
+                        stop = True
+            if stop:
+                converged = True
+                break
+            Qprev = Q.clone()
+            Gprev, Wprev = Gq, W
+            have_ritz = False
         Z = backend.spmm(Xt, Y)
         comm.all_reduce_sum(Z)
 
-    # Rayleigh-Ritz on span(Q)
-    Y = backend.spmm(X, Q, out=Y)
-    G, cs = backend.gram(Y)
-    comm.all_reduce_sum(G, cs)
-    Gh = G.cpu().numpy()[:w, :w]
-    csh = cs.cpu().numpy()[:w]
-    lam, W = np.linalg.eigh(Gh)
-    order = np.argsort(lam)[::-1][:k]
-    lam = np.maximum(lam[order], 0)
-    W = W[:, order]
+    # Rayleigh-Ritz on span(Q): Y = X Q is already there
+    if not have_ritz:
+        lam, W, csh = ritz(Y)
     s = np.sqrt(lam)
     # deterministic signs: largest-magnitude coefficient of each Ritz vector positive
     sg = np.sign(W[np.argmax(np.abs(W), axis=0), np.arange(k)])
@@ -197,7 +235,7 @@ def lsi_device(
     stdev = s / np.sqrt(n_obs - 1)  # tools.py:65
     if return_info:
         info = {"iterations": it, "converged": bool(converged), "block": B, "width": w,
-                "svalues": s, "history": history}
+                "svalues": s, "history": history, "angles": angles, "predicted_angle": err}
         return U, stdev, V, info
     return U, stdev, V
 

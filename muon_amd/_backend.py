@@ -250,6 +250,18 @@ class HipBackend:
             check(self.lib.mu_gram_f32(n, B, _p(A), _p(G), _p(cs), _p(work), wb, self._stream()))
         return G, cs
 
+    def gram_cross(self, A: torch.Tensor, Bm: torch.Tensor) -> torch.Tensor:
+        """C = A^T Bm in f64 (A, Bm n x B f32)."""
+        n, B = A.shape
+        assert Bm.shape == A.shape and A.dtype == torch.float32 and Bm.dtype == torch.float32
+        assert A.is_contiguous() and Bm.is_contiguous()
+        Cm = self.empty((B, B), torch.float64)
+        wb = int(self.lib.mu_gram_worksize(n, B))
+        work = self.empty((wb,), torch.uint8)
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_gram_cross_f32(n, B, _p(A), _p(Bm), _p(Cm), _p(work), wb, self._stream()))
+        return Cm
+
     def apply(self, A: torch.Tensor, M: torch.Tensor, bias=None, out=None) -> torch.Tensor:
         n, B = A.shape
         assert M.shape == (B, B) and M.dtype == torch.float32 and M.is_contiguous()

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mu_spmm_f64": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "mu_gram_worksize": (_sz, [_i64, _i32]),
     "mu_gram_f32": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mu_gram_cross_f32": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_dense_apply_f32": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mu_randn_f32": (C.c_int, [_i64, _u64, _vp, _vp]),
     "mu_mofa_update_w": (C.c_int, [_i32, _i64, _i32, _i32] + [_vp] * 7 + [_i32] + [_vp] * 6),

@@ -105,6 +105,65 @@ __global__ __launch_bounds__(256) void k_gram_reduce(int n_partials, const doubl
   if (e < B * B) G[e] = acc; else if (colsum) colsum[e - B * B] = acc;
 }
 
+// C = A^T Bm (both n x B f32, f64 accumulate): every one of the T x T tiles, no column sums.
+// Used to measure the angle between the Ritz subspaces of consecutive iterations (lsi stopping rule).
+template <int B>
+__global__ __launch_bounds__(kGramThreads) void k_gram_cross_partial(int64_t n_rows,
+                                                                     const float* __restrict__ A,
+                                                                     const float* __restrict__ Bm,
+                                                                     double* __restrict__ partial) {
+  constexpr int T = B / 16;
+  __shared__ double red[B * B + B];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane >> 4, lc = lane & 15;
+  d4 acc[T * T];
+#pragma unroll
+  for (int i = 0; i < T * T; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  const int64_t n_groups = (n_rows + 3) / 4;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t gstride = (int64_t)gridDim.x * 4;
+  for (int64_t grp = gw; grp < n_groups; grp += gstride) {
+    const int64_t row = grp * 4 + lr;
+    double x[T], y[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      x[t] = (row < n_rows) ? (double)A[row * B + 16 * t + lc] : 0.0;
+      y[t] = (row < n_rows) ? (double)Bm[row * B + 16 * t + lc] : 0.0;
+    }
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < T; ++tj)
+        acc[ti * T + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ti], y[tj], acc[ti * T + tj], 0, 0, 0);
+  }
+  for (int i = threadIdx.x; i < B * B + B; i += kGramThreads) red[i] = 0.0;
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < T; ++tj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(16 * ti + lr + 4 * r) * B + 16 * tj + lc] += acc[ti * T + tj][r];
+    }
+    __syncthreads();
+  }
+  double* dst = partial + (int64_t)blockIdx.x * (B * B + B);
+  for (int i = threadIdx.x; i < B * B + B; i += kGramThreads) dst[i] = red[i];
+}
+
+// plain sum of the folded partials (no mirroring: the cross-Gram is not symmetric)
+template <int B>
+__global__ __launch_bounds__(256) void k_gram_cross_reduce(int n_partials, const double* __restrict__ partial,
+                                                           double* __restrict__ C) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * B) return;
+  double acc = 0.0;
+  for (int p = 0; p < n_partials; ++p) acc += partial[(int64_t)p * (B * B + B) + e];
+  C[e] = acc;
+}
+
 // first level of the partial reduction: fold chunk y of the workgroup partials (fixed order)
 constexpr int kGramFold = 32;
 template <int B>
@@ -188,6 +247,35 @@ extern "C" {
 
 size_t mu_gram_worksize(int64_t n_rows, int B) {
   return (size_t)(gram_blocks(n_rows) + kGramFold) * (size_t)(B * B + B) * sizeof(double) + 256;
+}
+
+int mu_gram_cross_f32(int64_t n_rows, int B, const float* d_A, const float* d_Bm, double* d_C,
+                      void* d_work, size_t work_bytes, void* stream) {
+  MU_REQUIRE(B == 16 || B == 32 || B == 64, "B must be 16, 32 or 64");
+  MU_REQUIRE(n_rows >= 0 && d_C, "bad arguments");
+  MU_REQUIRE(n_rows == 0 || (d_A && d_Bm), "null input");
+  MU_REQUIRE(d_work && work_bytes >= mu_gram_worksize(n_rows, B), "work buffer too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = gram_blocks(n_rows);
+  double* partial = (double*)d_work;
+  double* folded = partial + (size_t)blocks * (size_t)(B * B + B);
+  const unsigned rblocks = (unsigned)((B * B + B + 255) / 256);
+#define MU_CROSS(BB)                                                                                  \
+  hipLaunchKernelGGL(k_gram_cross_partial<BB>, dim3(blocks), dim3(kGramThreads), 0, st, n_rows, d_A,  \
+                     d_Bm, partial);                                                                  \
+  MU_CHECK_LAUNCH();                                                                                  \
+  hipLaunchKernelGGL(k_gram_fold<BB>, dim3(rblocks, kGramFold), dim3(256), 0, st, blocks, partial,    \
+                     folded);                                                                         \
+  MU_CHECK_LAUNCH();                                                                                  \
+  hipLaunchKernelGGL(k_gram_cross_reduce<BB>, dim3(rblocks), dim3(256), 0, st, kGramFold, folded, d_C);
+  switch (B) {
+    case 64: MU_CROSS(64) break;
+    case 32: MU_CROSS(32) break;
+    default: MU_CROSS(16) break;
+  }
+#undef MU_CROSS
+  MU_CHECK_LAUNCH();
+  return MU_OK;
 }
 
 int mu_gram_f32(int64_t n_rows, int B, const float* d_A, double* d_G, double* d_colsum, void* d_work,

@@ -99,6 +99,9 @@ class CpuTestBackend:
         a = A.double()
         return a.T @ a, a.sum(dim=0)
 
+    def gram_cross(self, A, Bm):
+        return A.double().T @ Bm.double()
+
     def apply(self, A, M, bias=None, out=None):
         r = A @ M
         if bias is not None:
