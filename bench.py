@@ -2,9 +2,16 @@
 """bench.py - TF-IDF + LSI(k=50) throughput on synthetic planted-topic CSR (BASELINE.json).
 
 A "step" is one pass of the hot path over one batch: tfidf (counts -> TF-IDF values) followed
-by lsi (CSR transpose, block subspace iteration to convergence, Rayleigh-Ritz), with the
-count matrix already resident in HBM when the timed region starts and U / stdev / V left in
-HBM at the end.
+by lsi (packed copies of X and X^T, block subspace iteration to convergence, Rayleigh-Ritz),
+with the count matrix already resident in HBM when the timed region starts and U / stdev / V
+left in HBM at the end.
+
+roofline: the dominant kernel is the packed SpMM (both X*Q and X^T*Y).  `achieved` =
+algorithmic bytes per launch (8 B per stored entry + row pointers + the two dense blocks,
+SURVEY.md 8d / DESIGN.md 4) / mean launch time from HIP events recorded on the launch stream
+inside the timed region.  `traffic` = HBM bytes per launch from rocprofv3 PMC counters
+(FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction) for the default workload, read
+from profiles/r01_spmm_traffic.json; null for any other shape.
 
 Workloads (--workload):
   c3shard (default)  125 000 cells x 200 000 peaks per GPU, 3 % nnz: rank r holds rows
@@ -175,6 +182,17 @@ def main():
     achieved = float(np.mean(byt)) / (avg_ms * 1e-3) / 1e9
     spmm_total_ms = float(np.sum(ms))
 
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_spmm_traffic.json")
+    if args.workload == "c3shard" and not args.cells and not args.peaks and not args.no_pack \
+            and os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic = {"bytes_per_launch": tj["spmm_mean_bytes_per_launch"],
+                   "x_q": tj["spmm_xq_bytes_per_launch"], "xt_y": tj["spmm_xty_bytes_per_launch"],
+                   "vs_algorithmic": tj["spmm_mean_bytes_per_launch"] / tj["algorithmic_bytes_per_launch"],
+                   "source": "profiles/r01_spmm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
+
     if rank == 0:
         out = {
             "metric": "cells/sec for TF-IDF+LSI(k=50)",
@@ -207,7 +225,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "avg_launch_ms": avg_ms,
                 "launches": len(ms),
                 "share_of_step": spmm_total_ms / (dt * 1e3),

@@ -209,7 +209,7 @@ class HipBackend:
             check(self.lib.mu_exclusive_scan_i64(d, _p(row_chunks), _p(cptr), st))
             n_chunks = int(cptr[-1].item()) if d > 0 else 0
             ent = self.empty((max(n_chunks, 1) * 128,), torch.uint8)
-            check(self.lib.mu_csr_tpack_fill(n, d, _p(X.indptr), _p(X.indices), _p(X.values),
+            check(self.lib.mu_csr_tpack_fill(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
                                              _p(cptr), _p(ent), _p(work), wb, st))
         return DevicePackedCSR(cptr, ent, (d, n), X.nnz)
 

@@ -452,7 +452,7 @@ int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
   return MU_OK;
 }
 
-int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
                       const int32_t* d_indices, const float* d_values, const int64_t* d_cptr,
                       void* d_ent, void* d_work, size_t work_bytes, void* stream) {
   MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
@@ -469,9 +469,6 @@ int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
                          d_indices, d_values, w.sp, d_cptr, w.cnt, (unsigned long long*)d_ent);
     } else {
       // slab width: the expected tile (nnz / G rows x C columns) fills ~80 % of the staging buffer
-      int64_t nnz = 0;
-      MU_CHECK_HIP(hipMemcpyAsync(&nnz, d_indptr + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-      MU_CHECK_HIP(hipStreamSynchronize(st));
       const double per_col = (double)nnz / (double)G / (double)n_cols;  // pairs of a tile per column
       int64_t C = per_col > 0 ? (int64_t)(0.8 * kF2Cap / per_col) : kF2Cols;
       C = (C / 64) * 64;

@@ -5,6 +5,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -60,3 +62,43 @@ def test_no_reference_sources_copied():
     assert not os.path.exists(os.path.join(ROOT, "muon"))
     for f in os.listdir(os.path.join(ROOT, "tests", "golden")):
         assert f.endswith((".npz", ".py")), f
+
+
+def test_packed_spmm_isa_keeps_out_of_the_asm_owned_registers(tmp_path):
+    """The packed SpMM issues its chunk requests from inline asm into v[110..126], registers hipcc
+    must never touch (a compiler copy of a register whose load is in flight reads stale data), and
+    hipcc must not spill (its scratch loads would share vmcnt with the hand-counted requests).
+    Audit the generated gfx950 ISA of every instance: no scratch, no compiler-issued instruction
+    naming v110+, 127 allocated VGPRs."""
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "muon_amd", "csrc", "spmm_packed.hip")
+    out = tmp_path / "spmm_packed.s"
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "muon_amd", "csrc"), "-S", "--cuda-device-only", "-w",
+                           "-o", str(out), src])
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN[^\n:]*k_spmm_pcr64_w16[^\n:]*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
+                         flags=re.S | re.M)
+    assert len(kernels) >= 8
+    reg = re.compile(r"\bv(\d+)\b|v\[(\d+):(\d+)\]")
+    for name, body in kernels:
+        assert "scratch_" not in body, name
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body), name
+        m = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
+        assert m and int(m.group(1)) == 127, (name, m and m.group(1))
+        inasm = False
+        for line in body.splitlines():
+            if "#ASMSTART" in line:
+                inasm = True
+            elif "#ASMEND" in line:
+                inasm = False
+            elif not inasm and not line.lstrip().startswith((".", ";")):
+                for a, b, c in reg.findall(line.split(";")[0]):
+                    hi = int(a) if a else int(c)
+                    assert hi < 110, (name, line)
