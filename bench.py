@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--density", type=float, default=0.03)
     ap.add_argument("--n-comps", type=int, default=50)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-sample-cells", type=int, default=4000)
+    ap.add_argument("--cpu-sample-cells", type=int, default=12000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pack", action="store_true",
                     help="ablation: run the SpMM on plain CSR (k_spmm_lds64) instead of the packed copy")
@@ -183,15 +183,17 @@ def main():
     spmm_total_ms = float(np.sum(ms))
 
     traffic = None
+    traffic_detail = None
     tpath = os.path.join(ROOT, "profiles", "r01_spmm_traffic.json")
     if args.workload == "c3shard" and not args.cells and not args.peaks and not args.no_pack \
             and os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
-        traffic = {"bytes_per_launch": tj["spmm_mean_bytes_per_launch"],
-                   "x_q": tj["spmm_xq_bytes_per_launch"], "xt_y": tj["spmm_xty_bytes_per_launch"],
-                   "vs_algorithmic": tj["spmm_mean_bytes_per_launch"] / tj["algorithmic_bytes_per_launch"],
-                   "source": "profiles/r01_spmm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
+        traffic = tj["spmm_mean_bytes_per_launch"]  # bytes per launch, like algorithmic_bytes_per_launch
+        traffic_detail = {"x_q": tj["spmm_xq_bytes_per_launch"], "xt_y": tj["spmm_xty_bytes_per_launch"],
+                          "vs_algorithmic": traffic / tj["algorithmic_bytes_per_launch"],
+                          "source": "profiles/r01_spmm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 "
+                                    "correction + WRITE_SIZE, separate passes)"}
 
     if rank == 0:
         out = {
@@ -226,6 +228,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_detail": traffic_detail,
                 "avg_launch_ms": avg_ms,
                 "launches": len(ms),
                 "share_of_step": spmm_total_ms / (dt * 1e3),

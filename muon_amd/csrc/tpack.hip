@@ -226,6 +226,72 @@ __device__ __forceinline__ int64_t readlane_i64(int64_t v, int l) {
 }
 
 // PHASE 0: count pairs per (wave, column).  PHASE 1: place them (LDS when `staged`, else global).
+// A wave takes its rows 64 at a time (lane l keeps the cursor of row l), eight rows per batch;
+// the entries of the next batch are requested before the current batch is processed, so the LDS
+// bucket chains of one batch hide the memory latency of the next.
+struct F2Batch {
+  int32_t ci[kF2Rows];
+  float cv[kF2Rows];
+};
+
+template <int PHASE>
+__device__ __forceinline__ void f2_load(F2Batch& b, int64_t cur, int64_t end, int first,
+                                        const int32_t* __restrict__ indices,
+                                        const float* __restrict__ values) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < kF2Rows; ++j) {
+    const int src = (first + j) & 63;
+    const int64_t p = readlane_i64(cur, src) + lane;
+    const bool in = (first + j < 64) && (p < readlane_i64(end, src));  // rows past the range: cur = end = 0
+    b.ci[j] = in ? indices[p] : 0x7fffffff;
+    if (PHASE == 1) b.cv[j] = in ? values[p] : 0.f;
+  }
+}
+
+template <int PHASE>
+__device__ __forceinline__ void f2_process(const F2Batch& b, int64_t& cur, int64_t end, int first,
+                                           int64_t row0, int32_t cbase, int32_t cend,
+                                           const int32_t* __restrict__ indices,
+                                           const float* __restrict__ values, uint32_t* wbucket,
+                                           const uint32_t* lpos, const uint32_t* gpos,
+                                           unsigned long long* stage, bool staged, int64_t slab_start,
+                                           unsigned long long* __restrict__ ent) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < kF2Rows; ++j) {
+    if (first + j >= 64) break;  // uniform
+    int64_t c0 = readlane_i64(cur, first + j);
+    const int64_t e0 = readlane_i64(end, first + j);
+    int32_t c = b.ci[j];
+    float v = (PHASE == 1) ? b.cv[j] : 0.f;
+    while (true) {
+      const bool valid = c < cend;  // sorted rows: a prefix of the 64 loaded entries
+      const int n = __popcll(__ballot(valid));
+      if (valid) {
+        const int cl = c - cbase;
+        if (PHASE == 0) {
+          wbucket[cl] += 1u;  // columns inside one row are distinct: no two lanes share a counter
+        } else {
+          const uint32_t k = wbucket[cl];
+          wbucket[cl] = k + 1u;
+          const unsigned long long e = (unsigned long long)(unsigned)(row0 + first + j) |
+                                       ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32);
+          if (staged) stage[lpos[cl] + k] = e;
+          else ent[slab_start + (int64_t)gpos[cl] + k] = e;
+        }
+      }
+      c0 += n;
+      if (n < 64) break;  // wave-uniform
+      const int64_t p = c0 + lane;  // a row with more than 64 entries in this slab
+      const bool in = p < e0;
+      c = in ? indices[p] : 0x7fffffff;
+      if (PHASE == 1) v = in ? values[p] : 0.f;
+    }
+    if (PHASE == 1 && lane == first + j) cur = c0;
+  }
+}
+
 template <int PHASE>
 __device__ __forceinline__ void f2_walk(int64_t wrow0, int64_t wrow1, int32_t cbase, int32_t cend,
                                         const int64_t* __restrict__ indptr,
@@ -235,53 +301,28 @@ __device__ __forceinline__ void f2_walk(int64_t wrow0, int64_t wrow1, int32_t cb
                                         unsigned long long* stage, bool staged, int64_t slab_start,
                                         unsigned long long* __restrict__ ent) {
   const int lane = threadIdx.x & 63;
-  for (int64_t rb = wrow0; rb < wrow1; rb += kF2Rows) {  // wave-uniform
+  for (int64_t sb = wrow0; sb < wrow1; sb += 64) {  // wave-uniform
+    const int nr = (wrow1 - sb) < 64 ? (int)(wrow1 - sb) : 64;
     int64_t cur = 0, end = 0;
-    if (lane < kF2Rows && rb + lane < wrow1) {
-      cur = curs[rb + lane];
-      end = indptr[rb + lane + 1];
+    if (lane < nr) {
+      cur = curs[sb + lane];
+      end = indptr[sb + lane + 1];
     }
-    int32_t ci[kF2Rows];
-    float cv[kF2Rows];
-#pragma unroll
-    for (int j = 0; j < kF2Rows; ++j) {
-      const int64_t p = readlane_i64(cur, j) + lane;
-      const bool in = p < readlane_i64(end, j);  // rows past wrow1 have cur = end = 0
-      ci[j] = in ? indices[p] : 0x7fffffff;
-      if (PHASE == 1) cv[j] = in ? values[p] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < kF2Rows; ++j) {
-      int64_t c0 = readlane_i64(cur, j);
-      const int64_t e0 = readlane_i64(end, j);
-      int32_t c = ci[j];
-      float v = (PHASE == 1) ? cv[j] : 0.f;
-      while (true) {
-        const bool valid = c < cend;  // sorted rows: a prefix of the 64 loaded entries
-        const int n = __popcll(__ballot(valid));
-        if (valid) {
-          const int cl = c - cbase;
-          if (PHASE == 0) {
-            wbucket[cl] += 1u;  // columns inside one row are distinct: no two lanes share a counter
-          } else {
-            const uint32_t k = wbucket[cl];
-            wbucket[cl] = k + 1u;
-            const unsigned long long e = (unsigned long long)(unsigned)(rb + j) |
-                                         ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32);
-            if (staged) stage[lpos[cl] + k] = e;
-            else ent[slab_start + (int64_t)gpos[cl] + k] = e;
-          }
-        }
-        c0 += n;
-        if (n < 64) break;  // wave-uniform
-        const int64_t p = c0 + lane;  // a row with more than 64 entries in this slab
-        const bool in = p < e0;
-        c = in ? indices[p] : 0x7fffffff;
-        if (PHASE == 1) v = in ? values[p] : 0.f;
+    F2Batch ba, bb;
+    f2_load<PHASE>(ba, cur, end, 0, indices, values);
+    for (int first = 0; first < nr; first += 2 * kF2Rows) {
+      // (the cursors of the rows of a batch are final before its loads are issued: rows are
+      //  independent, only `cur` of the rows being processed changes)
+      if (first + kF2Rows < nr) f2_load<PHASE>(bb, cur, end, first + kF2Rows, indices, values);
+      f2_process<PHASE>(ba, cur, end, first, sb, cbase, cend, indices, values, wbucket, lpos, gpos, stage,
+                        staged, slab_start, ent);
+      if (first + kF2Rows < nr) {
+        if (first + 2 * kF2Rows < nr) f2_load<PHASE>(ba, cur, end, first + 2 * kF2Rows, indices, values);
+        f2_process<PHASE>(bb, cur, end, first + kF2Rows, sb, cbase, cend, indices, values, wbucket, lpos,
+                          gpos, stage, staged, slab_start, ent);
       }
-      if (PHASE == 1 && lane == j) cur = c0;
     }
-    if (PHASE == 1 && lane < kF2Rows && rb + lane < wrow1) curs[rb + lane] = cur;
+    if (PHASE == 1 && lane < nr) curs[sb + lane] = cur;
   }
 }
 

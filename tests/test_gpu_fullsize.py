@@ -1,0 +1,92 @@
+"""Size-independent properties at BASELINE.json's per-GPU size (125 000 cells x 200 000 peaks,
+7.8e8 stored entries - far beyond what the CPU oracle finishes in seconds): round trips, adjoint
+identities, checksums of checksums and eigen-residuals, all evaluated on the device."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N, D = 125_000, 200_000
+
+
+@pytest.fixture(scope="module")
+def shard(hip):
+    from muon_amd._atac.preproc import tfidf_device
+
+    X = hip.synth_counts(0, N, D, 50, 0.03, 0)
+    T = tfidf_device(hip, X, N, 3, 1e4)
+    return X, T
+
+
+def _rows_of(X):
+    counts = (X.indptr[1:] - X.indptr[:-1])
+    return torch.repeat_interleave(torch.arange(X.shape[0], device=X.indptr.device), counts)
+
+
+def test_tfidf_inverts_back_to_the_counts(hip, shard):
+    """out = log1p(c / rowsum * 1e4) * log1p(n / colsum)  =>  c = expm1(out / idf) * rowsum / 1e4."""
+    X, T = shard
+    assert T.indices.data_ptr() == X.indices.data_ptr() or torch.equal(T.indices, X.indices)
+    rows = _rows_of(X)
+    cols = X.indices.long()
+    c = X.values.double()
+    rowsum = torch.zeros(N, dtype=torch.float64, device=c.device).index_add_(0, rows, c)
+    colsum = torch.zeros(D, dtype=torch.float64, device=c.device).index_add_(0, cols, c)
+    idf = torch.log1p(N / colsum)
+    back = torch.expm1(T.values.double() / idf[cols]) * rowsum[rows] / 1e4
+    assert torch.isfinite(T.values).all() and (T.values > 0).all()
+    rel = ((back - c).abs() / c).max().item()
+    assert rel < 2e-5, rel  # two f32 roundings of the forward pass, amplified by expm1
+
+
+def test_packed_spmm_adjoint_and_checksums_full_size(hip, shard):
+    _, T = shard
+    Tp = hip.pack(T)
+    Ttp = hip.transpose_pack(T)
+    q = hip.randn(D, 64, 3)
+    y = hip.randn(N, 64, 4)
+    Yq = hip.spmm(Tp, q)
+    Zy = hip.spmm(Ttp, y)
+    lhs = (Yq.double() * y.double()).sum(dim=0)
+    rhs = (q.double() * Zy.double()).sum(dim=0)
+    assert torch.allclose(lhs, rhs, rtol=2e-5, atol=1e-4 * float(lhs.abs().max()))
+    # X 1 = row sums, X^T 1 = column sums (checksum of checksums against index_add in f64)
+    ones_d = torch.ones((D, 64), dtype=torch.float32, device=q.device)
+    ones_n = torch.ones((N, 64), dtype=torch.float32, device=q.device)
+    rows, cols, v = _rows_of(T), T.indices.long(), T.values.double()
+    rs = torch.zeros(N, dtype=torch.float64, device=v.device).index_add_(0, rows, v)
+    cs = torch.zeros(D, dtype=torch.float64, device=v.device).index_add_(0, cols, v)
+    r1 = hip.spmm(Tp, ones_d)[:, 0].double()
+    c1 = hip.spmm(Ttp, ones_n)[:, 7].double()
+    assert ((r1 - rs).abs() / rs).max().item() < 2e-5
+    nz = cs > 0
+    assert ((c1[nz] - cs[nz]).abs() / cs[nz]).max().item() < 2e-5
+    assert (c1[~nz] == 0).all()
+    # bit-reproducible
+    assert torch.equal(hip.spmm(Tp, q), Yq) and torch.equal(hip.spmm(Ttp, y), Zy)
+
+
+def test_lsi_eigen_residuals_full_size(hip, shard):
+    """V orthonormal, singular values descending, and X^T X v_i = s_i^2 v_i for the leading
+    components to the accuracy a 1e-4 subspace angle implies; U has zero mean / unit variance."""
+    from muon_amd._atac.tools import lsi_device
+
+    _, T = shard
+    U, stdev, V, info = lsi_device(hip, T, n_comps=50, return_info=True)
+    s = stdev * np.sqrt(N - 1)
+    assert np.all(np.diff(s) <= 0) and info["converged"] and info["iterations"] <= 8
+    Vd = V.double()
+    G = Vd.T @ Vd
+    assert (G - torch.eye(50, dtype=torch.float64, device=G.device)).abs().max().item() < 1e-5
+    Vb = torch.zeros((D, 64), dtype=torch.float32, device=V.device)
+    Vb[:, :50] = V
+    W = hip.spmm(hip.transpose_pack(T), hip.spmm(hip.pack(T), Vb))[:, :50].double()
+    s2 = torch.as_tensor(s**2, device=W.device)
+    res = (W - Vd * s2).norm(dim=0) / s2
+    # the trailing components sit next to the bulk: their residual is bounded by the angle target
+    # times the spectral spread; the planted ones are far better
+    assert res.max().item() < 2e-3, res.max().item()
+    assert res[:40].max().item() < 2e-4, res[:40].max().item()
+    Ud = U.double()
+    assert Ud.mean(dim=0).abs().max().item() < 1e-3 and (Ud.std(dim=0, unbiased=False) - 1).abs().max().item() < 1e-3
