@@ -14,12 +14,14 @@ inside the timed region.  `traffic` = HBM bytes per launch from rocprofv3 PMC co
 from profiles/r01_spmm_traffic.json; null for any other shape.
 
 Workloads (--workload):
-  c3shard (default)  125 000 cells x 200 000 peaks per GPU, 3 % nnz: rank r holds rows
-                     [r*125k, (r+1)*125k) of BASELINE.json configs[2]; --gpus 8 is exactly the
-                     1M x 200k configuration, sharded by cells with RCCL all-reduce of the
-                     per-peak sums and of Z = X^T Y.  Weak scaling.
-  c2                 10 000 x 30 000, 3 % nnz (configs[1])
-  c3full             1 000 000 x 200 000 on ONE GPU (needs ~150 GB of HBM)
+  c3 (default)       BASELINE.json configs[2], the shape the metric is quoted on: 1 000 000 cells x
+                     200 000 peaks, 3 % nnz (6.3e9 stored entries), row-sharded over the N GPUs
+                     (rank r holds cells [r*1M/N, (r+1)*1M/N)) with RCCL all-reduce of the per-peak
+                     sums and of Z = X^T Y.  STRONG scaling: the whole matrix sits on one GPU at
+                     N = 1 (~170 GB of the 288 GB).
+  c3shard            125 000 cells x 200 000 peaks PER GPU (weak scaling; N = 8 is the same 1M x
+                     200k matrix)
+  c2                 10 000 x 30 000, 3 % nnz (configs[1]; launch/latency bound at this size)
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run.
 Prints ONE JSON line on rank 0.
@@ -37,10 +39,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-WORKLOADS = {
-    "c3shard": dict(cells=125_000, peaks=200_000),
-    "c2": dict(cells=10_000, peaks=30_000),
-    "c3full": dict(cells=1_000_000, peaks=200_000),
+WORKLOADS = {  # cells = TOTAL cells for strong scaling, cells PER GPU for weak scaling
+    "c3": dict(cells=1_000_000, peaks=200_000, scaling="strong"),
+    "c3shard": dict(cells=125_000, peaks=200_000, scaling="weak"),
+    "c2": dict(cells=10_000, peaks=30_000, scaling="weak"),
 }
 
 
@@ -98,8 +100,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3shard", choices=sorted(WORKLOADS))
-    ap.add_argument("--cells", type=int, default=None, help="override cells per GPU")
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cells", type=int, default=None, help="override cells (total if strong, per GPU if weak)")
     ap.add_argument("--peaks", type=int, default=None)
     ap.add_argument("--density", type=float, default=0.03)
     ap.add_argument("--n-comps", type=int, default=50)
@@ -136,11 +138,18 @@ def main():
         wl["cells"] = args.cells
     if args.peaks:
         wl["peaks"] = args.peaks
-    n_local, d = wl["cells"], wl["peaks"]
-    n_global = n_local * world
+    d = wl["peaks"]
+    if wl["scaling"] == "strong":
+        n_global = wl["cells"]
+        row0 = rank * n_global // world
+        n_local = (rank + 1) * n_global // world - row0
+    else:
+        n_local = wl["cells"]
+        n_global = n_local * world
+        row0 = rank * n_local
 
     be = TimedBackend(HipBackend(local_rank))
-    X = be.synth_counts(rank * n_local, n_local, d, 50, args.density, args.seed)
+    X = be.synth_counts(row0, n_local, d, 50, args.density, args.seed)
     nnz_local = X.nnz
     tf_vals = torch.empty_like(X.values)
     flags = 3  # log_tf | log_idf (reference defaults)
@@ -185,10 +194,11 @@ def main():
     traffic = None
     traffic_detail = None
     tpath = os.path.join(ROOT, "profiles", "r01_spmm_traffic.json")
-    if args.workload == "c3shard" and not args.cells and not args.peaks and not args.no_pack \
-            and os.path.exists(tpath):
+    tj = None
+    if not args.cells and not args.peaks and not args.no_pack and os.path.exists(tpath):
         with open(tpath) as f:
-            tj = json.load(f)
+            tj = json.load(f).get(f"{n_local}x{d}")  # measured per shape of the rank-0 shard
+    if tj:
         traffic = tj["spmm_mean_bytes_per_launch"]  # bytes per launch, like algorithmic_bytes_per_launch
         traffic_detail = {"x_q": tj["spmm_xq_bytes_per_launch"], "xt_y": tj["spmm_xty_bytes_per_launch"],
                           "vs_algorithmic": traffic / tj["algorithmic_bytes_per_launch"],
@@ -205,13 +215,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": wl["scaling"],
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: planted-topic CSR, {n_local} cells x {d} peaks per GPU "
-                            f"({n_global} x {d} total), {nnz_local} nnz on rank 0 "
+                "workload": f"{args.workload}: planted-topic CSR, {n_global} cells x {d} peaks in total, "
+                            f"{n_local} cells on rank 0 ({wl['scaling']} scaling), {nnz_local} nnz on rank 0 "
                             f"({nnz_local / n_local / d:.4f} dense), tfidf + lsi(n_comps={args.n_comps})",
                 "parallelism": f"cells row-sharded x{world}" if world > 1 else "1 GPU",
                 "lsi": {"block": info.get("block"), "iterations": info.get("iterations"),

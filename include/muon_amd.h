@@ -144,10 +144,11 @@ int mu_csr_pack_fill(int64_t n_rows, const int64_t* d_indptr, const int32_t* d_i
  *   1. mu_csr_tpack_count: row_chunks[c] = ceil(nnz of column c / 16) + 1 (and keeps its
  *      per-workgroup column offsets in d_work)
  *   2. caller scans row_chunks into cptr int64[n_cols + 1] and allocates ent (128 B x cptr[n_cols])
- *   3. mu_csr_tpack_fill with the SAME d_work (nnz = stored entries of X; it only sizes the tiles)
+ *   3. mu_csr_tpack_fill with the SAME d_work
+ * nnz = stored entries of X (it sizes the row blocks and tiles; pass the same value everywhere).
  * Stable and free of global atomics => bit-reproducible.  n_rows < ~1.04e6 (32-bit slab cursors). */
-size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols);
-int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz);
+int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
                        const int32_t* d_indices, int64_t* d_row_chunks, void* d_work,
                        size_t work_bytes, void* stream);
 int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,

@@ -200,11 +200,11 @@ class HipBackend:
         assert X.values.dtype == torch.float32
         row_chunks = self.empty((max(d, 1),), torch.int64)
         cptr = self.zeros((d + 1,), torch.int64)
-        wb = int(self.lib.mu_csr_tpack_worksize(n, d))
+        wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
         work = self.empty((wb,), torch.uint8)
         with torch.cuda.device(self.device):
             st = self._stream()
-            check(self.lib.mu_csr_tpack_count(n, d, _p(X.indptr), _p(X.indices), _p(row_chunks),
+            check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(row_chunks),
                                               _p(work), wb, st))
             check(self.lib.mu_exclusive_scan_i64(d, _p(row_chunks), _p(cptr), st))
             n_chunks = int(cptr[-1].item()) if d > 0 else 0

@@ -57,8 +57,8 @@ SIGNATURES = {
     "mu_spmm_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "mu_csr_pack_count": (C.c_int, [_i64, _vp, _vp, _vp]),
     "mu_csr_pack_fill": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mu_csr_tpack_worksize": (_sz, [_i64, _i64]),
-    "mu_csr_tpack_count": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mu_csr_tpack_worksize": (_sz, [_i64, _i64, _i64]),
+    "mu_csr_tpack_count": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_csr_tpack_fill": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_packed_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp]),
     "mu_tune_set": (C.c_int, [C.c_char_p, _i32]),

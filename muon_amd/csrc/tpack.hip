@@ -28,7 +28,17 @@ constexpr int kTWaves = kTThreads / 64;
 constexpr unsigned kPad = 0x7fffffffu;
 
 inline int64_t t_slabs(int64_t n_cols) { return (n_cols + kTSlab - 1) / kTSlab; }
-inline int t_grid() { return mu_num_cus(); }  // one 1024-thread workgroup per CU (the staged fill needs 140 KiB of LDS)
+// Row blocks (= workgroups of the count and fill sweeps): one per CU (the staged fill needs 140 KiB
+// of LDS), and more rounds of them for big inputs so that a block stays near 3.2e6 stored entries -
+// with bigger blocks the staging tile forces narrow slabs (64 columns at 1e6 rows), i.e. thousands
+// of tiles whose 64-lane row loads are mostly outside the slab (c3full: 1.2 s -> see DESIGN.md 4.1).
+inline int t_grid(int64_t nnz) {
+  const int64_t cus = mu_num_cus();
+  int64_t rounds = (nnz + 3200000ll * cus - 1) / (3200000ll * cus);
+  if (rounds < 1) rounds = 1;
+  if (rounds > 64) rounds = 64;
+  return (int)(cus * rounds);
+}
 
 // rows [r0, r1) owned by workgroup g of G: contiguous, balanced by nnz
 __device__ __forceinline__ void t_row_range(const int64_t* indptr, int64_t n_rows, int g, int G,
@@ -326,7 +336,7 @@ __device__ __forceinline__ void f2_walk(int64_t wrow0, int64_t wrow1, int32_t cb
   }
 }
 
-__global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n_cols, int C,
+__global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n_cols, int C, int abl,
                                                        const int64_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ indices,
                                                        const float* __restrict__ values,
@@ -389,6 +399,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
     __syncthreads();
     if (total == 0) continue;  // uniform: nothing of this row block falls into the slab
 
+    if (!(abl & 1))
     f2_walk<0>(wrow0, wrow1, cbase, cend, indptr, indices, values, curs, bucket[wave], lpos, gpos, stage,
                staged, slab_start, ent);
     __syncthreads();
@@ -402,10 +413,11 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
       }
     }
     __syncthreads();
+    if (!(abl & 2))
     f2_walk<1>(wrow0, wrow1, cbase, cend, indptr, indices, values, curs, bucket[wave], lpos, gpos, stage,
                staged, slab_start, ent);
     __syncthreads();
-    if (staged) {
+    if (staged && !(abl & 4)) {
       // write-out: one 16-lane group per column, consecutive lanes = consecutive pairs of the run
       const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
       for (int cl = grp; cl < cend - cbase; cl += kTThreads / 16) {
@@ -436,14 +448,14 @@ struct TWork {
   int64_t* curs;
 };
 inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
-inline TWork carve(void* work, int64_t n_rows, int64_t n_cols) {
+inline TWork carve(void* work, int64_t n_rows, int64_t n_cols, int64_t nnz) {
   const int64_t S = t_slabs(n_cols);
   char* w = (char*)work;
   TWork t;
   t.sp = (int64_t*)w;
   w += al((size_t)(n_rows * (S + 1)) * sizeof(int64_t));
   t.cnt = (uint32_t*)w;
-  w += al((size_t)t_grid() * (size_t)n_cols * sizeof(uint32_t));
+  w += al((size_t)t_grid(nnz) * (size_t)n_cols * sizeof(uint32_t));
   t.coltot = (int64_t*)w;
   w += al((size_t)n_cols * sizeof(int64_t));
   t.curs = (int64_t*)w;
@@ -454,14 +466,14 @@ inline TWork carve(void* work, int64_t n_rows, int64_t n_cols) {
 
 extern "C" {
 
-size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols) {
+size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz) {
   const int64_t S = t_slabs(n_cols);
   return al((size_t)(n_rows * (S + 1)) * sizeof(int64_t)) +
-         al((size_t)t_grid() * (size_t)n_cols * sizeof(uint32_t)) +
+         al((size_t)t_grid(nnz) * (size_t)n_cols * sizeof(uint32_t)) +
          al((size_t)n_cols * sizeof(int64_t)) + al((size_t)(n_rows + 1) * sizeof(int64_t)) + 256;
 }
 
-int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
                        const int32_t* d_indices, int64_t* d_row_chunks, void* d_work,
                        size_t work_bytes, void* stream) {
   MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
@@ -469,11 +481,11 @@ int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
   MU_REQUIRE((n_rows + 32) * (int64_t)kTSlab < ((int64_t)1 << 32), "too many rows for 32-bit slab cursors");
   if (n_cols == 0) return MU_OK;
   MU_REQUIRE(d_indptr && d_row_chunks && d_work, "null pointer");
-  MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols), "work buffer too small");
+  MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols, nnz), "work buffer too small");
   hipStream_t st = (hipStream_t)stream;
   const int64_t S = t_slabs(n_cols);
-  const int G = t_grid();
-  const TWork w = carve(d_work, n_rows, n_cols);
+  const int G = t_grid(nnz);
+  const TWork w = carve(d_work, n_rows, n_cols, nnz);
   MU_CHECK_HIP(hipMemsetAsync(w.cnt, 0, (size_t)G * (size_t)n_cols * sizeof(uint32_t), st));
   if (n_rows > 0) {
     const int64_t total = n_rows * (S + 1);
@@ -499,25 +511,29 @@ int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t
   MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
   if (n_cols == 0) return MU_OK;
   MU_REQUIRE(d_indptr && d_cptr && d_ent && d_work, "null pointer");
-  MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols), "work buffer too small");
+  MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols, nnz), "work buffer too small");
   hipStream_t st = (hipStream_t)stream;
   const int64_t S = t_slabs(n_cols);
-  const int G = t_grid();
-  const TWork w = carve(d_work, n_rows, n_cols);
+  const int G = t_grid(nnz);
+  const TWork w = carve(d_work, n_rows, n_cols, nnz);
   if (n_rows > 0) {
     if (mu_tune_get("tpack_v1")) {
       hipLaunchKernelGGL(k_t_fill, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, S, d_indptr,
                          d_indices, d_values, w.sp, d_cptr, w.cnt, (unsigned long long*)d_ent);
     } else {
-      // slab width: the expected tile (nnz / G rows x C columns) fills ~80 % of the staging buffer
+      // slab width: the expected tile (nnz / G rows x C columns) fills ~93 % of the staging buffer
+      // (measured best on the bench matrix: fewer, fuller tiles; a tile that overflows takes the
+      //  direct-store path)
       const double per_col = (double)nnz / (double)G / (double)n_cols;  // pairs of a tile per column
-      int64_t C = per_col > 0 ? (int64_t)(0.8 * kF2Cap / per_col) : kF2Cols;
-      C = (C / 64) * 64;
-      if (C < 64) C = 64;
+      int64_t C = per_col > 0 ? (int64_t)(0.93 * kF2Cap / per_col) : kF2Cols;
+      C = (C / 32) * 32;
+      if (C < 32) C = 32;
       if (C > kF2Cols) C = kF2Cols;
       MU_CHECK_HIP(hipMemcpyAsync(w.curs, d_indptr, sizeof(int64_t) * (size_t)n_rows,
                                   hipMemcpyDeviceToDevice, st));
-      hipLaunchKernelGGL(k_t_fill2, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C, d_indptr,
+      if (mu_tune_get("tpack_c") > 0) C = mu_tune_get("tpack_c");
+      hipLaunchKernelGGL(k_t_fill2, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,
+                         mu_tune_get("tpack_abl"), d_indptr,
                          d_indices, d_values, w.curs, d_cptr, w.cnt, w.coltot,
                          (unsigned long long*)d_ent);
     }

@@ -16,8 +16,11 @@ echo "rc=$?" | tee -a "$OUT/steps.txt"; tail -5 "$OUT/pytest_gpu.txt"
 echo "== bench (packed)" | tee -a "$OUT/steps.txt"
 timeout 600 python bench.py --steps 3 --warmup 1 > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "rc=$?" | tee -a "$OUT/steps.txt"; cat "$OUT/bench.json"; tail -3 "$OUT/bench.err"
+echo "== bench c3shard (weak-scaling shard, packed)" | tee -a "$OUT/steps.txt"
+timeout 600 python bench.py --workload c3shard --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_c3shard.json" 2> "$OUT/bench_c3shard.err"
+echo "rc=$?" | tee -a "$OUT/steps.txt"; cat "$OUT/bench_c3shard.json"
 echo "== bench (csr kernel, ablation)" | tee -a "$OUT/steps.txt"
-timeout 600 python bench.py --steps 2 --warmup 1 --no-pack --no-cpu-baseline > "$OUT/bench_nopack.json" 2> "$OUT/bench_nopack.err"
+timeout 600 python bench.py --workload c3shard --steps 2 --warmup 1 --no-pack --no-cpu-baseline > "$OUT/bench_nopack.json" 2> "$OUT/bench_nopack.err"
 echo "rc=$?" | tee -a "$OUT/steps.txt"; cat "$OUT/bench_nopack.json"
 echo "== rocprof kernel stats" | tee -a "$OUT/steps.txt"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err")

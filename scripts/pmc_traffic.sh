@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 200 rocprofv3 --pmc $c -d "$OUT/$c" -o pmc --output-format csv -- python "$OLDPWD/scripts/spmm_probe.py" --reps 1 --calibrate > "$OUT/$c.log" 2>&1
+  timeout 200 rocprofv3 --pmc $c -d "$OUT/$c" -o pmc --output-format csv -- python "$OLDPWD/scripts/spmm_probe.py" --reps 1 --calibrate --cells ${CELLS:-125000} > "$OUT/$c.log" 2>&1
   echo "$c rc=$?"
 done
 du -sh "$OUT"
