@@ -131,35 +131,52 @@ int mu_spmm_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const i
  * padded with (INT32_MAX, 0) and one all-padding chunk closes every row.  Built once per
  * lsi() call for X and for X^T; the subspace iteration then streams every line exactly once
  * per product.
- *   1. mu_csr_pack_count: row_chunks[i] = ceil(nnz_i / 16) + 1
- *   2. caller scans row_chunks into cptr int64[n_rows + 1] (mu_exclusive_scan_i64) and
- *      allocates ent: 128 bytes x cptr[n_rows]
+ *
+ * Layout: the copy has n_pos >= n_rows POSITIONS; position p holds row perm[p] of the matrix
+ * (perm[p] < 0: no row; perm == NULL: the identity, n_pos = n_rows).  The SpMM gives 4 consecutive
+ * positions to the four 16-lane groups of a wave, K such row-sets to a wave, 16 waves to a
+ * workgroup (K = mu_spmm_packed_k(n_rows)), so the host sorts the rows by length and deals the
+ * row-sets round robin to workgroups and waves (muon_amd/_backend.py packed_layout): rows that
+ * advance in lock step have similar lengths and every workgroup gets the same mix (-12 % / -20 %
+ * on X Q / X^T Y of the bench matrix).
+ *   1. mu_csr_pack_count: row_chunks[p] = ceil(nnz of row perm[p] / 16) + 1   (1 for an empty position)
+ *   2. caller scans row_chunks into cptr int64[n_pos + 1] (mu_exclusive_scan_i64) and
+ *      allocates ent: 128 bytes x cptr[n_pos]
  *   3. mu_csr_pack_fill
- * Requires sorted column indices inside rows (canonical CSR). */
-int mu_csr_pack_count(int64_t n_rows, const int64_t* d_indptr, int64_t* d_row_chunks, void* stream);
-int mu_csr_pack_fill(int64_t n_rows, const int64_t* d_indptr, const int32_t* d_indices,
-                     const float* d_values, const int64_t* d_cptr, void* d_ent, void* stream);
-/* The packed copy of X^T (n_cols rows, cell ids ascending inside every row) straight from the CSR
- * of X - what Z = X^T Y of the iteration streams; no CSR of X^T is materialised.
- *   1. mu_csr_tpack_count: row_chunks[c] = ceil(nnz of column c / 16) + 1 (and keeps its
- *      per-workgroup column offsets in d_work)
- *   2. caller scans row_chunks into cptr int64[n_cols + 1] and allocates ent (128 B x cptr[n_cols])
+ * Requires canonical CSR (sorted column indices, no duplicates). */
+int mu_spmm_packed_k(int64_t n_rows);
+int mu_csr_pack_count(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr,
+                      int64_t* d_row_chunks, void* stream);
+int mu_csr_pack_fill(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr,
+                     const int32_t* d_indices, const float* d_values, const int64_t* d_cptr,
+                     void* d_ent, void* stream);
+
+/* The packed copy of X^T (one output row per column of X, cell ids ascending inside every row)
+ * straight from the CSR of X - what Z = X^T Y of the iteration streams; no CSR of X^T is
+ * materialised.
+ *   1. mu_csr_tpack_count: col_nnz[c] = stored entries of column c (and keeps its per-row-block
+ *      column offsets in d_work)
+ *   2. caller lays the output rows out (perm int32[n_pos], its inverse inv int32[n_cols]; both NULL
+ *      for the identity), scans the chunk counts into cptr int64[n_pos + 1], allocates ent
  *   3. mu_csr_tpack_fill with the SAME d_work
  * nnz = stored entries of X (it sizes the row blocks and tiles; pass the same value everywhere).
- * Stable and free of global atomics => bit-reproducible.  n_rows < ~1.04e6 (32-bit slab cursors). */
+ * Stable and free of global atomics => bit-reproducible. */
 size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz);
 int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
-                       const int32_t* d_indices, int64_t* d_row_chunks, void* d_work,
+                       const int32_t* d_indices, int64_t* d_col_nnz, void* d_work,
                        size_t work_bytes, void* stream);
 int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
-                      const int32_t* d_indices, const float* d_values, const int64_t* d_cptr,
-                      void* d_ent, void* d_work, size_t work_bytes, void* stream);
+                      const int32_t* d_indices, const float* d_values, int64_t n_pos,
+                      const int64_t* d_cptr, const int32_t* d_perm, const int32_t* d_inv, void* d_ent,
+                      void* d_work, size_t work_bytes, void* stream);
 
-/* Y[n_rows x 64] = X * Q on the packed copy (B must be 64, n_cols <= 2^22).  Same result as
- * mu_spmm_f32 up to f32 summation order (entries of a row are accumulated in column order,
- * fmaf chain per dense column; bit-reproducible run to run). */
-int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, const void* d_ent,
-                       const float* d_Q, int B, float* d_Y, void* stream);
+/* Y[perm[p]][0..63] = row perm[p] of X times Q, for every position p < n_pos (B must be 64,
+ * n_cols <= 2^22).  k_layout = the K the layout was dealt for (0: mu_spmm_packed_k(n_pos)).  Same
+ * result as mu_spmm_f32 up to f32 summation order: the entries of a row are accumulated in column
+ * order with one fmaf chain per dense column, whatever the layout => bit-reproducible. */
+int mu_spmm_packed_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_cptr, const void* d_ent,
+                       const int32_t* d_perm, int k_layout, const float* d_Q, int B, float* d_Y,
+                       void* stream);
 
 /* Tuning / ablation knobs (tests and bench only; all default to 0 = what ships):
  *   "spmm_k"     row-sets per wave of the packed SpMM (0 = automatic)

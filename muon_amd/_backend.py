@@ -42,13 +42,21 @@ class DeviceCSR:
 
 @dataclass
 class DevicePackedCSR:
-    """Packed chunked-row copy of a CSR ("PCR16", include/muon_amd.h): cptr int64[n+1] chunk
-    offsets, ent uint8[128 * n_chunks] (16 (column, value) pairs per chunk).  SpMM-only."""
+    """Packed chunked-row copy of a CSR ("PCR16", include/muon_amd.h): cptr int64[n_pos+1] chunk
+    offsets, ent uint8[128 * n_chunks] (16 (column, value) pairs per chunk), perm int32[n_pos]
+    (position -> row of the matrix, -1 = none; None = identity), k = the row-sets-per-wave the
+    layout was dealt for.  SpMM-only."""
 
     cptr: torch.Tensor
     ent: torch.Tensor
     shape: Tuple[int, int]
     nnz: int
+    perm: Optional[torch.Tensor] = None
+    k: int = 0
+
+    @property
+    def n_pos(self) -> int:
+        return int(self.cptr.numel()) - 1
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -178,40 +186,77 @@ class HipBackend:
         """The packed SpMM exists for f32 values, B = 64 and at most 2^22 columns."""
         return X.values.dtype == torch.float32 and B == 64 and 0 < X.shape[1] <= (1 << 22)
 
-    def pack(self, X: DeviceCSR) -> DevicePackedCSR:
+    def packed_layout(self, lens: torch.Tensor):
+        """Where the rows go in a packed copy (include/muon_amd.h): sorted by length (descending,
+        stable) and dealt round robin - row-set q of the sorted order goes to workgroup q % n_wg,
+        inside it to wave (q // n_wg) % 16 and row-set slot (q // n_wg) // 16 - so that the four rows
+        a wave advances in lock step have similar lengths and every workgroup and wave gets the same
+        mix.  Returns (perm int32[n_pos], inv int32[n], K)."""
+        n = int(lens.numel())
+        K = max(1, int(self.lib.mu_spmm_packed_k(n)))
+        per_wg = 64 * K
+        n_wg = max(1, (n + per_wg - 1) // per_wg)
+        n_pos = n_wg * per_wg
+        order = torch.argsort(lens, descending=True, stable=True)
+        i = torch.arange(n, device=lens.device)
+        q, j = i // 4, i % 4
+        b, t = q % n_wg, q // n_wg
+        w, k = t % 16, t // 16
+        pos = ((b * 16 + w) * K + k) * 4 + j
+        perm = torch.full((n_pos,), -1, dtype=torch.int32, device=lens.device)
+        perm[pos] = order.to(torch.int32)
+        inv = torch.empty((n,), dtype=torch.int32, device=lens.device)
+        inv[order] = pos.to(torch.int32)
+        return perm, inv, K
+
+    def pack(self, X: DeviceCSR, sort_rows: bool = True) -> DevicePackedCSR:
         """Build the packed chunked-row copy used by the B = 64 SpMM (once per lsi call)."""
         n, d = X.shape
         assert X.values.dtype == torch.float32
-        row_chunks = self.empty((max(n, 1),), torch.int64)
-        cptr = self.zeros((n + 1,), torch.int64)
+        perm, K, n_pos = None, 0, n
+        if sort_rows and n > 0:
+            perm, _inv, K = self.packed_layout(X.indptr[1:] - X.indptr[:-1])
+            n_pos = int(perm.numel())
+        row_chunks = self.empty((max(n_pos, 1),), torch.int64)
+        cptr = self.zeros((n_pos + 1,), torch.int64)
         with torch.cuda.device(self.device):
             st = self._stream()
-            check(self.lib.mu_csr_pack_count(n, _p(X.indptr), _p(row_chunks), st))
-            check(self.lib.mu_exclusive_scan_i64(n, _p(row_chunks), _p(cptr), st))
-            n_chunks = int(cptr[-1].item()) if n > 0 else 0
+            check(self.lib.mu_csr_pack_count(n_pos, _p(perm), _p(X.indptr), _p(row_chunks), st))
+            check(self.lib.mu_exclusive_scan_i64(n_pos, _p(row_chunks), _p(cptr), st))
+            n_chunks = int(cptr[-1].item()) if n_pos > 0 else 0
             ent = self.empty((max(n_chunks, 1) * 128,), torch.uint8)
-            check(self.lib.mu_csr_pack_fill(n, _p(X.indptr), _p(X.indices), _p(X.values), _p(cptr),
-                                            _p(ent), st))
-        return DevicePackedCSR(cptr, ent, (n, d), X.nnz)
+            check(self.lib.mu_csr_pack_fill(n_pos, _p(perm), _p(X.indptr), _p(X.indices), _p(X.values),
+                                            _p(cptr), _p(ent), st))
+        return DevicePackedCSR(cptr, ent, (n, d), X.nnz, perm, K)
 
-    def transpose_pack(self, X: DeviceCSR) -> DevicePackedCSR:
+    def transpose_pack(self, X: DeviceCSR, sort_rows: bool = True) -> DevicePackedCSR:
         """Packed chunked-row copy of X^T straight from the CSR of X (no CSR of X^T)."""
         n, d = X.shape
         assert X.values.dtype == torch.float32
-        row_chunks = self.empty((max(d, 1),), torch.int64)
-        cptr = self.zeros((d + 1,), torch.int64)
+        col_nnz = self.empty((max(d, 1),), torch.int64)
         wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
         work = self.empty((wb,), torch.uint8)
         with torch.cuda.device(self.device):
             st = self._stream()
-            check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(row_chunks),
+            check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
                                               _p(work), wb, st))
-            check(self.lib.mu_exclusive_scan_i64(d, _p(row_chunks), _p(cptr), st))
-            n_chunks = int(cptr[-1].item()) if d > 0 else 0
+            perm, inv, K, n_pos = None, None, 0, d
+            lens = col_nnz[:d]
+            if sort_rows and d > 0:
+                perm, inv, K = self.packed_layout(lens)
+                n_pos = int(perm.numel())
+                plens = torch.zeros((n_pos,), dtype=torch.int64, device=self.device)
+                plens[inv.long()] = lens
+            else:
+                plens = lens
+            row_chunks = (plens + 15) // 16 + 1
+            cptr = self.zeros((n_pos + 1,), torch.int64)
+            check(self.lib.mu_exclusive_scan_i64(n_pos, _p(row_chunks), _p(cptr), st))
+            n_chunks = int(cptr[-1].item()) if n_pos > 0 else 0
             ent = self.empty((max(n_chunks, 1) * 128,), torch.uint8)
             check(self.lib.mu_csr_tpack_fill(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
-                                             _p(cptr), _p(ent), _p(work), wb, st))
-        return DevicePackedCSR(cptr, ent, (d, n), X.nnz)
+                                             n_pos, _p(cptr), _p(perm), _p(inv), _p(ent), _p(work), wb, st))
+        return DevicePackedCSR(cptr, ent, (d, n), X.nnz, perm, K)
 
     def tune(self, key: str, value: int) -> None:
         check(self.lib.mu_tune_set(key.encode(), int(value)))
@@ -226,8 +271,8 @@ class HipBackend:
             if out is None:
                 out = self.empty((n, B), Q.dtype)
             with torch.cuda.device(self.device):
-                check(self.lib.mu_spmm_packed_f32(n, d, _p(X.cptr), _p(X.ent), _p(Q), B, _p(out),
-                                                  self._stream()))
+                check(self.lib.mu_spmm_packed_f32(X.n_pos, d, _p(X.cptr), _p(X.ent), _p(X.perm), X.k,
+                                                  _p(Q), B, _p(out), self._stream()))
             return out
         if X.values.dtype != Q.dtype:
             raise TypeError("spmm needs values and dense block of one dtype")

@@ -207,6 +207,7 @@ template <int W, int K, int MODE, int PIPE>
 __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
                                                 const int64_t* __restrict__ cptr,
                                                 const unsigned long long* __restrict__ ent,
+                                                const int32_t* __restrict__ perm,
                                                 const float* __restrict__ Q, float* __restrict__ Y) {
   static_assert(K >= 1 && K <= Geo<W>::KMAX && K <= 16, "K out of range for this workgroup size");
   constexpr int kPieces = (kSlabCols * 256) / 1024;  // 1 KiB LDS-DMA pieces per slab (= 64)
@@ -387,35 +388,46 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
   static_for<K>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     const int64_t row = rb0 + ((int64_t)wave * K + k) * 4 + g;
-    if (row < rb1) *reinterpret_cast<float4*>(Y + row * 64 + sub * 4) = acc[k];
+    if (row < rb1) {
+      const int64_t out = perm ? (int64_t)perm[row] : row;  // position -> row of the product (-1: none)
+      if (out >= 0) *reinterpret_cast<float4*>(Y + out * 64 + sub * 4) = acc[k];
+    }
   });
 }
 
 #define MU_KARGS                                                                          \
   int64_t n_rows, int64_t n_cols, const int64_t *__restrict__ cptr,                       \
-      const unsigned long long *__restrict__ ent, const float *__restrict__ Q, float *__restrict__ Y
+      const unsigned long long *__restrict__ ent, const int32_t *__restrict__ perm,       \
+      const float *__restrict__ Q, float *__restrict__ Y
 template <int K, int MODE, int PIPE>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(55))) void k_spmm_pcr64_w16(MU_KARGS) {
-  spmm_pcr64_body<16, K, MODE, PIPE>(n_rows, n_cols, cptr, ent, Q, Y);
+  spmm_pcr64_body<16, K, MODE, PIPE>(n_rows, n_cols, cptr, ent, perm, Q, Y);
 }
 template <int K, int MODE, int PIPE>
 __global__ __launch_bounds__(768) __attribute__((amdgpu_num_vgpr(72))) void k_spmm_pcr64_w12(MU_KARGS) {
-  spmm_pcr64_body<12, K, MODE, PIPE>(n_rows, n_cols, cptr, ent, Q, Y);
+  spmm_pcr64_body<12, K, MODE, PIPE>(n_rows, n_cols, cptr, ent, perm, Q, Y);
 }
 template <int K, int MODE, int PIPE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(100))) void k_spmm_pcr64_w8(MU_KARGS) {
-  spmm_pcr64_body<8, K, MODE, PIPE>(n_rows, n_cols, cptr, ent, Q, Y);
+  spmm_pcr64_body<8, K, MODE, PIPE>(n_rows, n_cols, cptr, ent, perm, Q, Y);
 }
 
 // ---- packing -----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack_count(int64_t n_rows, const int64_t* __restrict__ indptr,
+// Position p of the packed copy holds row perm[p] of the matrix (perm == nullptr: the identity;
+// perm[p] < 0: no row, only the closing chunk).  The host deals the rows, sorted by length, round
+// robin to workgroups and waves (muon_amd/_backend.py: packed_layout) - see DESIGN.md 4.1.
+__global__ __launch_bounds__(256) void k_pack_count(int64_t n_pos, const int32_t* __restrict__ perm,
+                                                    const int64_t* __restrict__ indptr,
                                                     int64_t* __restrict__ row_chunks) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n_rows) row_chunks[r] = ((indptr[r + 1] - indptr[r] + 15) >> 4) + 1;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pos) return;
+  const int64_t r = perm ? (int64_t)perm[p] : p;
+  row_chunks[p] = (r < 0) ? 1 : ((indptr[r + 1] - indptr[r] + 15) >> 4) + 1;
 }
 
 // one 16-lane group per chunk would waste the closing chunks; a wave per row streams instead
-__global__ __launch_bounds__(256) void k_pack_fill(int64_t n_rows, const int64_t* __restrict__ indptr,
+__global__ __launch_bounds__(256) void k_pack_fill(int64_t n_pos, const int32_t* __restrict__ perm,
+                                                   const int64_t* __restrict__ indptr,
                                                    const int32_t* __restrict__ indices,
                                                    const float* __restrict__ values,
                                                    const int64_t* __restrict__ cptr,
@@ -423,9 +435,11 @@ __global__ __launch_bounds__(256) void k_pack_fill(int64_t n_rows, const int64_t
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = uniform64(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t row = wave0; row < n_rows; row += n_waves) {
-    const int64_t lo = uniform64(indptr[row]), hi = uniform64(indptr[row + 1]);
-    const int64_t o0 = uniform64(cptr[row]) * 16, o1 = uniform64(cptr[row + 1]) * 16;
+  for (int64_t pos = wave0; pos < n_pos; pos += n_waves) {
+    const int64_t row = perm ? (int64_t)uniform32(perm[pos]) : pos;
+    const int64_t lo = row < 0 ? 0 : uniform64(indptr[row]);
+    const int64_t hi = row < 0 ? 0 : uniform64(indptr[row + 1]);
+    const int64_t o0 = uniform64(cptr[pos]) * 16, o1 = uniform64(cptr[pos + 1]) * 16;
     for (int64_t j = lane; j < o1 - o0; j += 64) {
       const int64_t p = lo + j;
       unsigned long long e = (unsigned long long)(unsigned)kPadCol;
@@ -453,7 +467,7 @@ int pick_k(int64_t n_rows) {
   {                                                                                             \
     const int64_t wgs = (n_rows + 4 * W * KK - 1) / (4 * W * KK);                               \
     hipLaunchKernelGGL((KERNEL<KK, M, P>), dim3((unsigned)wgs), dim3(64 * W), 0, st, n_rows, n_cols, \
-                       cptr, ent, Q, Y);                                                        \
+                       cptr, ent, perm, Q, Y);                                                  \
     MU_CHECK_LAUNCH();                                                                          \
     return MU_OK;                                                                               \
   }
@@ -463,32 +477,37 @@ int pick_k(int64_t n_rows) {
 
 extern "C" {
 
-int mu_csr_pack_count(int64_t n_rows, const int64_t* d_indptr, int64_t* d_row_chunks, void* stream) {
-  MU_REQUIRE(n_rows >= 0, "negative size");
-  if (n_rows == 0) return MU_OK;
+int mu_spmm_packed_k(int64_t n_rows) { return pick_k<16>(n_rows); }
+
+int mu_csr_pack_count(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr,
+                      int64_t* d_row_chunks, void* stream) {
+  MU_REQUIRE(n_pos >= 0, "negative size");
+  if (n_pos == 0) return MU_OK;
   MU_REQUIRE(d_indptr && d_row_chunks, "null pointer");
-  hipLaunchKernelGGL(k_pack_count, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, n_rows, d_indptr, d_row_chunks);
+  hipLaunchKernelGGL(k_pack_count, dim3((unsigned)((n_pos + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, n_pos, d_perm, d_indptr, d_row_chunks);
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
 
-int mu_csr_pack_fill(int64_t n_rows, const int64_t* d_indptr, const int32_t* d_indices,
-                     const float* d_values, const int64_t* d_cptr, void* d_ent, void* stream) {
-  MU_REQUIRE(n_rows >= 0, "negative size");
-  if (n_rows == 0) return MU_OK;
+int mu_csr_pack_fill(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr,
+                     const int32_t* d_indices, const float* d_values, const int64_t* d_cptr,
+                     void* d_ent, void* stream) {
+  MU_REQUIRE(n_pos >= 0, "negative size");
+  if (n_pos == 0) return MU_OK;
   MU_REQUIRE(d_indptr && d_cptr && d_ent, "null pointer");
-  int64_t blocks = (n_rows + 3) / 4;
+  int64_t blocks = (n_pos + 3) / 4;
   const int64_t cap = (int64_t)mu_num_cus() * 32;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(k_pack_fill, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_rows,
-                     d_indptr, d_indices, d_values, d_cptr, (unsigned long long*)d_ent);
+  hipLaunchKernelGGL(k_pack_fill, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_pos,
+                     d_perm, d_indptr, d_indices, d_values, d_cptr, (unsigned long long*)d_ent);
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
 
 int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, const void* d_ent,
-                       const float* d_Q, int B, float* d_Y, void* stream) {
+                       const int32_t* d_perm, int k_layout, const float* d_Q, int B, float* d_Y,
+                       void* stream) {
   MU_REQUIRE(B == 64, "the packed SpMM is built for B = 64");
   MU_REQUIRE(n_rows >= 0 && n_cols > 0 && n_cols <= ((int64_t)1 << 22), "shape out of range");
   if (n_rows == 0) return MU_OK;
@@ -496,6 +515,7 @@ int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, co
   hipStream_t st = (hipStream_t)stream;
   const int64_t* cptr = d_cptr;
   const unsigned long long* ent = (const unsigned long long*)d_ent;
+  const int32_t* perm = d_perm;
   const float* Q = d_Q;
   float* Y = d_Y;
   // tests / tuning only (mu_tune_set); all 0 in production
@@ -504,7 +524,7 @@ int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, co
   const int waves = mu_tune_get("spmm_waves") ? mu_tune_get("spmm_waves") : 16;
   const int pipe = mu_tune_get("spmm_pipe");
   if (waves == 16) {
-    int K = pick_k<16>(n_rows);
+    int K = (k_layout >= 1 && k_layout <= Geo<16>::KMAX) ? k_layout : pick_k<16>(n_rows);
     if (force_k >= 1 && force_k <= Geo<16>::KMAX) K = force_k;
     if (mode != 0) {
       MU_REQUIRE(pipe == 0 && (K == 7 || K == 8), "ablation modes exist for W = 16, K = 7 / 8, pipe 0 only");

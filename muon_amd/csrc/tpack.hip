@@ -106,10 +106,11 @@ __global__ __launch_bounds__(kTThreads) void k_t_count(int64_t n_rows, int64_t n
   }
 }
 
-// cnt[g][c] <- sum_{g' < g} cnt[g'][c];  coltot[c] = sum_g cnt[g][c];  chunks[c] = ceil(coltot/16) + 1
+// cnt[g][c] <- sum_{g' < g} cnt[g'][c];  coltot[c] = sum_g cnt[g][c] (also handed to the caller,
+// who sorts the output rows by it and lays them out: muon_amd/_backend.py packed_layout)
 __global__ __launch_bounds__(256) void k_t_base(int64_t n_cols, int G, uint32_t* __restrict__ cnt,
                                                 int64_t* __restrict__ coltot,
-                                                int64_t* __restrict__ chunks) {
+                                                int64_t* __restrict__ col_nnz) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cols) return;
   uint32_t run = 0;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void k_t_base(int64_t n_cols, int G, uint32_t*
     run += t;
   }
   coltot[c] = (int64_t)run;
-  chunks[c] = (((int64_t)run + 15) >> 4) + 1;
+  col_nnz[c] = (int64_t)run;
 }
 
 __global__ __launch_bounds__(kTThreads) void k_t_fill(int64_t n_rows, int64_t n_cols, int64_t S,
@@ -128,9 +129,11 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill(int64_t n_rows, int64_t n_
                                                       const float* __restrict__ values,
                                                       const int64_t* __restrict__ sp,
                                                       const int64_t* __restrict__ cptr,
+                                                      const int32_t* __restrict__ inv,
                                                       const uint32_t* __restrict__ base,
                                                       unsigned long long* __restrict__ ent) {
-  __shared__ uint32_t pos[kTSlab];               // next free slot of the column, relative to the slab
+  __shared__ uint32_t pos[kTSlab];               // next free slot of the column (pairs written so far)
+  __shared__ int64_t rowbase[kTSlab];            // first pair of the column's output row
   __shared__ unsigned long long bm[2][kTSlab];   // per column: which rows of the batch hit it
   __shared__ int64_t s_r[2];
   const int g = blockIdx.x, G = gridDim.x;
@@ -143,11 +146,10 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill(int64_t n_rows, int64_t n_
 
   for (int64_t s = 0; s < S; ++s) {
     const int32_t cbase = (int32_t)(s * kTSlab);
-    const int64_t chunk0 = cptr[cbase];
-    const int64_t slab_start = chunk0 * 16;
     for (int t = threadIdx.x; t < kTSlab; t += kTThreads) {
       const int64_t c = (int64_t)cbase + t;
-      pos[t] = (c < n_cols) ? (uint32_t)((cptr[c] - chunk0) * 16) + mybase[c] : 0u;
+      pos[t] = (c < n_cols) ? mybase[c] : 0u;
+      rowbase[t] = (c < n_cols) ? cptr[inv ? (int64_t)inv[c] : c] * 16 : 0;
       bm[0][t] = 0ull;
       bm[1][t] = 0ull;
     }
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill(int64_t n_rows, int64_t n_
               const unsigned long long e =
                   (unsigned long long)(unsigned)row |
                   ((unsigned long long)__builtin_bit_cast(unsigned, values[p]) << 32);
-              ent[slab_start + (int64_t)pos[c] + rank] = e;
+              ent[rowbase[c] + (int64_t)pos[c] + rank] = e;
             }
           }
         }
@@ -264,8 +266,8 @@ __device__ __forceinline__ void f2_process(const F2Batch& b, int64_t& cur, int64
                                            int64_t row0, int32_t cbase, int32_t cend,
                                            const int32_t* __restrict__ indices,
                                            const float* __restrict__ values, uint32_t* wbucket,
-                                           const uint32_t* lpos, const uint32_t* gpos,
-                                           unsigned long long* stage, bool staged, int64_t slab_start,
+                                           const uint32_t* lpos, const int64_t* gdst,
+                                           unsigned long long* stage, bool staged,
                                            unsigned long long* __restrict__ ent) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -288,7 +290,7 @@ __device__ __forceinline__ void f2_process(const F2Batch& b, int64_t& cur, int64
           const unsigned long long e = (unsigned long long)(unsigned)(row0 + first + j) |
                                        ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32);
           if (staged) stage[lpos[cl] + k] = e;
-          else ent[slab_start + (int64_t)gpos[cl] + k] = e;
+          else ent[gdst[cl] + k] = e;
         }
       }
       c0 += n;
@@ -307,8 +309,8 @@ __device__ __forceinline__ void f2_walk(int64_t wrow0, int64_t wrow1, int32_t cb
                                         const int64_t* __restrict__ indptr,
                                         const int32_t* __restrict__ indices,
                                         const float* __restrict__ values, int64_t* __restrict__ curs,
-                                        uint32_t* wbucket, const uint32_t* lpos, const uint32_t* gpos,
-                                        unsigned long long* stage, bool staged, int64_t slab_start,
+                                        uint32_t* wbucket, const uint32_t* lpos, const int64_t* gdst,
+                                        unsigned long long* stage, bool staged,
                                         unsigned long long* __restrict__ ent) {
   const int lane = threadIdx.x & 63;
   for (int64_t sb = wrow0; sb < wrow1; sb += 64) {  // wave-uniform
@@ -324,12 +326,12 @@ __device__ __forceinline__ void f2_walk(int64_t wrow0, int64_t wrow1, int32_t cb
       // (the cursors of the rows of a batch are final before its loads are issued: rows are
       //  independent, only `cur` of the rows being processed changes)
       if (first + kF2Rows < nr) f2_load<PHASE>(bb, cur, end, first + kF2Rows, indices, values);
-      f2_process<PHASE>(ba, cur, end, first, sb, cbase, cend, indices, values, wbucket, lpos, gpos, stage,
-                        staged, slab_start, ent);
+      f2_process<PHASE>(ba, cur, end, first, sb, cbase, cend, indices, values, wbucket, lpos, gdst, stage,
+                        staged, ent);
       if (first + kF2Rows < nr) {
         if (first + 2 * kF2Rows < nr) f2_load<PHASE>(ba, cur, end, first + 2 * kF2Rows, indices, values);
         f2_process<PHASE>(bb, cur, end, first + kF2Rows, sb, cbase, cend, indices, values, wbucket, lpos,
-                          gpos, stage, staged, slab_start, ent);
+                          gdst, stage, staged, ent);
       }
     }
     if (PHASE == 1 && lane < nr) curs[sb + lane] = cur;
@@ -342,12 +344,14 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
                                                        const float* __restrict__ values,
                                                        int64_t* __restrict__ curs,
                                                        const int64_t* __restrict__ cptr,
+                                                       const int32_t* __restrict__ inv,
                                                        const uint32_t* __restrict__ base,
                                                        const int64_t* __restrict__ coltot,
                                                        unsigned long long* __restrict__ ent) {
   __shared__ unsigned long long stage[kF2Cap];     // 80 KiB
   __shared__ uint32_t bucket[kTWaves][kF2Cols];    // 48 KiB: per (wave, column) count, then cursor
-  __shared__ uint32_t lcount[kF2Cols], lpos[kF2Cols], gpos[kF2Cols];
+  __shared__ uint32_t lcount[kF2Cols], lpos[kF2Cols];
+  __shared__ int64_t gdst[kF2Cols];                // first pair this row block writes in the column's output row
   __shared__ uint32_t wsum[kTWaves];
   __shared__ int64_t s_r[2];
   const int g = blockIdx.x, G = gridDim.x;
@@ -364,8 +368,6 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
   for (int64_t cb = 0; cb < n_cols; cb += C) {
     const int32_t cbase = (int32_t)cb;
     const int32_t cend = (int32_t)((cb + C) < n_cols ? (cb + C) : n_cols);
-    const int64_t chunk0 = cptr[cbase];
-    const int64_t slab_start = chunk0 * 16;
     // tile counts per column, their exclusive scan, global run starts; clear the buckets
     for (int t = threadIdx.x; t < kTWaves * kF2Cols; t += kTThreads) (&bucket[0][0])[t] = 0u;
     uint32_t mine = 0;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
         const uint32_t b0 = base_g[c];
         const uint32_t b1 = base_n ? base_n[c] : (uint32_t)coltot[c];
         mine = b1 - b0;
-        gpos[threadIdx.x] = (uint32_t)((cptr[c] - chunk0) * 16) + b0;
+        gdst[threadIdx.x] = cptr[inv ? (int64_t)inv[c] : c] * 16 + (int64_t)b0;
       }
       lcount[threadIdx.x] = mine;
     }
@@ -400,8 +402,8 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
     if (total == 0) continue;  // uniform: nothing of this row block falls into the slab
 
     if (!(abl & 1))
-    f2_walk<0>(wrow0, wrow1, cbase, cend, indptr, indices, values, curs, bucket[wave], lpos, gpos, stage,
-               staged, slab_start, ent);
+    f2_walk<0>(wrow0, wrow1, cbase, cend, indptr, indices, values, curs, bucket[wave], lpos, gdst, stage,
+               staged, ent);
     __syncthreads();
     // per column: exclusive prefix of the wave counts = first slot of every wave inside the run
     if (threadIdx.x < kF2Cols) {
@@ -414,15 +416,15 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
     }
     __syncthreads();
     if (!(abl & 2))
-    f2_walk<1>(wrow0, wrow1, cbase, cend, indptr, indices, values, curs, bucket[wave], lpos, gpos, stage,
-               staged, slab_start, ent);
+    f2_walk<1>(wrow0, wrow1, cbase, cend, indptr, indices, values, curs, bucket[wave], lpos, gdst, stage,
+               staged, ent);
     __syncthreads();
     if (staged && !(abl & 4)) {
       // write-out: one 16-lane group per column, consecutive lanes = consecutive pairs of the run
       const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
       for (int cl = grp; cl < cend - cbase; cl += kTThreads / 16) {
         const uint32_t L = lcount[cl], src = lpos[cl];
-        const int64_t dst = slab_start + (int64_t)gpos[cl];
+        const int64_t dst = gdst[cl];
         for (uint32_t i = sub; i < L; i += 16) ent[dst + i] = stage[src + i];
       }
     }
@@ -433,12 +435,24 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
 // tail of the last real chunk + the closing chunk of every output row: at most 31 pads
 __global__ __launch_bounds__(256) void k_t_pads(int64_t n_cols, const int64_t* __restrict__ coltot,
                                                 const int64_t* __restrict__ cptr,
+                                                const int32_t* __restrict__ inv,
                                                 unsigned long long* __restrict__ ent) {
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t c = id >> 5;
   if (c >= n_cols) return;
-  const int64_t o = cptr[c] * 16 + coltot[c] + (id & 31);
-  if (o < cptr[c + 1] * 16) ent[o] = (unsigned long long)kPad;
+  const int64_t p = inv ? (int64_t)inv[c] : c;
+  const int64_t o = cptr[p] * 16 + coltot[c] + (id & 31);
+  if (o < cptr[p + 1] * 16) ent[o] = (unsigned long long)kPad;
+}
+
+// closing chunk of the positions that hold no output row (layout padding)
+__global__ __launch_bounds__(256) void k_t_empty(int64_t n_pos, const int32_t* __restrict__ perm,
+                                                 const int64_t* __restrict__ cptr,
+                                                 unsigned long long* __restrict__ ent) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t p = id >> 4;
+  if (p >= n_pos || perm[p] >= 0) return;
+  ent[cptr[p] * 16 + (id & 15)] = (unsigned long long)kPad;
 }
 
 struct TWork {
@@ -474,13 +488,12 @@ size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz) {
 }
 
 int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
-                       const int32_t* d_indices, int64_t* d_row_chunks, void* d_work,
+                       const int32_t* d_indices, int64_t* d_col_nnz, void* d_work,
                        size_t work_bytes, void* stream) {
   MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
-  // cursors inside a slab are 32-bit: a slab (kTSlab output rows, padding included) must stay below 2^32 slots
-  MU_REQUIRE((n_rows + 32) * (int64_t)kTSlab < ((int64_t)1 << 32), "too many rows for 32-bit slab cursors");
+  MU_REQUIRE(n_rows < ((int64_t)1 << 31), "row ids must fit int32");
   if (n_cols == 0) return MU_OK;
-  MU_REQUIRE(d_indptr && d_row_chunks && d_work, "null pointer");
+  MU_REQUIRE(d_indptr && d_col_nnz && d_work, "null pointer");
   MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols, nnz), "work buffer too small");
   hipStream_t st = (hipStream_t)stream;
   const int64_t S = t_slabs(n_cols);
@@ -500,17 +513,19 @@ int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_
     MU_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(k_t_base, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, n_cols, G,
-                     w.cnt, w.coltot, d_row_chunks);
+                     w.cnt, w.coltot, d_col_nnz);
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
 
 int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
-                      const int32_t* d_indices, const float* d_values, const int64_t* d_cptr,
-                      void* d_ent, void* d_work, size_t work_bytes, void* stream) {
+                      const int32_t* d_indices, const float* d_values, int64_t n_pos,
+                      const int64_t* d_cptr, const int32_t* d_perm, const int32_t* d_inv, void* d_ent,
+                      void* d_work, size_t work_bytes, void* stream) {
   MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
   if (n_cols == 0) return MU_OK;
   MU_REQUIRE(d_indptr && d_cptr && d_ent && d_work, "null pointer");
+  MU_REQUIRE((d_perm == nullptr) == (d_inv == nullptr) && n_pos >= n_cols, "perm / inv / n_pos inconsistent");
   MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols, nnz), "work buffer too small");
   hipStream_t st = (hipStream_t)stream;
   const int64_t S = t_slabs(n_cols);
@@ -519,7 +534,7 @@ int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t
   if (n_rows > 0) {
     if (mu_tune_get("tpack_v1")) {
       hipLaunchKernelGGL(k_t_fill, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, S, d_indptr,
-                         d_indices, d_values, w.sp, d_cptr, w.cnt, (unsigned long long*)d_ent);
+                         d_indices, d_values, w.sp, d_cptr, d_inv, w.cnt, (unsigned long long*)d_ent);
     } else {
       // slab width: the expected tile (nnz / G rows x C columns) fills ~93 % of the staging buffer
       // (measured best on the bench matrix: fewer, fuller tiles; a tile that overflows takes the
@@ -534,14 +549,19 @@ int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t
       if (mu_tune_get("tpack_c") > 0) C = mu_tune_get("tpack_c");
       hipLaunchKernelGGL(k_t_fill2, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,
                          mu_tune_get("tpack_abl"), d_indptr,
-                         d_indices, d_values, w.curs, d_cptr, w.cnt, w.coltot,
+                         d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt, w.coltot,
                          (unsigned long long*)d_ent);
     }
     MU_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(k_t_pads, dim3((unsigned)((n_cols * 32 + 255) / 256)), dim3(256), 0, st, n_cols,
-                     w.coltot, d_cptr, (unsigned long long*)d_ent);
+                     w.coltot, d_cptr, d_inv, (unsigned long long*)d_ent);
   MU_CHECK_LAUNCH();
+  if (d_perm && n_pos > n_cols) {
+    hipLaunchKernelGGL(k_t_empty, dim3((unsigned)((n_pos * 16 + 255) / 256)), dim3(256), 0, st, n_pos,
+                       d_perm, d_cptr, (unsigned long long*)d_ent);
+    MU_CHECK_LAUNCH();
+  }
   return MU_OK;
 }
 

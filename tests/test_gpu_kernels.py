@@ -181,6 +181,35 @@ def _pack_ref(m):
     return cptr, ent
 
 
+def _check_packed(hip, P, m):
+    """Decode a packed copy (any layout) on the host and compare it with the canonical CSR `m` it
+    must hold: every row at exactly one position, pairs bit-exact and in column order, tail padded
+    with (INT32_MAX, 0), ceil(nnz/16) + 1 chunks per row, one all-padding chunk per empty position."""
+    m = m.tocsr()
+    m.sort_indices()
+    n = m.shape[0]
+    cptr = hip.to_host(P.cptr)
+    ent = hip.to_host(P.ent).view(np.uint64)
+    perm = np.arange(n, dtype=np.int64) if P.perm is None else hip.to_host(P.perm).astype(np.int64)
+    assert cptr[0] == 0 and cptr.size == perm.size + 1 and ent.size >= cptr[-1] * 16
+    rows = perm[perm >= 0]
+    assert rows.size == n and np.array_equal(np.sort(rows), np.arange(n))
+    lens = np.diff(m.indptr)
+    plens = np.where(perm >= 0, lens[np.maximum(perm, 0)], 0)
+    assert np.array_equal(np.diff(cptr), (plens + 15) // 16 + 1)
+    col = (ent & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    val = (ent >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    # every slot: real pairs first, pads after
+    start = cptr[:-1] * 16
+    slot_pos = np.repeat(np.arange(perm.size), np.diff(cptr) * 16)
+    slot_off = np.arange(cptr[-1] * 16) - np.repeat(start, np.diff(cptr) * 16)
+    real = slot_off < plens[slot_pos]
+    assert np.all(col[: real.size][~real] == 0x7FFFFFFF) and np.all(val[: real.size][~real] == 0)
+    src = m.indptr[np.maximum(perm, 0)][slot_pos[real]] + slot_off[real]
+    assert np.array_equal(col[: real.size][real], m.indices[src].astype(np.uint32))
+    assert np.array_equal(val[: real.size][real].view(np.uint32), m.data[src].astype(np.float32).view(np.uint32))
+
+
 def _heavy_rows_csr(n, d, dens, rng, bursts=True):
     m = sp.random(n, d, density=dens, format="lil", random_state=rng, dtype=np.float32)
     if bursts and n > 8 and d > 40:
@@ -198,11 +227,19 @@ def _heavy_rows_csr(n, d, dens, rng, bursts=True):
 def test_pack_layout_bit_exact(hip):
     rng = np.random.default_rng(11)
     m = _heavy_rows_csr(203, 1000, 0.03, rng)
-    P = hip.pack(_up(hip, m))
+    P = hip.pack(_up(hip, m), sort_rows=False)  # identity layout: byte for byte the numpy packing
     cptr, ent = _pack_ref(m)
-    assert np.array_equal(hip.to_host(P.cptr), cptr)
+    assert P.perm is None and np.array_equal(hip.to_host(P.cptr), cptr)
     got = hip.to_host(P.ent).view(np.uint64)[: ent.size]
     assert np.array_equal(got, ent)
+    for mm in (m, _heavy_rows_csr(5000, 300, 0.05, rng), sp.csr_matrix((3, 9), dtype=np.float32)):
+        P = hip.pack(_up(hip, mm))  # sorted + dealt layout
+        assert P.perm is not None and P.n_pos % (64 * P.k) == 0
+        _check_packed(hip, P, mm)
+    # rows are dealt longest first: position 0 holds a longest row
+    lens = np.diff(m.indptr)
+    P = hip.pack(_up(hip, m))
+    assert lens[hip.to_host(P.perm)[0]] == lens.max()
 
 
 @pytest.mark.parametrize("n,d,dens", [(1, 3, 1.0), (5, 255, 0.3), (64, 256, 0.1), (100, 257, 0.2),
@@ -268,21 +305,25 @@ def test_transpose_pack_is_bit_exact(hip, n, d, dens):
     (cell ids ascending inside every output row, pads and closing chunks included)."""
     rng = np.random.default_rng(n * 13 + d)
     m = _heavy_rows_csr(n, d, dens, rng, bursts=(n > 8 and d > 40))
-    P = hip.transpose_pack(_up(hip, m))
     mt = m.T.tocsr()
     mt.sort_indices()
+    P = hip.transpose_pack(_up(hip, m), sort_rows=False)  # identity layout: byte for byte
     cptr, ent = _pack_ref(mt)
-    assert P.shape == (d, n)
+    assert P.shape == (d, n) and P.perm is None
     assert np.array_equal(hip.to_host(P.cptr), cptr)
     got = hip.to_host(P.ent).view(np.uint64)[: ent.size]
     assert np.array_equal(got, ent)
+    P = hip.transpose_pack(_up(hip, m))  # sorted + dealt layout
+    assert P.shape == (d, n)
+    _check_packed(hip, P, mt)
 
 
 def test_transpose_pack_empty_matrix(hip):
     m = sp.csr_matrix((5, 7), dtype=np.float32)
-    P = hip.transpose_pack(_up(hip, m))
+    P = hip.transpose_pack(_up(hip, m), sort_rows=False)
     assert np.array_equal(hip.to_host(P.cptr), np.arange(8))
     assert np.all(hip.to_host(P.ent).view(np.uint64)[: 7 * 16] == 0x7FFFFFFF)
+    _check_packed(hip, hip.transpose_pack(_up(hip, m)), m.T.tocsr())
 
 
 def test_transpose_pack_tile_overflow_falls_back_and_v1_agree(hip):
@@ -294,15 +335,21 @@ def test_transpose_pack_tile_overflow_falls_back_and_v1_agree(hip):
     m = sp.hstack([dense, sp.csr_matrix((n, d - 100), dtype=np.float32)], format="csr")
     m.sort_indices()
     X = _up(hip, m)
-    P = hip.transpose_pack(X)
+    P = hip.transpose_pack(X, sort_rows=False)
     mt = m.T.tocsr()
     mt.sort_indices()
     cptr, ent = _pack_ref(mt)
     assert np.array_equal(hip.to_host(P.cptr), cptr)
     assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
+    Ps = hip.transpose_pack(X)
+    _check_packed(hip, Ps, mt)
     try:
         hip.tune("tpack_v1", 1)
-        P1 = hip.transpose_pack(X)
+        P1 = hip.transpose_pack(X, sort_rows=False)
+        P1s = hip.transpose_pack(X)
     finally:
         hip.tune("tpack_v1", 0)
     assert torch.equal(P1.cptr, P.cptr) and torch.equal(P1.ent[: ent.size * 8], P.ent[: ent.size * 8])
+    assert torch.equal(P1s.cptr, Ps.cptr) and torch.equal(P1s.perm, Ps.perm)
+    nb = int(Ps.cptr[-1].item()) * 128
+    assert torch.equal(P1s.ent[:nb], Ps.ent[:nb])
