@@ -199,7 +199,7 @@ struct Win {      // what stage A of a pass hands to stage B
 
 // MODE is 0 in production; the other bits switch parts of the kernel off for timing ablations
 // (results are then wrong on purpose): 1 no LDS gathers / FMAs, 2 no slab DMA, 8 no chunk
-// requests (and no overflow passes), 16 no window rotation.
+// requests (and no overflow passes), 16 no window rotation, 32 overflow passes do not wait for their chunk.
 // PIPE: 0 = stage A(k) then B(k); 1 = A(k+1) is issued before B(k); 2 = additionally two quads of
 // LDS reads in flight inside B (needs ~28 more registers: W <= 12)
 // (the dispatcher uses PIPE 1; tune knob spmm_pipe = 1 selects PIPE 0 for comparison).
@@ -286,7 +286,8 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
       constexpr int k = decltype(kc)::value;
       constexpr bool SLOW = decltype(slowc)::value;
       int ncol, nval;
-      if constexpr (SLOW) wait_next_chunk<W, k, 0>(ncol, nval);
+      if constexpr (SLOW && !(MODE & 32)) wait_next_chunk<W, k, 0>(ncol, nval);
+      else if constexpr (SLOW) wait_next_chunk<W, k, 63>(ncol, nval);  // ablation: no wait (wrong data)
       else wait_next_chunk<W, k, K - 1>(ncol, nval);
       const int p = bcast_i<k>(posv);
       const bool from_cur = sub >= p;
@@ -376,7 +377,7 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
       } while (again);
       // an overflow request of row-set k is younger than the main-pass requests the next slab's
       // vmcnt(K-1) is counted against: drain, so that the count only ever guards main-pass requests
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (!(MODE & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // The DMA pieces of the next slab were issued before this slab's K requests: allowing K
     // outstanding VMEM operations proves they landed without draining the requests.
@@ -527,12 +528,13 @@ int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, co
     int K = (k_layout >= 1 && k_layout <= Geo<16>::KMAX) ? k_layout : pick_k<16>(n_rows);
     if (force_k >= 1 && force_k <= Geo<16>::KMAX) K = force_k;
     if (mode != 0) {
-      MU_REQUIRE(pipe == 0 && (K == 7 || K == 8), "ablation modes exist for W = 16, K = 7 / 8, pipe 0 only");
+      MU_REQUIRE((K == 7 || K == 8), "ablation modes exist for W = 16, K = 7 / 8 only");
 #define MU_ABL(KK)                                             \
   switch (mode) {                                              \
     case 1: MU_GO(k_spmm_pcr64_w16, 16, KK, 1, 0)              \
     case 9: MU_GO(k_spmm_pcr64_w16, 16, KK, 9, 0)              \
     case 11: MU_GO(k_spmm_pcr64_w16, 16, KK, 11, 0)            \
+    case 32: MU_GO(k_spmm_pcr64_w16, 16, KK, 32, 1)            \
     default: break;                                            \
   }
       if (K == 7) MU_ABL(7) else MU_ABL(8)

@@ -246,26 +246,29 @@ struct F2Batch {
   float cv[kF2Rows];
 };
 
+// (cursors are 32-bit offsets from the row block's first entry: one v_readlane instead of two and
+//  32-bit scalar arithmetic in the per-row code, which is instruction bound - an earlier variant
+//  with ~30 more scalar instructions per row was 45 % slower)
 template <int PHASE>
-__device__ __forceinline__ void f2_load(F2Batch& b, int64_t cur, int64_t end, int first,
-                                        const int32_t* __restrict__ indices,
-                                        const float* __restrict__ values) {
+__device__ __forceinline__ void f2_load(F2Batch& b, int cur, int end, int first,
+                                        const int32_t* __restrict__ indices_b,
+                                        const float* __restrict__ values_b) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < kF2Rows; ++j) {
     const int src = (first + j) & 63;
-    const int64_t p = readlane_i64(cur, src) + lane;
-    const bool in = (first + j < 64) && (p < readlane_i64(end, src));  // rows past the range: cur = end = 0
-    b.ci[j] = in ? indices[p] : 0x7fffffff;
-    if (PHASE == 1) b.cv[j] = in ? values[p] : 0.f;
+    const int p = __builtin_amdgcn_readlane(cur, src) + lane;
+    const bool in = (first + j < 64) && (p < __builtin_amdgcn_readlane(end, src));  // rows past the range: cur = end = 0
+    b.ci[j] = in ? indices_b[p] : 0x7fffffff;
+    if (PHASE == 1) b.cv[j] = in ? values_b[p] : 0.f;
   }
 }
 
 template <int PHASE>
-__device__ __forceinline__ void f2_process(const F2Batch& b, int64_t& cur, int64_t end, int first,
+__device__ __forceinline__ void f2_process(const F2Batch& b, int& cur, int end, int first,
                                            int64_t row0, int32_t cbase, int32_t cend,
-                                           const int32_t* __restrict__ indices,
-                                           const float* __restrict__ values, uint32_t* wbucket,
+                                           const int32_t* __restrict__ indices_b,
+                                           const float* __restrict__ values_b, uint32_t* wbucket,
                                            const uint32_t* lpos, const int64_t* gdst,
                                            unsigned long long* stage, bool staged,
                                            unsigned long long* __restrict__ ent) {
@@ -273,8 +276,8 @@ __device__ __forceinline__ void f2_process(const F2Batch& b, int64_t& cur, int64
 #pragma unroll
   for (int j = 0; j < kF2Rows; ++j) {
     if (first + j >= 64) break;  // uniform
-    int64_t c0 = readlane_i64(cur, first + j);
-    const int64_t e0 = readlane_i64(end, first + j);
+    int c0 = __builtin_amdgcn_readlane(cur, first + j);
+    const int e0 = __builtin_amdgcn_readlane(end, first + j);
     int32_t c = b.ci[j];
     float v = (PHASE == 1) ? b.cv[j] : 0.f;
     while (true) {
@@ -295,10 +298,10 @@ __device__ __forceinline__ void f2_process(const F2Batch& b, int64_t& cur, int64
       }
       c0 += n;
       if (n < 64) break;  // wave-uniform
-      const int64_t p = c0 + lane;  // a row with more than 64 entries in this slab
+      const int p = c0 + lane;  // a row with more than 64 entries in this slab
       const bool in = p < e0;
-      c = in ? indices[p] : 0x7fffffff;
-      if (PHASE == 1) v = in ? values[p] : 0.f;
+      c = in ? indices_b[p] : 0x7fffffff;
+      if (PHASE == 1) v = in ? values_b[p] : 0.f;
     }
     if (PHASE == 1 && lane == first + j) cur = c0;
   }
@@ -306,35 +309,37 @@ __device__ __forceinline__ void f2_process(const F2Batch& b, int64_t& cur, int64
 
 template <int PHASE>
 __device__ __forceinline__ void f2_walk(int64_t wrow0, int64_t wrow1, int32_t cbase, int32_t cend,
-                                        const int64_t* __restrict__ indptr,
+                                        int64_t wg_base, const int64_t* __restrict__ indptr,
                                         const int32_t* __restrict__ indices,
                                         const float* __restrict__ values, int64_t* __restrict__ curs,
                                         uint32_t* wbucket, const uint32_t* lpos, const int64_t* gdst,
                                         unsigned long long* stage, bool staged,
                                         unsigned long long* __restrict__ ent) {
   const int lane = threadIdx.x & 63;
+  const int32_t* __restrict__ indices_b = indices + wg_base;
+  const float* __restrict__ values_b = values + wg_base;
   for (int64_t sb = wrow0; sb < wrow1; sb += 64) {  // wave-uniform
     const int nr = (wrow1 - sb) < 64 ? (int)(wrow1 - sb) : 64;
-    int64_t cur = 0, end = 0;
+    int cur = 0, end = 0;
     if (lane < nr) {
-      cur = curs[sb + lane];
-      end = indptr[sb + lane + 1];
+      cur = (int)(curs[sb + lane] - wg_base);
+      end = (int)(indptr[sb + lane + 1] - wg_base);
     }
     F2Batch ba, bb;
-    f2_load<PHASE>(ba, cur, end, 0, indices, values);
+    f2_load<PHASE>(ba, cur, end, 0, indices_b, values_b);
     for (int first = 0; first < nr; first += 2 * kF2Rows) {
       // (the cursors of the rows of a batch are final before its loads are issued: rows are
       //  independent, only `cur` of the rows being processed changes)
-      if (first + kF2Rows < nr) f2_load<PHASE>(bb, cur, end, first + kF2Rows, indices, values);
-      f2_process<PHASE>(ba, cur, end, first, sb, cbase, cend, indices, values, wbucket, lpos, gdst, stage,
+      if (first + kF2Rows < nr) f2_load<PHASE>(bb, cur, end, first + kF2Rows, indices_b, values_b);
+      f2_process<PHASE>(ba, cur, end, first, sb, cbase, cend, indices_b, values_b, wbucket, lpos, gdst, stage,
                         staged, ent);
       if (first + kF2Rows < nr) {
-        if (first + 2 * kF2Rows < nr) f2_load<PHASE>(ba, cur, end, first + 2 * kF2Rows, indices, values);
-        f2_process<PHASE>(bb, cur, end, first + kF2Rows, sb, cbase, cend, indices, values, wbucket, lpos,
+        if (first + 2 * kF2Rows < nr) f2_load<PHASE>(ba, cur, end, first + 2 * kF2Rows, indices_b, values_b);
+        f2_process<PHASE>(bb, cur, end, first + kF2Rows, sb, cbase, cend, indices_b, values_b, wbucket, lpos,
                           gdst, stage, staged, ent);
       }
     }
-    if (PHASE == 1 && lane < nr) curs[sb + lane] = cur;
+    if (PHASE == 1 && lane < nr) curs[sb + lane] = wg_base + (int64_t)cur;
   }
 }
 
@@ -362,6 +367,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
   const int64_t rw = (r1 - r0 + kTWaves - 1) / kTWaves;  // rows per wave
   const int64_t wrow0 = (r0 + wave * rw) < r1 ? (r0 + wave * rw) : r1;
   const int64_t wrow1 = (wrow0 + rw) < r1 ? (wrow0 + rw) : r1;
+  const int64_t wg_base = uniform64(indptr[r0 < n_rows ? r0 : n_rows]);  // entries of this row block start here
   const uint32_t* base_g = base + (int64_t)g * n_cols;
   const uint32_t* base_n = (g + 1 < G) ? base + (int64_t)(g + 1) * n_cols : nullptr;
 
@@ -402,8 +408,8 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
     if (total == 0) continue;  // uniform: nothing of this row block falls into the slab
 
     if (!(abl & 1))
-    f2_walk<0>(wrow0, wrow1, cbase, cend, indptr, indices, values, curs, bucket[wave], lpos, gdst, stage,
-               staged, ent);
+    f2_walk<0>(wrow0, wrow1, cbase, cend, wg_base, indptr, indices, values, curs, bucket[wave], lpos, gdst,
+               stage, staged, ent);
     __syncthreads();
     // per column: exclusive prefix of the wave counts = first slot of every wave inside the run
     if (threadIdx.x < kF2Cols) {
@@ -416,8 +422,8 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
     }
     __syncthreads();
     if (!(abl & 2))
-    f2_walk<1>(wrow0, wrow1, cbase, cend, indptr, indices, values, curs, bucket[wave], lpos, gdst, stage,
-               staged, ent);
+    f2_walk<1>(wrow0, wrow1, cbase, cend, wg_base, indptr, indices, values, curs, bucket[wave], lpos, gdst,
+               stage, staged, ent);
     __syncthreads();
     if (staged && !(abl & 4)) {
       // write-out: one 16-lane group per column, consecutive lanes = consecutive pairs of the run
