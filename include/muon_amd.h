@@ -211,6 +211,18 @@ int mu_dense_apply_f32(int64_t n_rows, int B, const float* d_A, const float* d_M
 /* standard normal fill, counter based (seed, element index) -> reproducible */
 int mu_randn_f32(int64_t count, uint64_t seed, float* d_out, void* stream);
 
+/* ---- MOFA+: the two passes over a DENSE view per iteration (tall-skinny products on the matrix cores)
+ * Y [n_rows x D] row-major with leading dimension ldY (a row range of the view); the factor blocks are
+ * zero padded to 16 columns.  Replace the library GEMMs of the dense views (tools.py:583-585 ->
+ * mofapy2's Y W / Y^T Z products); both stream Y exactly once.
+ *   nn: out[n_rows x 16] = Y * T,  T [D x 16]            (Z update:  A = Y (tau o <W>))
+ *   tn: C[D x 16] = Y^T * Z,       Z [n_rows x 16]       (W / tau / ELBO:  B = Y^T <Z>) */
+size_t mu_skinny_tn_worksize(int dtype, int64_t n_rows, int64_t D);
+int mu_skinny_nn(int dtype, int64_t n_rows, int64_t D, int64_t ldY, const void* d_Y, const void* d_T,
+                 void* d_out, void* stream);
+int mu_skinny_tn(int dtype, int64_t n_rows, int64_t D, int64_t ldY, const void* d_Y, const void* d_Z,
+                 void* d_C, void* d_work, size_t work_bytes, void* stream);
+
 /* ---- MOFA+ coordinate updates (tools.py:585 ent.run(): mofapy2's W and Z node updates) ---- */
 /* Spike-and-slab + ARD update of the weights of ONE view, one thread per feature, Gauss-Seidel
  * over the K factors.  Inputs are the sufficient statistics of the current factors:

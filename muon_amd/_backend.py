@@ -322,6 +322,29 @@ class HipBackend:
             check(self.lib.mu_randn_f32(rows * B, int(seed) & (2**64 - 1), _p(out), self._stream()))
         return out
 
+    # -- MOFA+: tall-skinny products of a dense view with 16-column factor blocks ------------------
+    def skinny_nn(self, Y: torch.Tensor, T16: torch.Tensor) -> torch.Tensor:
+        """Y [n x D] (row slice of a row-major matrix) times T16 [D x 16] -> [n x 16]."""
+        n, D = Y.shape
+        assert T16.shape == (D, 16) and T16.dtype == Y.dtype and T16.is_contiguous() and Y.stride(1) == 1
+        out = self.empty((n, 16), Y.dtype)
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_skinny_nn(_dt(Y), n, D, Y.stride(0) if n > 1 else D, _p(Y), _p(T16), _p(out),
+                                        self._stream()))
+        return out
+
+    def skinny_tn(self, Y: torch.Tensor, Z16: torch.Tensor) -> torch.Tensor:
+        """Y^T [D x n] times Z16 [n x 16] -> [D x 16]."""
+        n, D = Y.shape
+        assert Z16.shape == (n, 16) and Z16.dtype == Y.dtype and Z16.is_contiguous() and Y.stride(1) == 1
+        out = self.empty((D, 16), Y.dtype)
+        wb = int(self.lib.mu_skinny_tn_worksize(_dt(Y), n, D))
+        work = self.empty((wb,), torch.uint8)
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_skinny_tn(_dt(Y), n, D, Y.stride(0) if n > 1 else D, _p(Y), _p(Z16), _p(out),
+                                        _p(work), wb, self._stream()))
+        return out
+
     # -- MOFA+ coordinate updates (reference tools.py:585 -> mofapy2 node updates) -----------
     def mofa_update_w(self, B, tau, Gz, Z2, alpha, lth, l1mth, spikeslab, EW, EW2, gamma, EWh2, sig2):
         G, D, K = B.shape

@@ -11,7 +11,8 @@ sufficient-statistics formulation that never densifies a sparse view
 Sparse views go through the CSR SpMM kernel in both directions (X and its device transpose),
 group blocks stacked along the dense dimension so that one pass serves all groups; centring is
 applied implicitly as a rank-one correction ((Y - 1 mu^T) W = Y W - 1 (mu^T W)), so the view
-stays CSR.  Dense views use PyTorch-ROCm GEMMs (the "dense factor blocks").  The Gauss-Seidel
+stays CSR.  Dense views go through the tall-skinny MFMA kernels mu_skinny_nn / mu_skinny_tn
+(n_factors <= 16; PyTorch-ROCm GEMMs otherwise and for the K x K blocks).  The Gauss-Seidel
 sweeps over factors are the fused HIP kernels mu_mofa_update_w / mu_mofa_update_z; the
 remaining O(D K + G K^2) node updates (tau, alpha, theta, ELBO) are torch element-wise ops.
 When samples are sharded over ranks, the statistics B, <Z>^T<Z>, sum <z^2> and the sample
@@ -100,6 +101,19 @@ class MofaEngine:
             self.comm.all_reduce_sum(t)
             t = t.to(dev)
         return t
+
+    def _pad16(self, A: torch.Tensor) -> torch.Tensor:
+        out = torch.zeros((A.shape[0], 16), dtype=A.dtype, device=A.device)
+        out[:, : A.shape[1]] = A
+        return out
+
+    def _tn(self, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+        """A^T B for tall blocks with <= 16 columns (K x K Grams of the factor / weight blocks).
+        rocBLAS' f64 GEMM takes 4-11 ms for these 10 x 10 outputs with a 1e5-long inner dimension
+        (Tensile 128x128 macro tiles); the tall-skinny MFMA kernel streams the blocks once."""
+        if A.shape[1] <= 16 and B.shape[1] <= 16 and A.shape[0] >= 1024 and hasattr(self.be, "skinny_tn"):
+            return self.be.skinny_tn(self._pad16(A), self._pad16(B))[: A.shape[1], : B.shape[1]]
+        return A.T @ B
 
     def _dev(self, arr, dtype=None):
         t = self.be.to_device(np.ascontiguousarray(arr))
@@ -240,10 +254,18 @@ class MofaEngine:
         Zs = torch.zeros((G, K), dtype=self.T, device=self.EZ.device)
         for g, (a, b) in enumerate(self.gslice):
             zp = self.EZ[a:b] * V.pres[a:b, None]
-            Gz[g] = zp.T @ zp
+            Gz[g] = self._tn(zp, zp)
             Z2[g] = (self.EZ2[a:b] * V.pres[a:b, None]).sum(dim=0)
             Zs[g] = zp.sum(dim=0)
-        if V.kind == "dense":
+        if V.kind == "dense" and K <= 16 and hasattr(self.be, "skinny_tn"):
+            # B_g = Y_g^T <Z_g> on the matrix cores, one pass over Y (csrc/skinny.hip)
+            Bl = []
+            for a, b in self.gslice:
+                Z16 = torch.zeros((b - a, 16), dtype=self.T, device=self.EZ.device)
+                Z16[:, :K] = self.EZ[a:b]
+                Bl.append(self.be.skinny_tn(V.Y[a:b], Z16)[:, :K])
+            B = torch.stack(Bl)
+        elif V.kind == "dense":
             B = torch.stack([V.Y[a:b].T @ self.EZ[a:b] for a, b in self.gslice])
         else:
             Bp = _pad_block(G * K)
@@ -276,9 +298,16 @@ class MofaEngine:
         for m, (V, Wm) in enumerate(zip(self.views, self.W)):
             TW = Wm.tau[:, :, None] * Wm.EW[None, :, :]  # G x D x K
             for g in range(G):
-                Gw[m, g] = Wm.EW.T @ TW[g]
+                Gw[m, g] = self._tn(Wm.EW, TW[g])
                 dw2[m, g] = (Wm.tau[g][:, None] * Wm.EW2).sum(dim=0)
-            if V.kind == "dense":
+            # (f32: hipBLASLt's N x D by D x K kernel already streams Y at 6 TB/s (1.3 ms vs 3.2 ms for
+            #  mu_skinny_nn); f64: rocBLAS needs 26 ms, mu_skinny_nn 4.6)
+            if V.kind == "dense" and K <= 16 and self.T == torch.float64 and hasattr(self.be, "skinny_nn"):
+                for g, (a, b) in enumerate(self.gslice):
+                    T16 = torch.zeros((V.D, 16), dtype=self.T, device=dev)
+                    T16[:, :K] = TW[g]
+                    A[m, a:b] = self.be.skinny_nn(V.Y[a:b], T16)[:, :K]
+            elif V.kind == "dense":
                 for g, (a, b) in enumerate(self.gslice):
                     A[m, a:b] = V.Y[a:b] @ TW[g]
             else:
@@ -288,7 +317,9 @@ class MofaEngine:
                     TWs[:, g * K:(g + 1) * K] = TW[g]
                 out = self.be.spmm(V.X, TWs)  # N x (G K)
                 for g, (a, b) in enumerate(self.gslice):
-                    corr = V.mu[g] @ TW[g]  # K: 1 (mu^T tau W), implicit centring
+                    # K: mu^T (tau o W), implicit centring (as a reduction: rocBLAS' f64 path takes
+                    # 10.7 ms for this 1 x 1e5 by 1e5 x 10 product)
+                    corr = (V.mu[g][:, None] * TW[g]).sum(dim=0)
                     A[m, a:b] = out[a:b, g * K:(g + 1) * K] - V.pres[a:b, None] * corr[None, :]
         az = self.alpha_z if self.opts["ard_factors"] else torch.ones_like(self.alpha_z)
         self.be.mofa_update_z(A.contiguous(), pres, self.grp, Gw.contiguous(), dw2.contiguous(),

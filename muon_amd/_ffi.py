@@ -70,6 +70,9 @@ SIGNATURES = {
     "mu_gram_cross_f32": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_dense_apply_f32": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mu_randn_f32": (C.c_int, [_i64, _u64, _vp, _vp]),
+    "mu_skinny_tn_worksize": (_sz, [_i32, _i64, _i64]),
+    "mu_skinny_nn": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "mu_skinny_tn": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_mofa_update_w": (C.c_int, [_i32, _i64, _i32, _i32] + [_vp] * 7 + [_i32] + [_vp] * 6),
     "mu_mofa_update_z": (C.c_int, [_i32, _i64, _i32, _i32, _i32] + [_vp] * 10),
     "mu_synth_row_nnz": (C.c_int, [_i64, _i64, _i64, _i32, _dbl, _u64, _vp, _vp]),

@@ -1,0 +1,236 @@
+// Tall-skinny products of a dense MOFA view Y [n x D] (row-major, leading dimension ldY) with the
+// factor blocks, on the matrix cores.  These are the two passes over a dense view that one MOFA+
+// iteration needs (the reference hands the arithmetic to mofapy2 through
+// /root/reference/muon/_core/tools.py:583-585):
+//
+//   nn :  A[n x 16]  = Y * T          T [D x 16] = tau o <W>  (zero padded to 16 columns)
+//   tn :  B[D x 16]  = Y^T * Z        Z [n x 16] = <Z>        (zero padded to 16 columns)
+//
+// Both stream Y exactly once (HBM bound: 2 x 16 flop per byte of f64 against ~10 needed to hide the
+// f64 matrix cores behind 8 TB/s), which the library GEMMs do not at K = 10: rocprof on
+// configs[3] in f64 shows 26 ms per product for Tensile's 128x64 / 128x128 macro tiles against
+// 2.5 ms of streaming.  v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32; operand maps as in
+// dense.hip:  A operand lane l = A[i = l & 15][k = l >> 4],  B operand lane l = B[k = l >> 4][j = l & 15],
+// C/D reg r of lane l = C[row = (l >> 4) + 4 r][col = l & 15] (f64) / C[row = 4 (l >> 4) + r][col] (f32).
+#include "common.hpp"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mma;
+template <> struct Mma<double> {
+  typedef d4 acc_t;
+  static __device__ __forceinline__ acc_t fma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lr, int r) { return lr + 4 * r; }
+};
+template <> struct Mma<float> {
+  typedef f4 acc_t;
+  static __device__ __forceinline__ acc_t fma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lr, int r) { return 4 * lr + r; }
+};
+
+// ---- nn: out[n x 16] = Y[n x D] * Tm[D x 16] --------------------------------------------------
+// MFMA roles i = row, j = output column, k = d: the A operand wants 16 ROWS x 4 consecutive d per
+// instruction, i.e. 16 different lines of Y.  Loading it like that runs at the texture unit's
+// line-lookup rate (measured 5.0 ms for 8 GB in f32, 1.6 TB/s), so a wave stages a 16-row x
+// 128-byte tile through LDS instead: two coalesced global_load_dwordx4 per tile (8 rows x one full
+// line each), ds_write_b128, then the transposed operand reads (row stride 144 B: conflict free).
+// Tiles are double buffered per wave; Tm (D x 16, a few MB) comes from L2 once per 16 rows.
+template <typename T>
+__global__ __launch_bounds__(256) void k_skinny_nn(int64_t n_rows, int64_t D, int64_t ldY,
+                                                   const T* __restrict__ Y, const T* __restrict__ Tm,
+                                                   T* __restrict__ out) {
+  typedef typename Mma<T>::acc_t acc_t;
+  constexpr int CW = 128 / (int)sizeof(T);   // columns per tile: 32 (f32) / 16 (f64)
+  constexpr int PE = 16 / (int)sizeof(T);    // elements per 16-byte piece: 4 / 2
+  constexpr int RS = 144;                    // LDS row stride in bytes
+  __shared__ __attribute__((aligned(16))) char tiles[4][2][16 * RS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane >> 4, lc = lane & 15;
+  const int prow = lane >> 3, piece = lane & 7;  // loader view: 8 rows x 8 pieces per instruction
+  const bool vec_ok = ((ldY * (int64_t)sizeof(T)) % 16 == 0) && ((reinterpret_cast<uintptr_t>(Y) % 16) == 0);
+  const int64_t n_tiles = (n_rows + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t r0 = tile * 16;
+    acc_t acc = acc_t{0, 0, 0, 0};
+    auto load_tile = [&](int64_t d0, int buf) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int64_t row = r0 + prow + 8 * h;
+        const int64_t d = d0 + piece * PE;
+        T v[PE];
+        if (row < n_rows && vec_ok && d + PE <= D) {
+          const float4 q = *reinterpret_cast<const float4*>(Y + row * ldY + d);
+          __builtin_memcpy(v, &q, 16);
+        } else {
+#pragma unroll
+          for (int e = 0; e < PE; ++e) v[e] = (row < n_rows && d + e < D) ? Y[row * ldY + d + e] : (T)0;
+        }
+        float4 q;
+        __builtin_memcpy(&q, v, 16);
+        *reinterpret_cast<float4*>(&tiles[wave][buf][(prow + 8 * h) * RS + piece * 16]) = q;
+      }
+    };
+    load_tile(0, 0);
+    int buf = 0;
+    for (int64_t d0 = 0; d0 < D; d0 += CW, buf ^= 1) {
+      if (d0 + CW < D) load_tile(d0 + CW, buf ^ 1);  // the wave's LDS accesses execute in order
+#pragma unroll
+      for (int u = 0; u < CW / 4; ++u) {
+        const int64_t d = d0 + 4 * u + lr;
+        const T b = (d < D) ? Tm[d * 16 + lc] : (T)0;
+        const T a = *reinterpret_cast<const T*>(&tiles[wave][buf][lc * RS + (4 * u + lr) * (int)sizeof(T)]);
+        acc = Mma<T>::fma(a, b, acc);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t orow = r0 + Mma<T>::row(lr, r);
+      if (orow < n_rows) out[orow * 16 + lc] = acc[r];
+    }
+  }
+}
+
+// ---- tn: C[D x 16] = Y^T[D x n] * Z[n x 16] ------------------------------------------------------
+// MFMA roles i = d (column of Y), j = output column, k = row n.  A wave owns kCT column tiles (128
+// columns of Y: 1 KiB contiguous per row) and a strided share of the workgroup's row range; both
+// operands load coalesced (4 rows x 16 consecutive elements per instruction).  Row splits give the
+// grid its width; partial blocks are reduced in a fixed order (bit-reproducible).
+constexpr int kCT = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_skinny_tn_partial(int64_t n_rows, int64_t D, int64_t ldY,
+                                                           const T* __restrict__ Y,
+                                                           const T* __restrict__ Z, int n_splits,
+                                                           T* __restrict__ partial) {
+  typedef typename Mma<T>::acc_t acc_t;
+  __shared__ T red[16 * kCT * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane >> 4, lc = lane & 15;
+  const int64_t cb = blockIdx.x;            // column block: columns [128 cb, 128 cb + 128)
+  const int split = blockIdx.y;
+  const int64_t c0 = cb * (16 * kCT);
+  const int64_t n_groups = (n_rows + 3) / 4;  // 4 rows per MFMA step
+  const int64_t g0 = n_groups * split / n_splits, g1 = n_groups * (split + 1) / n_splits;
+  acc_t acc[kCT];
+#pragma unroll
+  for (int t = 0; t < kCT; ++t) acc[t] = acc_t{0, 0, 0, 0};
+  bool cok[kCT];
+#pragma unroll
+  for (int t = 0; t < kCT; ++t) cok[t] = (c0 + 16 * t + lc) < D;
+  for (int64_t grp = g0 + wave; grp < g1; grp += 4) {
+    const int64_t row = grp * 4 + lr;
+    const bool rk = row < n_rows;
+    const T z = rk ? Z[row * 16 + lc] : (T)0;
+    T x[kCT];
+#pragma unroll
+    for (int t = 0; t < kCT; ++t) x[t] = (rk && cok[t]) ? Y[row * ldY + c0 + 16 * t + lc] : (T)0;
+#pragma unroll
+    for (int t = 0; t < kCT; ++t) acc[t] = Mma<T>::fma(x[t], z, acc[t]);
+  }
+  // reduce the four waves through LDS in a fixed order
+  for (int i = threadIdx.x; i < 16 * kCT * 16; i += 256) red[i] = (T)0;
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < kCT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(16 * t + Mma<T>::row(lr, r)) * 16 + lc] += acc[t][r];
+    }
+    __syncthreads();
+  }
+  T* dst = partial + ((int64_t)split * D + c0) * 16;
+  for (int i = threadIdx.x; i < 16 * kCT * 16; i += 256) {
+    const int64_t c = c0 + (i >> 4);
+    if (c < D) dst[i] = red[i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_skinny_tn_reduce(int64_t total, int n_splits,
+                                                          const T* __restrict__ partial,
+                                                          T* __restrict__ C) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  T acc = (T)0;
+  for (int s = 0; s < n_splits; ++s) acc += partial[(int64_t)s * total + e];
+  C[e] = acc;
+}
+
+inline int tn_splits(int64_t n_rows, int64_t D) {
+  // enough workgroups for ~8 per CU, at least 256 rows per split
+  const int64_t cbs = (D + 16 * kCT - 1) / (16 * kCT);
+  int64_t s = ((int64_t)mu_num_cus() * 8 + cbs - 1) / cbs;
+  const int64_t cap = (n_rows + 255) / 256;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mu_skinny_tn_worksize(int dtype, int64_t n_rows, int64_t D) {
+  const size_t es = dtype == MU_DTYPE_F64 ? 8 : 4;
+  return (size_t)tn_splits(n_rows, D) * (size_t)D * 16 * es + 256;
+}
+
+int mu_skinny_nn(int dtype, int64_t n_rows, int64_t D, int64_t ldY, const void* d_Y, const void* d_T,
+                 void* d_out, void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  MU_REQUIRE(n_rows >= 0 && D >= 0 && ldY >= D, "bad shape");
+  if (n_rows == 0) return MU_OK;
+  MU_REQUIRE(d_out && (D == 0 || (d_Y && d_T)), "null pointer");
+  const int64_t groups = (n_rows + 15) / 16;
+  int64_t blocks = (groups + 3) / 4;
+  const int64_t cap = (int64_t)mu_num_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MU_DTYPE_F64)
+    hipLaunchKernelGGL(k_skinny_nn<double>, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, D, ldY,
+                       (const double*)d_Y, (const double*)d_T, (double*)d_out);
+  else
+    hipLaunchKernelGGL(k_skinny_nn<float>, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, D, ldY,
+                       (const float*)d_Y, (const float*)d_T, (float*)d_out);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_skinny_tn(int dtype, int64_t n_rows, int64_t D, int64_t ldY, const void* d_Y, const void* d_Z,
+                 void* d_C, void* d_work, size_t work_bytes, void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  MU_REQUIRE(n_rows >= 0 && D >= 0 && ldY >= D, "bad shape");
+  if (D == 0) return MU_OK;
+  MU_REQUIRE(d_C && d_work && (n_rows == 0 || (d_Y && d_Z)), "null pointer");
+  MU_REQUIRE(work_bytes >= mu_skinny_tn_worksize(dtype, n_rows, D), "work buffer too small");
+  const int S = tn_splits(n_rows, D);
+  const int64_t cbs = (D + 16 * kCT - 1) / (16 * kCT);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = D * 16;
+  if (dtype == MU_DTYPE_F64) {
+    hipLaunchKernelGGL(k_skinny_tn_partial<double>, dim3((unsigned)cbs, (unsigned)S), dim3(256), 0, st,
+                       n_rows, D, ldY, (const double*)d_Y, (const double*)d_Z, S, (double*)d_work);
+    MU_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_skinny_tn_reduce<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       total, S, (const double*)d_work, (double*)d_C);
+  } else {
+    hipLaunchKernelGGL(k_skinny_tn_partial<float>, dim3((unsigned)cbs, (unsigned)S), dim3(256), 0, st,
+                       n_rows, D, ldY, (const float*)d_Y, (const float*)d_Z, S, (float*)d_work);
+    MU_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_skinny_tn_reduce<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       total, S, (const float*)d_work, (float*)d_C);
+  }
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+}  // extern "C"

@@ -353,3 +353,24 @@ def test_transpose_pack_tile_overflow_falls_back_and_v1_agree(hip):
     assert torch.equal(P1s.cptr, Ps.cptr) and torch.equal(P1s.perm, Ps.perm)
     nb = int(Ps.cptr[-1].item()) * 128
     assert torch.equal(P1s.ent[:nb], Ps.ent[:nb])
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("n,D", [(1, 1), (5, 3), (33, 130), (1000, 257), (4099, 2000), (20000, 301)])
+def test_skinny_products(hip, dt, n, D):
+    """Tall-skinny MFMA products of a dense MOFA view against numpy f64 (incl. a row slice with a
+    leading dimension, ragged row / column tiles)."""
+    rng = np.random.default_rng(n + D)
+    Yfull = rng.standard_normal((n + 3, D)).astype(dt)
+    T16 = np.zeros((D, 16), dtype=dt); T16[:, :10] = rng.standard_normal((D, 10))
+    Z16 = np.zeros((n, 16), dtype=dt); Z16[:, :10] = rng.standard_normal((n, 10))
+    Yd = hip.to_device(Yfull)[2:2 + n]  # row slice: non-zero offset, same leading dimension
+    tol = 2e-4 if dt == np.float32 else 1e-11
+    A = hip.to_host(hip.skinny_nn(Yd, hip.to_device(T16)))
+    refA = Yfull[2:2 + n].astype(np.float64) @ T16.astype(np.float64)
+    assert np.max(np.abs(A - refA)) <= tol * (1 + np.abs(refA).max())
+    Bm = hip.to_host(hip.skinny_tn(Yd, hip.to_device(Z16)))
+    refB = Yfull[2:2 + n].astype(np.float64).T @ Z16.astype(np.float64)
+    assert np.max(np.abs(Bm - refB)) <= tol * (1 + np.abs(refB).max())
+    assert np.all(A[:, 10:] == 0) and np.all(Bm[:, 10:] == 0)
+    assert torch.equal(hip.skinny_tn(Yd, hip.to_device(Z16)), hip.skinny_tn(Yd, hip.to_device(Z16)))
