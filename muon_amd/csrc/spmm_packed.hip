@@ -45,10 +45,10 @@ constexpr int kPadCol = 0x7fffffff;
 // two slab buffers take 128 KiB of LDS), so W fixes the register budget per lane: 512 / (W / 4).
 // hipcc is capped at v[0 .. NX-1] by amdgpu_num_vgpr(NX / 2) on the kernel wrappers; the asm
 // statements own v[NX .. NX + 2 KMAX] (see below).
+// (768- and 512-thread workgroups - 168 / 256 registers per lane, K up to 11 / 16, two quads of LDS
+//  reads in flight - were built and measured 3...20 % slower than 1024 threads: DESIGN.md 4.2)
 template <int W> struct Geo;
 template <> struct Geo<16> { static constexpr int NX = 110, KMAX = 8; };   // 128 regs: 110 + 17
-template <> struct Geo<12> { static constexpr int NX = 144, KMAX = 11; };  // 168 regs: 144 + 23
-template <> struct Geo<8> { static constexpr int NX = 200, KMAX = 16; };   // 256 regs: 200 + 33
 
 template <int E>
 __device__ __forceinline__ int bcast_i(int x) {
@@ -118,13 +118,6 @@ __device__ __forceinline__ void dma_piece(const float4* gsrc, unsigned lds_dst) 
 #define MU_CLOB_16                                                                                \
   "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", \
       "v122", "v123", "v124", "v125", "v126"
-#define MU_CLOB_12                                                                                \
-  "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", \
-      "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166"
-#define MU_CLOB_8                                                                                 \
-  "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", \
-      "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222",     \
-      "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232"
 
 // EXEC-masked chunk request: lanes of `mask` overwrite their pair, the others keep it.  Always
 // exactly one VMEM instruction, also when the mask is empty: on gfx950 a VMEM instruction issued
@@ -145,9 +138,8 @@ __device__ __forceinline__ void request_chunk(unsigned byte_off, const void* bas
                                               unsigned long long mask) {
   constexpr int NX = Geo<W>::NX;
   unsigned long long save;
-  if constexpr (W == 16) MU_REQUEST_ASM(MU_CLOB_16);
-  else if constexpr (W == 12) MU_REQUEST_ASM(MU_CLOB_12);
-  else MU_REQUEST_ASM(MU_CLOB_8);
+  static_assert(W == 16, "register ownership is laid out for 1024-thread workgroups");
+  MU_REQUEST_ASM(MU_CLOB_16);
 }
 
 // wait until at most N VMEM operations are outstanding, then read the next chunk of row-set k
@@ -162,9 +154,7 @@ __device__ __forceinline__ void request_chunk(unsigned byte_off, const void* bas
 template <int W, int k, int N>
 __device__ __forceinline__ void wait_next_chunk(int& col, int& valbits) {
   constexpr int NX = Geo<W>::NX;
-  if constexpr (W == 16) MU_WAIT_ASM(MU_CLOB_16);
-  else if constexpr (W == 12) MU_WAIT_ASM(MU_CLOB_12);
-  else MU_WAIT_ASM(MU_CLOB_8);
+  MU_WAIT_ASM(MU_CLOB_16);
 }
 
 #define MU_SET_ASM(CLOB)                                                   \
@@ -177,9 +167,7 @@ __device__ __forceinline__ void wait_next_chunk(int& col, int& valbits) {
 template <int W, int k>
 __device__ __forceinline__ void set_next_chunk(int col, int valbits) {
   constexpr int NX = Geo<W>::NX;
-  if constexpr (W == 16) MU_SET_ASM(MU_CLOB_16);
-  else if constexpr (W == 12) MU_SET_ASM(MU_CLOB_12);
-  else MU_SET_ASM(MU_CLOB_8);
+  MU_SET_ASM(MU_CLOB_16);
 }
 
 template <int... I, class F>
@@ -200,9 +188,8 @@ struct Win {      // what stage A of a pass hands to stage B
 // MODE is 0 in production; the other bits switch parts of the kernel off for timing ablations
 // (results are then wrong on purpose): 1 no LDS gathers / FMAs, 2 no slab DMA, 8 no chunk
 // requests (and no overflow passes), 16 no window rotation, 32 overflow passes do not wait for their chunk.
-// PIPE: 0 = stage A(k) then B(k); 1 = A(k+1) is issued before B(k); 2 = additionally two quads of
-// LDS reads in flight inside B (needs ~28 more registers: W <= 12)
-// (the dispatcher uses PIPE 1; tune knob spmm_pipe = 1 selects PIPE 0 for comparison).
+// PIPE: 0 = stage A(k) then B(k); 1 = A(k+1) is issued before B(k) (the dispatcher's choice; tune knob
+// spmm_pipe = 1 selects PIPE 0 for comparison).
 template <int W, int K, int MODE, int PIPE>
 __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
                                                 const int64_t* __restrict__ cptr,
@@ -323,23 +310,6 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
       constexpr int k = decltype(kc)::value;
       if constexpr (MODE & 1) {
         acc[k].x += w.vv + (float)w.a;
-      } else if constexpr (PIPE == 2) {
-        Quad r0 = quad_read<0>(qbase, w.a);
-        Quad r1 = quad_read<4>(qbase, w.a);
-        quad_fma<0>(r0, w.vv, acc[k]);
-        if (w.any16 & 0x0f00u) {
-          r0 = quad_read<8>(qbase, w.a);
-          quad_fma<4>(r1, w.vv, acc[k]);
-          if (w.any16 & 0xf000u) {
-            r1 = quad_read<12>(qbase, w.a);
-            quad_fma<8>(r0, w.vv, acc[k]);
-            quad_fma<12>(r1, w.vv, acc[k]);
-          } else {
-            quad_fma<8>(r0, w.vv, acc[k]);
-          }
-        } else {
-          quad_fma<4>(r1, w.vv, acc[k]);
-        }
       } else {
         { const Quad r = quad_read<0>(qbase, w.a); quad_fma<0>(r, w.vv, acc[k]); }
         if (w.any16 & 0x00f0u) { const Quad r = quad_read<4>(qbase, w.a); quad_fma<4>(r, w.vv, acc[k]); }
@@ -348,7 +318,7 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
       }
     };
 
-    if constexpr (PIPE == 1 || PIPE == 2) {
+    if constexpr (PIPE == 1) {
       Win w = stage_a(std::integral_constant<int, 0>{}, std::false_type{});
       static_for<K>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -404,15 +374,6 @@ template <int K, int MODE, int PIPE>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(55))) void k_spmm_pcr64_w16(MU_KARGS) {
   spmm_pcr64_body<16, K, MODE, PIPE>(n_rows, n_cols, cptr, ent, perm, Q, Y);
 }
-template <int K, int MODE, int PIPE>
-__global__ __launch_bounds__(768) __attribute__((amdgpu_num_vgpr(72))) void k_spmm_pcr64_w12(MU_KARGS) {
-  spmm_pcr64_body<12, K, MODE, PIPE>(n_rows, n_cols, cptr, ent, perm, Q, Y);
-}
-template <int K, int MODE, int PIPE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(100))) void k_spmm_pcr64_w8(MU_KARGS) {
-  spmm_pcr64_body<8, K, MODE, PIPE>(n_rows, n_cols, cptr, ent, perm, Q, Y);
-}
-
 // ---- packing -----------------------------------------------------------------------------
 // Position p of the packed copy holds row perm[p] of the matrix (perm == nullptr: the identity;
 // perm[p] < 0: no row, only the closing chunk).  The host deals the rows, sorted by length, round
