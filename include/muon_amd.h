@@ -126,7 +126,7 @@ int mu_spmm_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const i
                 const float* d_values, const float* d_Q, int B, float* d_Y, int accumulate,
                 void* stream);
 
-/* Packed chunked-row copy of a CSR for the B = 64 SpMM ("PCR16"): every row is cut into
+/* Packed chunked-row copy of a CSR for the packed SpMM ("PCR16"): every row is cut into
  * chunks of 16 (column int32, value f32) pairs = one aligned 128-byte line each, the tail is
  * padded with (INT32_MAX, 0) and one all-padding chunk closes every row.  Built once per
  * lsi() call for X and for X^T; the subspace iteration then streams every line exactly once
@@ -170,7 +170,7 @@ int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t
                       const int64_t* d_cptr, const int32_t* d_perm, const int32_t* d_inv, void* d_ent,
                       void* d_work, size_t work_bytes, void* stream);
 
-/* Y[perm[p]][0..63] = row perm[p] of X times Q, for every position p < n_pos (B must be 64,
+/* Y[perm[p]][0..B-1] = row perm[p] of X times Q, for every position p < n_pos (B = 16, 32 or 64,
  * n_cols <= 2^22).  k_layout = the K the layout was dealt for (0: mu_spmm_packed_k(n_pos)).  Same
  * result as mu_spmm_f32 up to f32 summation order: the entries of a row are accumulated in column
  * order with one fmaf chain per dense column, whatever the layout => bit-reproducible. */

@@ -183,8 +183,8 @@ class HipBackend:
         return DeviceCSR(t_indptr, t_indices, t_values, (d, n))
 
     def can_pack(self, X: DeviceCSR, B: int) -> bool:
-        """The packed SpMM exists for f32 values, B = 64 and at most 2^22 columns."""
-        return X.values.dtype == torch.float32 and B == 64 and 0 < X.shape[1] <= (1 << 22)
+        """The packed SpMM exists for f32 values, B in (16, 32, 64) and at most 2^22 columns."""
+        return X.values.dtype == torch.float32 and B in (16, 32, 64) and 0 < X.shape[1] <= (1 << 22)
 
     def packed_layout(self, lens: torch.Tensor):
         """Where the rows go in a packed copy (include/muon_amd.h): sorted by length (descending,
@@ -266,8 +266,8 @@ class HipBackend:
         B = Q.shape[1]
         assert Q.shape[0] == d and Q.dtype in (torch.float32, torch.float64) and Q.is_contiguous()
         if isinstance(X, DevicePackedCSR):
-            if Q.dtype != torch.float32 or B != 64:
-                raise TypeError("the packed SpMM needs an f32 dense block of width 64")
+            if Q.dtype != torch.float32 or B not in (16, 32, 64):
+                raise TypeError("the packed SpMM needs an f32 dense block of width 16, 32 or 64")
             if out is None:
                 out = self.empty((n, B), Q.dtype)
             with torch.cuda.device(self.device):

@@ -205,8 +205,14 @@ class MofaEngine:
             for g, (a, b) in enumerate(self.gslice):
                 V.Y[a:b] -= mu[g] * V.pres[a:b, None]  # explicit centring of the dense block
             V.Yt = None
+        elif self.T == torch.float32 and hasattr(be, "can_pack") and be.can_pack(V.X, 16) \
+                and 0 < V.X.shape[0] <= (1 << 22):
+            # f32: both directions stream packed chunked-row copies, built once
+            V.Xt = be.transpose_pack(V.X)
+            V.Xs = be.pack(V.X)
         else:
             V.Xt = be.transpose(V.X)
+            V.Xs = V.X
         return V
 
     def _init_state(self, seed, row_offset, n_total):
@@ -315,7 +321,7 @@ class MofaEngine:
                 TWs = torch.zeros((V.D, Bp), dtype=self.T, device=dev)
                 for g in range(G):
                     TWs[:, g * K:(g + 1) * K] = TW[g]
-                out = self.be.spmm(V.X, TWs)  # N x (G K)
+                out = self.be.spmm(V.Xs, TWs)  # N x (G K)
                 for g, (a, b) in enumerate(self.gslice):
                     # K: mu^T (tau o W), implicit centring (as a reduction: rocBLAS' f64 path takes
                     # 10.7 ms for this 1 x 1e5 by 1e5 x 10 product)

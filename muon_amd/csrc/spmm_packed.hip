@@ -59,37 +59,41 @@ __device__ __forceinline__ float bcast_f(float x) {
   return __builtin_bit_cast(float, bcast_i<E>(__builtin_bit_cast(int, x)));
 }
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) const f32x4* lds_f4p;
+// NB = dense columns a lane owns (B = 16 NB): 4 (ds_read_b128), 2 (b64), 1 (b32)
+template <int NB> struct Vec;
+template <> struct Vec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct Vec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Vec<1> { typedef float type __attribute__((ext_vector_type(1))); };
 
-struct Quad { f32x4 q0, q1, q2, q3; };
+template <int NB> struct Quad { typename Vec<NB>::type q0, q1, q2, q3; };
 
-// Entries E..E+3 of every group's window: four independent ds_read_b128.  `base` is the LDS byte
-// address of the slab buffer plus this lane's 16-byte column offset; slots a group does not use
-// carry a = 0, v = 0 (a broadcast read of slab row 0 and FMAs with zero).
-template <int E>
-__device__ __forceinline__ Quad quad_read(unsigned base, int a) {
+// Entries E..E+3 of every group's window: four independent LDS reads.  `base` is the LDS byte
+// address of the slab buffer plus this lane's column offset; slots a group does not use carry
+// a = 0, v = 0 (a broadcast read of slab row 0 and FMAs with zero).
+template <int E, int NB>
+__device__ __forceinline__ Quad<NB> quad_read(unsigned base, int a) {
+  typedef __attribute__((address_space(3))) const typename Vec<NB>::type* lds_p;
   const unsigned a0 = (unsigned)bcast_i<E>(a) + base, a1 = (unsigned)bcast_i<E + 1>(a) + base;
   const unsigned a2 = (unsigned)bcast_i<E + 2>(a) + base, a3 = (unsigned)bcast_i<E + 3>(a) + base;
-  Quad r;
-  r.q0 = *(lds_f4p)(a0);
-  r.q1 = *(lds_f4p)(a1);
-  r.q2 = *(lds_f4p)(a2);
-  r.q3 = *(lds_f4p)(a3);
+  Quad<NB> r;
+  r.q0 = *(lds_p)(a0);
+  r.q1 = *(lds_p)(a1);
+  r.q2 = *(lds_p)(a2);
+  r.q3 = *(lds_p)(a3);
   return r;
 }
-template <int E>
-__device__ __forceinline__ void quad_fma(const Quad& r, float v, float4& acc) {
+template <int E, int NB>
+__device__ __forceinline__ void quad_fma(const Quad<NB>& r, float v, typename Vec<NB>::type& acc) {
   const float v0 = bcast_f<E>(v), v1 = bcast_f<E + 1>(v);
   const float v2 = bcast_f<E + 2>(v), v3 = bcast_f<E + 3>(v);
-  acc.x = fmaf(v0, r.q0.x, acc.x); acc.y = fmaf(v0, r.q0.y, acc.y);
-  acc.z = fmaf(v0, r.q0.z, acc.z); acc.w = fmaf(v0, r.q0.w, acc.w);
-  acc.x = fmaf(v1, r.q1.x, acc.x); acc.y = fmaf(v1, r.q1.y, acc.y);
-  acc.z = fmaf(v1, r.q1.z, acc.z); acc.w = fmaf(v1, r.q1.w, acc.w);
-  acc.x = fmaf(v2, r.q2.x, acc.x); acc.y = fmaf(v2, r.q2.y, acc.y);
-  acc.z = fmaf(v2, r.q2.z, acc.z); acc.w = fmaf(v2, r.q2.w, acc.w);
-  acc.x = fmaf(v3, r.q3.x, acc.x); acc.y = fmaf(v3, r.q3.y, acc.y);
-  acc.z = fmaf(v3, r.q3.z, acc.z); acc.w = fmaf(v3, r.q3.w, acc.w);
+#pragma unroll
+  for (int c = 0; c < NB; ++c) acc[c] = fmaf(v0, r.q0[c], acc[c]);
+#pragma unroll
+  for (int c = 0; c < NB; ++c) acc[c] = fmaf(v1, r.q1[c], acc[c]);
+#pragma unroll
+  for (int c = 0; c < NB; ++c) acc[c] = fmaf(v2, r.q2[c], acc[c]);
+#pragma unroll
+  for (int c = 0; c < NB; ++c) acc[c] = fmaf(v3, r.q3[c], acc[c]);
 }
 
 // one LDS-DMA piece: 64 lanes x 16 B land contiguously at the wave-uniform LDS byte address
@@ -190,30 +194,34 @@ struct Win {      // what stage A of a pass hands to stage B
 // requests (and no overflow passes), 16 no window rotation, 32 overflow passes do not wait for their chunk.
 // PIPE: 0 = stage A(k) then B(k); 1 = A(k+1) is issued before B(k) (the dispatcher's choice; tune knob
 // spmm_pipe = 1 selects PIPE 0 for comparison).
-template <int W, int K, int MODE, int PIPE>
+template <int W, int K, int MODE, int PIPE, int NB>
 __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
                                                 const int64_t* __restrict__ cptr,
                                                 const unsigned long long* __restrict__ ent,
                                                 const int32_t* __restrict__ perm,
                                                 const float* __restrict__ Q, float* __restrict__ Y) {
   static_assert(K >= 1 && K <= Geo<W>::KMAX && K <= 16, "K out of range for this workgroup size");
-  constexpr int kPieces = (kSlabCols * 256) / 1024;  // 1 KiB LDS-DMA pieces per slab (= 64)
-  __shared__ float4 qs[2][kSlabCols * 16];  // 2 x 64 KiB; Q row c of a slab at [16 c .. 16 c + 15]
+  typedef typename Vec<NB>::type acc_t;
+  constexpr int kRowBytes = 64 * NB;                         // one Q row: 16 NB floats
+  constexpr int kSlabBytes = kSlabCols * kRowBytes;          // 64 / 32 / 16 KiB
+  constexpr int kRowShift = NB == 4 ? 8 : (NB == 2 ? 7 : 6);
+  constexpr int kPieces = kSlabBytes / 1024;                 // 1 KiB LDS-DMA pieces per slab
+  __shared__ float4 qs[2][kSlabBytes / 16];  // double buffer; Q row c of a slab at byte c * kRowBytes
   const int lane = threadIdx.x & 63;
   const int wave = uniform32(threadIdx.x >> 6);
   const int sub = lane & 15, g = lane >> 4;
-  const int sub16 = sub * 16;
+  const int sub_off = sub * (4 * NB);  // this lane's byte offset inside a Q row
   const int rot_base = (lane & 48) << 2;  // ds_bpermute byte address of the group's lane 0
   const int64_t rb0 = (int64_t)blockIdx.x * (4 * W * K);
   const int64_t rb1 = (rb0 + 4 * W * K) < n_rows ? (rb0 + 4 * W * K) : n_rows;
   const int64_t cbase = uniform64(cptr[rb0]);
   const unsigned long long* __restrict__ entb = ent + cbase * 16;  // wave-uniform
   const float4* __restrict__ Q4 = reinterpret_cast<const float4*>(Q);
-  const int64_t q4_total = n_cols * 16;
+  const int64_t q4_total = n_cols * (4 * NB);
   const int ncols32 = (int)n_cols;
   const unsigned qs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&qs[0][0]);
 
-  float4 acc[K];
+  acc_t acc[K];
   int cc[K], cv[K];  // current chunk: column / value bits of entry `sub`
   int posv;          // lane 16 g + k: consumed entries of the current chunk of (row-set k, group g)
   int cidv;          // lane 16 g + k: chunk to request next (relative to the workgroup's first chunk)
@@ -232,7 +240,8 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
   // prologue: chunk 0 and chunk min(1, last) of every row (plain loads, hipcc waits for them)
   static_for<K>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    acc[k] = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NB; ++c) acc[k][c] = 0.f;
     const int c0 = bcast_i<k>(hasv);
     const int l = bcast_i<k>(lastv);
     const bool has = c0 >= 0;
@@ -246,10 +255,10 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
   });
 
   auto slab_dma = [&](int64_t s0, int buf) {
-    for (int piece = wave; piece < kPieces; piece += W) {  // 1 KiB pieces of the 64 KiB slab
-      int64_t i = s0 * 16 + piece * 64 + lane;             // float4 index into Q
+    for (int piece = wave; piece < kPieces; piece += W) {  // 1 KiB pieces of the slab
+      int64_t i = s0 * (4 * NB) + piece * 64 + lane;       // float4 index into Q
       if (i >= q4_total) i = q4_total - 1;                 // tail slab: clamp (never consumed)
-      dma_piece(Q4 + i, qs_lds + (unsigned)buf * (kSlabCols * 256u) + (unsigned)piece * 1024u);
+      dma_piece(Q4 + i, qs_lds + (unsigned)buf * (unsigned)kSlabBytes + (unsigned)piece * 1024u);
     }
   };
   constexpr int kMyPiecesMax = (kPieces + W - 1) / W;  // DMA pieces one wave issues per slab
@@ -262,7 +271,7 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
     if ((s0 + kSlabCols) < n_cols && !(MODE & 2)) slab_dma(s0 + kSlabCols, buf ^ 1);  // lands while this slab is consumed
     const int s_lo = (int)s0;
     const int s_hi = (s_lo + kSlabCols) < ncols32 ? (s_lo + kSlabCols) : ncols32;
-    const unsigned qbase = qs_lds + (unsigned)buf * (kSlabCols * 256u) + (unsigned)sub16;
+    const unsigned qbase = qs_lds + (unsigned)buf * (unsigned)kSlabBytes + (unsigned)sub_off;
     unsigned again = 0;
 
     // Stage A of a pass: cut the 16-slot window of (row-set k, every group) out of (current chunk ++
@@ -289,7 +298,7 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
       const unsigned mm = (unsigned)m | (unsigned)(m >> 32);
       Win w;
       w.any16 = (mm | (mm >> 16)) & 0xffffu;  // bit e: some group has entry e
-      w.a = valid ? ((wc - s_lo) << 8) : 0;
+      w.a = valid ? ((wc - s_lo) << kRowShift) : 0;
       w.vv = valid ? __builtin_bit_cast(float, wv) : 0.f;
       const int np = p + cnt;
       const bool shift = np >= 16;
@@ -309,12 +318,12 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
     auto stage_b = [&](auto kc, const Win& w) {
       constexpr int k = decltype(kc)::value;
       if constexpr (MODE & 1) {
-        acc[k].x += w.vv + (float)w.a;
+        acc[k][0] += w.vv + (float)w.a;
       } else {
-        { const Quad r = quad_read<0>(qbase, w.a); quad_fma<0>(r, w.vv, acc[k]); }
-        if (w.any16 & 0x00f0u) { const Quad r = quad_read<4>(qbase, w.a); quad_fma<4>(r, w.vv, acc[k]); }
-        if (w.any16 & 0x0f00u) { const Quad r = quad_read<8>(qbase, w.a); quad_fma<8>(r, w.vv, acc[k]); }
-        if (w.any16 & 0xf000u) { const Quad r = quad_read<12>(qbase, w.a); quad_fma<12>(r, w.vv, acc[k]); }
+        { const Quad<NB> r = quad_read<0, NB>(qbase, w.a); quad_fma<0, NB>(r, w.vv, acc[k]); }
+        if (w.any16 & 0x00f0u) { const Quad<NB> r = quad_read<4, NB>(qbase, w.a); quad_fma<4, NB>(r, w.vv, acc[k]); }
+        if (w.any16 & 0x0f00u) { const Quad<NB> r = quad_read<8, NB>(qbase, w.a); quad_fma<8, NB>(r, w.vv, acc[k]); }
+        if (w.any16 & 0xf000u) { const Quad<NB> r = quad_read<12, NB>(qbase, w.a); quad_fma<12, NB>(r, w.vv, acc[k]); }
       }
     };
 
@@ -361,7 +370,7 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
     const int64_t row = rb0 + ((int64_t)wave * K + k) * 4 + g;
     if (row < rb1) {
       const int64_t out = perm ? (int64_t)perm[row] : row;  // position -> row of the product (-1: none)
-      if (out >= 0) *reinterpret_cast<float4*>(Y + out * 64 + sub * 4) = acc[k];
+      if (out >= 0) *reinterpret_cast<acc_t*>(Y + out * (16 * NB) + sub * NB) = acc[k];
     }
   });
 }
@@ -370,9 +379,9 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
   int64_t n_rows, int64_t n_cols, const int64_t *__restrict__ cptr,                       \
       const unsigned long long *__restrict__ ent, const int32_t *__restrict__ perm,       \
       const float *__restrict__ Q, float *__restrict__ Y
-template <int K, int MODE, int PIPE>
+template <int K, int MODE, int PIPE, int NB>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(55))) void k_spmm_pcr64_w16(MU_KARGS) {
-  spmm_pcr64_body<16, K, MODE, PIPE>(n_rows, n_cols, cptr, ent, perm, Q, Y);
+  spmm_pcr64_body<16, K, MODE, PIPE, NB>(n_rows, n_cols, cptr, ent, perm, Q, Y);
 }
 // ---- packing -----------------------------------------------------------------------------
 // Position p of the packed copy holds row perm[p] of the matrix (perm == nullptr: the identity;
@@ -428,8 +437,15 @@ int pick_k(int64_t n_rows) {
 #define MU_GO(KERNEL, W, KK, M, P)                                                              \
   {                                                                                             \
     const int64_t wgs = (n_rows + 4 * W * KK - 1) / (4 * W * KK);                               \
-    hipLaunchKernelGGL((KERNEL<KK, M, P>), dim3((unsigned)wgs), dim3(64 * W), 0, st, n_rows, n_cols, \
-                       cptr, ent, perm, Q, Y);                                                  \
+    if (B == 64)                                                                                \
+      hipLaunchKernelGGL((KERNEL<KK, M, P, 4>), dim3((unsigned)wgs), dim3(64 * W), 0, st, n_rows,   \
+                         n_cols, cptr, ent, perm, Q, Y);                                        \
+    else if (B == 32)                                                                           \
+      hipLaunchKernelGGL((KERNEL<KK, M, P, 2>), dim3((unsigned)wgs), dim3(64 * W), 0, st, n_rows,   \
+                         n_cols, cptr, ent, perm, Q, Y);                                        \
+    else                                                                                        \
+      hipLaunchKernelGGL((KERNEL<KK, M, P, 1>), dim3((unsigned)wgs), dim3(64 * W), 0, st, n_rows,   \
+                         n_cols, cptr, ent, perm, Q, Y);                                        \
     MU_CHECK_LAUNCH();                                                                          \
     return MU_OK;                                                                               \
   }
@@ -470,7 +486,7 @@ int mu_csr_pack_fill(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indp
 int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, const void* d_ent,
                        const int32_t* d_perm, int k_layout, const float* d_Q, int B, float* d_Y,
                        void* stream) {
-  MU_REQUIRE(B == 64, "the packed SpMM is built for B = 64");
+  MU_REQUIRE(B == 16 || B == 32 || B == 64, "B must be 16, 32 or 64");
   MU_REQUIRE(n_rows >= 0 && n_cols > 0 && n_cols <= ((int64_t)1 << 22), "shape out of range");
   if (n_rows == 0) return MU_OK;
   MU_REQUIRE(d_cptr && d_ent && d_Q && d_Y, "null pointer");

@@ -374,3 +374,21 @@ def test_skinny_products(hip, dt, n, D):
     assert np.max(np.abs(Bm - refB)) <= tol * (1 + np.abs(refB).max())
     assert np.all(A[:, 10:] == 0) and np.all(Bm[:, 10:] == 0)
     assert torch.equal(hip.skinny_tn(Yd, hip.to_device(Z16)), hip.skinny_tn(Yd, hip.to_device(Z16)))
+
+
+@pytest.mark.parametrize("B", [16, 32])
+@pytest.mark.parametrize("n,d,dens", [(5, 255, 0.3), (513, 700, 0.05), (3000, 20000, 0.01)])
+def test_spmm_packed_narrow_blocks(hip, B, n, d, dens):
+    """B = 16 / 32 instances of the packed SpMM (MOFA's sparse views, lsi with few components): same
+    fmaf chains as the CSR kernel."""
+    rng = np.random.default_rng(B + n)
+    m = _heavy_rows_csr(n, d, dens, rng)
+    Q = rng.standard_normal((d, B)).astype(np.float32)
+    X = _up(hip, m)
+    Qd = hip.to_device(Q)
+    Y = hip.to_host(hip.spmm(hip.pack(X), Qd))
+    ref = m.astype(np.float64) @ Q.astype(np.float64)
+    scale = np.abs(m).astype(np.float64) @ np.abs(Q).astype(np.float64) + 1e-30
+    assert Y.shape == (n, B) and np.max(np.abs(Y - ref) / scale) < 2e-6
+    Z = hip.to_host(hip.spmm(hip.transpose_pack(X), hip.to_device(rng.standard_normal((n, B)).astype(np.float32))))
+    assert Z.shape == (d, B) and np.all(np.isfinite(Z))
