@@ -24,6 +24,8 @@ compared iteration by iteration).
 from __future__ import annotations
 
 import math
+import os
+import warnings
 from typing import List, Optional
 
 import numpy as np
@@ -80,7 +82,16 @@ class MofaEngine:
         self.Ds = [v.D for v in self.views]
         self._init_state(seed, row_offset, n_total)
         self._stats = {}
+        self._stat_buf = {}
         self.elbo = []
+        # one iteration is ~150 short launches (the K x K algebra of the tau / alpha / theta / ELBO
+        # terms): on a GPU, and without collectives inside the step, it is captured once into a HIP
+        # graph and replayed, so the host only launches the graph and reads the ELBO back
+        self._graph = None
+        self._graph_elbo = None
+        self._graph_ok = (getattr(backend, "name", "") == "hip" and self.comm.world_size == 1
+                          and os.environ.get("MUON_AMD_MOFA_GRAPH", "1") != "0")
+        self._eager_steps = 0
 
     # -- helpers -------------------------------------------------------------------------
     def _global_max(self, groups):
@@ -241,6 +252,11 @@ class MofaEngine:
             self.W.append(w)
         self.alpha_z = torch.ones((G, K), dtype=T, device=dev)
         self.lalpha_z = torch.zeros((G, K), dtype=T, device=dev)
+        # constants of the Gamma updates, resident so that an iteration has no host -> device copies
+        self.Ng_d = self.Ng.to(dev).to(T)
+        for V, w in zip(self.views, self.W):
+            V.Ngm_d = V.Ngm.to(dev).to(T)
+            w.a_alpha = torch.tensor(A0 + 0.5 * V.D, dtype=T, device=dev)
 
     # -- sufficient statistics --------------------------------------------------------------
     def _zstats(self, m):
@@ -254,6 +270,17 @@ class MofaEngine:
         return st
 
     def _zstats_compute(self, m):
+        st = self._zstats_fresh(m)
+        buf = self._stat_buf.get(m)
+        if buf is None:
+            self._stat_buf[m] = buf = tuple(t.clone() for t in st)
+        else:
+            # fixed addresses: a captured iteration reads the statistics its predecessor wrote
+            for dst, src in zip(buf, st):
+                dst.copy_(src)
+        return buf
+
+    def _zstats_fresh(self, m):
         V, K, G = self.views[m], self.K, self.G
         Gz = torch.zeros((G, K, K), dtype=self.T, device=self.EZ.device)
         Z2 = torch.zeros((G, K), dtype=self.T, device=self.EZ.device)
@@ -344,7 +371,7 @@ class MofaEngine:
         for m, (V, Wm) in enumerate(zip(self.views, self.W)):
             Gz, Z2, B = self._zstats(m)
             EW, EW2 = Wm.EW, Wm.EW2
-            Ngm = V.Ngm.to(EW.device).to(self.T)
+            Ngm = V.Ngm_d
             for g in range(G):
                 S = (V.yy[g] - 2.0 * (EW * B[g]).sum(dim=1) + ((EW @ Gz[g]) * EW).sum(dim=1)
                      + EW2 @ Z2[g] - (EW ** 2) @ torch.diagonal(Gz[g]))
@@ -356,16 +383,16 @@ class MofaEngine:
                 elbo += self._gamma_kl(A0, B0, a, b, Wm.tau[g], Wm.ltau[g]).sum().double()
             D = V.D
             if o["ard_weights"]:
-                a = torch.tensor(A0 + 0.5 * D, dtype=self.T, device=EW.device)
+                a = Wm.a_alpha
                 b = B0 + 0.5 * Wm.EWh2.sum(dim=0)
-                Wm.alpha = a / b
-                Wm.lalpha = torch.digamma(a) - torch.log(b)
+                Wm.alpha.copy_(a / b)
+                Wm.lalpha.copy_(torch.digamma(a) - torch.log(b))
             if o["spikeslab_weights"]:
                 sg = Wm.gamma.sum(dim=0)
                 a = TH_A0 + sg
                 b = TH_B0 + D - sg
-                Wm.lth = torch.digamma(a) - torch.digamma(a + b)
-                Wm.l1mth = torch.digamma(b) - torch.digamma(a + b)
+                Wm.lth.copy_(torch.digamma(a) - torch.digamma(a + b))
+                Wm.l1mth.copy_(torch.digamma(b) - torch.digamma(a + b))
             # ELBO terms of the W, alpha_w and theta nodes
             aw = Wm.alpha if o["ard_weights"] else torch.ones_like(Wm.alpha)
             law = Wm.lalpha if o["ard_weights"] else torch.zeros_like(Wm.lalpha)
@@ -383,19 +410,19 @@ class MofaEngine:
                 lb0 = math.lgamma(TH_A0) + math.lgamma(TH_B0) - math.lgamma(TH_A0 + TH_B0)
                 elbo += ((lb - lb0) + (TH_A0 - a) * Wm.lth + (TH_B0 - b) * Wm.l1mth).sum().double()
             if o["ard_weights"]:
-                a = torch.tensor(A0 + 0.5 * D, dtype=self.T, device=EW.device)
+                a = Wm.a_alpha
                 b = B0 + 0.5 * Wm.EWh2.sum(dim=0)
                 elbo += self._gamma_kl(A0, B0, a, b, aw, law).sum().double()
         # factors: ARD per group
         z2g = torch.stack([self.EZ2[a:b].sum(dim=0) for a, b in self.gslice])
         if self.comm.world_size > 1:
             self.comm.all_reduce_sum(z2g)
-        Ng = self.Ng.to(z2g.device).to(self.T)
+        Ng = self.Ng_d
         if o["ard_factors"]:
             a = (A0 + 0.5 * Ng)[:, None].expand(G, K)
             b = B0 + 0.5 * z2g
-            self.alpha_z = a / b
-            self.lalpha_z = torch.digamma(a) - torch.log(b)
+            self.alpha_z.copy_(a / b)
+            self.lalpha_z.copy_(torch.digamma(a) - torch.log(b))
         az = self.alpha_z if o["ard_factors"] else torch.ones_like(self.alpha_z)
         laz = self.lalpha_z if o["ard_factors"] else torch.zeros_like(self.lalpha_z)
         zpart = torch.zeros((), dtype=torch.float64, device=self.EZ.device)
@@ -410,14 +437,42 @@ class MofaEngine:
             a = (A0 + 0.5 * Ng)[:, None].expand(G, K)
             b = B0 + 0.5 * z2g
             elbo += self._gamma_kl(A0, B0, a, b, az, laz).sum().double()
-        return float(elbo.item())
+        return elbo
 
     # -- driver --------------------------------------------------------------------------------
-    def step(self):
+    def _iteration(self) -> torch.Tensor:
+        """One coordinate-ascent sweep (W per view, Z, tau / alpha / theta, ELBO); device work only,
+        returns the ELBO as a device scalar."""
         for m in range(self.M):
             self._update_w(m)
         self._update_z()
-        e = self._update_rest_and_elbo()
+        return self._update_rest_and_elbo()
+
+    def _capture(self):
+        # the statistics the first W update reads must already sit in their fixed buffers
+        for m in range(self.M):
+            self._zstats(m)
+        torch.cuda.synchronize(self.be.device)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                out = self._iteration()
+        except Exception as e:  # capture refused (e.g. a library call that allocates): stay eager
+            warnings.warn(f"MOFA iteration not captured into a HIP graph ({e}); running eagerly")
+            self._graph_ok = False
+            self._stats = {}
+            return
+        self._graph, self._graph_elbo = g, out
+
+    def step(self):
+        if self._graph is None and self._graph_ok and self._eager_steps >= 2:
+            self._capture()
+        if self._graph is not None:
+            self._graph.replay()
+            e = float(self._graph_elbo.item())
+        else:
+            e = float(self._iteration().item())
+            self._eager_steps += 1
         self.elbo.append(e)
         return e
 

@@ -66,6 +66,25 @@ def test_engine_f32_and_larger_sparse_view(hip):
     assert np.all(np.diff(e) > -1e-4 * abs(e[0]))
 
 
+def test_captured_iteration_equals_eager(hip):
+    # from the third iteration on the sweep is replayed as a HIP graph; the ELBO trajectory and the
+    # final state must be the ones of the eager sweeps
+    y1, y2 = simple_views()
+    y2 = y2.copy(); y2[np.abs(y2) < 1.0] = 0
+    views = [y1, sp.csr_matrix(y2)]
+    groups = np.random.default_rng(2).integers(0, 2, 100)
+    out = []
+    for graph in (True, False):
+        eng = MofaEngine(hip, views, groups, 6, seed=1)
+        eng._graph_ok = graph
+        eng.run(12, "slow")
+        assert (eng._graph is not None) == graph
+        out.append((np.array(eng.elbo), eng.results(sort_factors=False)))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-13)
+    np.testing.assert_allclose(out[0][1]["Z"], out[1][1]["Z"], atol=1e-12)
+    np.testing.assert_allclose(out[0][1]["r2"], out[1][1]["r2"], atol=1e-9)
+
+
 class TestWrapperOnGpu:
     def setup_method(self):
         y1, y2 = simple_views()
