@@ -20,6 +20,48 @@ from .._ffi import TFIDF_LOG_IDF, TFIDF_LOG_TF, TFIDF_LOG_TFIDF
 DEVICE_ATTR = "_muon_amd_device"
 
 
+def _fingerprint(m: csr_matrix):
+    """Cheap identity of a host CSR's buffers and contents: buffer addresses, sizes and a strided
+    sample checksum of the values (<= 2^16 samples).  In-place edits that move or resize a buffer,
+    or touch a sampled value, invalidate the resident copy; a surgical edit of single entries
+    between two calls is not detected (documented in DESIGN.md 3)."""
+    d = m.data
+    step = max(1, d.size >> 16)
+    sample = d[::step]
+    return (m.shape, int(m.nnz), d.dtype.str, d.ctypes.data, m.indices.ctypes.data,
+            float(np.nansum(sample, dtype=np.float64)), int(np.isnan(sample).sum()))
+
+
+def attach_device(m: csr_matrix, dev_csr, backend) -> None:
+    """Remember the device-resident copy of host matrix ``m`` (binarize -> tfidf ->
+    lsi pays PCIe for the upload once)."""
+    try:
+        setattr(m, DEVICE_ATTR, (dev_csr, backend, _fingerprint(m)))
+    except Exception:  # noqa: BLE001  (objects without a __dict__)
+        pass
+
+
+def resident(m, backend):
+    """The DeviceCSR attached to ``m`` by an earlier call if it still describes ``m``, else None."""
+    if not issparse(m):
+        return None
+    ent = getattr(m, DEVICE_ATTR, None)
+    if ent is None or ent[1] is not backend or m.format != "csr":
+        return None
+    if ent[2] != _fingerprint(m):
+        try:
+            delattr(m, DEVICE_ATTR)
+        except Exception:  # noqa: BLE001
+            pass
+        return None
+    return ent[0]
+
+
+def _is_canonical(m) -> bool:
+    return (issparse(m) and m.format == "csr" and m.dtype in (np.float32, np.float64)
+            and m.has_canonical_format and m.has_sorted_indices)
+
+
 def _flags(log_tf, log_idf, log_tfidf):
     return (TFIDF_LOG_TF if log_tf else 0) | (TFIDF_LOG_IDF if log_idf else 0) | (
         TFIDF_LOG_TFIDF if log_tfidf else 0
@@ -156,10 +198,14 @@ def tfidf(
         backend = get_backend()  # raises without a GPU: there is no CPU fallback
     comm = default_comm(comm)
 
-    host = canonical_csr(counts)
+    X = resident(counts, backend)  # left on the device by binarize(): no second upload
+    if X is not None:
+        host = counts
+    else:
+        host = canonical_csr(counts)
+        X = backend.upload_csr(host.indptr, host.indices, host.data, host.shape)
     if n_obs is None:
         n_obs = comm.sum_scalar(adata.shape[0])
-    X = backend.upload_csr(host.indptr, host.indices, host.data, host.shape)
     flags = _flags(log_tf, log_idf, log_tfidf)
     R = tfidf_device(backend, X, n_obs, flags, _effective_scale(scale_factor), comm=comm)
 
@@ -174,11 +220,8 @@ def tfidf(
     res.has_sorted_indices = True
     if match_scipy_order and log_tf and not log_tfidf:
         res = _reverse_rows(res)
-    if keep_on_device:
-        try:
-            setattr(res, DEVICE_ATTR, (R, backend))
-        except Exception:  # noqa: BLE001
-            pass
+    if keep_on_device and not (match_scipy_order and log_tf and not log_tfidf):
+        attach_device(res, R, backend)
 
     # res = np.nan_to_num(tf_idf, nan=0.0) is a no-op on sparse matrices (preproc.py:119)
     if not inplace:
@@ -215,9 +258,17 @@ def binarize(data, *, backend=None):
         if data.dtype not in (np.float32, np.float64):
             data[data != 0] = 1  # integer counts: no floating-point kernel involved
             return
-        vals = backend.to_device(data)
-        backend.binarize_values(vals)
-        data[...] = backend.to_host(vals)
+        m = adata.X
+        if _is_canonical(m):
+            # upload the whole CSR once and leave it resident for the tfidf() that follows
+            Xd = backend.upload_csr(m.indptr, m.indices, data, m.shape)
+            backend.binarize_values(Xd.values)
+            data[...] = backend.to_host(Xd.values)
+            attach_device(m, Xd, backend)
+        else:
+            vals = backend.to_device(data)
+            backend.binarize_values(vals)
+            data[...] = backend.to_host(vals)
     else:
         # dense input is a toy-size branch in the reference too (:151-152)
         adata.X[adata.X != 0] = 1

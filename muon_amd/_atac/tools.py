@@ -25,7 +25,7 @@ from scipy.sparse import issparse
 
 from .._comm import default_comm
 from .._containers import is_anndata, is_mudata
-from .preproc import DEVICE_ATTR, canonical_csr
+from .preproc import canonical_csr, resident
 
 logger = logging.getLogger("muon_amd")
 
@@ -275,10 +275,8 @@ def lsi(data, scale_embeddings=True, n_comps=50, *, comm=None, n_iter: Optional[
     comm = default_comm(comm)
 
     X = adata.X
-    dev = getattr(X, DEVICE_ATTR, None) if issparse(X) else None
-    if dev is not None and dev[1] is backend and dev[0].nnz == X.nnz:
-        Xd = dev[0]  # still resident from tfidf(): no PCIe upload
-    else:
+    Xd = resident(X, backend)  # still on the device from tfidf(): no PCIe upload
+    if Xd is None:
         host = canonical_csr(X)
         Xd = backend.upload_csr(host.indptr, host.indices, host.data.astype(np.float32), host.shape)
     out_dtype = X.dtype if X.dtype in (np.float32, np.float64) else np.float64

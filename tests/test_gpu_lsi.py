@@ -64,3 +64,26 @@ def test_run_to_run_bit_reproducible():
         ac.tl.lsi(ad, n_comps=10)
     assert np.array_equal(a.obsm["X_lsi"], b.obsm["X_lsi"])
     assert np.array_equal(a.varm["LSI"], b.varm["LSI"])
+
+
+def test_binarize_tfidf_lsi_resident_pipeline(hip, monkeypatch):
+    # one upload for the three calls; results equal the oracle's on the binarised counts
+    from oracle import tfidf_oracle
+
+    X = planted_topics_csr(5000, 7000, n_topics=30, density=0.03, seed=4, dtype=np.float32)
+    uploads = []
+    real = hip.upload_csr
+    monkeypatch.setattr(hip, "upload_csr", lambda *a, **k: (uploads.append(1), real(*a, **k))[1])
+    ad = AnnData(X.copy())
+    ac.pp.binarize(ad, backend=hip)
+    assert set(np.unique(ad.X.data)) == {1.0}
+    ac.pp.tfidf(ad, backend=hip)
+    ac.tl.lsi(ad, n_comps=30, backend=hip)
+    assert len(uploads) == 1
+    B = X.copy()
+    B.data[:] = 1
+    T = tfidf_oracle.canonical(tfidf_oracle.tfidf(B))
+    np.testing.assert_array_equal(ad.X.indices, T.indices)
+    np.testing.assert_allclose(ad.X.data, T.data, rtol=1e-5)
+    ref = lsi_oracle.lsi(T, n_comps=30)
+    assert lsi_oracle.max_subspace_angle(ad.varm["LSI"], ref["LSI"]) < ANGLE

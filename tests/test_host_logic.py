@@ -127,3 +127,53 @@ def test_binarize():
     exp = np.ones(x.nnz, dtype=np.float32)
     exp[3] = 0
     assert np.array_equal(ad.X.data, exp)
+
+
+class _CountingBackend(CpuTestBackend):
+    def __init__(self):
+        super().__init__()
+        self.uploads = 0
+
+    def upload_csr(self, *a, **k):
+        self.uploads += 1
+        return super().upload_csr(*a, **k)
+
+
+def test_binarize_tfidf_lsi_upload_once():
+    # the standard workflow binarize -> tfidf -> lsi keeps the CSR on the device;
+    # results equal the ones of three independent calls
+    X = planted_topics_csr(400, 250, n_topics=6, density=0.08, seed=9, dtype=np.float32)
+    be = _CountingBackend()
+    ad = AnnData(X.copy())
+    ac.pp.binarize(ad, backend=be)
+    ac.pp.tfidf(ad, backend=be)
+    ac.tl.lsi(ad, n_comps=6, backend=be)
+    assert be.uploads == 1
+
+    ref = AnnData(X.copy())
+    ref.X.data[ref.X.data != 0] = 1
+    ac.pp.tfidf(ref, backend=BE, keep_on_device=False)
+    np.testing.assert_array_equal(ad.X.data, ref.X.data)
+    np.testing.assert_array_equal(ad.X.indices, ref.X.indices)
+    ac.tl.lsi(ref, n_comps=6, backend=BE)
+    np.testing.assert_allclose(ad.uns["lsi"]["stdev"], ref.uns["lsi"]["stdev"], rtol=1e-6)
+    assert lsi_oracle.max_subspace_angle(ad.varm["LSI"], ref.varm["LSI"]) < 1e-5
+
+
+def test_resident_copy_is_dropped_when_the_host_matrix_changes():
+    X = planted_topics_csr(300, 200, n_topics=5, density=0.1, seed=3, dtype=np.float32)
+    be = _CountingBackend()
+    ad = AnnData(X.copy())
+    ac.pp.tfidf(ad, backend=be)
+    assert be.uploads == 1
+    ad.X.data *= 2.0  # in-place edit between the calls: the device copy no longer describes X
+    ac.tl.lsi(ad, n_comps=5, backend=be)
+    assert be.uploads == 2
+    ad2 = AnnData(X.copy())
+    ac.pp.tfidf(ad2, backend=be)
+    ad2.X = ad2.X.copy()  # a new object: nothing attached
+    ac.tl.lsi(ad2, n_comps=5, backend=be)
+    assert be.uploads == 4
+    # the result of the edited run is the one of the edited matrix
+    ref = lsi_oracle.lsi(ad.X, n_comps=5)
+    np.testing.assert_allclose(ad.uns["lsi"]["stdev"], ref["stdev"], rtol=1e-5)
