@@ -17,10 +17,12 @@ stays in HBM; only B x B matrices cross PCIe.
 from __future__ import annotations
 
 import logging
+import time
 from typing import Optional
 
 import numpy as np
 import torch
+import scipy.linalg
 from scipy.sparse import issparse
 
 from .._comm import default_comm
@@ -73,8 +75,8 @@ def _ritz_subspace_sine(Ga, Cx, Gb, Wa, Wb) -> float:
 
 
 def _orthonormalize(backend, Z: torch.Tensor, w: int, passes: int = 2):
-    """CholeskyQR(passes) in place on the replicated d x B block; returns the eigenvalues
-    source (first Gram, host f64) for the convergence test."""
+    """CholeskyQR(passes) in place on the replicated d x B block; returns the first Gram (host
+    f64), whose trace tells how much of the block survived the projection before it."""
     first = None
     for _ in range(passes):
         G, _cs = backend.gram(Z)
@@ -86,7 +88,68 @@ def _orthonormalize(backend, Z: torch.Tensor, w: int, passes: int = 2):
     return Z, first
 
 
-def lsi_device(
+def _project_out(backend, Z: torch.Tensor, blocks, passes: int = 2) -> torch.Tensor:
+    """Z <- (I - K K^T) Z for the (near-)orthonormal blocks K = [Q_0 .. Q_j], classical
+    Gram-Schmidt per block with f64 coefficients, repeated ("twice is enough")."""
+    for _ in range(passes):
+        for Qi in blocks:
+            C = backend.gram_cross(Qi, Z)  # Q_i^T Z, B x B, f64
+            Z -= backend.apply(Qi, C.to(torch.float32).contiguous())
+    return Z
+
+
+def _ritz(Tm: np.ndarray, Mm: np.ndarray, want: int):
+    """Top ``want`` pairs of  T c = theta M c  (T = K^T X^T X K, M = K^T K from f64 Grams of the
+    stored f32 blocks), descending.  M is the identity up to f32 rounding unless the Krylov space is
+    exhausted: Cholesky reduction, and only if that is ill-conditioned an eigen-decomposition of M
+    whose directions without independent content are truncated instead of inverted."""
+    n = Mm.shape[0]
+    Mm = (Mm + Mm.T) / 2
+    S = None
+    try:
+        L = np.linalg.cholesky(Mm)
+        dg = np.diag(L)
+        if dg.min() > 1e-3 * dg.max():
+            S = np.ascontiguousarray(scipy.linalg.lapack.dtrtri(L, lower=1)[0].T)  # L^-T
+    except np.linalg.LinAlgError:
+        pass
+    if S is None:
+        mu, E = np.linalg.eigh(Mm)
+        keep = mu > 1e-8 * max(mu[-1], 1e-300)
+        S = E[:, keep] / np.sqrt(mu[keep])
+    Tr = S.T @ Tm @ S
+    Tr = (Tr + Tr.T) / 2
+    r = Tr.shape[0]
+    got = min(want, r)
+    th, Wr = np.linalg.eigh(Tr)  # (the full divide-and-conquer solve beats LAPACK's subset drivers here)
+    C = np.zeros((n, want))
+    C[:, :got] = S @ np.ascontiguousarray(Wr[:, r - got:][:, ::-1])  # (contiguous: stays on the BLAS path)
+    lam = np.zeros(want)
+    lam[:got] = np.maximum(th[::-1][:got], 0)
+    return lam, C
+
+
+_blas_threads = None
+
+
+def _single_threaded_host_blas():
+    """The host side factorises matrices of a few hundred rows between kernel launches; a
+    multi-threaded OpenBLAS turns those into millisecond-to-second stalls (thread wake-ups and
+    contention with the process' other pools), so they run on the calling thread."""
+    global _blas_threads
+    if _blas_threads is None:
+        from threadpoolctl import ThreadpoolController
+
+        _blas_threads = ThreadpoolController()
+    return _blas_threads.limit(limits=1, user_api="blas")
+
+
+def lsi_device(backend, X, n_comps: int = 50, scale_embeddings: bool = True, *args, **kwargs):
+    with _single_threaded_host_blas():
+        return _lsi_device(backend, X, n_comps, scale_embeddings, *args, **kwargs)
+
+
+def _lsi_device(
     backend,
     X,
     n_comps: int = 50,
@@ -95,19 +158,22 @@ def lsi_device(
     comm=None,
     n_iter: Optional[int] = None,
     tol: float = 1e-7,
-    angle_tol: float = 1e-5,
+    angle_tol: float = 3e-5,
     max_iter: int = 60,
     oversample: int = DEFAULT_OVERSAMPLE,
     seed: int = 1,
     Xt=None,
     return_info: bool = False,
     pack: Optional[bool] = None,
+    max_blocks: int = 3,
 ):
-    """Truncated SVD of a device-resident CSR (row shard) by block subspace iteration.
+    """Truncated SVD of a device-resident CSR (row shard) by block Lanczos on X^T X with full
+    reorthogonalisation and Rayleigh-Ritz over the whole block Krylov space.
 
     Returns ``(U, stdev, V[, info])``: U torch f32 [n_local, k] (this rank's rows, already
-    scaled if asked), stdev numpy f64 [k], V torch f32 [d, k].  ``n_iter=None`` iterates
-    until the top-k singular value estimates change by less than ``tol`` (relative)."""
+    scaled if asked), stdev numpy f64 [k], V torch f32 [d, k].  ``n_iter=None`` expands the
+    Krylov space until the top-k Ritz subspace has settled (``angle_tol``); ``n_iter=q`` does
+    exactly q expansions.  m blocks cost 2 m - 1 SpMMs."""
     comm = default_comm(comm)
     n_local, d = X.shape
     if n_obs is None:
@@ -120,7 +186,7 @@ def lsi_device(
     w = min(B, min(n_obs, d))
     if X.values.dtype != torch.float32:
         X = X.with_values(X.values.to(torch.float32))
-    # B = 64: both operands of the iteration are streamed from their packed chunked-row copies
+    # both operands of the iteration are streamed from their packed chunked-row copies
     # (DESIGN.md §4); X^T's is built straight from the CSR of X, no CSR of X^T in between.
     if pack is None:
         pack = (Xt is None and hasattr(backend, "can_pack") and backend.can_pack(X, B)
@@ -131,110 +197,209 @@ def lsi_device(
     elif Xt is None:
         Xt = backend.transpose(X)
 
-    Q = backend.randn(d, B, seed)
+    # Algorithm (ours; the reference's is ARPACK, tools.py:53).  Blocks Q_0 .. Q_j (d x B, replicated)
+    # are an orthonormal basis K_j of the block Krylov space of A = X^T X started at a random block:
+    #     Y_j = X Q_j                       (SpMM; rows sharded)
+    #     T   = K^T A K = [Y_i^T Y_j]       (f64 Grams on the matrix cores, all-reduced)
+    #     Rayleigh-Ritz on (T, M = K^T K)   -> theta (sigma^2), top-k Ritz vectors K c
+    #     Z   = X^T Y_j  (SpMM + all-reduce), Z <- (I - K K^T) Z twice, Q_{j+1} = CholeskyQR2(Z)
+    # Against plain subspace iteration (same two SpMMs per step) the Ritz step sees the whole Krylov
+    # space instead of its last block, i.e. the best polynomial filter of degree j instead of the
+    # monomial: the error drops like 1 / T_j(gamma) (Chebyshev) instead of gamma^-j.  Everything the
+    # Ritz step needs (Y_i) is a by-product of the iteration; U = X V comes from the Y_i as well.
+    #
+    # Stopping rule (n_iter=None).  s_j = sin of the largest principal angle between consecutive
+    # top-k Ritz subspaces (in the M inner product, from the f64 Grams: exact for the stored f32
+    # columns) measures the error of the PREVIOUS subspace; the error of the current one is
+    # err_j ~ s_j rho_j with the contraction rho_j estimated by the last measured one,
+    # s_j / s_{j-1}, but not below 1.5 x the asymptotic Chebyshev rate computed from the Ritz values
+    # (theta_k against the largest unwanted one) nor below 1e-3, nor above 0.9.  Stop when
+    # 3 err_j < angle_tol (default 3e-5, i.e. err_j < 1e-5, ten times under the 1e-4 parity target), when s_j stagnates
+    # at the f32 noise floor, or when the Krylov space is exhausted.  The test sits right after
+    # Y_j = X Q_j, so no product is wasted.
+    Q0 = backend.randn(d, B, seed)
     if w < B:
-        Q[:, w:] = 0
-    Y = backend.spmm(X, Q)
-    Z = backend.spmm(Xt, Y)
-    comm.all_reduce_sum(Z)
+        Q0[:, w:] = 0
+    Q0, _ = _orthonormalize(backend, Q0, w, passes=2)
+    Qs, Ys, css = [Q0], [], []
+    Tb, Mb = {}, {}  # (i, j), i <= j  ->  w x w f64 host blocks
 
-    # Stopping rule (n_iter=None): after Y = X Q_j the Rayleigh-Ritz step is cheap (Gram of the n x B
-    # block), so every iteration measures s_j = sin of the largest principal angle between the top-k
-    # Ritz subspaces V_{j-1} = Q_{j-1} W_{j-1} and V_j = Q_j W_j.  The angle is computed from f64
-    # Grams of the f32 blocks (Q_{j-1}^T Q_{j-1}, Q_{j-1}^T Q_j, Q_j^T Q_j), which is exact for the
-    # columns actually stored, whatever orthogonality they lost in f32.  With the contraction
-    # rho_j = s_j / s_{j-1} (floored at 0.05, capped at 0.9; 0.5 while unknown) the distance of V_j
-    # from the limit is  err_j ~ s_j rho_j / (1 - rho_j);  we stop when 3 err_j < angle_tol (default
-    # 1e-5, ten times under the 1e-4 parity target) or when s_j stagnates at the f32 noise floor.
-    # Stopping happens AFTER Y = X Q_j, which is exactly what the final Rayleigh-Ritz needs, so no
-    # product is wasted: q iterations cost 2 q + 1 SpMMs.
-    it = 0
+    def assemble(blocks, m):
+        A = np.zeros((m * w, m * w))
+        for (i, j), G in blocks.items():
+            A[i * w:(i + 1) * w, j * w:(j + 1) * w] = G
+            if i != j:
+                A[j * w:(j + 1) * w, i * w:(i + 1) * w] = G.T
+        return A
+
+    def launch_block_grams(j):
+        # new row/column j of T (needs the sum over row shards) and of M (replicated); the results
+        # travel to the host asynchronously so that the caller can queue more device work first
+        Gj, cs = backend.gram(Ys[j])
+        cross = [backend.gram_cross(Ys[i], Ys[j]) for i in range(j)]
+        comm.all_reduce_sum(Gj, cs, *cross)
+        mq = [backend.gram(Qs[j])[0]] + [backend.gram_cross(Qs[i], Qs[j]) for i in range(j)]
+        return backend.fetch_async([Gj, cs] + cross + mq)
+
+    def collect_block_grams(j, handle):
+        got = handle.wait()
+        Tb[(j, j)] = got[0][:w, :w]
+        css.append(got[1][:w])
+        for i in range(j):
+            Tb[(i, j)] = got[2 + i][:w, :w]
+        Mb[(j, j)] = got[2 + j][:w, :w]
+        for i in range(j):
+            Mb[(i, j)] = got[3 + j + i][:w, :w]
+
+    def add_block_grams(j):
+        collect_block_grams(j, launch_block_grams(j))
+
+    def combine(blocks, coef, bias=None):
+        # sum_i blocks[i] @ coef[i*w:(i+1)*w]  ->  [rows, k]
+        out = None
+        for i, Bi in enumerate(blocks):
+            Mi = np.zeros((B, B))
+            Mi[:w, :coef.shape[1]] = coef[i * w:(i + 1) * w]
+            part = backend.apply(Bi, backend.to_device(Mi.astype(np.float32)),
+                                 bias=bias if i == 0 else None)
+            out = part if out is None else out.add_(part)
+        return out
+
+    it = 0          # Krylov expansions done
+    restarts = 0
     converged = n_iter is not None
     limit = n_iter if n_iter is not None else max_iter
-    history = []   # singular value estimates per iteration
-    angles = []    # s_j
-    Qprev = Gprev = Wprev = None
-    have_ritz = False
-    lam = W = csh = None
+    history, angles = [], []
+    Cprev = None
     err = None
+    expect_final = False  # the last Ritz step predicted that the next one passes the test
+    wasted = 0
+    host = {"wait_ms": 0.0, "ritz_ms": 0.0}
 
-    def ritz(Yb):
-        G, cs = backend.gram(Yb)
-        comm.all_reduce_sum(G, cs)
-        Gh = G.cpu().numpy()[:w, :w]
-        lam_, W_ = np.linalg.eigh(Gh)
-        order = np.argsort(lam_)[::-1][:k]
-        return np.maximum(lam_[order], 0), W_[:, order], cs.cpu().numpy()[:w]
+    def expand_product(j):
+        Zn = backend.spmm(Xt, Ys[j])
+        comm.all_reduce_sum(Zn)
+        return Zn
 
     while True:
-        Z, _G1 = _orthonormalize(backend, Z, w, passes=2)
-        Q = Z
-        it += 1
-        Y = backend.spmm(X, Q, out=Y)
+        j = len(Qs) - 1
+        Ys.append(backend.spmm(X, Qs[j]))
+        grams = launch_block_grams(j)
+        # The host's Ritz step (a few ms of LAPACK on (m w)^2 matrices) would leave the GPU idle.
+        # Unless this step is expected to be the last one, X^T Y_j - needed by every step but the
+        # last - is queued BEFORE the host waits for the Grams, so the Ritz step runs under it.
+        Z = None
+        if it < limit and not (n_iter is None and expect_final):
+            Z = expand_product(j)
+        t_w = time.perf_counter()
+        collect_block_grams(j, grams)
+        t_r = time.perf_counter()
+        host["wait_ms"] += 1e3 * (t_r - t_w)
+        m = j + 1
+        Tm, Mm = assemble(Tb, m), assemble(Mb, m)
+        lam_all, C_all = _ritz(Tm, Mm, w + 1)  # top-k pairs, the restart's w, and the first unwanted value
+        lam, C, rest = lam_all[:k], C_all[:, :k], lam_all[k:]
+        history.append(np.sqrt(lam))
         if it >= limit:
+            host["ritz_ms"] += 1e3 * (time.perf_counter() - t_r)
             break
-        if n_iter is None:
-            lam, W, csh = ritz(Y)
-            have_ritz = True
-            history.append(np.sqrt(lam))
-            Gq = backend.gram(Q)[0].cpu().numpy()[:w, :w]
-            stop = False
-            if Qprev is not None:
-                Cx = backend.gram_cross(Qprev, Q).cpu().numpy()[:w, :w]
-                s_j = _ritz_subspace_sine(Gprev, Cx, Gq, Wprev, W)
-                angles.append(s_j)
-                rho = 0.5 if len(angles) < 2 or angles[-2] <= 0 else min(0.9, max(0.05, s_j / angles[-2]))
-                err = s_j * rho / (1.0 - rho)
-                if 3.0 * err < angle_tol:
+        stop = False
+        if n_iter is None and Cprev is not None:
+            Ca = np.zeros_like(C)
+            Ca[:Cprev.shape[0]] = Cprev
+            s_j = _ritz_subspace_sine(Mm, Mm, Mm, Ca, C)
+            angles.append(s_j)
+            rho = 0.5
+            # asymptotic Chebyshev rate from the Ritz values: unwanted spectrum in [0, theta_out]
+            th_k = lam[k - 1]
+            th_out = rest[-1]
+            cheb = 0.0
+            if th_k > th_out > 0:
+                g = 1.0 + 2.0 * (th_k - th_out) / th_out
+                cheb = 1.0 / (g + np.sqrt(g * g - 1.0))
+            if len(angles) >= 2 and angles[-2] > 0:
+                rho = min(0.9, max(s_j / angles[-2], 1.5 * cheb, 1e-3))
+            err = s_j * rho
+            # One more expansion multiplies the error by about the Chebyshev rate again (the measured
+            # ratio still carries the slow first steps).  A wrong "final" costs an exposed Ritz step
+            # (ms), a wrong "not final" an unused SpMM: lean towards "final".
+            r_next = max(1.5 * cheb, 1e-3) if cheb > 0 else rho
+            expect_final = len(angles) >= 1 and 3.0 * s_j * r_next * r_next < 10.0 * angle_tol
+            if len(angles) >= 2 and 3.0 * err < angle_tol:
+                stop = True
+            elif len(angles) >= 2 and s_j < 1e-4 and s_j > 0.5 * angles[-2]:
+                stop = True  # stagnated at the f32 noise floor
+            if len(history) >= 2:
+                dsv = np.max(np.abs(history[-1] - history[-2]) / np.maximum(history[-1], 1e-300))
+                if dsv < tol * 1e-3:
                     stop = True
-                elif len(angles) >= 2 and s_j < 1e-4 and s_j > 0.5 * angles[-2]:
-                    stop = True  # stagnated at the f32 noise floor
-                if len(history) >= 2:
-                    dsv = np.max(np.abs(history[-1] - history[-2]) / np.maximum(history[-1], 1e-300))
-                    if dsv < tol * 1e-3:
-                        stop = True
-            if stop:
-                converged = True
-                break
-            Qprev = Q.clone()
-            Gprev, Wprev = Gq, W
-            have_ritz = False
-        Z = backend.spmm(Xt, Y)
-        comm.all_reduce_sum(Z)
+        host["ritz_ms"] += 1e3 * (time.perf_counter() - t_r)
+        if stop:
+            converged = True
+            wasted += Z is not None  # queued on a wrong prediction; the result is simply not used
+            break
+        # expand: next Krylov block
+        if Z is None:
+            Z = expand_product(j)
+        if w < B:
+            Z[:, w:] = 0
+        before = float(np.trace(backend.gram(Z)[0].cpu().numpy()[:w, :w]))
+        # the next block is the part of A Q_j outside the WHOLE space built so far - also when that
+        # space is about to be compressed: the residuals of all its Ritz vectors lie in this block
+        Z = _project_out(backend, Z, Qs)
+        if len(Qs) >= max_blocks:
+            # thick restart: the top-w Ritz vectors (and their images X v, linear combinations of
+            # the Y_i: no SpMM) replace the blocks; the Krylov process continues from Z
+            Cw = C_all[:, :w]
+            Vw = combine(Qs, Cw)
+            Yw = combine(Ys, Cw)
+            if w < B:
+                Vw[:, w:] = 0
+                Yw[:, w:] = 0
+            Qs, Ys, css, Tb, Mb = [Vw], [Yw], [], {}, {}
+            add_block_grams(0)
+            Cprev = np.zeros((w, k))
+            Cprev[:k, :k] = np.eye(k)  # the kept Ritz vectors are the leading columns of the new block
+            restarts += 1
+        else:
+            Cprev = C
+        Z, G1 = _orthonormalize(backend, Z, w, passes=2)
+        if np.trace(G1[:w, :w]) <= 1e-12 * max(before, 1e-300):
+            converged = True  # nothing left outside the Krylov space: the Ritz pairs are exact
+            break
+        Z = _project_out(backend, Z, Qs, passes=1)  # the normalisation amplified what the f32 projection left
+        Qs.append(Z)
+        it += 1
 
-    # Rayleigh-Ritz on span(Q): Y = X Q is already there
-    if not have_ritz:
-        lam, W, csh = ritz(Y)
     s = np.sqrt(lam)
     # deterministic signs: largest-magnitude coefficient of each Ritz vector positive
-    sg = np.sign(W[np.argmax(np.abs(W), axis=0), np.arange(k)])
+    sg = np.sign(C[np.argmax(np.abs(C), axis=0), np.arange(k)])
     sg[sg == 0] = 1
-    W = W * sg
+    C = C * sg
 
-    Mv = np.zeros((B, B))
-    Mv[:w, :k] = W
-    V = backend.apply(Q, backend.to_device(Mv.astype(np.float32)))[:, :k]
+    V = combine(Qs, C)[:, :k]
 
     with np.errstate(divide="ignore", invalid="ignore"):
-        WS = W / s  # U = Y W S^-1 has unit-norm columns
+        CS = C / s  # U = Y C S^-1 has unit-norm columns
     bias = None
     if scale_embeddings:
         # tools.py:60-63: (U - mean) / std with population std; mean(u^2) = 1/n exactly
-        mean = (csh @ WS) / n_obs
+        csh = np.concatenate(css)
+        mean = (csh @ CS) / n_obs
         var = 1.0 / n_obs - mean**2
         std = np.sqrt(np.maximum(var, 0))
         with np.errstate(divide="ignore", invalid="ignore"):
-            WS = WS / std
+            CS = CS / std
             b = np.zeros(B)
             b[:k] = -mean / std
         bias = backend.to_device(b.astype(np.float32))
-    Mu = np.zeros((B, B))
-    Mu[:w, :k] = WS
-    U = backend.apply(Y, backend.to_device(Mu.astype(np.float32)), bias=bias)[:, :k]
+    U = combine(Ys, CS, bias=bias)[:, :k]
 
     stdev = s / np.sqrt(n_obs - 1)  # tools.py:65
     if return_info:
         info = {"iterations": it, "converged": bool(converged), "block": B, "width": w,
+                "blocks": len(Qs), "restarts": restarts, "spmm": 2 * it + 1 + wasted,
+                "spmm_unused": wasted, "host": host,
                 "svalues": s, "history": history, "angles": angles, "predicted_angle": err}
         return U, stdev, V, info
     return U, stdev, V

@@ -258,6 +258,26 @@ class HipBackend:
                                              n_pos, _p(cptr), _p(perm), _p(inv), _p(ent), _p(work), wb, st))
         return DevicePackedCSR(cptr, ent, (d, n), X.nnz, perm, K)
 
+    def fetch_async(self, tensors):
+        """Start device -> host copies of small tensors into pinned staging buffers; ``wait()`` on
+        the returned handle blocks only until these copies are done - work queued on the stream
+        afterwards keeps running (the host-side Ritz step of the LSI hides under the next SpMM)."""
+        pool = self.__dict__.setdefault("_pinned", {})
+        bufs = []
+        used = {}
+        for t in tensors:
+            key = (tuple(t.shape), t.dtype)
+            n = used.get(key, 0)
+            used[key] = n + 1
+            slot = pool.setdefault(key, [])
+            if len(slot) <= n:
+                slot.append(torch.empty(t.shape, dtype=t.dtype, pin_memory=True))
+            bufs.append(slot[n])
+            bufs[-1].copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return _Fetch(bufs, ev)
+
     def tune(self, key: str, value: int) -> None:
         check(self.lib.mu_tune_set(key.encode(), int(value)))
 
@@ -378,6 +398,15 @@ class HipBackend:
             check(self.lib.mu_synth_fill(row0, n_rows, n_cols, n_topics, density, seed, _p(indptr),
                                          _p(indices), _p(values), st))
         return DeviceCSR(indptr, indices, values, (n_rows, n_cols))
+
+
+class _Fetch:
+    def __init__(self, bufs, event):
+        self.bufs, self.event = bufs, event
+
+    def wait(self):
+        self.event.synchronize()
+        return [b.numpy().copy() for b in self.bufs]
 
 
 _default_backend = None

@@ -30,6 +30,15 @@ class CpuTestBackend:
     def to_host(self, t):
         return t.detach().numpy().copy()
 
+    def fetch_async(self, tensors):
+        got = [t.detach().numpy().copy() for t in tensors]
+
+        class _Done:
+            def wait(self):
+                return got
+
+        return _Done()
+
     def upload_csr(self, indptr, indices, values, shape):
         return DeviceCSR(self.to_device(np.asarray(indptr, dtype=np.int64)),
                          self.to_device(np.asarray(indices, dtype=np.int32)),

@@ -177,3 +177,41 @@ def test_resident_copy_is_dropped_when_the_host_matrix_changes():
     # the result of the edited run is the one of the edited matrix
     ref = lsi_oracle.lsi(ad.X, n_comps=5)
     np.testing.assert_allclose(ad.uns["lsi"]["stdev"], ref["stdev"], rtol=1e-5)
+
+
+def _device_tfidf(X):
+    T = tfidf_oracle.canonical(tfidf_oracle.tfidf(X)).astype(np.float32)
+    return T, BE.upload_csr(T.indptr, T.indices, T.data, T.shape)
+
+
+def test_lsi_block_lanczos_thick_restart():
+    from muon_amd._atac.tools import lsi_device
+
+    X = planted_topics_csr(600, 400, n_topics=8, density=0.08, seed=11, dtype=np.float32)
+    T, Xd = _device_tfidf(X)
+    ref = lsi_oracle.lsi(T, n_comps=8)
+    _, sd, V, info = lsi_device(BE, Xd, n_comps=8, oversample=8, max_blocks=2, return_info=True)
+    assert info["restarts"] >= 1 and info["converged"]
+    assert info["spmm"] == 2 * info["iterations"] + 1
+    assert lsi_oracle.max_subspace_angle(V.numpy(), ref["LSI"]) < 1e-4
+    np.testing.assert_allclose(sd, ref["stdev"], rtol=1e-5)
+    # without the cap: same answer, no restart, not more products
+    _, sd2, V2, info2 = lsi_device(BE, Xd, n_comps=8, oversample=8, max_blocks=12, return_info=True)
+    assert info2["restarts"] == 0 and info2["iterations"] <= info["iterations"]
+    assert lsi_oracle.max_subspace_angle(V2.numpy(), ref["LSI"]) < 1e-4
+
+
+def test_lsi_krylov_space_exhausted_on_tiny_matrices():
+    from muon_amd._atac.tools import lsi_device
+
+    rng = np.random.default_rng(3)
+    for n, d, k in ((40, 25, 5), (18, 60, 4), (30, 16, 15)):
+        A = sp.random(n, d, density=0.4, format="csr", dtype=np.float32, random_state=rng)
+        A.data[:] = rng.random(A.nnz).astype(np.float32) + 0.5
+        Xd = BE.upload_csr(A.indptr, A.indices, A.data, A.shape)
+        _, sd, V, info = lsi_device(BE, Xd, n_comps=k, return_info=True)
+        s_ref = np.linalg.svd(A.toarray().astype(np.float64), compute_uv=False)[:k]
+        np.testing.assert_allclose(sd * np.sqrt(n - 1), s_ref, rtol=1e-5)
+        assert info["converged"] and info["iterations"] <= 6
+        G = V.numpy().astype(np.float64).T @ V.numpy().astype(np.float64)
+        np.testing.assert_allclose(G, np.eye(k), atol=1e-5)
