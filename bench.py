@@ -2,7 +2,7 @@
 """bench.py - TF-IDF + LSI(k=50) throughput on synthetic planted-topic CSR (BASELINE.json).
 
 A "step" is one pass of the hot path over one batch: tfidf (counts -> TF-IDF values) followed
-by lsi (packed copies of X and X^T, block subspace iteration to convergence, Rayleigh-Ritz),
+by lsi (packed copies of X and X^T, block Lanczos to convergence, Rayleigh-Ritz over the Krylov space),
 with the count matrix already resident in HBM when the timed region starts and U / stdev / V
 left in HBM at the end.
 

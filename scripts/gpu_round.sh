@@ -30,3 +30,17 @@ f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -
 # keep the merged output small: traces can be large
 find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
 du -sh "$OUT"
+db=$(find "$OUT/prof" -name "*.db" | head -1)
+if [ -n "$db" ]; then
+  python scripts/kstats.py "$db" "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (c3, 1 GPU)" > "$OUT/kernel_stats.md"
+  rm -f "$db"
+fi
+echo "== lsi convergence" | tee -a "$OUT/steps.txt"
+{ echo "# 125000 x 200000 (one of eight shards as a matrix of its own)"; timeout 300 python scripts/lsi_convergence.py 2>&1 | grep -v amdgpu.ids
+  echo "# 1000000 x 200000 (configs[2])"; timeout 400 python scripts/lsi_convergence.py --cells 1000000 2>&1 | grep -v amdgpu.ids; } > "$OUT/lsi_convergence.txt"
+tail -2 "$OUT/lsi_convergence.txt"
+echo "== mofa" | tee -a "$OUT/steps.txt"
+timeout 300 python scripts/bench_mofa.py --iters 100 --warmup 4 2>/dev/null | tail -1 > "$OUT/mofa_f32.json"
+timeout 300 python scripts/bench_mofa.py --f64 --iters 100 --warmup 4 2>/dev/null | tail -1 > "$OUT/mofa_f64.json"
+cat "$OUT/mofa_f32.json" "$OUT/mofa_f64.json" | cut -c1-300
+du -sh "$OUT"
