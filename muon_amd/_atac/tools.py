@@ -202,7 +202,7 @@ def _lsi_device(
     #     Y_j = X Q_j                       (SpMM; rows sharded)
     #     T   = K^T A K = [Y_i^T Y_j]       (f64 Grams on the matrix cores, all-reduced)
     #     Rayleigh-Ritz on (T, M = K^T K)   -> theta (sigma^2), top-k Ritz vectors K c
-    #     Z   = X^T Y_j  (SpMM + all-reduce), Z <- (I - K K^T) Z twice, Q_{j+1} = CholeskyQR2(Z)
+    #     Z   = X^T Y_j  (SpMM + all-reduce), Z <- (I - K K^T) Z, Q_{j+1} = CholeskyQR2(Z), projected once more
     # Against plain subspace iteration (same two SpMMs per step) the Ritz step sees the whole Krylov
     # space instead of its last block, i.e. the best polynomial filter of degree j instead of the
     # monomial: the error drops like 1 / T_j(gamma) (Chebyshev) instead of gamma^-j.  Everything the
@@ -346,7 +346,7 @@ def _lsi_device(
         before = float(np.trace(backend.gram(Z)[0].cpu().numpy()[:w, :w]))
         # the next block is the part of A Q_j outside the WHOLE space built so far - also when that
         # space is about to be compressed: the residuals of all its Ritz vectors lie in this block
-        Z = _project_out(backend, Z, Qs)
+        Z = _project_out(backend, Z, Qs, passes=1)  # (the second pass follows the normalisation below)
         if len(Qs) >= max_blocks:
             # thick restart: the top-w Ritz vectors (and their images X v, linear combinations of
             # the Y_i: no SpMM) replace the blocks; the Krylov process continues from Z

@@ -39,11 +39,20 @@ __global__ __launch_bounds__(kGramThreads) void k_gram_partial(int64_t n_rows,
   const int64_t n_groups = (n_rows + 3) / 4;
   const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
   const int64_t gstride = (int64_t)gridDim.x * 4;
+  float xn[T];
+  {
+    const int64_t row = gw * 4 + lr;
+#pragma unroll
+    for (int t = 0; t < T; ++t) xn[t] = (gw < n_groups && row < n_rows) ? A[row * B + 16 * t + lc] : 0.f;
+  }
   for (int64_t grp = gw; grp < n_groups; grp += gstride) {
-    const int64_t row = grp * 4 + lr;
     double x[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) x[t] = (row < n_rows) ? (double)A[row * B + 16 * t + lc] : 0.0;
+    for (int t = 0; t < T; ++t) x[t] = (double)xn[t];
+    const int64_t nrow = (grp + gstride) * 4 + lr;
+    const bool more = (grp + gstride < n_groups) && (nrow < n_rows);
+#pragma unroll
+    for (int t = 0; t < T; ++t) xn[t] = more ? A[nrow * B + 16 * t + lc] : 0.f;
 #pragma unroll
     for (int t = 0; t < T; ++t) cs[t] += x[t];
     int k = 0;
@@ -122,13 +131,30 @@ __global__ __launch_bounds__(kGramThreads) void k_gram_cross_partial(int64_t n_r
   const int64_t n_groups = (n_rows + 3) / 4;
   const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
   const int64_t gstride = (int64_t)gridDim.x * 4;
+  // (the loads of the next four rows are in flight while the 16 MFMAs of the current ones issue:
+  //  with one dependent load -> MFMA chain per iteration the kernel ran at memory latency)
+  float xn[T], yn[T];
+  {
+    const int64_t row = gw * 4 + lr;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      xn[t] = (gw < n_groups && row < n_rows) ? A[row * B + 16 * t + lc] : 0.f;
+      yn[t] = (gw < n_groups && row < n_rows) ? Bm[row * B + 16 * t + lc] : 0.f;
+    }
+  }
   for (int64_t grp = gw; grp < n_groups; grp += gstride) {
-    const int64_t row = grp * 4 + lr;
     double x[T], y[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      x[t] = (row < n_rows) ? (double)A[row * B + 16 * t + lc] : 0.0;
-      y[t] = (row < n_rows) ? (double)Bm[row * B + 16 * t + lc] : 0.0;
+      x[t] = (double)xn[t];
+      y[t] = (double)yn[t];
+    }
+    const int64_t nrow = (grp + gstride) * 4 + lr;
+    const bool more = (grp + gstride < n_groups) && (nrow < n_rows);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      xn[t] = more ? A[nrow * B + 16 * t + lc] : 0.f;
+      yn[t] = more ? Bm[nrow * B + 16 * t + lc] : 0.f;
     }
 #pragma unroll
     for (int ti = 0; ti < T; ++ti)
@@ -182,7 +208,8 @@ __global__ __launch_bounds__(256) void k_gram_fold(int n_partials, const double*
 static inline int gram_blocks(int64_t n_rows) {
   int64_t groups = (n_rows + 15) / 16;  // one workgroup step = 16 rows
   int64_t blocks = groups < 1 ? 1 : groups;
-  const int64_t cap = (int64_t)mu_num_cus() * 4;
+  const int per_cu = mu_tune_get("gram_wg") > 0 ? mu_tune_get("gram_wg") : 2;  // (probe: 1, 2, 4, 8 -> 81, 88, 104, 134 us per cross-Gram at 200k rows)
+  const int64_t cap = (int64_t)mu_num_cus() * per_cu;
   return (int)(blocks > cap ? cap : blocks);
 }
 
