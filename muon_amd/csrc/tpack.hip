@@ -438,6 +438,208 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
   }
 }
 
+// ---- fill, version 3: the count walk rides on the previous tile's place walk ---------------------
+// The row loops of version 2 are instruction bound and run twice per tile (count, place).  The 64
+// entries a wave loads from a row's cursor reach well past the tile (a row has ~20 entries per
+// tile), i.e. the place walk of tile t has already seen tile t+1's entries of that row: it counts
+// them into a second, 16-bit bucket array, and tile t+1 starts with its counts done.  Only the
+// first tile (and a tile that follows an empty one) needs an explicit count walk.
+constexpr int kF3Cols = 640;  // u32 cursors 40 KiB + u16 counts 20 KiB + 80 KiB staging fit 160 KiB
+constexpr int64_t kF3MaxRows = 16ll * 65535;  // a wave's count of one column fits 16 bits
+
+template <int PHASE>
+__device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, int first,
+                                           int64_t row0, int32_t cbase, int32_t cend, int32_t cend2,
+                                           const int32_t* __restrict__ indices_b,
+                                           const float* __restrict__ values_b, uint32_t* wcur,
+                                           uint16_t* wcnt, const uint32_t* lpos, const int64_t* gdst,
+                                           unsigned long long* stage, bool staged,
+                                           unsigned long long* __restrict__ ent) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < kF2Rows; ++j) {
+    if (first + j >= 64) break;  // uniform
+    int c0 = __builtin_amdgcn_readlane(cur, first + j);
+    const int e0 = __builtin_amdgcn_readlane(end, first + j);
+    int ws = c0;  // where the loaded window starts
+    int32_t c = b.ci[j];
+    float v = (PHASE == 1) ? b.cv[j] : 0.f;
+    while (true) {
+      const bool valid = c < cend;  // sorted rows: a prefix of the 64 loaded entries
+      const int n = __popcll(__ballot(valid));
+      if (PHASE == 0) {
+        if (valid) wcnt[c - cbase] += (uint16_t)1;  // columns inside one row are distinct
+      } else {
+        if (valid) {
+          const int cl = c - cbase;
+          const uint32_t k = wcur[cl];
+          wcur[cl] = k + 1u;
+          const unsigned long long e = (unsigned long long)(unsigned)(row0 + first + j) |
+                                       ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32);
+          if (staged) stage[lpos[cl] + k] = e;
+          else ent[gdst[cl] + k] = e;
+        } else if (c < cend2) {
+          wcnt[c - cend] += (uint16_t)1;  // belongs to the next tile: its count walk is this one
+        }
+      }
+      c0 += n;
+      if (n == 64) {  // wave-uniform: a row with more than 64 entries in this tile
+        ws = c0;
+        const int p = c0 + lane;
+        const bool in = p < e0;
+        c = in ? indices_b[p] : 0x7fffffff;
+        if (PHASE == 1) v = in ? values_b[p] : 0.f;
+        continue;
+      }
+      if (PHASE == 1) {
+        // the window ends inside the next tile: keep counting that tile (rare: > 64 entries in two tiles)
+        while (__popcll(__ballot(c < cend2)) == 64) {
+          ws += 64;
+          const int p = ws + lane;
+          c = (p < e0) ? indices_b[p] : 0x7fffffff;
+          if (c < cend2) wcnt[c - cend] += (uint16_t)1;
+        }
+      }
+      break;
+    }
+    if (PHASE == 1 && lane == first + j) cur = c0;
+  }
+}
+
+template <int PHASE>
+__device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cbase, int32_t cend,
+                                        int32_t cend2, int64_t wg_base,
+                                        const int64_t* __restrict__ indptr,
+                                        const int32_t* __restrict__ indices,
+                                        const float* __restrict__ values, int64_t* __restrict__ curs,
+                                        uint32_t* wcur, uint16_t* wcnt, const uint32_t* lpos,
+                                        const int64_t* gdst, unsigned long long* stage, bool staged,
+                                        unsigned long long* __restrict__ ent) {
+  const int lane = threadIdx.x & 63;
+  const int32_t* __restrict__ indices_b = indices + wg_base;
+  const float* __restrict__ values_b = values + wg_base;
+  for (int64_t sb = wrow0; sb < wrow1; sb += 64) {  // wave-uniform
+    const int nr = (wrow1 - sb) < 64 ? (int)(wrow1 - sb) : 64;
+    int cur = 0, end = 0;
+    if (lane < nr) {
+      cur = (int)(curs[sb + lane] - wg_base);
+      end = (int)(indptr[sb + lane + 1] - wg_base);
+    }
+    F2Batch ba, bb;
+    f2_load<PHASE>(ba, cur, end, 0, indices_b, values_b);
+    for (int first = 0; first < nr; first += 2 * kF2Rows) {
+      if (first + kF2Rows < nr) f2_load<PHASE>(bb, cur, end, first + kF2Rows, indices_b, values_b);
+      f3_process<PHASE>(ba, cur, end, first, sb, cbase, cend, cend2, indices_b, values_b, wcur, wcnt, lpos,
+                        gdst, stage, staged, ent);
+      if (first + kF2Rows < nr) {
+        if (first + 2 * kF2Rows < nr) f2_load<PHASE>(ba, cur, end, first + 2 * kF2Rows, indices_b, values_b);
+        f3_process<PHASE>(bb, cur, end, first + kF2Rows, sb, cbase, cend, cend2, indices_b, values_b, wcur,
+                          wcnt, lpos, gdst, stage, staged, ent);
+      }
+    }
+    if (PHASE == 1 && lane < nr) curs[sb + lane] = wg_base + (int64_t)cur;
+  }
+}
+
+__global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n_cols, int C,
+                                                       const int64_t* __restrict__ indptr,
+                                                       const int32_t* __restrict__ indices,
+                                                       const float* __restrict__ values,
+                                                       int64_t* __restrict__ curs,
+                                                       const int64_t* __restrict__ cptr,
+                                                       const int32_t* __restrict__ inv,
+                                                       const uint32_t* __restrict__ base,
+                                                       const int64_t* __restrict__ coltot,
+                                                       unsigned long long* __restrict__ ent) {
+  __shared__ unsigned long long stage[kF2Cap];     // 80 KiB
+  __shared__ uint32_t wcur_all[kTWaves][kF3Cols];  // 40 KiB: per (wave, column) cursor of this tile
+  __shared__ uint16_t wcnt_all[kTWaves][kF3Cols];  // 20 KiB: per (wave, column) count of the tile in the making
+  __shared__ uint32_t lcount[kF3Cols], lpos[kF3Cols];
+  __shared__ int64_t gdst[kF3Cols];
+  __shared__ uint32_t wsum[kTWaves];
+  __shared__ int64_t s_r[2];
+  const int g = blockIdx.x, G = gridDim.x;
+  if (threadIdx.x == 0) t_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
+  for (int t = threadIdx.x; t < kTWaves * kF3Cols; t += kTThreads) (&wcnt_all[0][0])[t] = (uint16_t)0;
+  __syncthreads();
+  const int64_t r0 = s_r[0], r1 = s_r[1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t rw = (r1 - r0 + kTWaves - 1) / kTWaves;  // rows per wave
+  const int64_t wrow0 = (r0 + wave * rw) < r1 ? (r0 + wave * rw) : r1;
+  const int64_t wrow1 = (wrow0 + rw) < r1 ? (wrow0 + rw) : r1;
+  const int64_t wg_base = uniform64(indptr[r0 < n_rows ? r0 : n_rows]);
+  const uint32_t* base_g = base + (int64_t)g * n_cols;
+  const uint32_t* base_n = (g + 1 < G) ? base + (int64_t)(g + 1) * n_cols : nullptr;
+  bool have = false;  // wcnt_all holds the counts of the tile about to be processed (uniform)
+
+  for (int64_t cb = 0; cb < n_cols; cb += C) {
+    const int32_t cbase = (int32_t)cb;
+    const int32_t cend = (int32_t)((cb + C) < n_cols ? (cb + C) : n_cols);
+    const int32_t cend2 = (int32_t)((cb + 2 * (int64_t)C) < n_cols ? (cb + 2 * (int64_t)C) : n_cols);
+    uint32_t mine = 0;
+    if (threadIdx.x < kF3Cols) {
+      const int64_t c = (int64_t)cbase + threadIdx.x;
+      if (c < cend) {
+        const uint32_t b0 = base_g[c];
+        const uint32_t b1 = base_n ? base_n[c] : (uint32_t)coltot[c];
+        mine = b1 - b0;
+        gdst[threadIdx.x] = cptr[inv ? (int64_t)inv[c] : c] * 16 + (int64_t)b0;
+      }
+      lcount[threadIdx.x] = mine;
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t wpre = 0, total = 0;
+    for (int w = 0; w < kTWaves; ++w) {
+      const uint32_t t = wsum[w];
+      if (w < wave) wpre += t;
+      total += t;
+    }
+    if (threadIdx.x < kF3Cols) lpos[threadIdx.x] = wpre + incl - mine;
+    const bool staged = total <= (uint32_t)kF2Cap;
+    __syncthreads();
+    if (total == 0) {  // uniform: nothing here, so nobody counted the next tile either
+      have = false;    // (the counts of an empty tile are zeros: wcnt_all stays clear)
+      continue;
+    }
+    if (!have)
+      f3_walk<0>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs, wcur_all[wave],
+                 wcnt_all[wave], lpos, gdst, stage, staged, ent);
+    __syncthreads();
+    // per column: exclusive prefix of the wave counts = first slot of every wave inside the run;
+    // the counts are consumed (zeroed) for the next tile
+    if (threadIdx.x < kF3Cols) {
+      uint32_t run = 0;
+      for (int w = 0; w < kTWaves; ++w) {
+        const uint32_t t = wcnt_all[w][threadIdx.x];
+        wcnt_all[w][threadIdx.x] = (uint16_t)0;
+        wcur_all[w][threadIdx.x] = run;
+        run += t;
+      }
+    }
+    __syncthreads();
+    f3_walk<1>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs, wcur_all[wave],
+               wcnt_all[wave], lpos, gdst, stage, staged, ent);
+    have = true;
+    __syncthreads();
+    if (staged) {
+      const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+      for (int cl = grp; cl < cend - cbase; cl += kTThreads / 16) {
+        const uint32_t L = lcount[cl], src = lpos[cl];
+        const int64_t dst = gdst[cl];
+        for (uint32_t i = sub; i < L; i += 16) ent[dst + i] = stage[src + i];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // tail of the last real chunk + the closing chunk of every output row: at most 31 pads
 __global__ __launch_bounds__(256) void k_t_pads(int64_t n_cols, const int64_t* __restrict__ coltot,
                                                 const int64_t* __restrict__ cptr,
@@ -553,10 +755,17 @@ int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t
       MU_CHECK_HIP(hipMemcpyAsync(w.curs, d_indptr, sizeof(int64_t) * (size_t)n_rows,
                                   hipMemcpyDeviceToDevice, st));
       if (mu_tune_get("tpack_c") > 0) C = mu_tune_get("tpack_c");
-      hipLaunchKernelGGL(k_t_fill2, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,
-                         mu_tune_get("tpack_abl"), d_indptr,
-                         d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt, w.coltot,
-                         (unsigned long long*)d_ent);
+      if (n_rows <= kF3MaxRows && !mu_tune_get("tpack_v2")) {
+        if (C > kF3Cols) C = kF3Cols;
+        hipLaunchKernelGGL(k_t_fill3, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C, d_indptr,
+                           d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt, w.coltot,
+                           (unsigned long long*)d_ent);
+      } else {
+        hipLaunchKernelGGL(k_t_fill2, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,
+                           mu_tune_get("tpack_abl"), d_indptr,
+                           d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt, w.coltot,
+                           (unsigned long long*)d_ent);
+      }
     }
     MU_CHECK_LAUNCH();
   }

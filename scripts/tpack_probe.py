@@ -1,27 +1,48 @@
 #!/usr/bin/env python
-"""Timing ablations of the transpose-pack fill on the bench matrix (tune knobs tpack_abl / tpack_c)."""
-import os, sys
+"""Timing of the transpose-pack on the bench matrix: third-generation fill (count rides on the
+previous tile's place walk) against the two-walk kernel, with its ablations and tile widths."""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+
 from muon_amd._atac.preproc import tfidf_device
 from muon_amd._backend import HipBackend
+
 be = HipBackend(0)
-X = be.synth_counts(0, 125000, 200000, 50, 0.03, 0)
-T = tfidf_device(be, X, 125000, 3, 1e4)
-import sys
+cells = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 125000
+X = be.synth_counts(0, cells, 200000, 50, 0.03, 0)
+T = tfidf_device(be, X, cells, 3, 1e4)
 SORT = "--natural" not in sys.argv
+
+
 def t(label):
-    be.transpose_pack(T, sort_rows=SORT); torch.cuda.synchronize()
-    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    be.transpose_pack(T, sort_rows=SORT)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(3): be.transpose_pack(T, sort_rows=SORT)
-    e.record(); torch.cuda.synchronize()
-    print(f"{label}: {s.elapsed_time(e)/3:.2f} ms (count + layout + scan + fill + pads; sorted layout = {SORT})", flush=True)
-t("full")
-be.tune("tpack_abl", 8); t("row loads from the cursor (not line aligned)"); be.tune("tpack_abl", 0)
-for abl, name in ((1, "no count walk"), (2, "no place walk"), (4, "no write-out"), (3, "no walks"), (7, "setup/scans/barriers only")):
-    be.tune("tpack_abl", abl); t(name)
-be.tune("tpack_abl", 0)
-for c in (256, 384, 640, 768):
-    be.tune("tpack_c", c); t(f"C={c}")
+    for _ in range(3):
+        be.transpose_pack(T, sort_rows=SORT)
+    e.record()
+    torch.cuda.synchronize()
+    print(f"{label}: {s.elapsed_time(e) / 3:.2f} ms (count + layout + scan + fill + pads; sorted layout = {SORT})", flush=True)
+
+
+t("v3 full")
+for c in (384, 512, 640):
+    be.tune("tpack_c", c)
+    t(f"v3 C={c}")
 be.tune("tpack_c", 0)
+be.tune("tpack_v2", 1)
+t("v2 full")
+for abl, name in ((1, "v2 no count walk"), (2, "v2 no place walk"), (4, "v2 no write-out"), (3, "v2 no walks"),
+                  (7, "v2 setup/scans/barriers only")):
+    be.tune("tpack_abl", abl)
+    t(name)
+be.tune("tpack_abl", 0)
+for c in (640, 768):
+    be.tune("tpack_c", c)
+    t(f"v2 C={c}")
+be.tune("tpack_c", 0)
+be.tune("tpack_v2", 0)

@@ -355,6 +355,41 @@ def test_transpose_pack_tile_overflow_falls_back_and_v1_agree(hip):
     assert torch.equal(P1s.ent[:nb], Ps.ent[:nb])
 
 
+@pytest.mark.parametrize("C", [32, 64, 0])
+def test_transpose_pack_count_rides_on_previous_tile(hip, C):
+    """Third-generation fill: the place walk of a tile counts the next tile's entries.  Narrow tiles
+    against rows with long dense bursts (more than 64 entries inside one / two tiles), empty column
+    ranges (the tile after an empty one counts for itself) and ragged rows; the bytes equal the
+    numpy packing and the ones of the two-walk kernel."""
+    rng = np.random.default_rng(77 + C)
+    n, d = 3000, 2600
+    m = sp.random(n, d, density=0.02, format="lil", random_state=rng, dtype=np.float32)
+    for r in rng.choice(n, 60, replace=False):      # dense bursts of 70..400 consecutive columns
+        c0 = int(rng.integers(0, d - 450))
+        L = int(rng.integers(70, 400))
+        m[r, c0:c0 + L] = rng.random(L).astype(np.float32) + 0.5
+    m = m.tocsr()
+    m[:, 900:1400] = 0                              # empty column ranges
+    m[:, 2000:2100] = 0
+    m.eliminate_zeros()
+    m.sort_indices()
+    X = _up(hip, m)
+    mt = m.T.tocsr()
+    mt.sort_indices()
+    cptr, ent = _pack_ref(mt)
+    try:
+        hip.tune("tpack_c", C)
+        P = hip.transpose_pack(X, sort_rows=False)
+        hip.tune("tpack_v2", 1)
+        P2 = hip.transpose_pack(X, sort_rows=False)
+    finally:
+        hip.tune("tpack_c", 0)
+        hip.tune("tpack_v2", 0)
+    assert np.array_equal(hip.to_host(P.cptr), cptr)
+    assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
+    assert torch.equal(P2.ent[: ent.size * 8], P.ent[: ent.size * 8])
+
+
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("n,D", [(1, 1), (5, 3), (33, 130), (1000, 257), (4099, 2000), (20000, 301)])
 def test_skinny_products(hip, dt, n, D):
