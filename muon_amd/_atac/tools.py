@@ -181,9 +181,12 @@ def _lsi_device(
     k = int(n_comps)
     if k < 1 or k >= min(n_obs, d):
         raise ValueError(f"`k` must be an integer satisfying `0 < k < min(A.shape)`; got k={k}")
-    w = min(k + max(int(oversample), 0), min(n_obs, d))  # active block width
-    B = _pick_block(max(w, k))
-    w = min(B, min(n_obs, d))
+    target = min(k + max(int(oversample), 0), min(n_obs, d))  # Ritz vectors worth keeping
+    B = _pick_block(min(target, 64))           # block width of the products (16 / 32 / 64)
+    w = min(B, min(n_obs, d))                   # its active columns
+    keep_blocks = -(-target // w)               # blocks a thick restart keeps (1 for n_comps <= 50)
+    keep = keep_blocks * w
+    max_blocks = max(int(max_blocks), keep_blocks + 2)
     if X.values.dtype != torch.float32:
         X = X.with_values(X.values.to(torch.float32))
     # both operands of the iteration are streamed from their packed chunked-row copies
@@ -254,16 +257,30 @@ def _lsi_device(
     def add_block_grams(j):
         collect_block_grams(j, launch_block_grams(j))
 
-    def combine(blocks, coef, bias=None):
-        # sum_i blocks[i] @ coef[i*w:(i+1)*w]  ->  [rows, k]
-        out = None
-        for i, Bi in enumerate(blocks):
-            Mi = np.zeros((B, B))
-            Mi[:w, :coef.shape[1]] = coef[i * w:(i + 1) * w]
-            part = backend.apply(Bi, backend.to_device(Mi.astype(np.float32)),
-                                 bias=bias if i == 0 else None)
-            out = part if out is None else out.add_(part)
-        return out
+    def combine(blocks, coef, bias=None, chunk=None):
+        # sum_i blocks[i] @ coef[i*w:(i+1)*w]  ->  list of [rows, B] tensors, `chunk` columns of coef each
+        chunk = B if chunk is None else chunk
+        chunks = []
+        for c0 in range(0, coef.shape[1], chunk):
+            cols = coef[:, c0:c0 + chunk]
+            bvec = None
+            if bias is not None:
+                bb = np.zeros(B)
+                bb[:cols.shape[1]] = bias[c0:c0 + chunk]
+                bvec = backend.to_device(bb.astype(np.float32))
+            out = None
+            for i, Bi in enumerate(blocks):
+                Mi = np.zeros((B, B))
+                Mi[:w, :cols.shape[1]] = cols[i * w:(i + 1) * w]
+                part = backend.apply(Bi, backend.to_device(Mi.astype(np.float32)),
+                                     bias=bvec if i == 0 else None)
+                out = part if out is None else out.add_(part)
+            chunks.append(out)
+        return chunks
+
+    def first_columns(chunks, ncol):
+        full = chunks[0] if len(chunks) == 1 else torch.cat(chunks, dim=1)
+        return full[:, :ncol]
 
     it = 0          # Krylov expansions done
     restarts = 0
@@ -297,14 +314,15 @@ def _lsi_device(
         host["wait_ms"] += 1e3 * (t_r - t_w)
         m = j + 1
         Tm, Mm = assemble(Tb, m), assemble(Mb, m)
-        lam_all, C_all = _ritz(Tm, Mm, w + 1)  # top-k pairs, the restart's w, and the first unwanted value
+        lam_all, C_all = _ritz(Tm, Mm, keep + 1)  # top-k pairs, the restart's `keep`, the first unwanted value
         lam, C, rest = lam_all[:k], C_all[:, :k], lam_all[k:]
         history.append(np.sqrt(lam))
-        if it >= limit:
+        enough = m * w > k  # (n_comps > block width: the first Ritz steps cannot deliver k vectors yet)
+        if it >= limit and enough:
             host["ritz_ms"] += 1e3 * (time.perf_counter() - t_r)
             break
         stop = False
-        if n_iter is None and Cprev is not None:
+        if n_iter is None and Cprev is not None and enough:
             Ca = np.zeros_like(C)
             Ca[:Cprev.shape[0]] = Cprev
             s_j = _ritz_subspace_sine(Mm, Mm, Mm, Ca, C)
@@ -341,6 +359,8 @@ def _lsi_device(
         # expand: next Krylov block
         if Z is None:
             Z = expand_product(j)
+        if not enough:
+            expect_final = False
         if w < B:
             Z[:, w:] = 0
         before = float(np.trace(backend.gram(Z)[0].cpu().numpy()[:w, :w]))
@@ -350,19 +370,17 @@ def _lsi_device(
         if len(Qs) >= max_blocks:
             # thick restart: the top-w Ritz vectors (and their images X v, linear combinations of
             # the Y_i: no SpMM) replace the blocks; the Krylov process continues from Z
-            Cw = C_all[:, :w]
-            Vw = combine(Qs, Cw)
-            Yw = combine(Ys, Cw)
-            if w < B:
-                Vw[:, w:] = 0
-                Yw[:, w:] = 0
-            Qs, Ys, css, Tb, Mb = [Vw], [Yw], [], {}, {}
-            add_block_grams(0)
-            Cprev = np.zeros((w, k))
-            Cprev[:k, :k] = np.eye(k)  # the kept Ritz vectors are the leading columns of the new block
+            Cw = C_all[:, :keep]
+            Vw = combine(Qs, Cw, chunk=w)  # `keep_blocks` new blocks of w active columns
+            Yw = combine(Ys, Cw, chunk=w)
+            Qs, Ys, css, Tb, Mb = list(Vw), list(Yw), [], {}, {}
+            for jj in range(keep_blocks):
+                add_block_grams(jj)
+            Cprev = np.zeros((keep, k))
+            Cprev[:k, :k] = np.eye(k)  # the kept Ritz vectors are the leading columns of the new blocks
             restarts += 1
         else:
-            Cprev = C
+            Cprev = C if enough else None
         Z, G1 = _orthonormalize(backend, Z, w, passes=2)
         if np.trace(G1[:w, :w]) <= 1e-12 * max(before, 1e-300):
             converged = True  # nothing left outside the Krylov space: the Ritz pairs are exact
@@ -377,7 +395,7 @@ def _lsi_device(
     sg[sg == 0] = 1
     C = C * sg
 
-    V = combine(Qs, C)[:, :k]
+    V = first_columns(combine(Qs, C), k)
 
     with np.errstate(divide="ignore", invalid="ignore"):
         CS = C / s  # U = Y C S^-1 has unit-norm columns
@@ -390,10 +408,8 @@ def _lsi_device(
         std = np.sqrt(np.maximum(var, 0))
         with np.errstate(divide="ignore", invalid="ignore"):
             CS = CS / std
-            b = np.zeros(B)
-            b[:k] = -mean / std
-        bias = backend.to_device(b.astype(np.float32))
-    U = combine(Ys, CS, bias=bias)[:, :k]
+            bias = -mean / std
+    U = first_columns(combine(Ys, CS, bias=bias), k)
 
     stdev = s / np.sqrt(n_obs - 1)  # tools.py:65
     if return_info:

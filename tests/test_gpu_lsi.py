@@ -87,3 +87,14 @@ def test_binarize_tfidf_lsi_resident_pipeline(hip, monkeypatch):
     np.testing.assert_allclose(ad.X.data, T.data, rtol=1e-5)
     ref = lsi_oracle.lsi(T, n_comps=30)
     assert lsi_oracle.max_subspace_angle(ad.varm["LSI"], ref["LSI"]) < ANGLE
+
+
+def test_more_components_than_the_block_width():
+    X = planted_topics_csr(5000, 6000, n_topics=100, density=0.04, seed=8, dtype=np.float32)
+    ad = AnnData(X.copy())
+    ac.pp.tfidf(ad)
+    ref = lsi_oracle.lsi(ad.X, n_comps=100)
+    ac.tl.lsi(ad, n_comps=100)
+    assert ad.obsm["X_lsi"].shape == (5000, 100) and ad.varm["LSI"].shape == (6000, 100)
+    assert lsi_oracle.max_subspace_angle(ad.varm["LSI"], ref["LSI"]) < ANGLE
+    np.testing.assert_allclose(ad.uns["lsi"]["stdev"], ref["stdev"], rtol=1e-5)

@@ -215,3 +215,18 @@ def test_lsi_krylov_space_exhausted_on_tiny_matrices():
         assert info["converged"] and info["iterations"] <= 6
         G = V.numpy().astype(np.float64).T @ V.numpy().astype(np.float64)
         np.testing.assert_allclose(G, np.eye(k), atol=1e-5)
+
+
+def test_lsi_more_components_than_the_block_width():
+    # n_comps > 64: several 64-wide blocks are kept across thick restarts
+    from muon_amd._atac.tools import lsi_device
+
+    X = planted_topics_csr(2000, 1500, n_topics=70, density=0.06, seed=5, dtype=np.float32)
+    T, Xd = _device_tfidf(X)
+    ref = lsi_oracle.lsi(T, n_comps=70)
+    U, sd, V, info = lsi_device(BE, Xd, n_comps=70, return_info=True)
+    assert U.shape == (2000, 70) and V.shape == (1500, 70) and info["converged"]
+    assert lsi_oracle.max_subspace_angle(V.numpy(), ref["LSI"]) < 1e-4
+    np.testing.assert_allclose(sd, ref["stdev"], rtol=1e-5)
+    np.testing.assert_allclose(U.numpy().mean(axis=0), 0, atol=1e-3)
+    np.testing.assert_allclose(U.numpy().std(axis=0), 1, rtol=1e-3)
