@@ -93,6 +93,17 @@ int mu_tfidf_scale(int dtype, int64_t n_rows, const int64_t* d_indptr, const int
                    const void* d_values, const double* d_rowsum, const void* d_idf, double scale,
                    int flags, void* d_out, unsigned long long* d_zero_count, void* stream);
 
+/* The same pass walked slab by slab with the slab of idf in LDS (the per-lane idf gather of
+ * mu_tfidf_scale is what bounds it); results are bit-identical.  d_work: a buffer of
+ * mu_csr_row_col_sums_worksize bytes; have_slab_ptr != 0 says it is the one a preceding
+ * mu_csr_row_col_sums filled for this very (d_indptr, d_indices), whose row/slab pointers are
+ * then reused instead of being searched again. */
+int mu_tfidf_scale_sweep(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                         const int32_t* d_indices, const void* d_values, const double* d_rowsum,
+                         const void* d_idf, double scale, int flags, void* d_out,
+                         unsigned long long* d_zero_count, void* d_work, size_t work_bytes,
+                         int have_slab_ptr, void* stream);
+
 /* Drop stored entries whose value is exactly 0 (what csr_matmat does to explicit zeros).
  * Step 1 writes the surviving count of every row; the caller scans it into the new
  * indptr (mu_exclusive_scan_i64); step 2 compacts. */

@@ -125,6 +125,8 @@ class HipBackend:
             check(self.lib.mu_csr_row_col_sums(_dt(X.values), n, d, _p(X.indptr), _p(X.indices),
                                                _p(X.values), _p(rowsum), _p(colsum), _p(work), wb,
                                                self._stream()))
+        # the row / slab pointers at the head of `work` serve the scale pass of the same matrix
+        self._sweep_work = (work, wb, (X.indptr.data_ptr(), X.indices.data_ptr(), n, d))
         return rowsum, colsum
 
     def idf(self, colsum: torch.Tensor, n_obs: float, flags: int, dtype) -> torch.Tensor:
@@ -139,10 +141,25 @@ class HipBackend:
         if out is None:
             out = torch.empty_like(X.values)
         zc = self.zeros((1,), torch.int64)
+        n, d = X.shape
+        kept = self.__dict__.pop("_sweep_work", None)
+        key = (X.indptr.data_ptr(), X.indices.data_ptr(), n, d)
         with torch.cuda.device(self.device):
-            check(self.lib.mu_tfidf_scale(_dt(X.values), X.shape[0], _p(X.indptr), _p(X.indices),
-                                          _p(X.values), _p(rowsum), _p(idf), float(scale), flags,
-                                          _p(out), _p(zc), self._stream()))
+            if self.__dict__.get("_scale_gather"):  # comparison / tests: the per-lane gather kernel
+                check(self.lib.mu_tfidf_scale(_dt(X.values), n, _p(X.indptr), _p(X.indices),
+                                              _p(X.values), _p(rowsum), _p(idf), float(scale), flags,
+                                              _p(out), _p(zc), self._stream()))
+                return out, zc
+            have = kept is not None and kept[2] == key
+            if have:
+                work, wb = kept[0], kept[1]
+            else:
+                wb = int(self.lib.mu_csr_row_col_sums_worksize(n, d))
+                work = self.empty((wb,), torch.uint8)
+            check(self.lib.mu_tfidf_scale_sweep(_dt(X.values), n, d, _p(X.indptr), _p(X.indices),
+                                                _p(X.values), _p(rowsum), _p(idf), float(scale), flags,
+                                                _p(out), _p(zc), _p(work), wb, int(have),
+                                                self._stream()))
         return out, zc
 
     def compact_nonzero(self, X: DeviceCSR) -> DeviceCSR:

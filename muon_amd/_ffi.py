@@ -48,6 +48,8 @@ SIGNATURES = {
     "mu_csr_row_col_sums": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_tfidf_idf": (C.c_int, [_i32, _i64, _dbl, _vp, _i32, _vp, _vp]),
     "mu_tfidf_scale": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _dbl, _i32, _vp, _vp, _vp]),
+    "mu_tfidf_scale_sweep": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _dbl, _i32, _vp, _vp, _vp,
+                                       _sz, _i32, _vp]),
     "mu_csr_count_nonzero": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp]),
     "mu_csr_compact_nonzero": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_exclusive_scan_i64": (C.c_int, [_i64, _vp, _vp, _vp]),

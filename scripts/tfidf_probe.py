@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Times the TF-IDF passes on the bench matrix: sum sweep, scale (slab sweep vs per-lane gather)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from muon_amd._backend import HipBackend
+
+be = HipBackend(0)
+cells = int(sys.argv[1]) if len(sys.argv) > 1 else 125000
+X = be.synth_counts(0, cells, 200000, 50, 0.03, 0)
+nnz = X.nnz
+
+
+def timeit(f, reps=5):
+    f()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        f()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+rs, cs = be.row_col_sums(X)
+idf = be.idf(cs, cells, 3, torch.float32)
+out = torch.empty_like(X.values)
+t = timeit(lambda: be.row_col_sums(X))
+print(f"sum sweep (with slab pointers): {t:.2f} ms  {8 * nnz / t / 1e9:.2f} TB/s")
+be._scale_gather = True
+t = timeit(lambda: be.tfidf_scale(X, rs, idf, 1e4, 3, out=out))
+print(f"scale, per-lane idf gather:     {t:.2f} ms  {12 * nnz / t / 1e9:.2f} TB/s")
+be._scale_gather = False
+t = timeit(lambda: be.tfidf_scale(X, rs, idf, 1e4, 3, out=out))
+print(f"scale, slab sweep (+ pointers): {t:.2f} ms  {12 * nnz / t / 1e9:.2f} TB/s")
+
+
+def both():
+    be.row_col_sums(X)
+    be.tfidf_scale(X, rs, idf, 1e4, 3, out=out)
+
+
+t = timeit(both)
+print(f"sum sweep + scale sweep (pointers shared): {t:.2f} ms  {20 * nnz / t / 1e9:.2f} TB/s")

@@ -145,3 +145,34 @@ def test_properties_at_scale(hip):
     R2 = tfidf_device(hip, X2, 400000, 1, 1e4)  # log_tf only, n_obs doubled keeps idf equal
     R1 = tfidf_device(hip, X, 200000, 1, 1e4)
     torch.testing.assert_close(R2.values, R1.values, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("flags", [3, 1, 2, 0, 4])
+def test_scale_sweep_equals_gather_kernel(hip, dt, flags):
+    """The slab-sweep scale pass (idf slab in LDS) and the per-lane gather kernel are the same
+    arithmetic: identical bits, with and without reusable slab pointers, ragged / empty rows and
+    more than one slab of columns."""
+    import torch
+    rng = np.random.default_rng(3)
+    n, d = 3000, 20000   # 3 slabs of 8192 columns
+    m = sp.random(n, d, density=0.01, format="csr", random_state=rng, dtype=np.float64)
+    m.data[:] = rng.integers(1, 5, m.nnz)
+    m = m.tolil()
+    m[5, :] = 0            # an empty row
+    m[7, 100:9000:3] = 2   # a long row
+    m = m.tocsr().astype(dt)
+    m.sort_indices()
+    X = hip.upload_csr(m.indptr, m.indices, m.data, m.shape)
+    rs, cs = hip.row_col_sums(X)
+    idf = hip.idf(cs, n, flags, X.values.dtype)
+    a, za = hip.tfidf_scale(X, rs, idf, 1e4, flags)            # slab pointers reused
+    b, zb = hip.tfidf_scale(X, rs, idf, 1e4, flags)            # searched again
+    hip._scale_gather = True
+    try:
+        c, zc = hip.tfidf_scale(X, rs, idf, 1e4, flags)
+    finally:
+        hip._scale_gather = False
+    assert torch.equal(a.view(torch.uint8), c.view(torch.uint8))
+    assert torch.equal(b.view(torch.uint8), c.view(torch.uint8))
+    assert int(za.item()) == int(zc.item()) == int(zb.item())
