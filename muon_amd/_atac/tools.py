@@ -378,6 +378,7 @@ def _lsi_device(
                 add_block_grams(jj)
             Cprev = np.zeros((keep, k))
             Cprev[:k, :k] = np.eye(k)  # the kept Ritz vectors are the leading columns of the new blocks
+            C = Cprev.copy()           # (the current Ritz vectors in the new basis, should the loop end here)
             restarts += 1
         else:
             Cprev = C if enough else None
@@ -436,7 +437,7 @@ def lsi(data, scale_embeddings=True, n_comps=50, *, comm=None, n_iter: Optional[
             Number of components to calculate with SVD
 
     Keyword-only extras (not in the reference): ``comm`` for row-sharded input, ``n_iter`` /
-    ``tol`` / ``oversample`` / ``seed`` of the block subspace iteration.
+    ``tol`` / ``oversample`` / ``seed`` of the block Lanczos iteration (``lsi_device``).
     """
     if is_anndata(data):
         adata = data
