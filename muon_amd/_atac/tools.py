@@ -194,7 +194,9 @@ def _lsi_device(
     if pack is None:
         pack = (Xt is None and hasattr(backend, "can_pack") and backend.can_pack(X, B)
                 and 0 < n_local <= (1 << 20))
-    if pack:
+    if pack and hasattr(backend, "pack_both"):
+        X, Xt = backend.pack_both(X)
+    elif pack:
         Xt = backend.transpose_pack(X)
         X = backend.pack(X)
     elif Xt is None:

@@ -246,6 +246,24 @@ class HipBackend:
                                             _p(cptr), _p(ent), st))
         return DevicePackedCSR(cptr, ent, (n, d), X.nnz, perm, K)
 
+    def pack_both(self, X: DeviceCSR):
+        """(packed X, packed X^T).  The two builders are independent; the streaming copy of X
+        (HBM bound) runs on a second stream under the transpose-pack, whose fill is instruction
+        bound and leaves half of every CU's wave slots free."""
+        cur = torch.cuda.current_stream(self.device)
+        side = self.__dict__.get("_side_stream")
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            Xp = self.pack(X)
+        Xt = self.transpose_pack(X)
+        cur.wait_stream(side)
+        for t in (Xp.cptr, Xp.ent, Xp.perm):
+            if t is not None:
+                t.record_stream(cur)
+        return Xp, Xt
+
     def transpose_pack(self, X: DeviceCSR, sort_rows: bool = True) -> DevicePackedCSR:
         """Packed chunked-row copy of X^T straight from the CSR of X (no CSR of X^T)."""
         n, d = X.shape
