@@ -7,6 +7,8 @@
 // peaks by w_tj ~ Gamma(2,1); count_ij ~ Poisson(depth_i * (0.5*bg_j/(2d) + 0.5*w_tj/(0.1d))).
 // Every random number is a hash of (seed, global row, column), so a row shard generated on
 // any rank equals the same rows of the single-GPU matrix, and columns come out sorted.
+// n_topics = 0 selects the UNSTRUCTURED variant of SURVEY.md 8d (raw kernel throughput only): every
+// (row, column) is stored with probability `density`, value 1 + Poisson(0.5) capped at 4.
 #include "common.hpp"
 
 struct SynthRow {
@@ -19,7 +21,11 @@ __device__ __forceinline__ SynthRow synth_row(uint64_t seed, int64_t grow, int64
   const uint64_t h = splitmix64(seed * 0x9E3779B97F4A7C15ull + 0x1000000000ull + (uint64_t)grow);
   const uint64_t h2 = splitmix64(h);
   SynthRow r;
-  r.topic = (int)(h2 % (uint64_t)n_topics);
+  r.topic = n_topics > 0 ? (int)(h2 % (uint64_t)n_topics) : -1;
+  if (n_topics <= 0) {
+    r.depth = 0.f;
+    return r;
+  }
   const float u1 = u01(h), u2 = u01(h << 24 | (h2 >> 40));
   const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
   const float d = expf(logf((float)(1.15 * density * (double)n_cols)) + 0.3f * z);
@@ -74,7 +80,16 @@ __global__ __launch_bounds__(256) void k_synth(int64_t row0, int64_t n_rows, int
     for (int64_t j0 = 0; j0 < n_cols; j0 += 64) {
       const int64_t j = j0 + lane;
       int cnt = 0;
-      if (j < n_cols) cnt = synth_count(seed, grow, j, r.depth * synth_p(seed, r.topic, j, inv2d, inv01d));
+      if (j < n_cols) {
+        if (r.topic >= 0) {
+          cnt = synth_count(seed, grow, j, r.depth * synth_p(seed, r.topic, j, inv2d, inv01d));
+        } else {
+          const uint64_t hu = splitmix64((seed + 0xA5ull) * 0xBF58476D1CE4E5B9ull +
+                                         (uint64_t)grow * 0x100000001B3ull + (uint64_t)j);
+          if (u01(hu) < (float)density) cnt = 1 + synth_count(seed + 7, grow, j, 0.5f);
+          cnt = cnt > 4 ? 4 : cnt;
+        }
+      }
       const unsigned long long m = __ballot(cnt > 0);
       if (FILL && cnt > 0) {
         const int rank = __popcll(m & ((1ull << lane) - 1ull));
@@ -98,7 +113,7 @@ extern "C" {
 
 int mu_synth_row_nnz(int64_t row0, int64_t n_rows, int64_t n_cols, int n_topics, double density,
                      uint64_t seed, int64_t* d_row_nnz, void* stream) {
-  MU_REQUIRE(n_rows >= 0 && n_cols > 0 && n_topics > 0 && density > 0, "bad arguments");
+  MU_REQUIRE(n_rows >= 0 && n_cols > 0 && n_topics >= 0 && density > 0, "bad arguments");
   if (n_rows == 0) return MU_OK;
   MU_REQUIRE(d_row_nnz, "null pointer");
   hipLaunchKernelGGL(k_synth<false>, dim3(synth_blocks(n_rows)), dim3(256), 0, (hipStream_t)stream,
@@ -111,7 +126,7 @@ int mu_synth_row_nnz(int64_t row0, int64_t n_rows, int64_t n_cols, int n_topics,
 int mu_synth_fill(int64_t row0, int64_t n_rows, int64_t n_cols, int n_topics, double density,
                   uint64_t seed, const int64_t* d_indptr, int32_t* d_indices, float* d_values,
                   void* stream) {
-  MU_REQUIRE(n_rows >= 0 && n_cols > 0 && n_topics > 0 && density > 0, "bad arguments");
+  MU_REQUIRE(n_rows >= 0 && n_cols > 0 && n_topics >= 0 && density > 0, "bad arguments");
   if (n_rows == 0) return MU_OK;
   MU_REQUIRE(d_indptr && d_indices && d_values, "null pointer");
   hipLaunchKernelGGL(k_synth<true>, dim3(synth_blocks(n_rows)), dim3(256), 0, (hipStream_t)stream,

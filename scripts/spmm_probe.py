@@ -21,6 +21,7 @@ ap.add_argument("--waves", default="0")
 ap.add_argument("--pipe", default="0")
 ap.add_argument("--ks", default="0")
 ap.add_argument("--csr", action="store_true", help="also time the CSR kernel")
+ap.add_argument("--unstructured", action="store_true", help="uniform random pattern, values 1 + Poisson(0.5) (SURVEY 8d)")
 ap.add_argument("--calibrate", action="store_true",
                 help="run a 4 GiB device copy first (known HBM byte count for PMC calibration)")
 args = ap.parse_args()
@@ -32,7 +33,8 @@ if args.calibrate:
     dst.copy_(src)  # reads 4 GiB, writes 4 GiB (far beyond the 256 MiB Infinity Cache)
     torch.cuda.synchronize()
     del src, dst
-X = be.synth_counts(0, args.cells, args.peaks, 50, 0.03, 0)
+X = be.synth_counts(0, args.cells, args.peaks, 0 if args.unstructured else 50, 0.03, 0)
+print(f"{'unstructured' if args.unstructured else 'planted-topic'} {args.cells} x {args.peaks}, nnz {X.nnz}")
 T = tfidf_device(be, X, args.cells, 3, 1e4)
 Tp, Ttp = be.pack(T), be.transpose_pack(T)
 Q = be.randn(args.peaks, 64, 1)

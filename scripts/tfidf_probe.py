@@ -9,8 +9,10 @@ import torch
 from muon_amd._backend import HipBackend
 
 be = HipBackend(0)
-cells = int(sys.argv[1]) if len(sys.argv) > 1 else 125000
-X = be.synth_counts(0, cells, 200000, 50, 0.03, 0)
+cells = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 125000
+uns = "--unstructured" in sys.argv  # uniform random pattern, values 1 + Poisson(0.5)
+X = be.synth_counts(0, cells, 200000, 0 if uns else 50, 0.03, 0)
+print(f"{'unstructured' if uns else 'planted-topic'} {cells} x 200000, nnz {X.nnz}")
 nnz = X.nnz
 
 
