@@ -62,6 +62,11 @@ def _is_canonical(m) -> bool:
             and m.has_canonical_format and m.has_sorted_indices)
 
 
+def _is_canonical_csc(m) -> bool:
+    return (issparse(m) and m.format == "csc" and m.dtype in (np.float32, np.float64)
+            and m.has_canonical_format and m.has_sorted_indices)
+
+
 def _flags(log_tf, log_idf, log_tfidf):
     return (TFIDF_LOG_TF if log_tf else 0) | (TFIDF_LOG_IDF if log_idf else 0) | (
         TFIDF_LOG_TFIDF if log_tfidf else 0
@@ -201,6 +206,13 @@ def tfidf(
     X = resident(counts, backend)  # left on the device by binarize(): no second upload
     if X is not None:
         host = counts
+    elif _is_canonical_csc(counts):
+        # column-compressed input (.h5ad / .h5mu files may store X that way): its arrays are the CSR
+        # of the transpose, which the device turns into the CSR of X instead of a
+        # single-threaded scipy tocsr() on the host
+        n_r, n_c = counts.shape
+        X = backend.transpose(backend.upload_csr(counts.indptr, counts.indices, counts.data, (n_c, n_r)))
+        host = None
     else:
         host = canonical_csr(counts)
         X = backend.upload_csr(host.indptr, host.indices, host.data, host.shape)
@@ -210,13 +222,15 @@ def tfidf(
     R = tfidf_device(backend, X, n_obs, flags, _effective_scale(scale_factor), comm=comm)
 
     vals = backend.to_host(R.values)
-    if R.indices is X.indices:
+    if host is not None and R.indices is X.indices:
         res = csr_matrix((vals, host.indices.copy(), host.indptr.copy()), shape=host.shape)
-    else:  # explicit zeros were dropped on the device
-        res = csr_matrix(
-            (vals, backend.to_host(R.indices), backend.to_host(R.indptr).astype(host.indptr.dtype)),
-            shape=host.shape,
-        )
+    else:  # explicit zeros were dropped on the device, or the CSR only ever existed there
+        ip = backend.to_host(R.indptr)
+        if host is not None:
+            ip = ip.astype(host.indptr.dtype)
+        elif ip[-1] < 2**31:
+            ip = ip.astype(np.int32)  # what scipy would have chosen
+        res = csr_matrix((vals, backend.to_host(R.indices), ip), shape=tuple(counts.shape))
     res.has_sorted_indices = True
     if match_scipy_order and log_tf and not log_tfidf:
         res = _reverse_rows(res)

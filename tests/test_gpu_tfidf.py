@@ -176,3 +176,15 @@ def test_scale_sweep_equals_gather_kernel(hip, dt, flags):
     assert torch.equal(a.view(torch.uint8), c.view(torch.uint8))
     assert torch.equal(b.view(torch.uint8), c.view(torch.uint8))
     assert int(za.item()) == int(zc.item()) == int(zb.item())
+
+
+def test_column_compressed_input_goes_through_the_device_transpose():
+    X = planted_topics_csr(4000, 3000, n_topics=10, density=0.03, seed=6, dtype=np.float32)
+    a = AnnData(X.copy())
+    ac.pp.tfidf(a)
+    b = AnnData(X.tocsc())
+    ac.pp.tfidf(b)
+    assert b.X.format == "csr"
+    np.testing.assert_array_equal(b.X.indptr, a.X.indptr)
+    np.testing.assert_array_equal(b.X.indices, a.X.indices)
+    np.testing.assert_array_equal(b.X.data, a.X.data)

@@ -230,3 +230,17 @@ def test_lsi_more_components_than_the_block_width():
     np.testing.assert_allclose(sd, ref["stdev"], rtol=1e-5)
     np.testing.assert_allclose(U.numpy().mean(axis=0), 0, atol=1e-3)
     np.testing.assert_allclose(U.numpy().std(axis=0), 1, rtol=1e-3)
+
+
+def test_tfidf_takes_column_compressed_input_through_the_device_transpose():
+    X = planted_topics_csr(300, 200, n_topics=5, density=0.1, seed=4, dtype=np.float32)
+    a = AnnData(X.copy())
+    ac.pp.tfidf(a, backend=BE)
+    b = AnnData(X.tocsc())
+    ac.pp.tfidf(b, backend=BE)
+    assert b.X.format == "csr" and b.X.has_sorted_indices
+    np.testing.assert_array_equal(b.X.indptr, a.X.indptr)
+    np.testing.assert_array_equal(b.X.indices, a.X.indices)
+    np.testing.assert_array_equal(b.X.data, a.X.data)
+    ac.tl.lsi(b, n_comps=5, backend=BE)   # the device copy attached to the result serves lsi
+    assert b.obsm["X_lsi"].shape == (300, 5)
