@@ -21,12 +21,14 @@ ap.add_argument("--waves", default="0")
 ap.add_argument("--pipe", default="0")
 ap.add_argument("--ks", default="0")
 ap.add_argument("--csr", action="store_true", help="also time the CSR kernel")
+ap.add_argument("--no-round-fill", action="store_true", help="layout without the whole-rounds rule")
 ap.add_argument("--unstructured", action="store_true", help="uniform random pattern, values 1 + Poisson(0.5) (SURVEY 8d)")
 ap.add_argument("--calibrate", action="store_true",
                 help="run a 4 GiB device copy first (known HBM byte count for PMC calibration)")
 args = ap.parse_args()
 
 be = HipBackend(0)
+be._no_round_fill = args.no_round_fill
 if args.calibrate:
     src = torch.empty(1 << 30, dtype=torch.float32, device="cuda").normal_()
     dst = torch.empty_like(src)
