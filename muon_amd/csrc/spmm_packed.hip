@@ -96,6 +96,27 @@ __device__ __forceinline__ void quad_fma(const Quad<NB>& r, float v, typename Ve
   for (int c = 0; c < NB; ++c) acc[c] = fmaf(v3, r.q3[c], acc[c]);
 }
 
+// Entries E, E+1 only: the upper half of the window is used by few groups (8 entries per row and
+// slab on the bench matrices), so it is gated pair by pair instead of quad by quad.
+template <int NB> struct Pair { typename Vec<NB>::type q0, q1; };
+template <int E, int NB>
+__device__ __forceinline__ Pair<NB> pair_read(unsigned base, int a) {
+  typedef __attribute__((address_space(3))) const typename Vec<NB>::type* lds_p;
+  const unsigned a0 = (unsigned)bcast_i<E>(a) + base, a1 = (unsigned)bcast_i<E + 1>(a) + base;
+  Pair<NB> r;
+  r.q0 = *(lds_p)(a0);
+  r.q1 = *(lds_p)(a1);
+  return r;
+}
+template <int E, int NB>
+__device__ __forceinline__ void pair_fma(const Pair<NB>& r, float v, typename Vec<NB>::type& acc) {
+  const float v0 = bcast_f<E>(v), v1 = bcast_f<E + 1>(v);
+#pragma unroll
+  for (int c = 0; c < NB; ++c) acc[c] = fmaf(v0, r.q0[c], acc[c]);
+#pragma unroll
+  for (int c = 0; c < NB; ++c) acc[c] = fmaf(v1, r.q1[c], acc[c]);
+}
+
 // one LDS-DMA piece: 64 lanes x 16 B land contiguously at the wave-uniform LDS byte address
 __device__ __forceinline__ void dma_piece(const float4* gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -190,7 +211,8 @@ struct Win {      // what stage A of a pass hands to stage B
 };
 
 // MODE is 0 in production; the other bits switch parts of the kernel off for timing ablations
-// (results are then wrong on purpose): 1 no LDS gathers / FMAs, 2 no slab DMA, 8 no chunk
+// (results are then wrong on purpose, except 4): 1 no LDS gathers / FMAs, 2 no slab DMA, 4 upper window
+// half gated by quads as in r01a-n (right results, 2-3 % slower), 8 no chunk
 // requests (and no overflow passes), 16 no window rotation, 32 overflow passes do not wait for their chunk.
 // PIPE: 0 = stage A(k) then B(k); 1 = A(k+1) is issued before B(k) (the dispatcher's choice; tune knob
 // spmm_pipe = 1 selects PIPE 0 for comparison).
@@ -322,8 +344,16 @@ __device__ __forceinline__ void spmm_pcr64_body(int64_t n_rows, int64_t n_cols,
       } else {
         { const Quad<NB> r = quad_read<0, NB>(qbase, w.a); quad_fma<0, NB>(r, w.vv, acc[k]); }
         if (w.any16 & 0x00f0u) { const Quad<NB> r = quad_read<4, NB>(qbase, w.a); quad_fma<4, NB>(r, w.vv, acc[k]); }
-        if (w.any16 & 0x0f00u) { const Quad<NB> r = quad_read<8, NB>(qbase, w.a); quad_fma<8, NB>(r, w.vv, acc[k]); }
-        if (w.any16 & 0xf000u) { const Quad<NB> r = quad_read<12, NB>(qbase, w.a); quad_fma<12, NB>(r, w.vv, acc[k]); }
+        if constexpr (MODE & 4) {
+          if (w.any16 & 0x0f00u) { const Quad<NB> r = quad_read<8, NB>(qbase, w.a); quad_fma<8, NB>(r, w.vv, acc[k]); }
+          if (w.any16 & 0xf000u) { const Quad<NB> r = quad_read<12, NB>(qbase, w.a); quad_fma<12, NB>(r, w.vv, acc[k]); }
+        } else if (w.any16 & 0xff00u) {
+          // sorted rows fill the window from slot 0: bit e set => every lower bit is set
+          { const Pair<NB> r = pair_read<8, NB>(qbase, w.a); pair_fma<8, NB>(r, w.vv, acc[k]); }
+          if (w.any16 & 0x0c00u) { const Pair<NB> r = pair_read<10, NB>(qbase, w.a); pair_fma<10, NB>(r, w.vv, acc[k]); }
+          if (w.any16 & 0x3000u) { const Pair<NB> r = pair_read<12, NB>(qbase, w.a); pair_fma<12, NB>(r, w.vv, acc[k]); }
+          if (w.any16 & 0xc000u) { const Pair<NB> r = pair_read<14, NB>(qbase, w.a); pair_fma<14, NB>(r, w.vv, acc[k]); }
+        }
       }
     };
 
@@ -512,6 +542,7 @@ int mu_spmm_packed_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_cptr, co
     case 9: MU_GO(k_spmm_pcr64_w16, 16, KK, 9, 0)              \
     case 11: MU_GO(k_spmm_pcr64_w16, 16, KK, 11, 0)            \
     case 32: MU_GO(k_spmm_pcr64_w16, 16, KK, 32, 1)            \
+    case 4: MU_GO(k_spmm_pcr64_w16, 16, KK, 4, 1)              \
     default: break;                                            \
   }
       if (K == 7) MU_ABL(7) else MU_ABL(8)

@@ -82,7 +82,7 @@ for waves in [int(x) for x in args.waves.split(",")]:
                     print(f"waves={waves} pipe={pipe} K={K} mode={mode} {name}: {e}")
                     continue
                 same = ""
-                if mode == 0 and name in ref:
+                if mode in (0, 4) and name in ref:
                     same = " bit-identical" if torch.equal(be.spmm(M, D), ref[name]) else " DIFFERS"
                 n, d = M.shape
                 byt = 8 * M.nnz + 8 * (n + 1) + 4 * 64 * (n + d)
