@@ -262,18 +262,26 @@ class HipBackend:
         side = self.__dict__.get("_side_stream")
         if side is None:
             side = self._side_stream = torch.cuda.Stream(self.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            Xp = self.pack(X)
-        Xt = self.transpose_pack(X)
+        got = []
+
+        def start_pack():
+            # right before the fill: the count phase of the transpose-pack (binary searches and a
+            # histogram, latency bound) slowed down 4x next to the streaming copy, the fill does not
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                got.append(self.pack(X))
+
+        Xt = self.transpose_pack(X, before_fill=start_pack)
+        Xp = got[0]
         cur.wait_stream(side)
         for t in (Xp.cptr, Xp.ent, Xp.perm):
             if t is not None:
                 t.record_stream(cur)
         return Xp, Xt
 
-    def transpose_pack(self, X: DeviceCSR, sort_rows: bool = True) -> DevicePackedCSR:
-        """Packed chunked-row copy of X^T straight from the CSR of X (no CSR of X^T)."""
+    def transpose_pack(self, X: DeviceCSR, sort_rows: bool = True, before_fill=None) -> DevicePackedCSR:
+        """Packed chunked-row copy of X^T straight from the CSR of X (no CSR of X^T).
+        ``before_fill``: called once the count phase is done and before the fill is queued."""
         n, d = X.shape
         assert X.values.dtype == torch.float32
         col_nnz = self.empty((max(d, 1),), torch.int64)
@@ -297,6 +305,8 @@ class HipBackend:
             check(self.lib.mu_exclusive_scan_i64(n_pos, _p(row_chunks), _p(cptr), st))
             n_chunks = int(cptr[-1].item()) if n_pos > 0 else 0
             ent = self.empty((max(n_chunks, 1) * 128,), torch.uint8)
+            if before_fill is not None:
+                before_fill()
             check(self.lib.mu_csr_tpack_fill(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
                                              n_pos, _p(cptr), _p(perm), _p(inv), _p(ent), _p(work), wb, st))
         return DevicePackedCSR(cptr, ent, (d, n), X.nnz, perm, K)
