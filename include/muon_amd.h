@@ -140,7 +140,7 @@ int mu_spmm_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const i
 /* Packed chunked-row copy of a CSR for the packed SpMM ("PCR16"): every row is cut into
  * chunks of 16 (column int32, value f32) pairs = one aligned 128-byte line each, the tail is
  * padded with (INT32_MAX, 0) and one all-padding chunk closes every row.  Built once per
- * lsi() call for X and for X^T; the subspace iteration then streams every line exactly once
+ * lsi() call for X and for X^T; the block Lanczos iteration then streams every line exactly once
  * per product.
  *
  * Layout: the copy has n_pos >= n_rows POSITIONS; position p holds row perm[p] of the matrix
