@@ -1,6 +1,6 @@
 // Packed chunked-row copy of X^T built straight from the CSR of X ("transpose-pack").
 //
-// Z = X^T * Y of the block subspace iteration (the rmatvec side of scipy svds, _svds.py:441-466,
+// Z = X^T * Y of the block Lanczos iteration (the rmatvec side of scipy svds, _svds.py:441-466,
 // reached from /root/reference/muon/_atac/tools.py:53) runs through the same packed SpMM as
 // Y = X * Q; this file builds its operand without materialising a CSR of X^T first.
 // Stable (every output row lists the cells in ascending order => canonical rows, and the f32 sums
@@ -11,18 +11,16 @@
 //      column in LDS, slab by slab                                           -> cnt[g][col]
 //   3. base:  per column, exclusive prefix of cnt over g (in place), the column total and its
 //      chunk count ceil(total / 16) + 1                                      -> caller scans -> cptr
-//   4. fill:  same sweep.  Rows are taken in batches of 64 (four per wave).  A batch first ORs one
-//      bit per entry into a 64-bit row mask per column (LDS), then every entry finds its rank
-//      among the batch's entries of its column with a popcount of the lower bits and writes its
-//      (cell, value) pair to  slab_start + pos[col] + rank;  the entry that owns the highest bit
-//      advances pos[col] and clears the mask.  Masks are double buffered, so a batch costs two
-//      workgroup barriers and no global traffic besides the entries themselves.
+//   4. fill:  a workgroup stages a (row block x column tile) in LDS sorted by (column, cell) and
+//      writes every column's run with consecutive lanes (k_t_fill3 / k_t_fill2 below; the first
+//      generation, a bitmap-rank fill with one 8-byte store per pair, ran at the fabric's
+//      partial-write rate and is gone)
 //   5. pads:  the tail of the last real chunk and the closing chunk of every output row.
 #include "common.hpp"
 
 namespace {
 
-constexpr int kTSlab = 4096;  // columns per slab: pos 16 KiB + two mask buffers 64 KiB of LDS
+constexpr int kTSlab = 8192;  // columns per slab of the count pass: 32 KiB of LDS bins
 constexpr int kTThreads = 1024;
 constexpr int kTWaves = kTThreads / 64;
 constexpr unsigned kPad = 0x7fffffffu;
@@ -121,98 +119,6 @@ __global__ __launch_bounds__(256) void k_t_base(int64_t n_cols, int G, uint32_t*
   }
   coltot[c] = (int64_t)run;
   col_nnz[c] = (int64_t)run;
-}
-
-__global__ __launch_bounds__(kTThreads) void k_t_fill(int64_t n_rows, int64_t n_cols, int64_t S,
-                                                      const int64_t* __restrict__ indptr,
-                                                      const int32_t* __restrict__ indices,
-                                                      const float* __restrict__ values,
-                                                      const int64_t* __restrict__ sp,
-                                                      const int64_t* __restrict__ cptr,
-                                                      const int32_t* __restrict__ inv,
-                                                      const uint32_t* __restrict__ base,
-                                                      unsigned long long* __restrict__ ent) {
-  __shared__ uint32_t pos[kTSlab];               // next free slot of the column (pairs written so far)
-  __shared__ int64_t rowbase[kTSlab];            // first pair of the column's output row
-  __shared__ unsigned long long bm[2][kTSlab];   // per column: which rows of the batch hit it
-  __shared__ int64_t s_r[2];
-  const int g = blockIdx.x, G = gridDim.x;
-  if (threadIdx.x == 0) t_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
-  __syncthreads();
-  const int64_t r0 = s_r[0], r1 = s_r[1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t* mybase = base + (int64_t)g * n_cols;
-  const int64_t n_batches = (r1 - r0 + 63) >> 6;
-
-  for (int64_t s = 0; s < S; ++s) {
-    const int32_t cbase = (int32_t)(s * kTSlab);
-    for (int t = threadIdx.x; t < kTSlab; t += kTThreads) {
-      const int64_t c = (int64_t)cbase + t;
-      pos[t] = (c < n_cols) ? mybase[c] : 0u;
-      rowbase[t] = (c < n_cols) ? cptr[inv ? (int64_t)inv[c] : c] * 16 : 0;
-      bm[0][t] = 0ull;
-      bm[1][t] = 0ull;
-    }
-    __syncthreads();
-    for (int64_t b = 0; b <= n_batches; ++b) {
-      // phase X: close batch b-1 (advance cursors, clear its masks), announce batch b
-      if (b > 0) {
-        unsigned long long* m_prev = bm[(b - 1) & 1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int rl = wave * 4 + j;
-          const int64_t row = r0 + ((b - 1) << 6) + rl;
-          if (row < r1) {
-            const int64_t lo = sp[row * (S + 1) + s], hi = sp[row * (S + 1) + s + 1];
-            for (int64_t p = lo + lane; p < hi; p += 64) {
-              const int c = indices[p] - cbase;
-              const unsigned long long m = m_prev[c];
-              if ((m >> rl) == 1ull) {  // this entry owns the highest bit (0 once cleared)
-                pos[c] += (uint32_t)__popcll(m);
-                m_prev[c] = 0ull;
-              }
-            }
-          }
-        }
-      }
-      if (b < n_batches) {
-        unsigned long long* m_cur = bm[b & 1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int rl = wave * 4 + j;
-          const int64_t row = r0 + (b << 6) + rl;
-          if (row < r1) {
-            const int64_t lo = sp[row * (S + 1) + s], hi = sp[row * (S + 1) + s + 1];
-            for (int64_t p = lo + lane; p < hi; p += 64)
-              atomicOr(&m_cur[indices[p] - cbase], 1ull << rl);
-          }
-        }
-      }
-      __syncthreads();
-      // phase Y: emit batch b at  slab_start + pos[col] + rank
-      if (b < n_batches) {
-        const unsigned long long* m_cur = bm[b & 1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int rl = wave * 4 + j;
-          const int64_t row = r0 + (b << 6) + rl;
-          if (row < r1) {
-            const int64_t lo = sp[row * (S + 1) + s], hi = sp[row * (S + 1) + s + 1];
-            for (int64_t p = lo + lane; p < hi; p += 64) {
-              const int c = indices[p] - cbase;
-              const unsigned long long m = m_cur[c];
-              const int rank = __popcll(m & ((1ull << rl) - 1ull));
-              const unsigned long long e =
-                  (unsigned long long)(unsigned)row |
-                  ((unsigned long long)__builtin_bit_cast(unsigned, values[p]) << 32);
-              ent[rowbase[c] + (int64_t)pos[c] + rank] = e;
-            }
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
 }
 
 // ---- fill, version 2: LDS-staged, run-coalesced stores -----------------------------------------
@@ -740,10 +646,7 @@ int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t
   const int G = t_grid(nnz);
   const TWork w = carve(d_work, n_rows, n_cols, nnz);
   if (n_rows > 0) {
-    if (mu_tune_get("tpack_v1")) {
-      hipLaunchKernelGGL(k_t_fill, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, S, d_indptr,
-                         d_indices, d_values, w.sp, d_cptr, d_inv, w.cnt, (unsigned long long*)d_ent);
-    } else {
+    {
       // slab width: the expected tile (nnz / G rows x C columns) fills ~93 % of the staging buffer
       // (measured best on the bench matrix: fewer, fuller tiles; a tile that overflows takes the
       //  direct-store path)
