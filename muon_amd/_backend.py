@@ -12,6 +12,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -268,8 +270,13 @@ class HipBackend:
             # right before the fill: the count phase of the transpose-pack (binary searches and a
             # histogram, latency bound) slowed down 4x next to the streaming copy, the fill does not
             side.wait_stream(cur)
+            wg = int(os.environ.get("MUON_AMD_PACK_WG", "2"))  # (A/B on one box, c3: 32 -> 451, 4 -> 449, 2 -> 441 ms per step)
             with torch.cuda.stream(side):
-                got.append(self.pack(X))
+                self.tune("pack_wg", wg)  # few workgroups per CU: the fill's 1024-thread groups must fit next to them
+                try:
+                    got.append(self.pack(X))
+                finally:
+                    self.tune("pack_wg", 0)
 
         Xt = self.transpose_pack(X, before_fill=start_pack)
         Xp = got[0]

@@ -29,9 +29,9 @@ int mu_num_cus() {
 
 // tuning / ablation knobs (tests and bench only)
 static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "spmm_waves", "spmm_pipe",
-                                        "tpack_abl", "tpack_c", "gram_wg", "tpack_v2"};
-constexpr int kTuneN = 8;
-static int g_tune[kTuneN] = {0, 0, 0, 0, 0, 0, 0, 0};
+                                        "tpack_abl", "tpack_c", "gram_wg", "tpack_v2", "pack_wg"};
+constexpr int kTuneN = 9;
+static int g_tune[kTuneN] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 extern "C" {
 

@@ -505,7 +505,10 @@ int mu_csr_pack_fill(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indp
   if (n_pos == 0) return MU_OK;
   MU_REQUIRE(d_indptr && d_cptr && d_ent, "null pointer");
   int64_t blocks = (n_pos + 3) / 4;
-  const int64_t cap = (int64_t)mu_num_cus() * 32;
+  // workgroups per CU: 32 alone; a caller that runs the copy next to a kernel that needs whole CUs
+  // (the transpose-pack fill on another stream) lowers it so that both stay resident (tune pack_wg)
+  const int per_cu = mu_tune_get("pack_wg") > 0 ? mu_tune_get("pack_wg") : 32;
+  const int64_t cap = (int64_t)mu_num_cus() * per_cu;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(k_pack_fill, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_pos,
                      d_perm, d_indptr, d_indices, d_values, d_cptr, (unsigned long long*)d_ent);

@@ -629,6 +629,11 @@ int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_
   hipLaunchKernelGGL(k_t_base, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, n_cols, G,
                      w.cnt, w.coltot, d_col_nnz);
   MU_CHECK_LAUNCH();
+  // the fill's per-row cursors start at the row starts.  Done here, not in the fill: a caller that
+  // overlaps the fill with other work (the pack of X on a second stream) would have this small copy
+  // wait for a free CU behind that work, and the fill behind the copy.
+  if (n_rows > 0)
+    MU_CHECK_HIP(hipMemcpyAsync(w.curs, d_indptr, sizeof(int64_t) * (size_t)n_rows, hipMemcpyDeviceToDevice, st));
   return MU_OK;
 }
 
@@ -655,8 +660,6 @@ int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t
       C = (C / 32) * 32;
       if (C < 32) C = 32;
       if (C > kF2Cols) C = kF2Cols;
-      MU_CHECK_HIP(hipMemcpyAsync(w.curs, d_indptr, sizeof(int64_t) * (size_t)n_rows,
-                                  hipMemcpyDeviceToDevice, st));
       if (mu_tune_get("tpack_c") > 0) C = mu_tune_get("tpack_c");
       if (n_rows <= kF3MaxRows && !mu_tune_get("tpack_v2")) {
         if (C > kF3Cols) C = kF3Cols;
