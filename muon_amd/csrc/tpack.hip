@@ -358,7 +358,7 @@ __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, 
                                            int64_t row0, int32_t cbase, int32_t cend, int32_t cend2,
                                            const int32_t* __restrict__ indices_b,
                                            const float* __restrict__ values_b, uint32_t* wcur,
-                                           uint16_t* wcnt, const uint32_t* lpos, const int64_t* gdst,
+                                           uint16_t* wcnt, uint32_t* dummy, const int64_t* gdst,
                                            unsigned long long* stage, bool staged,
                                            unsigned long long* __restrict__ ent) {
   const int lane = threadIdx.x & 63;
@@ -376,16 +376,22 @@ __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, 
       if (PHASE == 0) {
         if (valid) wcnt[c - cbase] += (uint16_t)1;  // columns inside one row are distinct
       } else {
+        // Both bucket updates of the visit - the cursor of this tile for the lanes inside it, the
+        // count of the next tile for the lanes just past it - are issued together and waited for
+        // once; lanes that take part in neither go to a private dummy slot instead of being masked
+        // off (the two masked read-modify-write sequences cost two LDS round trips per visit).
+        const bool nxt = !valid && c < cend2;
+        uint32_t* pc = valid ? &wcur[c - cbase] : dummy;
+        uint16_t* pn = nxt ? &wcnt[c - cend] : reinterpret_cast<uint16_t*>(dummy) + 1;
+        const uint32_t k = *pc;   // absolute slot in the staging buffer (run-relative when not staged)
+        const uint16_t t = *pn;
+        *pc = k + 1u;
+        *pn = (uint16_t)(t + 1);
         if (valid) {
-          const int cl = c - cbase;
-          const uint32_t k = wcur[cl];
-          wcur[cl] = k + 1u;
           const unsigned long long e = (unsigned long long)(unsigned)(row0 + first + j) |
                                        ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32);
-          if (staged) stage[lpos[cl] + k] = e;
-          else ent[gdst[cl] + k] = e;
-        } else if (c < cend2) {
-          wcnt[c - cend] += (uint16_t)1;  // belongs to the next tile: its count walk is this one
+          if (staged) stage[k] = e;
+          else ent[gdst[c - cbase] + k] = e;
         }
       }
       c0 += n;
@@ -418,7 +424,7 @@ __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cb
                                         const int64_t* __restrict__ indptr,
                                         const int32_t* __restrict__ indices,
                                         const float* __restrict__ values, int64_t* __restrict__ curs,
-                                        uint32_t* wcur, uint16_t* wcnt, const uint32_t* lpos,
+                                        uint32_t* wcur, uint16_t* wcnt, uint32_t* dummy,
                                         const int64_t* gdst, unsigned long long* stage, bool staged,
                                         unsigned long long* __restrict__ ent) {
   const int lane = threadIdx.x & 63;
@@ -435,12 +441,12 @@ __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cb
     f2_load<PHASE>(ba, cur, end, 0, indices_b, values_b);
     for (int first = 0; first < nr; first += 2 * kF2Rows) {
       if (first + kF2Rows < nr) f2_load<PHASE>(bb, cur, end, first + kF2Rows, indices_b, values_b);
-      f3_process<PHASE>(ba, cur, end, first, sb, cbase, cend, cend2, indices_b, values_b, wcur, wcnt, lpos,
+      f3_process<PHASE>(ba, cur, end, first, sb, cbase, cend, cend2, indices_b, values_b, wcur, wcnt, dummy,
                         gdst, stage, staged, ent);
       if (first + kF2Rows < nr) {
         if (first + 2 * kF2Rows < nr) f2_load<PHASE>(ba, cur, end, first + 2 * kF2Rows, indices_b, values_b);
         f3_process<PHASE>(bb, cur, end, first + kF2Rows, sb, cbase, cend, cend2, indices_b, values_b, wcur,
-                          wcnt, lpos, gdst, stage, staged, ent);
+                          wcnt, dummy, gdst, stage, staged, ent);
       }
     }
     if (PHASE == 1 && lane < nr) curs[sb + lane] = wg_base + (int64_t)cur;
@@ -460,6 +466,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
   __shared__ unsigned long long stage[kF2Cap];     // 80 KiB
   __shared__ uint32_t wcur_all[kTWaves][kF3Cols];  // 40 KiB: per (wave, column) cursor of this tile
   __shared__ uint16_t wcnt_all[kTWaves][kF3Cols];  // 20 KiB: per (wave, column) count of the tile in the making
+  __shared__ uint32_t dummy_all[kTWaves][64];      // where the bucket updates of idle lanes go
   __shared__ uint32_t lcount[kF3Cols], lpos[kF3Cols];
   __shared__ int64_t gdst[kF3Cols];
   __shared__ uint32_t wsum[kTWaves];
@@ -516,12 +523,14 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
     }
     if (!have)
       f3_walk<0>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs, wcur_all[wave],
-                 wcnt_all[wave], lpos, gdst, stage, staged, ent);
+                 wcnt_all[wave], &dummy_all[wave][threadIdx.x & 63], gdst, stage, staged, ent);
     __syncthreads();
     // per column: exclusive prefix of the wave counts = first slot of every wave inside the run;
     // the counts are consumed (zeroed) for the next tile
     if (threadIdx.x < kF3Cols) {
-      uint32_t run = 0;
+      // a staged tile's cursors are absolute staging slots (no lpos lookup in the walk), a direct
+      // one's are relative to the column's run in the output
+      uint32_t run = staged ? lpos[threadIdx.x] : 0u;
       for (int w = 0; w < kTWaves; ++w) {
         const uint32_t t = wcnt_all[w][threadIdx.x];
         wcnt_all[w][threadIdx.x] = (uint16_t)0;
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
     }
     __syncthreads();
     f3_walk<1>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs, wcur_all[wave],
-               wcnt_all[wave], lpos, gdst, stage, staged, ent);
+               wcnt_all[wave], &dummy_all[wave][threadIdx.x & 63], gdst, stage, staged, ent);
     have = true;
     __syncthreads();
     if (staged) {
