@@ -145,6 +145,7 @@ def _single_threaded_host_blas():
 
 
 def lsi_device(backend, X, n_comps: int = 50, scale_embeddings: bool = True, *args, **kwargs):
+    """See ``_lsi_device`` (same arguments); runs it with the host BLAS pinned to the calling thread."""
     with _single_threaded_host_blas():
         return _lsi_device(backend, X, n_comps, scale_embeddings, *args, **kwargs)
 

@@ -244,3 +244,23 @@ def test_tfidf_takes_column_compressed_input_through_the_device_transpose():
     np.testing.assert_array_equal(b.X.data, a.X.data)
     ac.tl.lsi(b, n_comps=5, backend=BE)   # the device copy attached to the result serves lsi
     assert b.obsm["X_lsi"].shape == (300, 5)
+
+
+def test_ritz_step_handles_dependent_krylov_directions():
+    # M = K^T K with (numerically) dependent columns: the Ritz step truncates them instead of
+    # inverting them, and reproduces the eigenpairs of the operator restricted to span(K)
+    from muon_amd._atac.tools import _ritz
+
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((40, 40)); A = A @ A.T            # SPD operator
+    K = np.linalg.qr(rng.standard_normal((40, 12)))[0]
+    K = np.hstack([K, K[:, :3] + 1e-9 * rng.standard_normal((40, 3))])  # three near-copies
+    T, M = K.T @ A @ K, K.T @ K
+    lam, C = _ritz(T, M, 5)
+    ref = np.linalg.eigvalsh(K[:, :12].T @ A @ K[:, :12])[::-1][:5]
+    np.testing.assert_allclose(lam, ref, rtol=1e-6)
+    V = K @ C
+    np.testing.assert_allclose(V.T @ V, np.eye(5), atol=1e-6)
+    # more pairs wanted than the space holds: the rest comes back as zeros
+    lam2, C2 = _ritz(T, M, 20)
+    assert lam2.shape == (20,) and np.all(lam2[12:] == 0) and np.all(C2[:, 12:] == 0)
