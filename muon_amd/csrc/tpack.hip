@@ -94,7 +94,14 @@ __global__ __launch_bounds__(kTThreads) void k_t_count(int64_t n_rows, int64_t n
     const int32_t cbase = (int32_t)(s * kTSlab);
     for (int64_t row = r0 + wave; row < r1; row += kTWaves) {
       const int64_t lo = sp[row * (S + 1) + s], hi = sp[row * (S + 1) + s + 1];
-      for (int64_t p = lo + lane; p < hi; p += 64) atomicAdd(&bins[indices[p] - cbase], 1u);
+      for (int64_t p = lo + lane; p < hi; p += 256) {  // four independent chunks in flight per wave
+        int32_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = (p + 64 * u < hi) ? indices[p + 64 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (c[u] >= 0) atomicAdd(&bins[c[u] - cbase], 1u);
+      }
     }
     __syncthreads();
     const int64_t here = (n_cols - (int64_t)cbase) < kTSlab ? (n_cols - (int64_t)cbase) : kTSlab;
