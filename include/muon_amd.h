@@ -113,7 +113,8 @@ int mu_csr_compact_nonzero(int dtype, int64_t n_rows, const int64_t* d_indptr,
                            const int32_t* d_indices, const void* d_values,
                            const int64_t* d_new_indptr, int32_t* d_new_indices, void* d_new_values,
                            void* stream);
-/* out[0]=0, out[i+1]=out[i]+in[i], i<n (single workgroup; n up to ~1e8). */
+/* out[0]=0, out[i+1]=out[i]+in[i], i<n.  d_in and d_out must not overlap (n >= 65536 runs as a
+ * three-pass chunked scan that parks the chunk sums in d_out). */
 int mu_exclusive_scan_i64(int64_t n, const int64_t* d_in, int64_t* d_out, void* stream);
 
 /* binarize (preproc.py:148-150): X.data[X.data != 0] = 1, in place (NaN != 0, so NaN -> 1;

@@ -323,6 +323,74 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan_i64(int64_t n, const in
   }
 }
 
+// Large n: the same scan over G chunks with no scratch memory.  Pass 1 leaves the sum of chunk g in
+// out[e_g] (the chunk's last output slot), pass 2 turns these G values into their inclusive scan -
+// which is exactly what out[e_g] has to hold in the end - and pass 3 fills the rest of every chunk
+// from out[e_{g-1}].  (in and out must not overlap.)
+constexpr int kScanChunks = 256;
+__device__ __forceinline__ void scan_chunk_range(int64_t n, int g, int64_t& b, int64_t& e) {
+  const int64_t chunk = (n + kScanChunks - 1) / kScanChunks;
+  b = (int64_t)g * chunk;
+  if (b > n) b = n;
+  e = (b + chunk < n) ? (b + chunk) : n;
+}
+// block-wide sum / exclusive scan helpers over 1024 per-thread values
+__device__ __forceinline__ int64_t block_exclusive_scan_1024(int64_t v, int64_t* part, int64_t& total) {
+  const int t = threadIdx.x;
+  part[t] = v;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int64_t u = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += u;
+    __syncthreads();
+  }
+  total = part[1023];
+  return part[t] - v;
+}
+__global__ __launch_bounds__(1024) void k_scan_chunk_sums(int64_t n, const int64_t* __restrict__ in,
+                                                          int64_t* __restrict__ out) {
+  __shared__ int64_t part[1024];
+  int64_t b, e;
+  scan_chunk_range(n, blockIdx.x, b, e);
+  int64_t s = 0;
+  for (int64_t i = b + threadIdx.x; i < e; i += 1024) s += in[i];
+  int64_t total;
+  block_exclusive_scan_1024(s, part, total);
+  if (threadIdx.x == 0 && e > b) out[e] = total;
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+}
+__global__ __launch_bounds__(1024) void k_scan_chunk_offsets(int64_t n, int64_t* __restrict__ out) {
+  __shared__ int64_t part[1024];
+  int64_t b = 0, e = 0;
+  const bool has = threadIdx.x < kScanChunks;
+  if (has) scan_chunk_range(n, threadIdx.x, b, e);
+  const int64_t v = (has && e > b) ? out[e] : 0;
+  int64_t total;
+  const int64_t excl = block_exclusive_scan_1024(v, part, total);
+  if (has && e > b) out[e] = excl + v;
+}
+__global__ __launch_bounds__(1024) void k_scan_chunk_fill(int64_t n, const int64_t* __restrict__ in,
+                                                          int64_t* __restrict__ out) {
+  __shared__ int64_t part[1024];
+  int64_t b, e;
+  scan_chunk_range(n, blockIdx.x, b, e);
+  if (e <= b) return;
+  const int64_t base = (b == 0) ? 0 : out[b];  // = out[e_{g-1}]
+  // thread t owns a contiguous piece of the chunk
+  const int64_t len = e - b, per = (len + 1023) / 1024;
+  const int64_t tb = b + (int64_t)threadIdx.x * per;
+  const int64_t te = (tb + per < e) ? (tb + per) : e;
+  int64_t s = 0;
+  for (int64_t i = tb; i < te; ++i) s += in[i];
+  int64_t total;
+  int64_t run = base + block_exclusive_scan_1024(s, part, total);
+  for (int64_t i = tb; i < te; ++i) {
+    run += in[i];
+    if (i + 1 < e) out[i + 1] = run;  // out[e] is already final
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_binarize(int64_t n, T* __restrict__ v) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -495,8 +563,17 @@ int mu_csr_compact_nonzero(int dtype, int64_t n_rows, const int64_t* d_indptr,
 int mu_exclusive_scan_i64(int64_t n, const int64_t* d_in, int64_t* d_out, void* stream) {
   MU_REQUIRE(n >= 0 && d_out, "bad arguments");
   MU_REQUIRE(n == 0 || d_in, "null input");
-  hipLaunchKernelGGL(k_exclusive_scan_i64, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, d_in,
-                     d_out);
+  hipStream_t st = (hipStream_t)stream;
+  if (n < 65536) {
+    hipLaunchKernelGGL(k_exclusive_scan_i64, dim3(1), dim3(1024), 0, st, n, d_in, d_out);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+  }
+  hipLaunchKernelGGL(k_scan_chunk_sums, dim3(kScanChunks), dim3(1024), 0, st, n, d_in, d_out);
+  MU_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_scan_chunk_offsets, dim3(1), dim3(1024), 0, st, n, d_out);
+  MU_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_scan_chunk_fill, dim3(kScanChunks), dim3(1024), 0, st, n, d_in, d_out);
   MU_CHECK_LAUNCH();
   return MU_OK;
 }

@@ -119,7 +119,7 @@ def test_dense_apply(hip, B, n):
 
 def test_scan_and_compact(hip):
     rng = np.random.default_rng(0)
-    for n in (0, 1, 5, 1023, 1024, 1025, 100003):
+    for n in (0, 1, 5, 1023, 1024, 1025, 65535, 65536, 65537, 100003, 262144, 1000448):
         v = rng.integers(0, 1000, size=n).astype(np.int64)
         vin = hip.to_device(v) if n else hip.empty((0,), torch.int64)
         out = hip.empty((n + 1,), torch.int64)
