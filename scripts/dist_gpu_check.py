@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Multi-rank GPU path against the single-process result, on ONE GPU (all ranks on cuda:0, gloo):
+tfidf + lsi of a row-sharded matrix must give the single-process values / subspace.
+
+  python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 scripts/dist_gpu_check.py
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from muon_amd._atac.preproc import tfidf_device
+from muon_amd._atac.tools import lsi_device
+from muon_amd._backend import HipBackend
+from muon_amd._comm import TorchDistComm
+
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+comm = TorchDistComm()
+be = HipBackend(0)
+n, d, k = 60000, 40000, 50
+cuts = [0] + [int(n * (r + 1) / world * (0.9 if r + 1 < world else 1.0)) for r in range(world)]  # uneven shards
+r0, r1 = cuts[rank], cuts[rank + 1]
+X = be.synth_counts(r0, r1 - r0, d, 50, 0.03, 0)
+T = tfidf_device(be, X, n, 3, 1e4, comm=comm)
+U, sd, V, info = lsi_device(be, T, n_comps=k, n_obs=n, comm=comm, return_info=True)
+if rank == 0:
+    Xf = be.synth_counts(0, n, d, 50, 0.03, 0)
+    Tf = tfidf_device(be, Xf, n, 3, 1e4)
+    Uf, sdf, Vf, inff = lsi_device(be, Tf, n_comps=k, return_info=True)
+    lo, hi = int(Xf.indptr[r0].item()), int(Xf.indptr[r1].item())
+    dv = float((Tf.values[lo:hi] - T.values).abs().max() / Tf.values.abs().max())
+    qa, _ = torch.linalg.qr(V.double())
+    qb, _ = torch.linalg.qr(Vf.double())
+    ang = float(torch.linalg.matrix_norm(qb - qa @ (qa.T @ qb), ord=2))
+    ds = float(np.max(np.abs(sd - sdf) / sdf))
+    du = float((U.abs() - Uf[r0:r1].abs()).abs().max())
+    print(f"ranks {world}: tfidf max rel diff {dv:.2e}, subspace angle vs single process {ang:.2e}, stdev rel diff {ds:.2e}, "
+          f"|U| max diff {du:.2e}, iterations {info['iterations']} / {inff['iterations']}")
+    assert dv < 1e-6 and ang < 1e-4 and ds < 1e-5
+    print("dist gpu check ok")
+dist.barrier()
