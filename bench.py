@@ -67,7 +67,7 @@ class TimedBackend:
         e.record()
         B = Q.shape[1]
         n, d = X.shape
-        self.events.append((s, e, 8 * X.nnz + 8 * (n + 1) + 4 * B * (n + d)))
+        self.events.append((s, e, 8 * X.nnz + 8 * (n + 1) + 4 * B * (n + d), n))
         return r
 
 
@@ -193,8 +193,8 @@ def main():
         dt = float(t.item())
 
     # dominant kernel: the CSR SpMM (both X*Q and X^T*Y run through it)
-    ms = [s.elapsed_time(e) for s, e, _ in be.events]
-    byt = [b for _, _, b in be.events]
+    ms = [s.elapsed_time(e) for s, e, _, _ in be.events]
+    byt = [b for _, _, b, _ in be.events]
     avg_ms = float(np.mean(ms))
     achieved = float(np.mean(byt)) / (avg_ms * 1e-3) / 1e9
     spmm_total_ms = float(np.sum(ms))
@@ -207,7 +207,10 @@ def main():
         with open(tpath) as f:
             tj = json.load(f).get(f"{n_local}x{d}")  # measured per shape of the rank-0 shard
     if tj:
-        traffic = tj["spmm_mean_bytes_per_launch"]  # bytes per launch, like algorithmic_bytes_per_launch
+        # bytes per launch, like algorithmic_bytes_per_launch: the two directions weighted as launched
+        n_xq = sum(1 for _, _, _, rows in be.events if rows == n_local)
+        n_xt = len(be.events) - n_xq
+        traffic = (tj["spmm_xq_bytes_per_launch"] * n_xq + tj["spmm_xty_bytes_per_launch"] * n_xt) / max(len(be.events), 1)
         traffic_detail = {"x_q": tj["spmm_xq_bytes_per_launch"], "xt_y": tj["spmm_xty_bytes_per_launch"],
                           "vs_algorithmic": traffic / tj["algorithmic_bytes_per_launch"],
                           "source": "profiles/r01_spmm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 "
