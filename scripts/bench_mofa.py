@@ -30,13 +30,19 @@ args = ap.parse_args()
 world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
 local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+shared_gpu = os.environ.get("MUON_AMD_BENCH_SHARED_GPU") == "1"  # test hook: all ranks on GPU 0 over gloo
+if shared_gpu:
+    local_rank = 0
 torch.cuda.set_device(local_rank)
 comm = None
 if world > 1:
     import torch.distributed as dist
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if shared_gpu:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from muon_amd._comm import TorchDistComm
 
     comm = TorchDistComm()
