@@ -62,6 +62,7 @@ SIGNATURES = {
     "mu_csr_pack_fill": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_csr_tpack_worksize": (_sz, [_i64, _i64, _i64]),
     "mu_csr_tpack_count": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mu_csr_tpack_count_sp": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_csr_tpack_fill": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_packed_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "mu_tune_set": (C.c_int, [C.c_char_p, _i32]),
