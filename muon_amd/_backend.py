@@ -127,12 +127,8 @@ class HipBackend:
             check(self.lib.mu_csr_row_col_sums(_dt(X.values), n, d, _p(X.indptr), _p(X.indices),
                                                _p(X.values), _p(rowsum), _p(colsum), _p(work), wb,
                                                self._stream()))
-        # the row / slab pointers at the head of `work` serve the scale pass of the same matrix and
-        # the count pass of the transpose-pack of anything with the same pattern (tfidf -> lsi)
+        # the row / slab pointers at the head of `work` serve the scale pass of the same matrix
         self._sweep_work = (work, wb, (X.indptr.data_ptr(), X.indices.data_ptr(), n, d))
-        # (the pattern tensors are referenced too: while they live, their addresses cannot be handed
-        #  to another matrix, so the address key is a safe identity)
-        self._slab_ptr = (work, (X.indptr.data_ptr(), X.indices.data_ptr(), n, d), X.indptr, X.indices)
         return rowsum, colsum
 
     def idf(self, colsum: torch.Tensor, n_obs: float, flags: int, dtype) -> torch.Tensor:
@@ -300,10 +296,8 @@ class HipBackend:
         work = self.empty((wb,), torch.uint8)
         with torch.cuda.device(self.device):
             st = self._stream()
-            kept = self.__dict__.get("_slab_ptr")
-            sp = kept[0] if kept is not None and kept[1] == (X.indptr.data_ptr(), X.indices.data_ptr(), n, d) else None
-            check(self.lib.mu_csr_tpack_count_sp(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
-                                                 _p(sp), _p(work), wb, st))
+            check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
+                                              _p(work), wb, st))
             perm, inv, K, n_pos = None, None, 0, d
             lens = col_nnz[:d]
             if sort_rows and d > 0:

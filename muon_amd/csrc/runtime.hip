@@ -35,7 +35,7 @@ static int g_tune[kTuneN] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 extern "C" {
 
-int mu_version(void) { return 102; }
+int mu_version(void) { return 103; }
 
 int mu_tune_set(const char* key, int value) {
   MU_REQUIRE(key, "null key");
