@@ -27,6 +27,9 @@ class LocalComm:
     def sum_scalar(self, x):
         return x
 
+    def agree(self, flag):
+        return bool(flag)
+
 
 class TorchDistComm:
     def __init__(self, group=None):
@@ -63,6 +66,18 @@ class TorchDistComm:
             t = t.cuda()
         self._dist.all_reduce(t, group=self.group)
         return float(t.item())
+
+
+    def agree(self, flag):
+        """Rank 0's decision, for every rank: stop / restart / convergence tests are taken from host
+        LAPACK results that need not be bit-identical across ranks (different BLAS builds or CPUs),
+        and a rank that leaves a loop alone strands the others in their next collective."""
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if self._dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        self._dist.broadcast(t, src=self._dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                             group=self.group)
+        return bool(int(t.item()))
 
 
 def default_comm(comm=None):

@@ -98,3 +98,54 @@ def test_more_components_than_the_block_width():
     assert ad.obsm["X_lsi"].shape == (5000, 100) and ad.varm["LSI"].shape == (6000, 100)
     assert lsi_oracle.max_subspace_angle(ad.varm["LSI"], ref["LSI"]) < ANGLE
     np.testing.assert_allclose(ad.uns["lsi"]["stdev"], ref["stdev"], rtol=1e-5)
+
+
+def test_baseline_shape_10k_by_30k_against_the_f64_oracle(hip):
+    # BASELINE.json configs[0]/[1]: 10 000 cells x 30 000 peaks, 3 % nnz, tfidf + lsi(n_comps=50).
+    # The reference path (/root/reference/muon/_atac/tools.py:53-69) restated in f64 is the oracle.
+    from muon_amd._atac.tools import lsi_device
+
+    X = planted_topics_csr(10_000, 30_000, n_topics=50, density=0.03, seed=0, dtype=np.float32)
+    ad = AnnData(X.copy())
+    ac.pp.tfidf(ad, backend=hip)
+    ref = lsi_oracle.lsi(ad.X, n_comps=50)
+    ac.tl.lsi(ad, n_comps=50, backend=hip)
+    angle = lsi_oracle.max_subspace_angle(ad.varm["LSI"], ref["LSI"])
+    print(f"10k x 30k: angle {angle:.2e}, stdev rel {np.max(np.abs(ad.uns['lsi']['stdev'] / ref['stdev'] - 1)):.1e}")
+    assert angle < ANGLE
+    np.testing.assert_allclose(ad.uns["lsi"]["stdev"], ref["stdev"], rtol=1e-5)
+    assert lsi_oracle.max_subspace_angle(ad.obsm["X_lsi"], ref["X_lsi"]) < 5 * ANGLE
+    from muon_amd._atac.preproc import resident
+    _, _, _, info = lsi_device(hip, resident(ad.X, hip), n_comps=50, return_info=True)
+    assert info["converged"] and info["angle_bound"] < ANGLE and angle <= info["angle_bound"]
+
+
+@pytest.mark.parametrize("case", ["k_inside_cluster", "k_past_the_planted_rank", "unstructured"])
+def test_k_not_at_a_spectral_gap_is_never_silently_wrong(hip, case):
+    # n_topics=80 / n_comps=50 (k inside the planted cluster), n_topics=30 /
+    # n_comps=50 (k past the planted rank, inside the bulk) and the unstructured generator.  Either
+    # `converged` is True and the subspace is within 1e-4 of f64 ARPACK, or `converged` is False;
+    # `angle_bound` covers the true angle in every case.  The gap is printed with the angle.
+    from muon_amd._atac.tools import lsi_device
+    from oracle import tfidf_oracle
+    from tests.synth import unstructured_csr
+
+    if case == "k_inside_cluster":
+        X = planted_topics_csr(3000, 2500, n_topics=80, density=0.03, seed=3, dtype=np.float32)
+    elif case == "k_past_the_planted_rank":
+        X = planted_topics_csr(2000, 1500, n_topics=30, density=0.03, seed=4, dtype=np.float32)
+    else:
+        X = unstructured_csr(2000, 1500, density=0.03, seed=5)
+    T = tfidf_oracle.canonical(tfidf_oracle.tfidf(X)).astype(np.float32)
+    ref = lsi_oracle.lsi(T, n_comps=50)
+    Xd = hip.upload_csr(T.indptr, T.indices, T.data, T.shape)
+    _, sd, V, info = lsi_device(hip, Xd, n_comps=50, return_info=True)
+    angle = lsi_oracle.max_subspace_angle(hip.to_host(V), ref["LSI"])
+    print(f"{case}: gap_rel={info['gap_rel']:.2e} angle={angle:.2e} bound={info['angle_bound']:.2e} "
+          f"converged={info['converged']} spmm={info['spmm']}")
+    assert angle <= max(info["angle_bound"], 1e-6)
+    if info["converged"]:
+        assert angle < ANGLE
+    np.testing.assert_allclose(sd, ref["stdev"], rtol=1e-5)
+    if case == "k_inside_cluster":
+        assert info["converged"]  # gap 1.3 %: reachable in f32, and reached

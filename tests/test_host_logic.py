@@ -264,3 +264,30 @@ def test_ritz_step_handles_dependent_krylov_directions():
     # more pairs wanted than the space holds: the rest comes back as zeros
     lam2, C2 = _ritz(T, M, 20)
     assert lam2.shape == (20,) and np.all(lam2[12:] == 0) and np.all(C2[:, 12:] == 0)
+
+
+@pytest.mark.parametrize("case", ["k_inside_cluster", "k_past_the_planted_rank", "unstructured"])
+def test_lsi_reports_unconverged_instead_of_being_silently_wrong(case):
+    # k not at a planted spectral gap.  Whatever the spectrum, either the
+    # reported `converged` is True and the top-k right singular subspace is within the 1e-4 target of
+    # f64 ARPACK, or `converged` is False; `angle_bound` (Lanczos residuals / Ritz gap + f32 floor)
+    # always covers the true angle.
+    from muon_amd._atac.tools import lsi_device
+    from tests.synth import unstructured_csr
+
+    if case == "k_inside_cluster":
+        X, k = planted_topics_csr(1200, 900, n_topics=40, density=0.05, seed=3, dtype=np.float32), 25
+    elif case == "k_past_the_planted_rank":
+        X, k = planted_topics_csr(1000, 800, n_topics=12, density=0.05, seed=4, dtype=np.float32), 20
+    else:
+        X, k = unstructured_csr(700, 500, density=0.05, seed=5), 20
+    T, Xd = _device_tfidf(X)
+    ref = lsi_oracle.lsi(T, n_comps=k)
+    _, sd, V, info = lsi_device(BE, Xd, n_comps=k, return_info=True, max_iter=40)
+    angle = lsi_oracle.max_subspace_angle(V.numpy(), ref["LSI"])
+    print(f"{case}: gap_rel={info['gap_rel']:.2e} angle={angle:.2e} bound={info['angle_bound']:.2e} "
+          f"converged={info['converged']} spmm={info['spmm']}")
+    assert angle <= max(info["angle_bound"], 1e-6)
+    if info["converged"]:
+        assert angle < 1e-4
+    np.testing.assert_allclose(sd, ref["stdev"], rtol=1e-5)  # singular values converge with the angle squared
