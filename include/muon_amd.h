@@ -188,6 +188,44 @@ int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t
                       const int64_t* d_cptr, const int32_t* d_perm, const int32_t* d_inv, void* d_ent,
                       void* d_work, size_t work_bytes, void* stream);
 
+/* The same transposition written as a plain CSR of X^T (t_indptr int64[n_cols + 1] = exclusive scan
+ * of col_nnz, t_indices int32[nnz] = cell ids ascending inside every row, t_values f32[nnz]): step 3
+ * of the sequence above with the CSR arrays as the target.  This is what mu_spmm_csr_f32 streams for
+ * Z = X^T Y (r02: the SpMM reads CSR directly, no packed copies). */
+int mu_csr_tpack_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
+                          const int32_t* d_indices, const float* d_values, const int64_t* d_t_indptr,
+                          int32_t* d_t_indices, float* d_t_values, void* d_work, size_t work_bytes,
+                          void* stream);
+
+/* Y[perm[p]][0..B-1] = row perm[p] of X times Q, for every position p < n_pos, straight from the
+ * CSR arrays (B = 16, 32 or 64; canonical CSR: sorted columns, no duplicates).  The operator of
+ * scipy svds (tools.py:53; _svds.py:441-466 matvec / rmatvec) for a block of B vectors.
+ * Positions: the kernel gives 4 consecutive positions to the four 16-lane groups of a wave, K such
+ * row-sets to a wave, 16 waves to a workgroup; perm (int32[n_pos], -1 = no row, NULL = identity with
+ * n_pos = n_rows) only decides which rows share a wave - nothing is moved in memory.  The host sorts
+ * the rows by length and deals them round robin (muon_amd/_backend.py spmm_layout), K =
+ * mu_spmm_csr_k(n_rows) (k_layout = 0: chosen here).  The entries of a row are accumulated in column
+ * order with one fmaf chain per dense column, whatever the layout => bit-reproducible, and
+ * bit-identical to mu_spmm_packed_f32. */
+int mu_spmm_csr_k(int64_t n_rows);
+int mu_spmm_csr_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
+                    const float* d_values, const int32_t* d_perm, int k_layout, const float* d_Q, int B,
+                    float* d_Y, void* stream);
+
+/* The same product from the PAIR STREAM of the matrix: ent[p] = column (int32) | value bits (f32) << 32
+ * for the entries in CSR order, addressed with the same row pointers (8 bytes per entry in one array:
+ * a 16-entry window is one 128-byte request instead of two 64-byte ones, and half as many distinct
+ * lines are alive in the L2).  mu_csr_pairs_fill copies a CSR into it; mu_csr_tpack_fill_pairs writes
+ * the pair stream of X^T straight from the CSR of X (same sequence as mu_csr_tpack_fill_csr). */
+int mu_csr_pairs_fill(int64_t nnz, const int32_t* d_indices, const float* d_values, void* d_ent,
+                      void* stream);
+int mu_csr_tpack_fill_pairs(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
+                            const int32_t* d_indices, const float* d_values, const int64_t* d_t_indptr,
+                            void* d_t_ent, void* d_work, size_t work_bytes, void* stream);
+int mu_spmm_pairs_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_indptr, const void* d_ent,
+                      const int32_t* d_perm, int k_layout, const float* d_Q, int B, float* d_Y,
+                      void* stream);
+
 /* Y[perm[p]][0..B-1] = row perm[p] of X times Q, for every position p < n_pos (B = 16, 32 or 64,
  * n_cols <= 2^22).  k_layout = the K the layout was dealt for (0: mu_spmm_packed_k(n_pos)).  Same
  * result as mu_spmm_f32 up to f32 summation order: the entries of a row are accumulated in column

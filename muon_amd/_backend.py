@@ -29,6 +29,10 @@ class DeviceCSR:
     indices: torch.Tensor
     values: torch.Tensor
     shape: Tuple[int, int]
+    # SpMM launch layout (HipBackend.spmm_layout): position p of the launch handles row perm[p]
+    # (-1: none); k = row-sets per wave it was dealt for.  None: rows in matrix order.
+    perm: Optional[torch.Tensor] = None
+    k: int = 0
 
     @property
     def nnz(self) -> int:
@@ -39,7 +43,7 @@ class DeviceCSR:
         return self.values.dtype
 
     def with_values(self, values: torch.Tensor) -> "DeviceCSR":
-        return DeviceCSR(self.indptr, self.indices, values, self.shape)
+        return DeviceCSR(self.indptr, self.indices, values, self.shape, self.perm, self.k)
 
 
 @dataclass
@@ -59,6 +63,22 @@ class DevicePackedCSR:
     @property
     def n_pos(self) -> int:
         return int(self.cptr.numel()) - 1
+
+
+@dataclass
+class DevicePairs:
+    """Pair stream of a CSR (include/muon_amd.h): indptr int64[n+1] (the CSR's), ent int64[nnz] =
+    column | value bits << 32, plus the SpMM launch layout (perm, k).  SpMM-only."""
+
+    indptr: torch.Tensor
+    ent: torch.Tensor
+    shape: Tuple[int, int]
+    perm: Optional[torch.Tensor] = None
+    k: int = 0
+
+    @property
+    def nnz(self) -> int:
+        return int(self.ent.numel())
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -201,18 +221,85 @@ class HipBackend:
                                             _p(t_values), _p(work), wb, self._stream()))
         return DeviceCSR(t_indptr, t_indices, t_values, (d, n))
 
+    def spmm_layout(self, X: DeviceCSR) -> DeviceCSR:
+        """The same CSR with a launch layout for mu_spmm_csr_f32 attached: rows sorted by length
+        (descending, stable) and dealt round robin to workgroups and waves (``packed_layout``), so
+        that the four rows a wave advances in lock step have similar lengths and every workgroup
+        gets the same mix.  Nothing is moved in memory."""
+        n = X.shape[0]
+        if n == 0:
+            return X
+        perm, _inv, K = self.packed_layout(X.indptr[1:] - X.indptr[:-1], k_fn=self.lib.mu_spmm_csr_k)
+        return DeviceCSR(X.indptr, X.indices, X.values, X.shape, perm, K)
+
+    def transpose_csr(self, X: DeviceCSR, layout: bool = True) -> DeviceCSR:
+        """CSR of X^T straight from the CSR of X (f32; stable: cells ascending inside every row =>
+        canonical rows and bit-reproducible SpMM sums), with the SpMM launch layout attached."""
+        n, d = X.shape
+        assert X.values.dtype == torch.float32
+        col_nnz = self.empty((max(d, 1),), torch.int64)
+        t_indptr = self.zeros((d + 1,), torch.int64)
+        t_indices = self.empty((max(X.nnz, 1),), torch.int32)[:X.nnz]
+        t_values = self.empty((max(X.nnz, 1),), torch.float32)[:X.nnz]
+        wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
+        work = self.empty((wb,), torch.uint8)
+        with torch.cuda.device(self.device):
+            st = self._stream()
+            check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
+                                              _p(work), wb, st))
+            check(self.lib.mu_exclusive_scan_i64(d, _p(col_nnz), _p(t_indptr), st))
+            check(self.lib.mu_csr_tpack_fill_csr(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
+                                                 _p(t_indptr), _p(t_indices), _p(t_values), _p(work), wb, st))
+        Xt = DeviceCSR(t_indptr, t_indices, t_values, (d, n))
+        if layout and d > 0:
+            perm, _inv, K = self.packed_layout(col_nnz[:d], k_fn=self.lib.mu_spmm_csr_k)
+            Xt = DeviceCSR(t_indptr, t_indices, t_values, (d, n), perm, K)
+        return Xt
+
+    def pairs(self, X: DeviceCSR, layout: bool = True) -> DevicePairs:
+        """Pair stream of X (streaming copy) with the SpMM launch layout attached."""
+        assert X.values.dtype == torch.float32
+        ent = self.empty((max(X.nnz, 1),), torch.int64)[:X.nnz]
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_csr_pairs_fill(X.nnz, _p(X.indices), _p(X.values), _p(ent), self._stream()))
+        perm, K = X.perm, X.k
+        if layout and perm is None and X.shape[0] > 0:
+            perm, _inv, K = self.packed_layout(X.indptr[1:] - X.indptr[:-1], k_fn=self.lib.mu_spmm_csr_k)
+        return DevicePairs(X.indptr, ent, X.shape, perm, K)
+
+    def transpose_pairs(self, X: DeviceCSR, layout: bool = True) -> DevicePairs:
+        """Pair stream of X^T straight from the CSR of X (stable: cells ascending inside every row)."""
+        n, d = X.shape
+        assert X.values.dtype == torch.float32
+        col_nnz = self.empty((max(d, 1),), torch.int64)
+        t_indptr = self.zeros((d + 1,), torch.int64)
+        ent = self.empty((max(X.nnz, 1),), torch.int64)[:X.nnz]
+        wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
+        work = self.empty((wb,), torch.uint8)
+        with torch.cuda.device(self.device):
+            st = self._stream()
+            check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
+                                              _p(work), wb, st))
+            check(self.lib.mu_exclusive_scan_i64(d, _p(col_nnz), _p(t_indptr), st))
+            check(self.lib.mu_csr_tpack_fill_pairs(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
+                                                   _p(t_indptr), _p(ent), _p(work), wb, st))
+        perm, K = None, 0
+        if layout and d > 0:
+            perm, _inv, K = self.packed_layout(col_nnz[:d], k_fn=self.lib.mu_spmm_csr_k)
+        return DevicePairs(t_indptr, ent, (d, n), perm, K)
+
     def can_pack(self, X: DeviceCSR, B: int) -> bool:
         """The packed SpMM exists for f32 values, B in (16, 32, 64) and at most 2^22 columns."""
         return X.values.dtype == torch.float32 and B in (16, 32, 64) and 0 < X.shape[1] <= (1 << 22)
 
-    def packed_layout(self, lens: torch.Tensor):
+    def packed_layout(self, lens: torch.Tensor, k_fn=None):
         """Where the rows go in a packed copy (include/muon_amd.h): sorted by length (descending,
         stable) and dealt round robin - row-set q of the sorted order goes to workgroup q % n_wg,
         inside it to wave (q // n_wg) % 16 and row-set slot (q // n_wg) // 16 - so that the four rows
         a wave advances in lock step have similar lengths and every workgroup and wave gets the same
         mix.  Returns (perm int32[n_pos], inv int32[n], K)."""
         n = int(lens.numel())
-        K = max(1, int(self.lib.mu_spmm_packed_k(n)))
+        K = max(1, int((k_fn or self.lib.mu_spmm_packed_k)(n)))
         per_wg = 64 * K
         n_wg = max(1, (n + per_wg - 1) // per_wg)
         # One workgroup per CU runs at a time (128 KiB of LDS) and the dealt workgroups take equally
@@ -345,6 +432,17 @@ class HipBackend:
         n, d = X.shape
         B = Q.shape[1]
         assert Q.shape[0] == d and Q.dtype in (torch.float32, torch.float64) and Q.is_contiguous()
+        if isinstance(X, DevicePairs):
+            if Q.dtype != torch.float32 or B not in (16, 32, 64):
+                raise TypeError("the pair-stream SpMM needs an f32 dense block of width 16, 32 or 64")
+            if out is None:
+                out = self.empty((n, B), Q.dtype)
+            n_pos = int(X.perm.numel()) if X.perm is not None else n
+            with torch.cuda.device(self.device):
+                check(self.lib.mu_spmm_pairs_f32(n_pos, d, _p(X.indptr), _p(X.ent), _p(X.perm),
+                                                 X.k if X.perm is not None else 0, _p(Q), B, _p(out),
+                                                 self._stream()))
+            return out
         if isinstance(X, DevicePackedCSR):
             if Q.dtype != torch.float32 or B not in (16, 32, 64):
                 raise TypeError("the packed SpMM needs an f32 dense block of width 16, 32 or 64")
@@ -358,6 +456,15 @@ class HipBackend:
             raise TypeError("spmm needs values and dense block of one dtype")
         if out is None:
             out = self.empty((n, B), Q.dtype)
+        if (Q.dtype == torch.float32 and B in (16, 32, 64) and n > 0 and d > 0
+                and not self.__dict__.get("_no_csr_win")):
+            # the LDS-slab kernel on the CSR arrays; rows in matrix order unless a layout is attached
+            n_pos = int(X.perm.numel()) if X.perm is not None else n
+            with torch.cuda.device(self.device):
+                check(self.lib.mu_spmm_csr_f32(n_pos, d, _p(X.indptr), _p(X.indices), _p(X.values),
+                                               _p(X.perm), X.k if X.perm is not None else 0, _p(Q), B,
+                                               _p(out), self._stream()))
+            return out
         fn = self.lib.mu_spmm_f32 if Q.dtype == torch.float32 else self.lib.mu_spmm_f64
         with torch.cuda.device(self.device):
             check(fn(n, d, _p(X.indptr), _p(X.indices), _p(X.values), _p(Q), B, _p(out), 0,

@@ -157,7 +157,7 @@ __device__ __forceinline__ void dma_piece(const float4* gsrc, unsigned lds_dst) 
       "s_mov_b64 exec, %0"                                                            \
       : "=&s"(save)                                                                   \
       : "v"(byte_off), "s"(base), "s"(mask), "i"(NX + 2 * k), "i"(NX + 2 * k + 1)     \
-      : CLOB)
+      : CLOB, "scc")
 template <int W, int k>
 __device__ __forceinline__ void request_chunk(unsigned byte_off, const void* base,
                                               unsigned long long mask) {

@@ -140,6 +140,23 @@ __global__ __launch_bounds__(256) void k_t_base(int64_t n_cols, int G, uint32_t*
 //     atomics, no per-batch barriers (4 barriers per tile);
 //   * per-row cursors (first entry not yet consumed) live in global memory: no slab pointers;
 //   * a tile that does not fit the staging buffer falls back to direct stores (same slots).
+// Where a (cell, value) pair of output row `column` goes: slot `pos` of the packed chunk stream
+// (`ent`, 8 bytes per pair) or of the CSR arrays of X^T (split == true: t_indices / t_values).
+struct TOut {
+  unsigned long long* ent;
+  int32_t* idx;
+  float* val;
+  int shift;  // row pointers count chunks of 16 pairs (4) or pairs (0)
+};
+__device__ __forceinline__ void t_store(const TOut& o, int64_t pos, unsigned long long e) {
+  if (o.idx) {
+    o.idx[pos] = (int32_t)(unsigned)e;
+    o.val[pos] = __builtin_bit_cast(float, (unsigned)(e >> 32));
+  } else {
+    o.ent[pos] = e;
+  }
+}
+
 constexpr int kF2Cols = 768;     // max columns per slab (the host picks C <= kF2Cols from nnz / d)
 constexpr int kF2Cap = 10240;    // staged pairs: 80 KiB
 constexpr int kF2Rows = 8;       // rows a wave has in flight
@@ -184,7 +201,7 @@ __device__ __forceinline__ void f2_process(const F2Batch& b, int& cur, int end, 
                                            const float* __restrict__ values_b, uint32_t* wbucket,
                                            const uint32_t* lpos, const int64_t* gdst,
                                            unsigned long long* stage, bool staged,
-                                           unsigned long long* __restrict__ ent) {
+                                           const TOut& ent) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < kF2Rows; ++j) {
@@ -206,7 +223,7 @@ __device__ __forceinline__ void f2_process(const F2Batch& b, int& cur, int end, 
           const unsigned long long e = (unsigned long long)(unsigned)(row0 + first + j) |
                                        ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32);
           if (staged) stage[lpos[cl] + k] = e;
-          else ent[gdst[cl] + k] = e;
+          else t_store(ent, gdst[cl] + k, e);
         }
       }
       c0 += n;
@@ -227,7 +244,7 @@ __device__ __forceinline__ void f2_walk(int64_t wrow0, int64_t wrow1, int32_t cb
                                         const float* __restrict__ values, int64_t* __restrict__ curs,
                                         uint32_t* wbucket, const uint32_t* lpos, const int64_t* gdst,
                                         unsigned long long* stage, bool staged,
-                                        unsigned long long* __restrict__ ent) {
+                                        const TOut& ent) {
   const int lane = threadIdx.x & 63;
   const int32_t* __restrict__ indices_b = indices + wg_base;
   const float* __restrict__ values_b = values + wg_base;
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
                                                        const int32_t* __restrict__ inv,
                                                        const uint32_t* __restrict__ base,
                                                        const int64_t* __restrict__ coltot,
-                                                       unsigned long long* __restrict__ ent) {
+                                                       TOut ent) {
   __shared__ unsigned long long stage[kF2Cap];     // 80 KiB
   __shared__ uint32_t bucket[kTWaves][kF2Cols];    // 48 KiB: per (wave, column) count, then cursor
   __shared__ uint32_t lcount[kF2Cols], lpos[kF2Cols];
@@ -296,7 +313,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
         const uint32_t b0 = base_g[c];
         const uint32_t b1 = base_n ? base_n[c] : (uint32_t)coltot[c];
         mine = b1 - b0;
-        gdst[threadIdx.x] = cptr[inv ? (int64_t)inv[c] : c] * 16 + (int64_t)b0;
+        gdst[threadIdx.x] = (cptr[inv ? (int64_t)inv[c] : c] << ent.shift) + (int64_t)b0;
       }
       lcount[threadIdx.x] = mine;
     }
@@ -344,7 +361,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
       for (int cl = grp; cl < cend - cbase; cl += kTThreads / 16) {
         const uint32_t L = lcount[cl], src = lpos[cl];
         const int64_t dst = gdst[cl];
-        for (uint32_t i = sub; i < L; i += 16) ent[dst + i] = stage[src + i];
+        for (uint32_t i = sub; i < L; i += 16) t_store(ent, dst + i, stage[src + i]);
       }
     }
     __syncthreads();
@@ -367,7 +384,7 @@ __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, 
                                            const float* __restrict__ values_b, uint32_t* wcur,
                                            uint16_t* wcnt, uint32_t* dummy, const int64_t* gdst,
                                            unsigned long long* stage, bool staged,
-                                           unsigned long long* __restrict__ ent) {
+                                           const TOut& ent) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < kF2Rows; ++j) {
@@ -398,7 +415,7 @@ __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, 
           const unsigned long long e = (unsigned long long)(unsigned)(row0 + first + j) |
                                        ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32);
           if (staged) stage[k] = e;
-          else ent[gdst[c - cbase] + k] = e;
+          else t_store(ent, gdst[c - cbase] + k, e);
         }
       }
       c0 += n;
@@ -433,7 +450,7 @@ __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cb
                                         const float* __restrict__ values, int64_t* __restrict__ curs,
                                         uint32_t* wcur, uint16_t* wcnt, uint32_t* dummy,
                                         const int64_t* gdst, unsigned long long* stage, bool staged,
-                                        unsigned long long* __restrict__ ent) {
+                                        const TOut& ent) {
   const int lane = threadIdx.x & 63;
   const int32_t* __restrict__ indices_b = indices + wg_base;
   const float* __restrict__ values_b = values + wg_base;
@@ -469,7 +486,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
                                                        const int32_t* __restrict__ inv,
                                                        const uint32_t* __restrict__ base,
                                                        const int64_t* __restrict__ coltot,
-                                                       unsigned long long* __restrict__ ent) {
+                                                       TOut ent) {
   __shared__ unsigned long long stage[kF2Cap];     // 80 KiB
   __shared__ uint32_t wcur_all[kTWaves][kF3Cols];  // 40 KiB: per (wave, column) cursor of this tile
   __shared__ uint16_t wcnt_all[kTWaves][kF3Cols];  // 20 KiB: per (wave, column) count of the tile in the making
@@ -503,7 +520,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
         const uint32_t b0 = base_g[c];
         const uint32_t b1 = base_n ? base_n[c] : (uint32_t)coltot[c];
         mine = b1 - b0;
-        gdst[threadIdx.x] = cptr[inv ? (int64_t)inv[c] : c] * 16 + (int64_t)b0;
+        gdst[threadIdx.x] = (cptr[inv ? (int64_t)inv[c] : c] << ent.shift) + (int64_t)b0;
       }
       lcount[threadIdx.x] = mine;
     }
@@ -555,7 +572,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
       for (int cl = grp; cl < cend - cbase; cl += kTThreads / 16) {
         const uint32_t L = lcount[cl], src = lpos[cl];
         const int64_t dst = gdst[cl];
-        for (uint32_t i = sub; i < L; i += 16) ent[dst + i] = stage[src + i];
+        for (uint32_t i = sub; i < L; i += 16) t_store(ent, dst + i, stage[src + i]);
       }
     }
     __syncthreads();
@@ -664,6 +681,35 @@ int mu_csr_tpack_count_sp(int64_t n_rows, int64_t n_cols, int64_t nnz, const int
   return MU_OK;
 }
 
+static int tpack_fill_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
+                           const int32_t* d_indices, const float* d_values, const int64_t* d_cptr,
+                           const int32_t* d_inv, TOut out, void* d_work, hipStream_t st) {
+  const int G = t_grid(nnz);
+  const TWork w = carve(d_work, n_rows, n_cols, nnz);
+  if (n_rows > 0) {
+    // slab width: the expected tile (nnz / G rows x C columns) fills ~93 % of the staging buffer
+    // (measured best on the bench matrix: fewer, fuller tiles; a tile that overflows takes the
+    //  direct-store path)
+    const double per_col = (double)nnz / (double)G / (double)n_cols;  // pairs of a tile per column
+    int64_t C = per_col > 0 ? (int64_t)(0.93 * kF2Cap / per_col) : kF2Cols;
+    C = (C / 32) * 32;
+    if (C < 32) C = 32;
+    if (C > kF2Cols) C = kF2Cols;
+    if (mu_tune_get("tpack_c") > 0) C = mu_tune_get("tpack_c");
+    if (n_rows <= kF3MaxRows && !mu_tune_get("tpack_v2")) {
+      if (C > kF3Cols) C = kF3Cols;
+      hipLaunchKernelGGL(k_t_fill3, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C, d_indptr,
+                         d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt, w.coltot, out);
+    } else {
+      hipLaunchKernelGGL(k_t_fill2, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,
+                         mu_tune_get("tpack_abl"), d_indptr, d_indices, d_values, w.curs, d_cptr, d_inv,
+                         w.cnt, w.coltot, out);
+    }
+    MU_CHECK_LAUNCH();
+  }
+  return MU_OK;
+}
+
 int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
                       const int32_t* d_indices, const float* d_values, int64_t n_pos,
                       const int64_t* d_cptr, const int32_t* d_perm, const int32_t* d_inv, void* d_ent,
@@ -674,34 +720,11 @@ int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t
   MU_REQUIRE((d_perm == nullptr) == (d_inv == nullptr) && n_pos >= n_cols, "perm / inv / n_pos inconsistent");
   MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols, nnz), "work buffer too small");
   hipStream_t st = (hipStream_t)stream;
-  const int64_t S = t_slabs(n_cols);
-  const int G = t_grid(nnz);
   const TWork w = carve(d_work, n_rows, n_cols, nnz);
-  if (n_rows > 0) {
-    {
-      // slab width: the expected tile (nnz / G rows x C columns) fills ~93 % of the staging buffer
-      // (measured best on the bench matrix: fewer, fuller tiles; a tile that overflows takes the
-      //  direct-store path)
-      const double per_col = (double)nnz / (double)G / (double)n_cols;  // pairs of a tile per column
-      int64_t C = per_col > 0 ? (int64_t)(0.93 * kF2Cap / per_col) : kF2Cols;
-      C = (C / 32) * 32;
-      if (C < 32) C = 32;
-      if (C > kF2Cols) C = kF2Cols;
-      if (mu_tune_get("tpack_c") > 0) C = mu_tune_get("tpack_c");
-      if (n_rows <= kF3MaxRows && !mu_tune_get("tpack_v2")) {
-        if (C > kF3Cols) C = kF3Cols;
-        hipLaunchKernelGGL(k_t_fill3, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C, d_indptr,
-                           d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt, w.coltot,
-                           (unsigned long long*)d_ent);
-      } else {
-        hipLaunchKernelGGL(k_t_fill2, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,
-                           mu_tune_get("tpack_abl"), d_indptr,
-                           d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt, w.coltot,
-                           (unsigned long long*)d_ent);
-      }
-    }
-    MU_CHECK_LAUNCH();
-  }
+  const TOut out{(unsigned long long*)d_ent, nullptr, nullptr, 4};
+  const int rc = tpack_fill_impl(n_rows, n_cols, nnz, d_indptr, d_indices, d_values, d_cptr, d_inv, out,
+                                 d_work, st);
+  if (rc != MU_OK) return rc;
   hipLaunchKernelGGL(k_t_pads, dim3((unsigned)((n_cols * 32 + 255) / 256)), dim3(256), 0, st, n_cols,
                      w.coltot, d_cptr, d_inv, (unsigned long long*)d_ent);
   MU_CHECK_LAUNCH();
@@ -711,6 +734,32 @@ int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t
     MU_CHECK_LAUNCH();
   }
   return MU_OK;
+}
+
+int mu_csr_tpack_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
+                          const int32_t* d_indices, const float* d_values, const int64_t* d_t_indptr,
+                          int32_t* d_t_indices, float* d_t_values, void* d_work, size_t work_bytes,
+                          void* stream) {
+  MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
+  if (n_cols == 0 || nnz == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_t_indptr && d_t_indices && d_t_values && d_work, "null pointer");
+  MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols, nnz), "work buffer too small");
+  const TOut out{nullptr, d_t_indices, d_t_values, 0};
+  return tpack_fill_impl(n_rows, n_cols, nnz, d_indptr, d_indices, d_values, d_t_indptr, nullptr, out,
+                         d_work, (hipStream_t)stream);
+}
+
+/* the same with the pair stream as the target: ent[t_indptr[c] + i] = (cell, value bits) */
+int mu_csr_tpack_fill_pairs(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
+                            const int32_t* d_indices, const float* d_values, const int64_t* d_t_indptr,
+                            void* d_t_ent, void* d_work, size_t work_bytes, void* stream) {
+  MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
+  if (n_cols == 0 || nnz == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_t_indptr && d_t_ent && d_work, "null pointer");
+  MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols, nnz), "work buffer too small");
+  const TOut out{(unsigned long long*)d_t_ent, nullptr, nullptr, 0};
+  return tpack_fill_impl(n_rows, n_cols, nnz, d_indptr, d_indices, d_values, d_t_indptr, nullptr, out,
+                         d_work, (hipStream_t)stream);
 }
 
 }  // extern "C"

