@@ -2,16 +2,20 @@
 """bench.py - TF-IDF + LSI(k=50) throughput on synthetic planted-topic CSR (BASELINE.json).
 
 A "step" is one pass of the hot path over one batch: tfidf (counts -> TF-IDF values) followed
-by lsi (packed copies of X and X^T, block Lanczos to convergence, Rayleigh-Ritz over the Krylov space),
+by lsi (row streams of X and X^T, block Lanczos to convergence, Rayleigh-Ritz over the Krylov space),
 with the count matrix already resident in HBM when the timed region starts and U / stdev / V
 left in HBM at the end.
 
-roofline: the dominant kernel is the packed SpMM (both X*Q and X^T*Y).  `achieved` =
+roofline: the dominant kernel is the row-stream SpMM (both X*Q and X^T*Y).  `achieved` =
 algorithmic bytes per launch (8 B per stored entry + row pointers + the two dense blocks,
 SURVEY.md 8d / DESIGN.md 4) / mean launch time from HIP events recorded on the launch stream
 inside the timed region.  `traffic` = HBM bytes per launch from rocprofv3 PMC counters
 (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction) for the default workload, read
-from profiles/r01_spmm_traffic.json; null for any other shape.
+from profiles/r02_spmm_traffic.json; null for any other shape.
+
+parity: the CPU leg's f32 ARPACK result on its sample is kept, the GPU path runs tfidf + lsi on the
+same sample, and the largest principal angle between the two top-k right singular subspaces and
+the largest relative difference of the singular values go into the JSON line (`parity`).
 
 Workloads (--workload):
   c3 (default)       BASELINE.json configs[2], the shape the metric is quoted on: 1 000 000 cells x
@@ -71,10 +75,13 @@ class TimedBackend:
         return r
 
 
-def cpu_baseline(be, peaks, density, seed, sample_cells):
+def cpu_baseline(be, peaks, density, seed, sample_cells, n_comps):
     """The reference's CPU path (scipy tfidf + ARPACK svds, f32 like sc.read_10x_h5 data) on a
-    bounded sample of the same generator.  Checker-side code: uses oracle/."""
+    bounded sample of the same generator, and the GPU path's parity with it on that sample.
+    Checker-side code: uses oracle/."""
     import scipy.sparse as sp
+    from muon_amd._atac.preproc import tfidf_device
+    from muon_amd._atac.tools import lsi_device
     from oracle import lsi_oracle, tfidf_oracle
 
     Xs = be.synth_counts(0, sample_cells, peaks, 50, density, seed)
@@ -82,17 +89,42 @@ def cpu_baseline(be, peaks, density, seed, sample_cells):
     t0 = time.perf_counter()
     tf = tfidf_oracle.tfidf(m)
     t1 = time.perf_counter()
-    lsi_oracle.lsi(tf, n_comps=50, dtype=np.float32)
+    ref = lsi_oracle.lsi(tf, n_comps=n_comps, dtype=np.float32)
     t2 = time.perf_counter()
+    # threads the timed legs could use: scipy's sparse kernels and ARPACK's matvec loop are serial
+    # (measured: user+sys CPU time / wall time of the two legs)
+    cpu = time.process_time()
+    tfidf_oracle.tfidf(m[:2000])
+    w0 = time.perf_counter()
+    c0 = time.process_time()
+    tfidf_oracle.tfidf(m[:2000])
+    busy = (time.process_time() - c0) / max(time.perf_counter() - w0, 1e-9)
+    del cpu
+    # parity of the product path on the same sample (tolerances of BASELINE.json north_star)
+    T = tfidf_device(be, Xs, sample_cells, 3, 1e4)
+    _U, stdev, V, info = lsi_device(be, T, n_comps=n_comps, n_obs=sample_cells, return_info=True)
+    tfc = tfidf_oracle.canonical(tf)
+    Th = be.to_host(T.values)
+    parity = {
+        "sample": f"first {sample_cells} cells of the bench matrix (the cpu_baseline sample)",
+        "tfidf_pattern_identical": bool(np.array_equal(tfc.indices, be.to_host(T.indices))
+                                        and np.array_equal(tfc.indptr, be.to_host(T.indptr))),
+        "tfidf_values_max_rel": float(np.max(np.abs(Th - tfc.data) / np.abs(tfc.data))),
+        "lsi_angle_rad": lsi_oracle.max_subspace_angle(be.to_host(V), ref["LSI"]),
+        "lsi_stdev_max_rel": float(np.max(np.abs(stdev - ref["stdev"]) / ref["stdev"])),
+        "lsi_converged": bool(info["converged"]),
+        "lsi_angle_bound": float(info["angle_bound"]),
+        "oracle": "scipy svds(k, f32) - the reference's own precision on f32 data; its repeatability is ~1e-5 rad on this spectrum",
+    }
     return {
         "value": sample_cells / (t2 - t0),
         "unit": "cells/s",
-        "cores": int(os.environ.get("OMP_NUM_THREADS", 0)) or 1,
+        "cores": max(1, int(round(busy))),
         "kind": "port",
         "sample": f"{sample_cells} cells x {peaks} peaks ({m.nnz} nnz, same generator, rows 0..{sample_cells - 1}); "
-                  f"scipy tfidf {t1 - t0:.2f}s + svds(k=50,f32) {t2 - t1:.2f}s; scipy sparse kernels use 1 core "
-                  f"(host has {os.cpu_count()})",
-    }
+                  f"scipy tfidf {t1 - t0:.2f}s + svds(k={n_comps},f32) {t2 - t1:.2f}s; measured CPU/wall of the scipy "
+                  f"leg {busy:.2f} (host has {os.cpu_count()} cores)",
+    }, parity
 
 
 def main():
@@ -109,7 +141,7 @@ def main():
     ap.add_argument("--cpu-sample-cells", type=int, default=12000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pack", action="store_true",
-                    help="ablation: run the SpMM on plain CSR (k_spmm_lds64) instead of the packed copy")
+                    help="ablation: run the SpMM on plain CSR (k_spmm_rowwave, one wave per row) instead of the row streams")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,7 +233,7 @@ def main():
 
     traffic = None
     traffic_detail = None
-    tpath = os.path.join(ROOT, "profiles", "r01_spmm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_spmm_traffic.json")
     tj = None
     if not args.cells and not args.peaks and not args.no_pack and os.path.exists(tpath):
         with open(tpath) as f:
@@ -213,7 +245,7 @@ def main():
         traffic = (tj["spmm_xq_bytes_per_launch"] * n_xq + tj["spmm_xty_bytes_per_launch"] * n_xt) / max(len(be.events), 1)
         traffic_detail = {"x_q": tj["spmm_xq_bytes_per_launch"], "xt_y": tj["spmm_xty_bytes_per_launch"],
                           "vs_algorithmic": traffic / tj["algorithmic_bytes_per_launch"],
-                          "source": "profiles/r01_spmm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 "
+                          "source": "profiles/r02_spmm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 "
                                     "correction + WRITE_SIZE, separate passes)"}
 
     if rank == 0:
@@ -239,10 +271,10 @@ def main():
                         "converged": info.get("converged"), "spmm_per_step": len(ms) // max(args.steps, 1)},
             },
             "roofline": {
-                "kernel": ("k_spmm_lds64 (CSR SpMM, f32, B=64: Q column slabs in LDS, DPP broadcast)"
+                "kernel": ("k_spmm_rowwave (CSR SpMM, f32, B=64: one wave per row, Q rows gathered through L2)"
                            if args.no_pack else
-                           "k_spmm_pcr64 (packed chunked-row SpMM, f32, B=64: Q column slabs in LDS via "
-                           "LDS-DMA, counted-vmcnt chunk stream, DPP broadcast)"),
+                           "k_spmm_win (row-stream SpMM, f32, B=64: Q column slabs in LDS via LDS-DMA, one "
+                           "counted-vmcnt window request per row-set and slab, DPP broadcast)"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -258,7 +290,8 @@ def main():
             },
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(be, d, args.density, args.seed, args.cpu_sample_cells)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(be._be, d, args.density, args.seed,
+                                                              args.cpu_sample_cells, args.n_comps)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

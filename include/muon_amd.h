@@ -138,39 +138,12 @@ int mu_spmm_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const i
                 const float* d_values, const float* d_Q, int B, float* d_Y, int accumulate,
                 void* stream);
 
-/* Packed chunked-row copy of a CSR for the packed SpMM ("PCR16"): every row is cut into
- * chunks of 16 (column int32, value f32) pairs = one aligned 128-byte line each, the tail is
- * padded with (INT32_MAX, 0) and one all-padding chunk closes every row.  Built once per
- * lsi() call for X and for X^T; the block Lanczos iteration then streams every line exactly once
- * per product.
- *
- * Layout: the copy has n_pos >= n_rows POSITIONS; position p holds row perm[p] of the matrix
- * (perm[p] < 0: no row; perm == NULL: the identity, n_pos = n_rows).  The SpMM gives 4 consecutive
- * positions to the four 16-lane groups of a wave, K such row-sets to a wave, 16 waves to a
- * workgroup (K = mu_spmm_packed_k(n_rows)), so the host sorts the rows by length and deals the
- * row-sets round robin to workgroups and waves (muon_amd/_backend.py packed_layout): rows that
- * advance in lock step have similar lengths and every workgroup gets the same mix (-12 % / -20 %
- * on X Q / X^T Y of the bench matrix).
- *   1. mu_csr_pack_count: row_chunks[p] = ceil(nnz of row perm[p] / 16) + 1   (1 for an empty position)
- *   2. caller scans row_chunks into cptr int64[n_pos + 1] (mu_exclusive_scan_i64) and
- *      allocates ent: 128 bytes x cptr[n_pos]
- *   3. mu_csr_pack_fill
- * Requires canonical CSR (sorted column indices, no duplicates). */
-int mu_spmm_packed_k(int64_t n_rows);
-int mu_csr_pack_count(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr,
-                      int64_t* d_row_chunks, void* stream);
-int mu_csr_pack_fill(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr,
-                     const int32_t* d_indices, const float* d_values, const int64_t* d_cptr,
-                     void* d_ent, void* stream);
-
-/* The packed copy of X^T (one output row per column of X, cell ids ascending inside every row)
- * straight from the CSR of X - what Z = X^T Y of the iteration streams; no CSR of X^T is
- * materialised.
+/* X^T straight from the CSR of X (csrc/tpack.hip), cell ids ascending inside every output row -
+ * what Z = X^T Y of the iteration streams; no intermediate copy.
  *   1. mu_csr_tpack_count: col_nnz[c] = stored entries of column c (and keeps its per-row-block
  *      column offsets in d_work)
- *   2. caller lays the output rows out (perm int32[n_pos], its inverse inv int32[n_cols]; both NULL
- *      for the identity), scans the chunk counts into cptr int64[n_pos + 1], allocates ent
- *   3. mu_csr_tpack_fill with the SAME d_work
+ *   2. caller lays the output rows out and scans their lengths into row pointers
+ *   3. mu_csr_tpack_fill_stream (row stream, below) or mu_csr_tpack_fill_csr with the SAME d_work
  * nnz = stored entries of X (it sizes the row blocks and tiles; pass the same value everywhere).
  * Stable and free of global atomics => bit-reproducible. */
 size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz);
@@ -183,56 +156,48 @@ int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_
 int mu_csr_tpack_count_sp(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
                           const int32_t* d_indices, int64_t* d_col_nnz, const int64_t* d_slab_ptr,
                           void* d_work, size_t work_bytes, void* stream);
-int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
-                      const int32_t* d_indices, const float* d_values, int64_t n_pos,
-                      const int64_t* d_cptr, const int32_t* d_perm, const int32_t* d_inv, void* d_ent,
-                      void* d_work, size_t work_bytes, void* stream);
-
 /* The same transposition written as a plain CSR of X^T (t_indptr int64[n_cols + 1] = exclusive scan
  * of col_nnz, t_indices int32[nnz] = cell ids ascending inside every row, t_values f32[nnz]): step 3
- * of the sequence above with the CSR arrays as the target.  This is what mu_spmm_csr_f32 streams for
- * Z = X^T Y (r02: the SpMM reads CSR directly, no packed copies). */
+ * of the sequence above with the CSR arrays as the target (the fast stable transpose). */
 int mu_csr_tpack_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
                           const int32_t* d_indices, const float* d_values, const int64_t* d_t_indptr,
                           int32_t* d_t_indices, float* d_t_values, void* d_work, size_t work_bytes,
                           void* stream);
 
-/* Y[perm[p]][0..B-1] = row perm[p] of X times Q, for every position p < n_pos, straight from the
- * CSR arrays (B = 16, 32 or 64; canonical CSR: sorted columns, no duplicates).  The operator of
- * scipy svds (tools.py:53; _svds.py:441-466 matvec / rmatvec) for a block of B vectors.
- * Positions: the kernel gives 4 consecutive positions to the four 16-lane groups of a wave, K such
- * row-sets to a wave, 16 waves to a workgroup; perm (int32[n_pos], -1 = no row, NULL = identity with
- * n_pos = n_rows) only decides which rows share a wave - nothing is moved in memory.  The host sorts
- * the rows by length and deals them round robin (muon_amd/_backend.py spmm_layout), K =
- * mu_spmm_csr_k(n_rows) (k_layout = 0: chosen here).  The entries of a row are accumulated in column
- * order with one fmaf chain per dense column, whatever the layout => bit-reproducible, and
- * bit-identical to mu_spmm_packed_f32. */
-int mu_spmm_csr_k(int64_t n_rows);
-int mu_spmm_csr_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
-                    const float* d_values, const int32_t* d_perm, int k_layout, const float* d_Q, int B,
-                    float* d_Y, void* stream);
-
-/* The same product from the PAIR STREAM of the matrix: ent[p] = column (int32) | value bits (f32) << 32
- * for the entries in CSR order, addressed with the same row pointers (8 bytes per entry in one array:
- * a 16-entry window is one 128-byte request instead of two 64-byte ones, and half as many distinct
- * lines are alive in the L2).  mu_csr_pairs_fill copies a CSR into it; mu_csr_tpack_fill_pairs writes
- * the pair stream of X^T straight from the CSR of X (same sequence as mu_csr_tpack_fill_csr). */
-int mu_csr_pairs_fill(int64_t nnz, const int32_t* d_indices, const float* d_values, void* d_ent,
+/* ---- the SpMM of the LSI iteration and its operand, the ROW STREAM (r02) --------------------------
+ * Y[perm[p]][0..B-1] = row perm[p] of X times Q for every position p < n_pos (B = 16, 32 or 64): the
+ * operator of scipy svds (tools.py:53; _svds.py:441-466 matvec / rmatvec) for a block of B vectors.
+ *
+ * Row stream: the (column int32, value f32) pairs of the matrix, 8 bytes each, row after row in
+ * LAUNCH ORDER without padding - position p holds row perm[p] (perm[p] < 0: no row; perm == NULL: the
+ * identity, n_pos = n_rows) at ent[sptr[p] .. sptr[p+1]), sptr int64[n_pos + 1].  The kernel gives 4
+ * consecutive positions to the four 16-lane groups of a wave, K such row-sets to a wave, 16 waves
+ * to a workgroup (K = mu_spmm_stream_k(n_rows)); the host sorts the rows by length and deals the
+ * row-sets round robin to workgroups and waves (muon_amd/_backend.py spmm_layout), so that rows that
+ * advance in lock step have similar lengths and every workgroup gets the same mix.  The 64 K rows of
+ * one workgroup must span less than 4 GiB of the stream (cursors are 32-bit byte offsets).
+ *   1. mu_csr_stream_len: len[p] = stored entries of row perm[p] (0 for an empty position)
+ *   2. caller scans len into sptr (mu_exclusive_scan_i64) and allocates ent: 8 bytes x sptr[n_pos]
+ *   3. mu_csr_stream_fill (a streaming copy), or - for X^T straight from the CSR of X -
+ *      mu_csr_tpack_count, the layout of the output rows from col_nnz, and mu_csr_tpack_fill_stream
+ *      (inv int32[n_cols]: output row -> position) with the SAME d_work
+ * Requires canonical CSR (sorted column indices, no duplicates).  The entries of a row are
+ * accumulated in column order with one fmaf chain per dense column, whatever the layout =>
+ * bit-reproducible and layout-independent. */
+int mu_spmm_stream_k(int64_t n_rows);
+int mu_csr_stream_len(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr, int64_t* d_len,
                       void* stream);
-int mu_csr_tpack_fill_pairs(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
-                            const int32_t* d_indices, const float* d_values, const int64_t* d_t_indptr,
-                            void* d_t_ent, void* d_work, size_t work_bytes, void* stream);
-int mu_spmm_pairs_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_indptr, const void* d_ent,
-                      const int32_t* d_perm, int k_layout, const float* d_Q, int B, float* d_Y,
-                      void* stream);
-
-/* Y[perm[p]][0..B-1] = row perm[p] of X times Q, for every position p < n_pos (B = 16, 32 or 64,
- * n_cols <= 2^22).  k_layout = the K the layout was dealt for (0: mu_spmm_packed_k(n_pos)).  Same
- * result as mu_spmm_f32 up to f32 summation order: the entries of a row are accumulated in column
- * order with one fmaf chain per dense column, whatever the layout => bit-reproducible. */
-int mu_spmm_packed_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_cptr, const void* d_ent,
+int mu_csr_stream_fill(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr,
+                       const int32_t* d_indices, const float* d_values, const int64_t* d_sptr,
+                       void* d_ent, void* stream);
+int mu_csr_tpack_fill_stream(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
+                             const int32_t* d_indices, const float* d_values, const int64_t* d_sptr,
+                             const int32_t* d_inv, void* d_ent, void* d_work, size_t work_bytes,
+                             void* stream);
+int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, const void* d_ent,
                        const int32_t* d_perm, int k_layout, const float* d_Q, int B, float* d_Y,
                        void* stream);
+
 
 /* Tuning / ablation knobs (tests and bench only; all default to 0 = what ships):
  *   "spmm_k"     row-sets per wave of the packed SpMM (0 = automatic)

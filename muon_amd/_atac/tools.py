@@ -193,16 +193,16 @@ def _lsi_device(
     max_blocks = max(int(max_blocks), keep_blocks + 2)
     if X.values.dtype != torch.float32:
         X = X.with_values(X.values.to(torch.float32))
-    # both operands of the iteration are streamed from their packed chunked-row copies
-    # (DESIGN.md §4); X^T's is built straight from the CSR of X, no CSR of X^T in between.
+    # both operands of the iteration are read from their row streams; X^T's is built
+    # straight from the CSR of X, no CSR of X^T in between.  (`pack=False`: plain CSR kernels.)
     if pack is None:
-        pack = (Xt is None and hasattr(backend, "can_pack") and backend.can_pack(X, B)
-                and 0 < n_local <= (1 << 20))
-    if pack and hasattr(backend, "pack_both"):
-        X, Xt = backend.pack_both(X)
+        pack = Xt is None and hasattr(backend, "can_stream") and backend.can_stream(X, B)
+    if pack and getattr(X, "stream", None) is not None:
+        Xs = X.stream  # written by the TF-IDF scale pass of the same call sequence
+        Xt = backend.transpose_stream(X)
+        X = Xs
     elif pack:
-        Xt = backend.transpose_pack(X)
-        X = backend.pack(X)
+        X, Xt = backend.stream_both(X)
     elif Xt is None:
         Xt = backend.transpose(X)
 

@@ -29,10 +29,6 @@ class DeviceCSR:
     indices: torch.Tensor
     values: torch.Tensor
     shape: Tuple[int, int]
-    # SpMM launch layout (HipBackend.spmm_layout): position p of the launch handles row perm[p]
-    # (-1: none); k = row-sets per wave it was dealt for.  None: rows in matrix order.
-    perm: Optional[torch.Tensor] = None
-    k: int = 0
 
     @property
     def nnz(self) -> int:
@@ -43,17 +39,17 @@ class DeviceCSR:
         return self.values.dtype
 
     def with_values(self, values: torch.Tensor) -> "DeviceCSR":
-        return DeviceCSR(self.indptr, self.indices, values, self.shape, self.perm, self.k)
+        return DeviceCSR(self.indptr, self.indices, values, self.shape)
 
 
 @dataclass
-class DevicePackedCSR:
-    """Packed chunked-row copy of a CSR ("PCR16", include/muon_amd.h): cptr int64[n_pos+1] chunk
-    offsets, ent uint8[128 * n_chunks] (16 (column, value) pairs per chunk), perm int32[n_pos]
-    (position -> row of the matrix, -1 = none; None = identity), k = the row-sets-per-wave the
-    layout was dealt for.  SpMM-only."""
+class DeviceStream:
+    """Row stream of a CSR (include/muon_amd.h): the (column, value) pairs, 8 bytes each, row after
+    row in the launch order of the SpMM - position p holds row perm[p] (-1 = none; None = identity)
+    at ent[sptr[p] : sptr[p+1]], no padding; k = the row-sets-per-wave the layout was dealt for.
+    SpMM-only."""
 
-    cptr: torch.Tensor
+    sptr: torch.Tensor
     ent: torch.Tensor
     shape: Tuple[int, int]
     nnz: int
@@ -62,23 +58,7 @@ class DevicePackedCSR:
 
     @property
     def n_pos(self) -> int:
-        return int(self.cptr.numel()) - 1
-
-
-@dataclass
-class DevicePairs:
-    """Pair stream of a CSR (include/muon_amd.h): indptr int64[n+1] (the CSR's), ent int64[nnz] =
-    column | value bits << 32, plus the SpMM launch layout (perm, k).  SpMM-only."""
-
-    indptr: torch.Tensor
-    ent: torch.Tensor
-    shape: Tuple[int, int]
-    perm: Optional[torch.Tensor] = None
-    k: int = 0
-
-    @property
-    def nnz(self) -> int:
-        return int(self.ent.numel())
+        return int(self.sptr.numel()) - 1
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -221,20 +201,9 @@ class HipBackend:
                                             _p(t_values), _p(work), wb, self._stream()))
         return DeviceCSR(t_indptr, t_indices, t_values, (d, n))
 
-    def spmm_layout(self, X: DeviceCSR) -> DeviceCSR:
-        """The same CSR with a launch layout for mu_spmm_csr_f32 attached: rows sorted by length
-        (descending, stable) and dealt round robin to workgroups and waves (``packed_layout``), so
-        that the four rows a wave advances in lock step have similar lengths and every workgroup
-        gets the same mix.  Nothing is moved in memory."""
-        n = X.shape[0]
-        if n == 0:
-            return X
-        perm, _inv, K = self.packed_layout(X.indptr[1:] - X.indptr[:-1], k_fn=self.lib.mu_spmm_csr_k)
-        return DeviceCSR(X.indptr, X.indices, X.values, X.shape, perm, K)
-
-    def transpose_csr(self, X: DeviceCSR, layout: bool = True) -> DeviceCSR:
+    def transpose_csr(self, X: DeviceCSR) -> DeviceCSR:
         """CSR of X^T straight from the CSR of X (f32; stable: cells ascending inside every row =>
-        canonical rows and bit-reproducible SpMM sums), with the SpMM launch layout attached."""
+        canonical rows), through the tile-staged transposition of csrc/tpack.hip."""
         n, d = X.shape
         assert X.values.dtype == torch.float32
         col_nnz = self.empty((max(d, 1),), torch.int64)
@@ -250,56 +219,79 @@ class HipBackend:
             check(self.lib.mu_exclusive_scan_i64(d, _p(col_nnz), _p(t_indptr), st))
             check(self.lib.mu_csr_tpack_fill_csr(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
                                                  _p(t_indptr), _p(t_indices), _p(t_values), _p(work), wb, st))
-        Xt = DeviceCSR(t_indptr, t_indices, t_values, (d, n))
-        if layout and d > 0:
-            perm, _inv, K = self.packed_layout(col_nnz[:d], k_fn=self.lib.mu_spmm_csr_k)
-            Xt = DeviceCSR(t_indptr, t_indices, t_values, (d, n), perm, K)
-        return Xt
+        return DeviceCSR(t_indptr, t_indices, t_values, (d, n))
 
-    def pairs(self, X: DeviceCSR, layout: bool = True) -> DevicePairs:
-        """Pair stream of X (streaming copy) with the SpMM launch layout attached."""
-        assert X.values.dtype == torch.float32
-        ent = self.empty((max(X.nnz, 1),), torch.int64)[:X.nnz]
+    def can_stream(self, X: DeviceCSR, B: int) -> bool:
+        """The row-stream SpMM exists for f32 values and B in (16, 32, 64)."""
+        return X.values.dtype == torch.float32 and B in (16, 32, 64) and X.shape[0] > 0 and X.shape[1] > 0
+
+    def _stream_sptr(self, lens_by_pos: torch.Tensor, K: int):
+        n_pos = int(lens_by_pos.numel())
+        sptr = self.zeros((n_pos + 1,), torch.int64)
         with torch.cuda.device(self.device):
-            check(self.lib.mu_csr_pairs_fill(X.nnz, _p(X.indices), _p(X.values), _p(ent), self._stream()))
-        perm, K = X.perm, X.k
-        if layout and perm is None and X.shape[0] > 0:
-            perm, _inv, K = self.packed_layout(X.indptr[1:] - X.indptr[:-1], k_fn=self.lib.mu_spmm_csr_k)
-        return DevicePairs(X.indptr, ent, X.shape, perm, K)
+            check(self.lib.mu_exclusive_scan_i64(n_pos, _p(lens_by_pos), _p(sptr), self._stream()))
+        # cursors are 32-bit byte offsets from the first pair of the workgroup's 64 K rows
+        per_wg = 64 * K
+        span = sptr[per_wg::per_wg] - sptr[:-per_wg:per_wg] if n_pos > per_wg else sptr[-1:] - sptr[:1]
+        if span.numel() and int(span.max().item()) * 8 >= (1 << 32) - 256:
+            raise NotImplementedError("row stream: the rows of one workgroup span 4 GiB or more")
+        return sptr
 
-    def transpose_pairs(self, X: DeviceCSR, layout: bool = True) -> DevicePairs:
-        """Pair stream of X^T straight from the CSR of X (stable: cells ascending inside every row)."""
+    def stream(self, X: DeviceCSR, sort_rows: bool = True) -> DeviceStream:
+        """Row stream of X for the SpMM of the iteration (a streaming copy, once per lsi call)."""
+        n, d = X.shape
+        assert X.values.dtype == torch.float32
+        perm, K, n_pos = None, max(1, int(self.lib.mu_spmm_stream_k(n))), n
+        if sort_rows and n > 0:
+            perm, _inv, K = self.launch_layout(X.indptr[1:] - X.indptr[:-1])
+            n_pos = int(perm.numel())
+        lens = self.empty((max(n_pos, 1),), torch.int64)[:n_pos]
+        with torch.cuda.device(self.device):
+            st = self._stream()
+            check(self.lib.mu_csr_stream_len(n_pos, _p(perm), _p(X.indptr), _p(lens), st))
+            sptr = self._stream_sptr(lens, K)
+            ent = self.empty((max(X.nnz, 1),), torch.int64)
+            check(self.lib.mu_csr_stream_fill(n_pos, _p(perm), _p(X.indptr), _p(X.indices), _p(X.values),
+                                              _p(sptr), _p(ent), st))
+        return DeviceStream(sptr, ent, (n, d), X.nnz, perm, K)
+
+    def transpose_stream(self, X: DeviceCSR, sort_rows: bool = True, before_fill=None) -> DeviceStream:
+        """Row stream of X^T straight from the CSR of X (no CSR of X^T; stable: cells ascending inside
+        every row).  ``before_fill``: called once the count phase is done and before the fill is queued."""
         n, d = X.shape
         assert X.values.dtype == torch.float32
         col_nnz = self.empty((max(d, 1),), torch.int64)
-        t_indptr = self.zeros((d + 1,), torch.int64)
-        ent = self.empty((max(X.nnz, 1),), torch.int64)[:X.nnz]
         wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
         work = self.empty((wb,), torch.uint8)
         with torch.cuda.device(self.device):
             st = self._stream()
             check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
                                               _p(work), wb, st))
-            check(self.lib.mu_exclusive_scan_i64(d, _p(col_nnz), _p(t_indptr), st))
-            check(self.lib.mu_csr_tpack_fill_pairs(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
-                                                   _p(t_indptr), _p(ent), _p(work), wb, st))
-        perm, K = None, 0
-        if layout and d > 0:
-            perm, _inv, K = self.packed_layout(col_nnz[:d], k_fn=self.lib.mu_spmm_csr_k)
-        return DevicePairs(t_indptr, ent, (d, n), perm, K)
+            perm, inv, K, n_pos = None, None, max(1, int(self.lib.mu_spmm_stream_k(d))), d
+            lens = col_nnz[:d]
+            if sort_rows and d > 0:
+                perm, inv, K = self.launch_layout(lens)
+                n_pos = int(perm.numel())
+                plens = torch.zeros((n_pos,), dtype=torch.int64, device=self.device)
+                plens[inv.long()] = lens
+            else:
+                plens = lens.contiguous()
+            sptr = self._stream_sptr(plens, K)
+            ent = self.empty((max(X.nnz, 1),), torch.int64)
+            if before_fill is not None:
+                before_fill()
+            check(self.lib.mu_csr_tpack_fill_stream(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
+                                                    _p(sptr), _p(inv), _p(ent), _p(work), wb, st))
+        return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K)
 
-    def can_pack(self, X: DeviceCSR, B: int) -> bool:
-        """The packed SpMM exists for f32 values, B in (16, 32, 64) and at most 2^22 columns."""
-        return X.values.dtype == torch.float32 and B in (16, 32, 64) and 0 < X.shape[1] <= (1 << 22)
-
-    def packed_layout(self, lens: torch.Tensor, k_fn=None):
-        """Where the rows go in a packed copy (include/muon_amd.h): sorted by length (descending,
+    def launch_layout(self, lens: torch.Tensor):
+        """Where the rows go in a row stream (include/muon_amd.h): sorted by length (descending,
         stable) and dealt round robin - row-set q of the sorted order goes to workgroup q % n_wg,
         inside it to wave (q // n_wg) % 16 and row-set slot (q // n_wg) // 16 - so that the four rows
         a wave advances in lock step have similar lengths and every workgroup and wave gets the same
         mix.  Returns (perm int32[n_pos], inv int32[n], K)."""
         n = int(lens.numel())
-        K = max(1, int((k_fn or self.lib.mu_spmm_packed_k)(n)))
+        K = max(1, int(self.lib.mu_spmm_stream_k(n)))
         per_wg = 64 * K
         n_wg = max(1, (n + per_wg - 1) // per_wg)
         # One workgroup per CU runs at a time (128 KiB of LDS) and the dealt workgroups take equally
@@ -323,87 +315,35 @@ class HipBackend:
         inv[order] = pos.to(torch.int32)
         return perm, inv, K
 
-    def pack(self, X: DeviceCSR, sort_rows: bool = True) -> DevicePackedCSR:
-        """Build the packed chunked-row copy used by the B = 64 SpMM (once per lsi call)."""
-        n, d = X.shape
-        assert X.values.dtype == torch.float32
-        perm, K, n_pos = None, 0, n
-        if sort_rows and n > 0:
-            perm, _inv, K = self.packed_layout(X.indptr[1:] - X.indptr[:-1])
-            n_pos = int(perm.numel())
-        row_chunks = self.empty((max(n_pos, 1),), torch.int64)
-        cptr = self.zeros((n_pos + 1,), torch.int64)
-        with torch.cuda.device(self.device):
-            st = self._stream()
-            check(self.lib.mu_csr_pack_count(n_pos, _p(perm), _p(X.indptr), _p(row_chunks), st))
-            check(self.lib.mu_exclusive_scan_i64(n_pos, _p(row_chunks), _p(cptr), st))
-            n_chunks = int(cptr[-1].item()) if n_pos > 0 else 0
-            ent = self.empty((max(n_chunks, 1) * 128,), torch.uint8)
-            check(self.lib.mu_csr_pack_fill(n_pos, _p(perm), _p(X.indptr), _p(X.indices), _p(X.values),
-                                            _p(cptr), _p(ent), st))
-        return DevicePackedCSR(cptr, ent, (n, d), X.nnz, perm, K)
-
-    def pack_both(self, X: DeviceCSR):
-        """(packed X, packed X^T).  The two builders are independent; the streaming copy of X
-        (HBM bound) runs on a second stream under the transpose-pack, whose fill is instruction
-        bound and leaves half of every CU's wave slots free."""
+    def stream_both(self, X: DeviceCSR):
+        """(row stream of X, row stream of X^T).  The two builders are independent; the streaming
+        copy of X (HBM bound) runs on a second stream under the transposition, whose fill is
+        instruction bound and leaves half of every CU's wave slots free."""
         cur = torch.cuda.current_stream(self.device)
         side = self.__dict__.get("_side_stream")
         if side is None:
             side = self._side_stream = torch.cuda.Stream(self.device)
         got = []
 
-        def start_pack():
-            # right before the fill: the count phase of the transpose-pack (binary searches and a
+        def start_copy():
+            # right before the fill: the count phase of the transposition (binary searches and a
             # histogram, latency bound) slowed down 4x next to the streaming copy, the fill does not
             side.wait_stream(cur)
             wg = int(os.environ.get("MUON_AMD_PACK_WG", "2"))  # (A/B on one box, c3: 32 -> 451, 4 -> 449, 2 -> 441 ms per step)
             with torch.cuda.stream(side):
                 self.tune("pack_wg", wg)  # few workgroups per CU: the fill's 1024-thread groups must fit next to them
                 try:
-                    got.append(self.pack(X))
+                    got.append(self.stream(X))
                 finally:
                     self.tune("pack_wg", 0)
 
-        Xt = self.transpose_pack(X, before_fill=start_pack)
-        Xp = got[0]
+        Xt = self.transpose_stream(X, before_fill=start_copy)
+        Xs = got[0]
         cur.wait_stream(side)
-        for t in (Xp.cptr, Xp.ent, Xp.perm):
+        for t in (Xs.sptr, Xs.ent, Xs.perm):
             if t is not None:
                 t.record_stream(cur)
-        return Xp, Xt
-
-    def transpose_pack(self, X: DeviceCSR, sort_rows: bool = True, before_fill=None) -> DevicePackedCSR:
-        """Packed chunked-row copy of X^T straight from the CSR of X (no CSR of X^T).
-        ``before_fill``: called once the count phase is done and before the fill is queued."""
-        n, d = X.shape
-        assert X.values.dtype == torch.float32
-        col_nnz = self.empty((max(d, 1),), torch.int64)
-        wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
-        work = self.empty((wb,), torch.uint8)
-        with torch.cuda.device(self.device):
-            st = self._stream()
-            check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
-                                              _p(work), wb, st))
-            perm, inv, K, n_pos = None, None, 0, d
-            lens = col_nnz[:d]
-            if sort_rows and d > 0:
-                perm, inv, K = self.packed_layout(lens)
-                n_pos = int(perm.numel())
-                plens = torch.zeros((n_pos,), dtype=torch.int64, device=self.device)
-                plens[inv.long()] = lens
-            else:
-                plens = lens
-            row_chunks = (plens + 15) // 16 + 1
-            cptr = self.zeros((n_pos + 1,), torch.int64)
-            check(self.lib.mu_exclusive_scan_i64(n_pos, _p(row_chunks), _p(cptr), st))
-            n_chunks = int(cptr[-1].item()) if n_pos > 0 else 0
-            ent = self.empty((max(n_chunks, 1) * 128,), torch.uint8)
-            if before_fill is not None:
-                before_fill()
-            check(self.lib.mu_csr_tpack_fill(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
-                                             n_pos, _p(cptr), _p(perm), _p(inv), _p(ent), _p(work), wb, st))
-        return DevicePackedCSR(cptr, ent, (d, n), X.nnz, perm, K)
+        return Xs, Xt
 
     def fetch_async(self, tensors):
         """Start device -> host copies of small tensors into pinned staging buffers; ``wait()`` on
@@ -432,39 +372,19 @@ class HipBackend:
         n, d = X.shape
         B = Q.shape[1]
         assert Q.shape[0] == d and Q.dtype in (torch.float32, torch.float64) and Q.is_contiguous()
-        if isinstance(X, DevicePairs):
+        if isinstance(X, DeviceStream):
             if Q.dtype != torch.float32 or B not in (16, 32, 64):
-                raise TypeError("the pair-stream SpMM needs an f32 dense block of width 16, 32 or 64")
-            if out is None:
-                out = self.empty((n, B), Q.dtype)
-            n_pos = int(X.perm.numel()) if X.perm is not None else n
-            with torch.cuda.device(self.device):
-                check(self.lib.mu_spmm_pairs_f32(n_pos, d, _p(X.indptr), _p(X.ent), _p(X.perm),
-                                                 X.k if X.perm is not None else 0, _p(Q), B, _p(out),
-                                                 self._stream()))
-            return out
-        if isinstance(X, DevicePackedCSR):
-            if Q.dtype != torch.float32 or B not in (16, 32, 64):
-                raise TypeError("the packed SpMM needs an f32 dense block of width 16, 32 or 64")
+                raise TypeError("the row-stream SpMM needs an f32 dense block of width 16, 32 or 64")
             if out is None:
                 out = self.empty((n, B), Q.dtype)
             with torch.cuda.device(self.device):
-                check(self.lib.mu_spmm_packed_f32(X.n_pos, d, _p(X.cptr), _p(X.ent), _p(X.perm), X.k,
+                check(self.lib.mu_spmm_stream_f32(X.n_pos, d, _p(X.sptr), _p(X.ent), _p(X.perm), X.k,
                                                   _p(Q), B, _p(out), self._stream()))
             return out
         if X.values.dtype != Q.dtype:
             raise TypeError("spmm needs values and dense block of one dtype")
         if out is None:
             out = self.empty((n, B), Q.dtype)
-        if (Q.dtype == torch.float32 and B in (16, 32, 64) and n > 0 and d > 0
-                and not self.__dict__.get("_no_csr_win")):
-            # the LDS-slab kernel on the CSR arrays; rows in matrix order unless a layout is attached
-            n_pos = int(X.perm.numel()) if X.perm is not None else n
-            with torch.cuda.device(self.device):
-                check(self.lib.mu_spmm_csr_f32(n_pos, d, _p(X.indptr), _p(X.indices), _p(X.values),
-                                               _p(X.perm), X.k if X.perm is not None else 0, _p(Q), B,
-                                               _p(out), self._stream()))
-            return out
         fn = self.lib.mu_spmm_f32 if Q.dtype == torch.float32 else self.lib.mu_spmm_f64
         with torch.cuda.device(self.device):
             check(fn(n, d, _p(X.indptr), _p(X.indices), _p(X.values), _p(Q), B, _p(out), 0,

@@ -216,11 +216,10 @@ class MofaEngine:
             for g, (a, b) in enumerate(self.gslice):
                 V.Y[a:b] -= mu[g] * V.pres[a:b, None]  # explicit centring of the dense block
             V.Yt = None
-        elif self.T == torch.float32 and hasattr(be, "can_pack") and be.can_pack(V.X, 16) \
-                and 0 < V.X.shape[0] <= (1 << 22):
-            # f32: both directions stream packed chunked-row copies, built once
-            V.Xt = be.transpose_pack(V.X)
-            V.Xs = be.pack(V.X)
+        elif self.T == torch.float32 and hasattr(be, "can_stream") and be.can_stream(V.X, 16):
+            # f32: both directions read row streams, built once
+            V.Xt = be.transpose_stream(V.X)
+            V.Xs = be.stream(V.X)
         else:
             V.Xt = be.transpose(V.X)
             V.Xs = V.X

@@ -57,20 +57,15 @@ SIGNATURES = {
     "mu_csr_transpose_worksize": (_sz, [_i64, _i64, _i64]),
     "mu_csr_transpose": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
-    "mu_spmm_packed_k": (C.c_int, [_i64]),
-    "mu_csr_pack_count": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
-    "mu_csr_pack_fill": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_csr_tpack_worksize": (_sz, [_i64, _i64, _i64]),
     "mu_csr_tpack_count": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_csr_tpack_count_sp": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "mu_csr_tpack_fill": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_csr_tpack_fill_csr": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "mu_spmm_csr_k": (C.c_int, [_i64]),
-    "mu_spmm_csr_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
-    "mu_csr_pairs_fill": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
-    "mu_csr_tpack_fill_pairs": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "mu_spmm_pairs_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
-    "mu_spmm_packed_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
+    "mu_spmm_stream_k": (C.c_int, [_i64]),
+    "mu_csr_stream_len": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "mu_csr_stream_fill": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mu_csr_tpack_fill_stream": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mu_spmm_stream_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "mu_tune_set": (C.c_int, [C.c_char_p, _i32]),
     "mu_tune_get": (C.c_int, [C.c_char_p]),
     "mu_spmm_f64": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),

@@ -1,35 +1,38 @@
-// SpMM straight from the CSR arrays (f32):  Y[n x B] = X[n x d] * Q[d x B],  B = 64 / 32 / 16.
+// SpMM on the row stream of a CSR (f32):  Y[n x B] = X[n x d] * Q[d x B],  B = 64 / 32 / 16.
 //
 // This is the kernel the block Lanczos iteration of muon_amd.atac.tl.lsi spends its time in; it
 // stands where ARPACK's reverse-communication loop calls csr_matvec / csr_matvecs through
 // scipy.sparse.linalg.svds (/root/reference/muon/_atac/tools.py:53, scipy _svds.py:441-466,516).
-// The transposed product runs through the same kernel on the CSR of X^T (tpack.hip).
+// The transposed product runs through the same kernel on the row stream of X^T (tpack.hip).
 //
-// r02: no packed copy any more.  r01 re-laid every operand out as 128-byte chunks ("PCR16") so
-// that the chunk stream could be fetched line by line; cutting a 16-slot window out of (current
-// chunk ++ next chunk) cost two ds_bpermute and ~30 VALU per (row-set, slab) - 30 % of the launch
-// - and building the copies cost a quarter of an lsi() call.  Here a 16-lane group reads the 16
-// entries behind its row's cursor directly (two 64-byte pieces of indices[] and values[],
-// unaligned), so the window IS the load result; what is left of stage A is a compare, a ballot,
-// four scalar popcounts and the cursor update.  A line is requested about twice (the unconsumed
-// tail of a window is loaded again one slab later, from L2 / Infinity Cache).
+// Operand ("row stream", built once per lsi() call by mu_csr_stream_fill / mu_csr_tpack_fill_stream):
+// the (column, value) pairs of the matrix, 8 bytes each, row after row in LAUNCH ORDER - position p
+// of the launch holds row perm[p] at ent[sptr[p] .. sptr[p+1]) - without any padding.  The rows of
+// one workgroup are contiguous, so a cursor is a 32-bit byte offset from the workgroup's base.
+//
+// r02 (was: 128-byte chunks "PCR16", a window cut out of current ++ next chunk with two
+// ds_bpermute and ~30 VALU per pass): a 16-lane group reads the 16 pairs behind its row's cursor
+// with ONE unaligned 128-byte request, so the window IS the load result; what is left of stage A
+// is a compare, a ballot, four scalar popcounts and the cursor update (13 VALU).  The unconsumed
+// tail of a window is requested again one slab later and is served by the L2 (measured: HBM
+// fetch 1.15x the algorithmic bytes at K = 4, 2.5x at K = 8 where the XCD's live lines exceed
+// its 4 MiB).
 //
 // Kernel structure (one 1024-thread workgroup = 64*K rows, K <= 8, per CU):
 //   * the columns of X are swept in slabs of 256; the slab's 256 Q rows (64 KiB at B = 64) are
-//     copied to LDS by LDS-DMA, double buffered;
+//     copied to LDS by LDS-DMA, double buffered; a wave issues its 1 KiB pieces of the NEXT slab
+//     one per pass, not as one burst (the burst kept every wave ~200 cycles per pass in the issue
+//     queue of the texture path and delayed the window requests queued behind it);
 //   * a wave is four 16-lane groups, group g walks the row at position 4k+g of row-set k and keeps
 //     its K accumulators in registers; lane `sub` owns dense columns NB*sub .. NB*sub+NB-1;
 //   * rows are sorted, so the entries of this slab are a prefix of the window: count them per
 //     group (ballot + s_bcnt1), advance the cursor, and request the next window right away - it
-//     arrives a full slab sweep later (EXEC-masked global_load_dword x 2 from inline asm: exactly
-//     two VMEM instructions per row-set and slab, so completion is tracked with counted
+//     arrives a full slab sweep later (EXEC-masked global_load_dwordx2 from inline asm: exactly
+//     one VMEM instruction per row-set and slab, so completion is tracked with an exact counted
 //     s_waitcnt vmcnt instead of the vmcnt(0) hipcc falls back to for conditional loads);
 //   * entry e's (LDS address, value) is broadcast inside the group with DPP row_newbcast, one
-//     ds_read_b128 serves four rows, FMAs in f32.
-//
-// Row order: position p of the launch handles row perm[p] (-1: none); the host sorts the rows by
-// length and deals them round robin (muon_amd/_backend.py: spmm_layout) - nothing is moved in
-// memory, the positions only decide which rows share a wave.
+//     ds_read_b128 serves four rows, FMAs in f32; the LDS reads of window slots 0-7 are issued
+//     together (one LDS round trip instead of two; a pass is a chain of dependent round trips).
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -137,38 +140,21 @@ __device__ __forceinline__ void dma_piece(const float4* gsrc, unsigned lds_dst) 
       "v122", "v123", "v124", "v125"
 
 // Request the window at the group's cursor: lanes of `mask` (those still inside their row) load
-// (column, value); the others get the padding column.  Always exactly two VMEM instructions, also
-// when the mask is empty: gfx950 counts a VMEM instruction issued with EXEC = 0 in order
-// (scripts/probes/exec0_vmcnt.hip), which is what the counted waits rely on.
+// their (column, value) pair from base + off; the others get the padding column.  Always exactly
+// one VMEM instruction, also when the mask is empty: gfx950 counts a VMEM instruction issued with
+// EXEC = 0 in order (scripts/probes/exec0_vmcnt.hip), which is what the counted waits rely on.
 template <int k>
-__device__ __forceinline__ void request_window(const void* pidx, const void* pval,
-                                               unsigned long long mask) {
+__device__ __forceinline__ void request_window(unsigned off, const void* base, unsigned long long mask) {
   unsigned long long save;
   asm volatile(
       "s_mov_b64 %0, exec\n\t"
       "v_mov_b32 v%c4, 0x7fffffff\n\t"
       "s_and_b64 exec, exec, %3\n\t"
-      "global_load_dword v%c4, %1, off\n\t"
-      "global_load_dword v%c5, %2, off\n\t"
+      "global_load_dwordx2 v[%c4:%c5], %1, %2\n\t"
       "s_mov_b64 exec, %0"
       : "=&s"(save)
-      : "v"(pidx), "v"(pval), "s"(mask), "i"(kNX + 2 * k), "i"(kNX + 2 * k + 1)
+      : "v"(off), "s"(base), "s"(mask), "i"(kNX + 2 * k), "i"(kNX + 2 * k + 1)
       : MU_WIN_CLOB, "scc");  // s_and_b64 writes SCC: hipcc does keep compares alive across the asm
-}
-
-// Same for the pair stream (8 bytes per entry: column, value bits): one global_load_dwordx2.
-template <int k>
-__device__ __forceinline__ void request_window_pairs(const void* pent, unsigned long long mask) {
-  unsigned long long save;
-  asm volatile(
-      "s_mov_b64 %0, exec\n\t"
-      "v_mov_b32 v%c3, 0x7fffffff\n\t"
-      "s_and_b64 exec, exec, %2\n\t"
-      "global_load_dwordx2 v[%c3:%c4], %1, off\n\t"
-      "s_mov_b64 exec, %0"
-      : "=&s"(save)
-      : "v"(pent), "s"(mask), "i"(kNX + 2 * k), "i"(kNX + 2 * k + 1)
-      : MU_WIN_CLOB, "scc");
 }
 
 // wait until at most N VMEM operations are outstanding, then read the window of row-set k
@@ -209,15 +195,13 @@ struct Win {      // what stage A of a pass hands to stage B
 };
 
 // MODE is 0 in production; the other bits switch parts of the kernel off for timing ablations
-// (results are then wrong on purpose): 1 no LDS gathers / FMAs, 2 no slab DMA, 8 no window
-// requests (and no overflow passes).
-// PAIRS: `indices` points at the pair stream (ent[p] = column | value bits << 32, same row pointers as
-// the CSR), `values` is unused; one 8-byte load per lane and window instead of two 4-byte ones.
-template <int K, int MODE, int NB, bool PAIRS>
+// (results are then wrong on purpose): 1 no LDS gathers / FMAs, 8 no window requests (and no
+// overflow passes), 32 window slots 0-7 as two batches of four LDS reads (r01), 64 per-wave cycle
+// accounting instead of the product.
+template <int K, int MODE, int NB>
 __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
-                                              const int64_t* __restrict__ indptr,
-                                              const int32_t* __restrict__ indices,
-                                              const float* __restrict__ values,
+                                              const int64_t* __restrict__ sptr,
+                                              const unsigned long long* __restrict__ ent,
                                               const int32_t* __restrict__ perm,
                                               const float* __restrict__ Q, float* __restrict__ Y) {
   static_assert(K >= 1 && K <= kKMax, "K out of range");
@@ -229,18 +213,15 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
   constexpr int kPieces = kSlabBytes / 1024;                 // 1 KiB LDS-DMA pieces per slab
   constexpr int kMyPieces = kPieces / W;                     // per wave and slab: 4 / 2 / 1
   static_assert(kPieces % W == 0, "every wave issues the same number of DMA pieces");
+  constexpr bool kDeep = !(MODE & 32);
   // VMEM order of a wave in one slab: D0 R0 D1 R1 ... (DMA piece u of the NEXT slab goes out right
   // before pass u, the pieces a short K leaves over after the last pass; R = the window request of a
   // pass).  Between the request of (row-set k, slab s-1) and pass (k, s) that is always K - 1
   // requests and kMyPieces DMA pieces, whatever k - the last slab issues its (unused) pieces too -
   // so the wait for a window is exact: nothing younger is waited for.
-  // eight LDS reads in flight need 32 result registers: they fit next to K <= 6 accumulator sets
-  // (hipcc spills beyond - and scratch traffic would share vmcnt with the hand-counted requests)
-  constexpr bool kDeep = (K * NB <= 24) && !(MODE & 32);
-  constexpr int kPerPass = PAIRS ? 1 : 2;  // VMEM instructions of one window request
-  constexpr int kWaitMain = kPerPass * (K - 1) + kMyPieces;
+  constexpr int kWaitMain = (K - 1) + kMyPieces;
   // ... and after the last DMA piece come the requests of passes kMyPieces-1 .. K-1
-  constexpr int kWaitSlab = K >= kMyPieces ? kPerPass * (K - kMyPieces + 1) : 0;
+  constexpr int kWaitSlab = K >= kMyPieces ? (K - kMyPieces + 1) : 0;
   __shared__ float4 qs[2][kSlabBytes / 16];  // double buffer; Q row c of a slab at byte c * kRowBytes
   const int lane = threadIdx.x & 63;
   const int wave = uniform32(threadIdx.x >> 6);
@@ -253,32 +234,27 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
   const int64_t q4_total = n_cols * (4 * NB);
   const int ncols32 = (int)n_cols;
   const unsigned qs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&qs[0][0]);
-  const int64_t vdelta = PAIRS ? 4 : reinterpret_cast<const char*>(values) - reinterpret_cast<const char*>(indices);
-  constexpr int kEntShift = PAIRS ? 3 : 2;  // log2 of the stride of the stream `ptr` walks
+  // the rows of this workgroup are contiguous in the stream: cursors are byte offsets from here
+  const int64_t wg0 = uniform64(sptr[rb0]);
+  const char* __restrict__ entb = reinterpret_cast<const char*>(ent + wg0);  // wave-uniform
 
   acc_t acc[K];
-  const char* ptr[K];  // address of indices[cursor + sub] of (row-set k, this lane's group)
-  int rem[K];          // entries of that row from the cursor on
+  unsigned off[K];  // byte offset of pair (cursor + sub) of (row-set k, this lane's group)
+  unsigned endv;    // lane 16 g + k: byte offset of the end of the row of (row-set k, group g)
   {
     // lane 16 g + k looks the row of (row-set k, group g) up; the others idle
     const int64_t p = rb0 + ((int64_t)wave * K + sub) * 4 + g;
     const bool ok = (sub < K) && (p < rb1);
-    const int64_t row = ok ? (perm ? (int64_t)perm[p] : p) : -1;
-    const int64_t lo = row >= 0 ? indptr[row] : 0;
-    const int64_t hi = row >= 0 ? indptr[row + 1] : 0;
-    const int lo_l = (int)(lo & 0xffffffffll), lo_h = (int)(lo >> 32);
-    const int len = (int)(hi - lo);
+    const unsigned lo = ok ? (unsigned)((sptr[p] - wg0) << 3) : 0u;
+    endv = ok ? (unsigned)((sptr[p + 1] - wg0) << 3) : 0u;
     static_for<K>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
 #pragma unroll
       for (int c = 0; c < NB; ++c) acc[k][c] = 0.f;
-      const int64_t l = ((int64_t)bcast_i<k>(lo_h) << 32) | (int64_t)(unsigned)bcast_i<k>(lo_l);
-      rem[k] = bcast_i<k>(len);
-      ptr[k] = reinterpret_cast<const char*>(indices) + ((l + sub) << kEntShift);
-      const bool in = sub < rem[k];
-      const int c0 = in ? *reinterpret_cast<const int*>(ptr[k]) : kPadCol;
-      const int v0 = in ? *reinterpret_cast<const int*>(ptr[k] + vdelta) : 0;
-      set_window<k>(c0, v0);
+      off[k] = (unsigned)bcast_i<k>((int)lo) + (unsigned)sub * 8u;
+      const bool in = off[k] < (unsigned)bcast_i<k>((int)endv);
+      const unsigned long long e = in ? *reinterpret_cast<const unsigned long long*>(entb + off[k]) : 0ull;
+      set_window<k>(in ? (int)(unsigned)e : kPadCol, (int)(unsigned)(e >> 32));
     });
   }
 
@@ -293,7 +269,7 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // MODE & 64: per-wave cycle accounting (s_memtime) of the four places a pass can spend time in;
+  // MODE & 64: per-wave cycle accounting (s_memtime) of the places a pass can spend time in;
   // the passes run unpipelined (A(k) then B(k)) and the sums replace the product in Y.
   unsigned t_wait = 0, t_a = 0, t_b = 0, t_bar = 0, t_dma = 0;
   auto now = [&]() -> unsigned { return (unsigned)__builtin_amdgcn_s_memtime(); };
@@ -315,10 +291,18 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
     // Stage A of a pass: the window of (row-set k, every group) has arrived; the entries of this
     // slab are a prefix of it.  Count them per group, advance the cursors, request the next window.
     // SLOW = overflow pass (a row had more than 16 entries in this slab): its request was issued
-    // just now, so drain everything; a main pass only needs the request of the previous slab.
+    // just now, so drain everything; a main pass waits for exactly its request of the previous slab.
     auto stage_a = [&](auto kc, auto slowc) -> Win {
       constexpr int k = decltype(kc)::value;
       constexpr bool SLOW = decltype(slowc)::value;
+      if constexpr (MODE & 128) {  // stage B alone: a synthetic 12-entry window for every group
+        Win ws;
+        ws.a = ((lane * 37 + k * 13 + (int)s0) & (kSlabCols - 1)) << kRowShift;
+        ws.vv = 1.0f;
+        ws.any16 = 0x0fffu;
+        if constexpr (MODE & 64) t_a -= now();
+        return ws;
+      }
       int col, valbits;
       unsigned tw0 = 0;
       if constexpr (MODE & 64) tw0 = now();
@@ -334,18 +318,15 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
       const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
       const unsigned c0 = __popc(mlo & 0xffffu), c1 = __popc(mlo >> 16);
       const unsigned c2 = __popc(mhi & 0xffffu), c3 = __popc(mhi >> 16);
-      const unsigned packed = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);  // wave-uniform
+      const unsigned packed = (c0 << 3) | (c1 << 11) | (c2 << 19) | (c3 << 27);  // wave-uniform: 8 * count, a byte per group
       const unsigned mm = mlo | mhi;
       Win w;
       w.any16 = (mm | (mm >> 16)) & 0xffffu;  // bit e: some group has entry e
       w.a = (col & (kSlabCols - 1)) << kRowShift;  // always inside the slab buffer, valid or not
       w.vv = valid ? __builtin_bit_cast(float, valbits) : 0.f;
       if constexpr (!(MODE & 8)) {
-        const int cnt = (int)((packed >> g8) & 0xffu);
-        rem[k] -= cnt;
-        ptr[k] += cnt << kEntShift;
-        if constexpr (PAIRS) request_window_pairs<k>(ptr[k], __ballot(sub < rem[k]));
-        else request_window<k>(ptr[k], ptr[k] + vdelta, __ballot(sub < rem[k]));
+        off[k] += (packed >> g8) & 0xffu;  // 8 bytes per consumed pair
+        request_window<k>(off[k], entb, __ballot(off[k] < (unsigned)bcast_i<k>((int)endv)));
         if ((c0 | c1 | c2 | c3) & 16u) again |= 1u << k;  // a window used up: maybe more in this slab
       }
       return w;
@@ -353,32 +334,48 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
     // Stage B: the LDS gathers and FMAs of the window.
     auto stage_b = [&](auto kc, const Win& w) {
       constexpr int k = decltype(kc)::value;
+      // the gathers are the part that is bound by a shared pipe (LDS): a wave that is in them goes
+      // first (measured on X Q / X^T Y at 125k x 200k: -6.5 % / -2.8 %)
+      __builtin_amdgcn_s_setprio(1);
       if constexpr (MODE & 1) {
         acc[k][0] += w.vv + (float)w.a;
-      } else {
-        if constexpr (kDeep) {
-          if (w.any16 & 0x00f0u) {
-            // the usual case (8 entries per row and slab): eight LDS reads in flight, one latency
-            const Quad<NB> r0 = quad_read<0, NB>(qbase, w.a);
-            const Quad<NB> r1 = quad_read<4, NB>(qbase, w.a);
-            quad_fma<0, NB>(r0, w.vv, acc[k]);
-            quad_fma<4, NB>(r1, w.vv, acc[k]);
-          } else if (w.any16 & 0x000fu) {
-            const Quad<NB> r = quad_read<0, NB>(qbase, w.a);
-            quad_fma<0, NB>(r, w.vv, acc[k]);
-          }
-        } else {
-          if (w.any16 & 0x000fu) { const Quad<NB> r = quad_read<0, NB>(qbase, w.a); quad_fma<0, NB>(r, w.vv, acc[k]); }
-          if (w.any16 & 0x00f0u) { const Quad<NB> r = quad_read<4, NB>(qbase, w.a); quad_fma<4, NB>(r, w.vv, acc[k]); }
+      } else if constexpr (kDeep) {
+        // A pass is a chain of LDS round trips; sorted rows fill the window from slot 0 (bit e of
+        // any16 set => every lower bit set), 8 entries per row and slab on the bench matrices.
+        // Slots 0-7 go out as one batch of eight reads, the upper half as one more batch sized by
+        // the highest slot in use: two round trips for almost every pass (r01: three to six).
+        if (w.any16 & 0x00f0u) {
+          const Quad<NB> r0 = quad_read<0, NB>(qbase, w.a);
+          const Quad<NB> r1 = quad_read<4, NB>(qbase, w.a);
+          quad_fma<0, NB>(r0, w.vv, acc[k]);
+          quad_fma<4, NB>(r1, w.vv, acc[k]);
+        } else if (w.any16 & 0x000fu) {
+          const Quad<NB> r = quad_read<0, NB>(qbase, w.a);
+          quad_fma<0, NB>(r, w.vv, acc[k]);
         }
+        if (w.any16 & 0xf000u) {
+          const Quad<NB> r0 = quad_read<8, NB>(qbase, w.a);
+          const Quad<NB> r1 = quad_read<12, NB>(qbase, w.a);
+          quad_fma<8, NB>(r0, w.vv, acc[k]);
+          quad_fma<12, NB>(r1, w.vv, acc[k]);
+        } else if (w.any16 & 0x0c00u) {
+          const Quad<NB> r = quad_read<8, NB>(qbase, w.a);
+          quad_fma<8, NB>(r, w.vv, acc[k]);
+        } else if (w.any16 & 0x0300u) {
+          const Pair<NB> r = pair_read<8, NB>(qbase, w.a);
+          pair_fma<8, NB>(r, w.vv, acc[k]);
+        }
+      } else {
+        if (w.any16 & 0x000fu) { const Quad<NB> r = quad_read<0, NB>(qbase, w.a); quad_fma<0, NB>(r, w.vv, acc[k]); }
+        if (w.any16 & 0x00f0u) { const Quad<NB> r = quad_read<4, NB>(qbase, w.a); quad_fma<4, NB>(r, w.vv, acc[k]); }
         if (w.any16 & 0xff00u) {
-          // sorted rows fill the window from slot 0: bit e set => every lower bit is set
           { const Pair<NB> r = pair_read<8, NB>(qbase, w.a); pair_fma<8, NB>(r, w.vv, acc[k]); }
           if (w.any16 & 0x0c00u) { const Pair<NB> r = pair_read<10, NB>(qbase, w.a); pair_fma<10, NB>(r, w.vv, acc[k]); }
           if (w.any16 & 0x3000u) { const Pair<NB> r = pair_read<12, NB>(qbase, w.a); pair_fma<12, NB>(r, w.vv, acc[k]); }
           if (w.any16 & 0xc000u) { const Pair<NB> r = pair_read<14, NB>(qbase, w.a); pair_fma<14, NB>(r, w.vv, acc[k]); }
         }
       }
+      __builtin_amdgcn_s_setprio(0);
     };
 
     if constexpr (MODE & 64) {
@@ -459,35 +456,45 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
 }
 
 #define MU_KARGS                                                                                  \
-  int64_t n_pos, int64_t n_cols, const int64_t *__restrict__ indptr,                              \
-      const int32_t *__restrict__ indices, const float *__restrict__ values,                      \
-      const int32_t *__restrict__ perm, const float *__restrict__ Q, float *__restrict__ Y
-template <int K, int MODE, int NB, bool PAIRS>
+  int64_t n_pos, int64_t n_cols, const int64_t *__restrict__ sptr,                                \
+      const unsigned long long *__restrict__ ent, const int32_t *__restrict__ perm,               \
+      const float *__restrict__ Q, float *__restrict__ Y
+template <int K, int MODE, int NB>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(55))) void k_spmm_win(MU_KARGS) {
-  spmm_win_body<K, MODE, NB, PAIRS>(n_pos, n_cols, indptr, indices, values, perm, Q, Y);
+  spmm_win_body<K, MODE, NB>(n_pos, n_cols, sptr, ent, perm, Q, Y);
 }
 
-// pair stream of a CSR: ent[p] = (column, value bits); a streaming copy (8 B in, 8 B out per entry)
-__global__ __launch_bounds__(256) void k_pairs_fill(int64_t nnz, const int32_t* __restrict__ indices,
-                                                    const float* __restrict__ values,
-                                                    unsigned long long* __restrict__ ent) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
-  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < nnz; i += stride) {
-    if (i + 4 <= nnz) {
-      const int4 c = *reinterpret_cast<const int4*>(indices + i);
-      const float4 v = *reinterpret_cast<const float4*>(values + i);
-      ulonglong2 a, b;
-      a.x = (unsigned long long)(unsigned)c.x | ((unsigned long long)__builtin_bit_cast(unsigned, v.x) << 32);
-      a.y = (unsigned long long)(unsigned)c.y | ((unsigned long long)__builtin_bit_cast(unsigned, v.y) << 32);
-      b.x = (unsigned long long)(unsigned)c.z | ((unsigned long long)__builtin_bit_cast(unsigned, v.z) << 32);
-      b.y = (unsigned long long)(unsigned)c.w | ((unsigned long long)__builtin_bit_cast(unsigned, v.w) << 32);
-      *reinterpret_cast<ulonglong2*>(ent + i) = a;
-      *reinterpret_cast<ulonglong2*>(ent + i + 2) = b;
-    } else {
-      for (int64_t j = i; j < nnz; ++j)
-        ent[j] = (unsigned long long)(unsigned)indices[j] |
-                 ((unsigned long long)__builtin_bit_cast(unsigned, values[j]) << 32);
-    }
+// ---- the row stream ------------------------------------------------------------------------
+// Position p holds row perm[p] of the matrix (perm == nullptr: the identity; perm[p] < 0: no row).
+// The host deals the rows, sorted by length, round robin to workgroups and waves
+// (muon_amd/_backend.py: spmm_layout) - see DESIGN.md 4.1.
+__global__ __launch_bounds__(256) void k_stream_len(int64_t n_pos, const int32_t* __restrict__ perm,
+                                                    const int64_t* __restrict__ indptr,
+                                                    int64_t* __restrict__ len) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pos) return;
+  const int64_t r = perm ? (int64_t)perm[p] : p;
+  len[p] = (r < 0) ? 0 : (indptr[r + 1] - indptr[r]);
+}
+
+// a wave per row: streaming copy (8 B in, 8 B out per entry)
+__global__ __launch_bounds__(256) void k_stream_fill(int64_t n_pos, const int32_t* __restrict__ perm,
+                                                     const int64_t* __restrict__ indptr,
+                                                     const int32_t* __restrict__ indices,
+                                                     const float* __restrict__ values,
+                                                     const int64_t* __restrict__ sptr,
+                                                     unsigned long long* __restrict__ ent) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = uniform64(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t pos = wave0; pos < n_pos; pos += n_waves) {
+    const int64_t row = perm ? (int64_t)uniform32(perm[pos]) : pos;
+    if (row < 0) continue;
+    const int64_t lo = uniform64(indptr[row]), hi = uniform64(indptr[row + 1]);
+    const int64_t o0 = uniform64(sptr[pos]);
+    for (int64_t j = lane; j < hi - lo; j += 64)
+      ent[o0 + j] = (unsigned long long)(unsigned)indices[lo + j] |
+                    ((unsigned long long)__builtin_bit_cast(unsigned, values[lo + j]) << 32);
   }
 }
 
@@ -502,107 +509,101 @@ int pick_k(int64_t n_rows) {
   return kKMax;
 }
 
-template <int K, int MODE, bool PAIRS>
-int launch(int B, hipStream_t st, int64_t n_pos, int64_t n_cols, const int64_t* indptr,
-           const int32_t* indices, const float* values, const int32_t* perm, const float* Q, float* Y) {
+template <int K, int MODE>
+int launch(int B, hipStream_t st, int64_t n_pos, int64_t n_cols, const int64_t* sptr,
+           const unsigned long long* ent, const int32_t* perm, const float* Q, float* Y) {
   const int64_t wgs = (n_pos + 64 * K - 1) / (64 * K);
   if (B == 64)
-    hipLaunchKernelGGL((k_spmm_win<K, MODE, 4, PAIRS>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos, n_cols,
-                       indptr, indices, values, perm, Q, Y);
+    hipLaunchKernelGGL((k_spmm_win<K, MODE, 4>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos, n_cols,
+                       sptr, ent, perm, Q, Y);
   else if (B == 32)
-    hipLaunchKernelGGL((k_spmm_win<K, MODE, 2, PAIRS>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos, n_cols,
-                       indptr, indices, values, perm, Q, Y);
+    hipLaunchKernelGGL((k_spmm_win<K, MODE, 2>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos, n_cols,
+                       sptr, ent, perm, Q, Y);
   else
-    hipLaunchKernelGGL((k_spmm_win<K, MODE, 1, PAIRS>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos, n_cols,
-                       indptr, indices, values, perm, Q, Y);
+    hipLaunchKernelGGL((k_spmm_win<K, MODE, 1>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos, n_cols,
+                       sptr, ent, perm, Q, Y);
   MU_CHECK_LAUNCH();
   return MU_OK;
-}
-
-template <bool PAIRS>
-int dispatch(int64_t n_pos, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
-             const float* d_values, const int32_t* d_perm, int k_layout, const float* d_Q, int B,
-             float* d_Y, hipStream_t st) {
-  int K = (k_layout >= 1 && k_layout <= kKMax) ? k_layout : pick_k(n_pos);
-  const int force_k = mu_tune_get("spmm_k");  // tests / tuning only (mu_tune_set); 0 in production
-  if (force_k >= 1 && force_k <= kKMax) K = force_k;
-  const int mode = mu_tune_get("spmm_mode");
-#define MU_ARGS B, st, n_pos, n_cols, d_indptr, d_indices, d_values, d_perm, d_Q, d_Y
-  if (mode != 0) {
-    if (K != 8 && K != 4 && K != 6) {
-      mu_set_error("ablation modes exist for K = 4, 6 and 8 only");
-      return MU_ERR_ARG;
-    }
-    switch (mode + 100 * K) {
-      case 801: return launch<8, 1, PAIRS>(MU_ARGS);
-      case 809: return launch<8, 9, PAIRS>(MU_ARGS);
-      case 864: return launch<8, 64, PAIRS>(MU_ARGS);
-      case 601: return launch<6, 1, PAIRS>(MU_ARGS);
-      case 664: return launch<6, 64, PAIRS>(MU_ARGS);
-      case 632: return launch<6, 32, PAIRS>(MU_ARGS);
-      case 696: return launch<6, 96, PAIRS>(MU_ARGS);
-      case 401: return launch<4, 1, PAIRS>(MU_ARGS);
-      case 409: return launch<4, 9, PAIRS>(MU_ARGS);
-      case 464: return launch<4, 64, PAIRS>(MU_ARGS);
-      default: break;
-    }
-    mu_set_error("spmm_mode %d has no compiled instance", mode);
-    return MU_ERR_ARG;
-  }
-  switch (K) {
-    case 1: return launch<1, 0, PAIRS>(MU_ARGS);
-    case 2: return launch<2, 0, PAIRS>(MU_ARGS);
-    case 3: return launch<3, 0, PAIRS>(MU_ARGS);
-    case 4: return launch<4, 0, PAIRS>(MU_ARGS);
-    case 5: return launch<5, 0, PAIRS>(MU_ARGS);
-    case 6: return launch<6, 0, PAIRS>(MU_ARGS);
-    case 7: return launch<7, 0, PAIRS>(MU_ARGS);
-    default: return launch<8, 0, PAIRS>(MU_ARGS);
-  }
-#undef MU_ARGS
 }
 
 }  // namespace
 
 extern "C" {
 
-int mu_spmm_csr_k(int64_t n_rows) { return pick_k(n_rows); }
+int mu_spmm_stream_k(int64_t n_rows) { return pick_k(n_rows); }
 
-int mu_spmm_csr_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
-                    const float* d_values, const int32_t* d_perm, int k_layout, const float* d_Q, int B,
-                    float* d_Y, void* stream) {
-  MU_REQUIRE(B == 16 || B == 32 || B == 64, "B must be 16, 32 or 64");
-  MU_REQUIRE(n_pos >= 0 && n_cols > 0 && n_cols < ((int64_t)1 << 31), "shape out of range");
-  if (n_pos == 0) return MU_OK;
-  MU_REQUIRE(d_indptr && d_indices && d_values && d_Q && d_Y, "null pointer");
-  return dispatch<false>(n_pos, n_cols, d_indptr, d_indices, d_values, d_perm, k_layout, d_Q, B, d_Y,
-                         (hipStream_t)stream);
-}
-
-int mu_csr_pairs_fill(int64_t nnz, const int32_t* d_indices, const float* d_values, void* d_ent,
+int mu_csr_stream_len(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr, int64_t* d_len,
                       void* stream) {
-  MU_REQUIRE(nnz >= 0, "negative size");
-  if (nnz == 0) return MU_OK;
-  MU_REQUIRE(d_indices && d_values && d_ent, "null pointer");
-  int64_t blocks = (nnz / 4 + 255) / 256;
-  const int64_t cap = (int64_t)mu_num_cus() * 32;
-  if (blocks > cap) blocks = cap;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_pairs_fill, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, nnz,
-                     d_indices, d_values, (unsigned long long*)d_ent);
+  MU_REQUIRE(n_pos >= 0, "negative size");
+  if (n_pos == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_len, "null pointer");
+  hipLaunchKernelGGL(k_stream_len, dim3((unsigned)((n_pos + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, n_pos, d_perm, d_indptr, d_len);
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
 
-int mu_spmm_pairs_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_indptr, const void* d_ent,
-                      const int32_t* d_perm, int k_layout, const float* d_Q, int B, float* d_Y,
-                      void* stream) {
+int mu_csr_stream_fill(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr,
+                       const int32_t* d_indices, const float* d_values, const int64_t* d_sptr,
+                       void* d_ent, void* stream) {
+  MU_REQUIRE(n_pos >= 0, "negative size");
+  if (n_pos == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_sptr && d_ent, "null pointer");
+  int64_t blocks = (n_pos + 3) / 4;
+  // workgroups per CU: 32 alone; a caller that runs the copy next to a kernel that needs whole CUs
+  // (the transpose on another stream) lowers it so that both stay resident (tune pack_wg)
+  const int per_cu = mu_tune_get("pack_wg") > 0 ? mu_tune_get("pack_wg") : 32;
+  const int64_t cap = (int64_t)mu_num_cus() * per_cu;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_stream_fill, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_pos,
+                     d_perm, d_indptr, d_indices, d_values, d_sptr, (unsigned long long*)d_ent);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, const void* d_ent,
+                       const int32_t* d_perm, int k_layout, const float* d_Q, int B, float* d_Y,
+                       void* stream) {
   MU_REQUIRE(B == 16 || B == 32 || B == 64, "B must be 16, 32 or 64");
   MU_REQUIRE(n_pos >= 0 && n_cols > 0 && n_cols < ((int64_t)1 << 31), "shape out of range");
   if (n_pos == 0) return MU_OK;
-  MU_REQUIRE(d_indptr && d_ent && d_Q && d_Y, "null pointer");
-  return dispatch<true>(n_pos, n_cols, d_indptr, (const int32_t*)d_ent, nullptr, d_perm, k_layout, d_Q, B,
-                        d_Y, (hipStream_t)stream);
+  MU_REQUIRE(d_sptr && d_ent && d_Q && d_Y, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned long long* ent = (const unsigned long long*)d_ent;
+  int K = (k_layout >= 1 && k_layout <= kKMax) ? k_layout : pick_k(n_pos);
+  const int force_k = mu_tune_get("spmm_k");  // tests / tuning only (mu_tune_set); 0 in production
+  if (force_k >= 1 && force_k <= kKMax) K = force_k;
+  const int mode = mu_tune_get("spmm_mode");
+#define MU_ARGS B, st, n_pos, n_cols, d_sptr, ent, d_perm, d_Q, d_Y
+  if (mode != 0) {
+    switch ((mode & 0x7f) + 100 * K + (mode & 128 ? 100 : 0)) {  // (128 = stage B alone: ids 9xx)
+      case 801: return launch<8, 1>(MU_ARGS);
+      case 809: return launch<8, 9>(MU_ARGS);
+      case 832: return launch<8, 32>(MU_ARGS);
+      case 864: return launch<8, 64>(MU_ARGS);
+      case 896: return launch<8, 96>(MU_ARGS);
+      case 900: return launch<8, 128>(MU_ARGS);
+      case 932: return launch<8, 160>(MU_ARGS);
+      case 964: return launch<8, 192>(MU_ARGS);
+      case 996: return launch<8, 224>(MU_ARGS);
+      case 401: return launch<4, 1>(MU_ARGS);
+      case 464: return launch<4, 64>(MU_ARGS);
+      default: break;
+    }
+    mu_set_error("spmm_mode %d has no compiled instance for K = %d", mode, K);
+    return MU_ERR_ARG;
+  }
+  switch (K) {
+    case 1: return launch<1, 0>(MU_ARGS);
+    case 2: return launch<2, 0>(MU_ARGS);
+    case 3: return launch<3, 0>(MU_ARGS);
+    case 4: return launch<4, 0>(MU_ARGS);
+    case 5: return launch<5, 0>(MU_ARGS);
+    case 6: return launch<6, 0>(MU_ARGS);
+    case 7: return launch<7, 0>(MU_ARGS);
+    default: return launch<8, 0>(MU_ARGS);
+  }
+#undef MU_ARGS
 }
 
 }  // extern "C"

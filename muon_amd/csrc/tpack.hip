@@ -1,21 +1,21 @@
-// Packed chunked-row copy of X^T built straight from the CSR of X ("transpose-pack").
+// X^T built straight from the CSR of X: as the row stream the SpMM reads (csrc/spmm_win.hip) or as a
+// plain CSR ("transpose-pack"; the name is r01's, when the target was a chunked packed copy).
 //
 // Z = X^T * Y of the block Lanczos iteration (the rmatvec side of scipy svds, _svds.py:441-466,
-// reached from /root/reference/muon/_atac/tools.py:53) runs through the same packed SpMM as
-// Y = X * Q; this file builds its operand without materialising a CSR of X^T first.
+// reached from /root/reference/muon/_atac/tools.py:53) runs through the same SpMM as Y = X * Q;
+// this file builds its operand without materialising a CSR of X^T first.
 // Stable (every output row lists the cells in ascending order => canonical rows, and the f32 sums
 // of the SpMM are bit-reproducible), no global atomics.
 //
 //   1. slab pointers: sp[row][s] = first entry of `row` with column >= s * kTSlab
 //   2. count: workgroup g owns a contiguous, nnz-balanced row range and counts the entries of every
 //      column in LDS, slab by slab                                           -> cnt[g][col]
-//   3. base:  per column, exclusive prefix of cnt over g (in place), the column total and its
-//      chunk count ceil(total / 16) + 1                                      -> caller scans -> cptr
+//   3. base:  per column, exclusive prefix of cnt over g (in place) and the column total
+//                                                      -> caller lays the rows out, scans -> sptr
 //   4. fill:  a workgroup stages a (row block x column tile) in LDS sorted by (column, cell) and
 //      writes every column's run with consecutive lanes (k_t_fill3 / k_t_fill2 below; the first
 //      generation, a bitmap-rank fill with one 8-byte store per pair, ran at the fabric's
 //      partial-write rate and is gone)
-//   5. pads:  the tail of the last real chunk and the closing chunk of every output row.
 #include "common.hpp"
 
 namespace {
@@ -23,7 +23,6 @@ namespace {
 constexpr int kTSlab = 8192;  // columns per slab of the count pass: 32 KiB of LDS bins
 constexpr int kTThreads = 1024;
 constexpr int kTWaves = kTThreads / 64;
-constexpr unsigned kPad = 0x7fffffffu;
 
 inline int64_t t_slabs(int64_t n_cols) { return (n_cols + kTSlab - 1) / kTSlab; }
 // Row blocks (= workgroups of the count and fill sweeps): one per CU (the staged fill needs 140 KiB
@@ -140,13 +139,12 @@ __global__ __launch_bounds__(256) void k_t_base(int64_t n_cols, int G, uint32_t*
 //     atomics, no per-batch barriers (4 barriers per tile);
 //   * per-row cursors (first entry not yet consumed) live in global memory: no slab pointers;
 //   * a tile that does not fit the staging buffer falls back to direct stores (same slots).
-// Where a (cell, value) pair of output row `column` goes: slot `pos` of the packed chunk stream
-// (`ent`, 8 bytes per pair) or of the CSR arrays of X^T (split == true: t_indices / t_values).
+// Where a (cell, value) pair of an output row goes: slot `pos` of the row stream (`ent`, 8 bytes per
+// pair) or of the CSR arrays of X^T (idx != nullptr: t_indices / t_values).
 struct TOut {
   unsigned long long* ent;
   int32_t* idx;
   float* val;
-  int shift;  // row pointers count chunks of 16 pairs (4) or pairs (0)
 };
 __device__ __forceinline__ void t_store(const TOut& o, int64_t pos, unsigned long long e) {
   if (o.idx) {
@@ -313,7 +311,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
         const uint32_t b0 = base_g[c];
         const uint32_t b1 = base_n ? base_n[c] : (uint32_t)coltot[c];
         mine = b1 - b0;
-        gdst[threadIdx.x] = (cptr[inv ? (int64_t)inv[c] : c] << ent.shift) + (int64_t)b0;
+        gdst[threadIdx.x] = cptr[inv ? (int64_t)inv[c] : c] + (int64_t)b0;
       }
       lcount[threadIdx.x] = mine;
     }
@@ -520,7 +518,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
         const uint32_t b0 = base_g[c];
         const uint32_t b1 = base_n ? base_n[c] : (uint32_t)coltot[c];
         mine = b1 - b0;
-        gdst[threadIdx.x] = (cptr[inv ? (int64_t)inv[c] : c] << ent.shift) + (int64_t)b0;
+        gdst[threadIdx.x] = cptr[inv ? (int64_t)inv[c] : c] + (int64_t)b0;
       }
       lcount[threadIdx.x] = mine;
     }
@@ -577,29 +575,6 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
     }
     __syncthreads();
   }
-}
-
-// tail of the last real chunk + the closing chunk of every output row: at most 31 pads
-__global__ __launch_bounds__(256) void k_t_pads(int64_t n_cols, const int64_t* __restrict__ coltot,
-                                                const int64_t* __restrict__ cptr,
-                                                const int32_t* __restrict__ inv,
-                                                unsigned long long* __restrict__ ent) {
-  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t c = id >> 5;
-  if (c >= n_cols) return;
-  const int64_t p = inv ? (int64_t)inv[c] : c;
-  const int64_t o = cptr[p] * 16 + coltot[c] + (id & 31);
-  if (o < cptr[p + 1] * 16) ent[o] = (unsigned long long)kPad;
-}
-
-// closing chunk of the positions that hold no output row (layout padding)
-__global__ __launch_bounds__(256) void k_t_empty(int64_t n_pos, const int32_t* __restrict__ perm,
-                                                 const int64_t* __restrict__ cptr,
-                                                 unsigned long long* __restrict__ ent) {
-  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t p = id >> 4;
-  if (p >= n_pos || perm[p] >= 0) return;
-  ent[cptr[p] * 16 + (id & 15)] = (unsigned long long)kPad;
 }
 
 struct TWork {
@@ -710,32 +685,6 @@ static int tpack_fill_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const in
   return MU_OK;
 }
 
-int mu_csr_tpack_fill(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
-                      const int32_t* d_indices, const float* d_values, int64_t n_pos,
-                      const int64_t* d_cptr, const int32_t* d_perm, const int32_t* d_inv, void* d_ent,
-                      void* d_work, size_t work_bytes, void* stream) {
-  MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
-  if (n_cols == 0) return MU_OK;
-  MU_REQUIRE(d_indptr && d_cptr && d_ent && d_work, "null pointer");
-  MU_REQUIRE((d_perm == nullptr) == (d_inv == nullptr) && n_pos >= n_cols, "perm / inv / n_pos inconsistent");
-  MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols, nnz), "work buffer too small");
-  hipStream_t st = (hipStream_t)stream;
-  const TWork w = carve(d_work, n_rows, n_cols, nnz);
-  const TOut out{(unsigned long long*)d_ent, nullptr, nullptr, 4};
-  const int rc = tpack_fill_impl(n_rows, n_cols, nnz, d_indptr, d_indices, d_values, d_cptr, d_inv, out,
-                                 d_work, st);
-  if (rc != MU_OK) return rc;
-  hipLaunchKernelGGL(k_t_pads, dim3((unsigned)((n_cols * 32 + 255) / 256)), dim3(256), 0, st, n_cols,
-                     w.coltot, d_cptr, d_inv, (unsigned long long*)d_ent);
-  MU_CHECK_LAUNCH();
-  if (d_perm && n_pos > n_cols) {
-    hipLaunchKernelGGL(k_t_empty, dim3((unsigned)((n_pos * 16 + 255) / 256)), dim3(256), 0, st, n_pos,
-                       d_perm, d_cptr, (unsigned long long*)d_ent);
-    MU_CHECK_LAUNCH();
-  }
-  return MU_OK;
-}
-
 int mu_csr_tpack_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
                           const int32_t* d_indices, const float* d_values, const int64_t* d_t_indptr,
                           int32_t* d_t_indices, float* d_t_values, void* d_work, size_t work_bytes,
@@ -744,22 +693,24 @@ int mu_csr_tpack_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int
   if (n_cols == 0 || nnz == 0) return MU_OK;
   MU_REQUIRE(d_indptr && d_t_indptr && d_t_indices && d_t_values && d_work, "null pointer");
   MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols, nnz), "work buffer too small");
-  const TOut out{nullptr, d_t_indices, d_t_values, 0};
+  const TOut out{nullptr, d_t_indices, d_t_values};
   return tpack_fill_impl(n_rows, n_cols, nnz, d_indptr, d_indices, d_values, d_t_indptr, nullptr, out,
                          d_work, (hipStream_t)stream);
 }
 
-/* the same with the pair stream as the target: ent[t_indptr[c] + i] = (cell, value bits) */
-int mu_csr_tpack_fill_pairs(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
-                            const int32_t* d_indices, const float* d_values, const int64_t* d_t_indptr,
-                            void* d_t_ent, void* d_work, size_t work_bytes, void* stream) {
+/* the same with the row stream of X^T as the target (csrc/spmm_win.hip): output row c goes to
+ * position inv[c] of the launch layout, ent[sptr[inv[c]] + i] = (cell, value bits) */
+int mu_csr_tpack_fill_stream(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
+                             const int32_t* d_indices, const float* d_values, const int64_t* d_sptr,
+                             const int32_t* d_inv, void* d_ent, void* d_work, size_t work_bytes,
+                             void* stream) {
   MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
   if (n_cols == 0 || nnz == 0) return MU_OK;
-  MU_REQUIRE(d_indptr && d_t_indptr && d_t_ent && d_work, "null pointer");
+  MU_REQUIRE(d_indptr && d_sptr && d_ent && d_work, "null pointer");
   MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols, nnz), "work buffer too small");
-  const TOut out{(unsigned long long*)d_t_ent, nullptr, nullptr, 0};
-  return tpack_fill_impl(n_rows, n_cols, nnz, d_indptr, d_indices, d_values, d_t_indptr, nullptr, out,
-                         d_work, (hipStream_t)stream);
+  const TOut out{(unsigned long long*)d_ent, nullptr, nullptr};
+  return tpack_fill_impl(n_rows, n_cols, nnz, d_indptr, d_indices, d_values, d_sptr, d_inv, out, d_work,
+                         (hipStream_t)stream);
 }
 
 }  // extern "C"

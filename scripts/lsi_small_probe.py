@@ -25,9 +25,9 @@ for mb in (3, 2):
     print(f"max_blocks={mb}: {dt:.2f} ms, iterations {info['iterations']}, spmm {info['spmm']}, host {info['host']}")
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-Tp = be.pack(T); Tt = be.transpose_pack(T)
+Tp = be.stream(T); Tt = be.transpose_stream(T)
 torch.cuda.synchronize()
-print(f"pack + transpose_pack: {(time.perf_counter() - t0) * 1e3:.2f} ms")
+print(f"pack + transpose_stream: {(time.perf_counter() - t0) * 1e3:.2f} ms")
 t0 = time.perf_counter()
 T2 = tfidf_device(be, X, n, 3, 1e4)
 torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over the packed SpMM probe (counters only: no tracing domains alongside --pmc).
+# PMC passes over the CSR-direct SpMM probe (counters only: no tracing domains alongside --pmc).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=$PWD/gpurun_out/${1:-pmc}
 mkdir -p "$OUT"
@@ -7,10 +7,26 @@ export TMPDIR=/tmp
 cd /tmp
 run() {  # name, counters...
   local name=$1; shift
-  timeout 170 rocprofv3 --pmc "$@" -d "$OUT/$name" -o pmc --output-format csv -- python "$OLDPWD/scripts/spmm_probe.py" --reps 1 --modes ${MODES:-0} > "$OUT/$name.log" 2>&1
+  timeout 170 rocprofv3 --pmc "$@" -d "$OUT/$name" -o pmc --output-format csv -- python "$OLDPWD/scripts/spmm_probe.py" --reps 1 --modes "" ${PROBE_ARGS:-} > "$OUT/$name.log" 2>&1
   echo "$name rc=$?"
 }
+run fetch FETCH_SIZE
+run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY
 run sq2 SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM
-run grbm GRBM_GUI_ACTIVE GRBM_COUNT
-find "$OUT" -name "*.csv" | head; du -sh "$OUT"
+python - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(float)
+for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "spmm" not in k and "copy" not in k.lower():
+            continue
+        agg[(k[:60], r["Counter_Name"], r.get("Dispatch_Id"))] += float(r["Counter_Value"])
+per = collections.defaultdict(list)
+for (k, c, d), v in agg.items():
+    per[(k, c)].append(v)
+for (k, c), vs in sorted(per.items()):
+    print(f"{k:62s} {c:24s} n={len(vs):3d} mean={sum(vs)/len(vs):.4e}")
+PY

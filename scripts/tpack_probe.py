@@ -18,12 +18,12 @@ SORT = "--natural" not in sys.argv
 
 
 def t(label):
-    be.transpose_pack(T, sort_rows=SORT)
+    be.transpose_stream(T, sort_rows=SORT)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(3):
-        be.transpose_pack(T, sort_rows=SORT)
+        be.transpose_stream(T, sort_rows=SORT)
     e.record()
     torch.cuda.synchronize()
     print(f"{label}: {s.elapsed_time(e) / 3:.2f} ms (count + layout + scan + fill + pads; sorted layout = {SORT})", flush=True)

@@ -10,4 +10,4 @@ for sort in (False, True):
     for c in (0, 512):
         for abl in (0, 8):
             be.tune("tpack_c", c); be.tune("tpack_abl", abl)
-            be.transpose_pack(T, sort_rows=sort); torch.cuda.synchronize()
+            be.transpose_stream(T, sort_rows=sort); torch.cuda.synchronize()

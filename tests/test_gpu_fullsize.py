@@ -40,10 +40,10 @@ def test_tfidf_inverts_back_to_the_counts(hip, shard):
     assert rel < 2e-5, rel  # two f32 roundings of the forward pass, amplified by expm1
 
 
-def test_packed_spmm_adjoint_and_checksums_full_size(hip, shard):
+def test_stream_spmm_adjoint_and_checksums_full_size(hip, shard):
     _, T = shard
-    Tp = hip.pack(T)
-    Ttp = hip.transpose_pack(T)
+    Tp = hip.stream(T)
+    Ttp = hip.transpose_stream(T)
     q = hip.randn(D, 64, 3)
     y = hip.randn(N, 64, 4)
     Yq = hip.spmm(Tp, q)
@@ -81,7 +81,7 @@ def test_lsi_eigen_residuals_full_size(hip, shard):
     assert (G - torch.eye(50, dtype=torch.float64, device=G.device)).abs().max().item() < 1e-5
     Vb = torch.zeros((D, 64), dtype=torch.float32, device=V.device)
     Vb[:, :50] = V
-    W = hip.spmm(hip.transpose_pack(T), hip.spmm(hip.pack(T), Vb))[:, :50].double()
+    W = hip.spmm(hip.transpose_stream(T), hip.spmm(hip.stream(T), Vb))[:, :50].double()
     s2 = torch.as_tensor(s**2, device=W.device)
     res = (W - Vd * s2).norm(dim=0) / s2
     # the trailing components sit next to the bulk: their residual is bounded by the angle target

@@ -161,53 +161,38 @@ def test_synth_counts_structure(hip):
     assert (S != m[500:800]).nnz == 0
 
 
-# ---- packed chunked-row SpMM (B = 64) ---------------------------------------------------
-def _pack_ref(m):
-    """numpy restatement of the PCR16 layout (include/muon_amd.h): 16-pair chunks, padded with
-    (INT32_MAX, 0), one closing all-padding chunk per row."""
-    n = m.shape[0]
-    lens = np.diff(m.indptr)
-    chunks = (lens + 15) // 16 + 1
-    cptr = np.concatenate([[0], np.cumsum(chunks)]).astype(np.int64)
-    col = np.full(cptr[-1] * 16, 0x7FFFFFFF, dtype=np.uint32)
-    val = np.zeros(cptr[-1] * 16, dtype=np.float32)
-    for r in range(n):
-        lo, hi = m.indptr[r], m.indptr[r + 1]
-        o = cptr[r] * 16
-        col[o:o + hi - lo] = m.indices[lo:hi]
-        val[o:o + hi - lo] = m.data[lo:hi]
-    ent = np.empty(cptr[-1] * 16, dtype=np.uint64)
-    ent[:] = col.astype(np.uint64) | (val.view(np.uint32).astype(np.uint64) << np.uint64(32))
-    return cptr, ent
+# ---- row-stream SpMM (B = 64 / 32 / 16) -----------------------------------------------------
+def _stream_ref(m):
+    """numpy restatement of the row stream in matrix order (include/muon_amd.h): the (column, value)
+    pairs row after row, 8 bytes each, no padding; sptr = the CSR's row pointers."""
+    ent = m.indices.astype(np.uint32).astype(np.uint64) | \
+        (m.data.astype(np.float32).view(np.uint32).astype(np.uint64) << np.uint64(32))
+    return m.indptr.astype(np.int64), ent
 
 
-def _check_packed(hip, P, m):
-    """Decode a packed copy (any layout) on the host and compare it with the canonical CSR `m` it
-    must hold: every row at exactly one position, pairs bit-exact and in column order, tail padded
-    with (INT32_MAX, 0), ceil(nnz/16) + 1 chunks per row, one all-padding chunk per empty position."""
+def _check_stream(hip, P, m):
+    """Decode a row stream (any layout) on the host and compare it with the canonical CSR `m` it
+    must hold: every row at exactly one position, pairs bit-exact and in column order, no padding,
+    nothing at the empty positions."""
     m = m.tocsr()
     m.sort_indices()
     n = m.shape[0]
-    cptr = hip.to_host(P.cptr)
+    sptr = hip.to_host(P.sptr)
     ent = hip.to_host(P.ent).view(np.uint64)
     perm = np.arange(n, dtype=np.int64) if P.perm is None else hip.to_host(P.perm).astype(np.int64)
-    assert cptr[0] == 0 and cptr.size == perm.size + 1 and ent.size >= cptr[-1] * 16
+    assert sptr[0] == 0 and sptr.size == perm.size + 1 and sptr[-1] == m.nnz and ent.size >= m.nnz
     rows = perm[perm >= 0]
     assert rows.size == n and np.array_equal(np.sort(rows), np.arange(n))
     lens = np.diff(m.indptr)
     plens = np.where(perm >= 0, lens[np.maximum(perm, 0)], 0)
-    assert np.array_equal(np.diff(cptr), (plens + 15) // 16 + 1)
-    col = (ent & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    val = (ent >> np.uint64(32)).astype(np.uint32).view(np.float32)
-    # every slot: real pairs first, pads after
-    start = cptr[:-1] * 16
-    slot_pos = np.repeat(np.arange(perm.size), np.diff(cptr) * 16)
-    slot_off = np.arange(cptr[-1] * 16) - np.repeat(start, np.diff(cptr) * 16)
-    real = slot_off < plens[slot_pos]
-    assert np.all(col[: real.size][~real] == 0x7FFFFFFF) and np.all(val[: real.size][~real] == 0)
-    src = m.indptr[np.maximum(perm, 0)][slot_pos[real]] + slot_off[real]
-    assert np.array_equal(col[: real.size][real], m.indices[src].astype(np.uint32))
-    assert np.array_equal(val[: real.size][real].view(np.uint32), m.data[src].astype(np.float32).view(np.uint32))
+    assert np.array_equal(np.diff(sptr), plens)
+    slot_pos = np.repeat(np.arange(perm.size), plens)
+    slot_off = np.arange(m.nnz) - np.repeat(sptr[:-1], plens)
+    src = m.indptr[np.maximum(perm, 0)][slot_pos] + slot_off
+    col = (ent[: m.nnz] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    val = (ent[: m.nnz] >> np.uint64(32)).astype(np.uint32)
+    assert np.array_equal(col, m.indices[src].astype(np.uint32))
+    assert np.array_equal(val, m.data[src].astype(np.float32).view(np.uint32))
 
 
 def _heavy_rows_csr(n, d, dens, rng, bursts=True):
@@ -224,111 +209,115 @@ def _heavy_rows_csr(n, d, dens, rng, bursts=True):
     return m.astype(np.float32)
 
 
-def test_pack_layout_bit_exact(hip):
+def test_stream_layout_bit_exact(hip):
     rng = np.random.default_rng(11)
     m = _heavy_rows_csr(203, 1000, 0.03, rng)
-    P = hip.pack(_up(hip, m), sort_rows=False)  # identity layout: byte for byte the numpy packing
-    cptr, ent = _pack_ref(m)
-    assert P.perm is None and np.array_equal(hip.to_host(P.cptr), cptr)
-    got = hip.to_host(P.ent).view(np.uint64)[: ent.size]
-    assert np.array_equal(got, ent)
+    P = hip.stream(_up(hip, m), sort_rows=False)  # identity layout: byte for byte the numpy stream
+    sptr, ent = _stream_ref(m)
+    assert P.perm is None and np.array_equal(hip.to_host(P.sptr), sptr)
+    assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
     for mm in (m, _heavy_rows_csr(5000, 300, 0.05, rng), sp.csr_matrix((3, 9), dtype=np.float32)):
-        P = hip.pack(_up(hip, mm))  # sorted + dealt layout
+        P = hip.stream(_up(hip, mm))  # sorted + dealt layout
         assert P.perm is not None and P.n_pos % (64 * P.k) == 0
-        _check_packed(hip, P, mm)
+        _check_stream(hip, P, mm)
     # rows are dealt longest first: position 0 holds a longest row
     lens = np.diff(m.indptr)
-    P = hip.pack(_up(hip, m))
+    P = hip.stream(_up(hip, m))
     assert lens[hip.to_host(P.perm)[0]] == lens.max()
 
 
 @pytest.mark.parametrize("n,d,dens", [(1, 3, 1.0), (5, 255, 0.3), (64, 256, 0.1), (100, 257, 0.2),
                                       (513, 700, 0.05), (1000, 5000, 0.03), (3000, 20000, 0.01),
                                       (4097, 1031, 0.04)])
-def test_spmm_packed_matches_f64_and_csr_kernel(hip, n, d, dens):
+def test_spmm_stream_matches_f64_and_csr_kernel(hip, n, d, dens):
     rng = np.random.default_rng(n * 7 + d)
     m = _heavy_rows_csr(n, d, dens, rng)
     Q = rng.standard_normal((d, 64)).astype(np.float32)
     X = _up(hip, m)
     Qd = hip.to_device(Q)
     hip.tune("spmm_k", 0)
-    Y = hip.to_host(hip.spmm(hip.pack(X), Qd))
+    Y = hip.to_host(hip.spmm(hip.stream(X), Qd))
     ref = m.astype(np.float64) @ Q.astype(np.float64)
     scale = np.abs(m).astype(np.float64) @ np.abs(Q).astype(np.float64) + 1e-30
     assert np.max(np.abs(Y - ref) / scale) < 2e-6  # f32 accumulation
     assert np.all(Y[np.diff(m.indptr) == 0] == 0)
-    Yc = hip.to_host(hip.spmm(X, Qd))
+    Yc = hip.to_host(hip.spmm(X, Qd))  # the general CSR kernel (one wave per row)
     assert np.max(np.abs(Y - Yc) / scale) < 2e-6
+    # the layout only decides which wave owns a row: matrix order gives the same bits
+    assert np.array_equal(hip.to_host(hip.spmm(hip.stream(X, sort_rows=False), Qd)), Y)
 
 
 @pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 6, 7, 8])
-def test_spmm_packed_every_rowset_count_is_bit_identical(hip, K):
-    """K (row-sets per wave) only changes which wave owns a row: results must not depend on it."""
+def test_spmm_stream_every_rowset_count_is_bit_identical(hip, K):
+    """K (row-sets per wave) only changes which wave owns a row: results must not depend on it.
+    (The stream is laid out in matrix order here: any K can walk it.)"""
     rng = np.random.default_rng(5)
     m = _heavy_rows_csr(2500, 3000, 0.02, rng)
     Q = rng.standard_normal((3000, 64)).astype(np.float32)
-    P = hip.pack(_up(hip, m))
+    X = _up(hip, m)
+    P = hip.stream(X, sort_rows=False)
     Qd = hip.to_device(Q)
+    Ydealt = hip.spmm(hip.stream(X), Qd)
     try:
         hip.tune("spmm_k", K)
         Y = hip.spmm(P, Qd)
         Y2 = hip.spmm(P, Qd)
-        hip.tune("spmm_k", 0)
-        Y0 = hip.spmm(P, Qd)
     finally:
         hip.tune("spmm_k", 0)
-    assert torch.equal(Y, Y2) and torch.equal(Y, Y0)
+    assert torch.equal(Y, Y2) and torch.equal(Y, Ydealt)
     ref = m.astype(np.float64) @ Q.astype(np.float64)
     scale = np.abs(m).astype(np.float64) @ np.abs(Q).astype(np.float64) + 1e-30
     assert np.max(np.abs(hip.to_host(Y) - ref) / scale) < 2e-6
 
 
-def test_spmm_packed_transpose_round_trip_property(hip):
-    """<X q, y> == <q, X^T y> through the two packed operands of the subspace iteration
-    (size-independent adjoint property; planted-topic counts with the real row-length spread)."""
+def test_spmm_stream_transpose_round_trip_property(hip):
+    """<X q, y> == <q, X^T y> through the two operands of the Lanczos iteration (size-independent
+    adjoint property; planted-topic counts with the real row-length spread), the stream of X^T
+    built straight from X and through the general CSR transpose."""
     m = planted_topics_csr(6000, 9000, n_topics=20, density=0.03, seed=3, dtype=np.float32)
     X = _up(hip, m)
-    Xt = hip.transpose(X)
-    Xp, Xtp = hip.pack(X), hip.pack(Xt)
+    Xs, Xts = hip.stream(X), hip.transpose_stream(X)
     q = hip.randn(9000, 64, 7)
     y = hip.randn(6000, 64, 8)
-    lhs = (hip.spmm(Xp, q).double() * y.double()).sum(dim=0)
-    rhs = (q.double() * hip.spmm(Xtp, y).double()).sum(dim=0)
+    lhs = (hip.spmm(Xs, q).double() * y.double()).sum(dim=0)
+    rhs = (q.double() * hip.spmm(Xts, y).double()).sum(dim=0)
     assert torch.allclose(lhs, rhs, rtol=1e-5, atol=1e-3 * float(lhs.abs().max()))
+    assert torch.equal(hip.spmm(hip.stream(hip.transpose(X)), y), hip.spmm(Xts, y))
 
 
 @pytest.mark.parametrize("n,d,dens", [(1, 1, 1.0), (7, 5, 0.5), (100, 10, 0.2), (257, 131, 0.08),
                                       (300, 9000, 0.01), (2000, 20000, 0.004), (5000, 700, 0.03),
                                       (70, 4097, 0.2)])
-def test_transpose_pack_is_bit_exact(hip, n, d, dens):
-    """The packed copy of X^T built straight from X equals the numpy packing of scipy's transpose
-    (cell ids ascending inside every output row, pads and closing chunks included)."""
+def test_transpose_stream_is_bit_exact(hip, n, d, dens):
+    """The row stream (and the CSR) of X^T built straight from X equal scipy's transpose, cell ids
+    ascending inside every output row."""
     rng = np.random.default_rng(n * 13 + d)
     m = _heavy_rows_csr(n, d, dens, rng, bursts=(n > 8 and d > 40))
     mt = m.T.tocsr()
     mt.sort_indices()
-    P = hip.transpose_pack(_up(hip, m), sort_rows=False)  # identity layout: byte for byte
-    cptr, ent = _pack_ref(mt)
+    P = hip.transpose_stream(_up(hip, m), sort_rows=False)  # identity layout: byte for byte
+    sptr, ent = _stream_ref(mt)
     assert P.shape == (d, n) and P.perm is None
-    assert np.array_equal(hip.to_host(P.cptr), cptr)
-    got = hip.to_host(P.ent).view(np.uint64)[: ent.size]
-    assert np.array_equal(got, ent)
-    P = hip.transpose_pack(_up(hip, m))  # sorted + dealt layout
+    assert np.array_equal(hip.to_host(P.sptr), sptr)
+    assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
+    P = hip.transpose_stream(_up(hip, m))  # sorted + dealt layout
     assert P.shape == (d, n)
-    _check_packed(hip, P, mt)
+    _check_stream(hip, P, mt)
+    T = _down(hip, hip.transpose_csr(_up(hip, m)))
+    assert np.array_equal(T.indptr, mt.indptr) and np.array_equal(T.indices, mt.indices)
+    assert np.array_equal(T.data.view(np.uint32), mt.data.astype(np.float32).view(np.uint32))
 
 
-def test_transpose_pack_empty_matrix(hip):
+def test_transpose_stream_empty_matrix(hip):
     m = sp.csr_matrix((5, 7), dtype=np.float32)
-    P = hip.transpose_pack(_up(hip, m), sort_rows=False)
-    assert np.array_equal(hip.to_host(P.cptr), np.arange(8))
-    assert np.all(hip.to_host(P.ent).view(np.uint64)[: 7 * 16] == 0x7FFFFFFF)
-    _check_packed(hip, hip.transpose_pack(_up(hip, m)), m.T.tocsr())
+    P = hip.transpose_stream(_up(hip, m), sort_rows=False)
+    assert np.array_equal(hip.to_host(P.sptr), np.zeros(8, dtype=np.int64))
+    _check_stream(hip, hip.transpose_stream(_up(hip, m)), m.T.tocsr())
 
 
-def test_transpose_pack_tile_overflow_falls_back(hip):
+def test_transpose_stream_tile_overflow_falls_back(hip):
     """A (row block x column slab) tile larger than the staging buffer takes the direct-store path;
-    the staged kernels (v3, v2) and the fallback give the bytes of the numpy packing."""
+    the staged kernels (v3, v2) and the fallback give the bytes of the numpy stream."""
     rng = np.random.default_rng(21)
     n, d = 60000, 200
     dense = sp.random(n, 100, density=0.95, format="csr", random_state=rng, dtype=np.float32)
@@ -337,25 +326,25 @@ def test_transpose_pack_tile_overflow_falls_back(hip):
     X = _up(hip, m)
     mt = m.T.tocsr()
     mt.sort_indices()
-    cptr, ent = _pack_ref(mt)
+    sptr, ent = _stream_ref(mt)
     for v2 in (0, 1):
         try:
             hip.tune("tpack_v2", v2)
-            P = hip.transpose_pack(X, sort_rows=False)
-            Ps = hip.transpose_pack(X)
+            P = hip.transpose_stream(X, sort_rows=False)
+            Ps = hip.transpose_stream(X)
         finally:
             hip.tune("tpack_v2", 0)
-        assert np.array_equal(hip.to_host(P.cptr), cptr)
+        assert np.array_equal(hip.to_host(P.sptr), sptr)
         assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
-        _check_packed(hip, Ps, mt)
+        _check_stream(hip, Ps, mt)
 
 
 @pytest.mark.parametrize("C", [32, 64, 0])
-def test_transpose_pack_count_rides_on_previous_tile(hip, C):
+def test_transpose_stream_count_rides_on_previous_tile(hip, C):
     """Third-generation fill: the place walk of a tile counts the next tile's entries.  Narrow tiles
     against rows with long dense bursts (more than 64 entries inside one / two tiles), empty column
     ranges (the tile after an empty one counts for itself) and ragged rows; the bytes equal the
-    numpy packing and the ones of the two-walk kernel."""
+    numpy stream and the ones of the two-walk kernel."""
     rng = np.random.default_rng(77 + C)
     n, d = 3000, 2600
     m = sp.random(n, d, density=0.02, format="lil", random_state=rng, dtype=np.float32)
@@ -371,18 +360,18 @@ def test_transpose_pack_count_rides_on_previous_tile(hip, C):
     X = _up(hip, m)
     mt = m.T.tocsr()
     mt.sort_indices()
-    cptr, ent = _pack_ref(mt)
+    sptr, ent = _stream_ref(mt)
     try:
         hip.tune("tpack_c", C)
-        P = hip.transpose_pack(X, sort_rows=False)
+        P = hip.transpose_stream(X, sort_rows=False)
         hip.tune("tpack_v2", 1)
-        P2 = hip.transpose_pack(X, sort_rows=False)
+        P2 = hip.transpose_stream(X, sort_rows=False)
     finally:
         hip.tune("tpack_c", 0)
         hip.tune("tpack_v2", 0)
-    assert np.array_equal(hip.to_host(P.cptr), cptr)
+    assert np.array_equal(hip.to_host(P.sptr), sptr)
     assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
-    assert torch.equal(P2.ent[: ent.size * 8], P.ent[: ent.size * 8])
+    assert torch.equal(P2.ent[: ent.size], P.ent[: ent.size])
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
@@ -408,17 +397,19 @@ def test_skinny_products(hip, dt, n, D):
 
 @pytest.mark.parametrize("B", [16, 32])
 @pytest.mark.parametrize("n,d,dens", [(5, 255, 0.3), (513, 700, 0.05), (3000, 20000, 0.01)])
-def test_spmm_packed_narrow_blocks(hip, B, n, d, dens):
-    """B = 16 / 32 instances of the packed SpMM (MOFA's sparse views, lsi with few components): same
-    fmaf chains as the CSR kernel."""
+def test_spmm_stream_narrow_blocks(hip, B, n, d, dens):
+    """B = 16 / 32 instances of the row-stream SpMM (MOFA's sparse views, lsi with few components)."""
     rng = np.random.default_rng(B + n)
     m = _heavy_rows_csr(n, d, dens, rng)
     Q = rng.standard_normal((d, B)).astype(np.float32)
     X = _up(hip, m)
     Qd = hip.to_device(Q)
-    Y = hip.to_host(hip.spmm(hip.pack(X), Qd))
+    Y = hip.to_host(hip.spmm(hip.stream(X), Qd))
     ref = m.astype(np.float64) @ Q.astype(np.float64)
     scale = np.abs(m).astype(np.float64) @ np.abs(Q).astype(np.float64) + 1e-30
     assert Y.shape == (n, B) and np.max(np.abs(Y - ref) / scale) < 2e-6
-    Z = hip.to_host(hip.spmm(hip.transpose_pack(X), hip.to_device(rng.standard_normal((n, B)).astype(np.float32))))
-    assert Z.shape == (d, B) and np.all(np.isfinite(Z))
+    Yn = rng.standard_normal((n, B)).astype(np.float32)
+    Z = hip.to_host(hip.spmm(hip.transpose_stream(X), hip.to_device(Yn)))
+    refz = m.T.astype(np.float64) @ Yn.astype(np.float64)
+    scalez = np.abs(m.T).astype(np.float64) @ np.abs(Yn).astype(np.float64) + 1e-30
+    assert Z.shape == (d, B) and np.max(np.abs(Z - refz) / scalez) < 2e-6
