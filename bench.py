@@ -268,7 +268,9 @@ def main():
                             f"({nnz_local / n_local / d:.4f} dense), tfidf + lsi(n_comps={args.n_comps})",
                 "parallelism": f"cells row-sharded x{world}" if world > 1 else "1 GPU",
                 "lsi": {"block": info.get("block"), "iterations": info.get("iterations"),
-                        "converged": info.get("converged"), "spmm_per_step": len(ms) // max(args.steps, 1)},
+                        "converged": info.get("converged"), "spmm_per_step": len(ms) // max(args.steps, 1),
+                        "spmm_unused": info.get("spmm_unused"), "angle_bound": info.get("angle_bound"),
+                        "lanczos_bounds": [float(f"{b:.3g}") for b in info.get("bounds", [])]},
             },
             "roofline": {
                 "kernel": ("k_spmm_rowwave (CSR SpMM, f32, B=64: one wave per row, Q rows gathered through L2)"

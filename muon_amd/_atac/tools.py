@@ -290,6 +290,7 @@ def _lsi_device(
 
     it = 0          # Krylov expansions done
     beta_hat = 0.0
+    big_products = int(getattr(X, "nnz", 0)) > 500_000_000
     restarts = 0
     converged = n_iter is not None
     limit = n_iter if n_iter is not None else max_iter
@@ -363,8 +364,16 @@ def _lsi_device(
             if len(bounds) >= 2 and np.isfinite(bounds[-2]) and bounds[-2] > 0:
                 rho = min(0.9, max(bound / bounds[-2], 1.5 * cheb, 1e-3))
             # One more expansion multiplies the error by about rho again.  A wrong "final" costs an
-            # exposed Ritz step (ms), a wrong "not final" an unused SpMM (tens of ms): lean to "final".
-            expect_final = np.isfinite(bound) and bound * rho < 10.0 * angle_tol
+            # exposed Ritz step (ms), a wrong "not final" an unused SpMM (tens of ms at 1e6 rows): lean
+            # to "final" - the bound itself over-estimates 3x and more.
+            expect_final = np.isfinite(bound) and bound * rho < 100.0 * angle_tol
+            # Block Lanczos converges superlinearly once the space holds the wanted vectors (c3: bounds
+            # 1.27, 0.21, 2.7e-7 in consecutive steps), so the rate says little.  When a product costs
+            # more than the exposed Ritz step it would hide (> ~5e8 stored entries: 3 ms and up against
+            # ~6 ms of host LAPACK and launch gaps for a wrong "final"), stop speculating as soon as the
+            # vectors have started to converge.
+            if big_products and np.isfinite(bound) and bound < 1.0:
+                expect_final = True
             if bound < angle_tol:
                 stop = True
             elif len(bounds) >= 6 and bound > 0.7 * bounds[-5] and bound < 1e-2:
