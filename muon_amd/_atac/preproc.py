@@ -20,16 +20,33 @@ from .._ffi import TFIDF_LOG_IDF, TFIDF_LOG_TF, TFIDF_LOG_TFIDF
 DEVICE_ATTR = "_muon_amd_device"
 
 
+_HASH_CHUNK = 1 << 26  # 64 MiB per task
+
+
+def _hash_array(a: np.ndarray) -> int:
+    """xxh3-64 over ALL bytes of ``a`` (chunks hashed on a thread pool - the C extension releases
+    the GIL -, digests combined in order): ~10 GB/s per thread, i.e. milliseconds for the matrices
+    that travel through the AnnData API and comparable to the PCIe upload it saves at 1e9 entries."""
+    import xxhash
+
+    b = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    if b.size <= _HASH_CHUNK:
+        return xxhash.xxh3_64_intdigest(b)
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+
+    cuts = list(range(0, b.size, _HASH_CHUNK))
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        parts = list(ex.map(lambda o: xxhash.xxh3_64_intdigest(b[o:o + _HASH_CHUNK]), cuts))
+    return xxhash.xxh3_64_intdigest(np.asarray(parts, dtype=np.uint64))
+
+
 def _fingerprint(m: csr_matrix):
-    """Cheap identity of a host CSR's buffers and contents: buffer addresses, sizes and a strided
-    sample checksum of the values (<= 2^16 samples).  In-place edits that move or resize a buffer,
-    or touch a sampled value, invalidate the resident copy; a surgical edit of single entries
-    between two calls is not detected (documented in DESIGN.md 3)."""
-    d = m.data
-    step = max(1, d.size >> 16)
-    sample = d[::step]
-    return (m.shape, int(m.nnz), d.dtype.str, d.ctypes.data, m.indices.ctypes.data,
-            float(np.nansum(sample, dtype=np.float64)), int(np.isnan(sample).sum()))
+    """Identity of a host CSR: shape, dtype and a hash of EVERY byte of data, indices and indptr.
+    Any in-place edit between two calls - a single entry, a permuted index array - invalidates the
+    resident copy (r01 sampled 2^16 values and could serve stale HBM data; ADVICE r01 #1)."""
+    return (m.shape, int(m.nnz), m.data.dtype.str, m.indices.dtype.str, m.indptr.dtype.str,
+            _hash_array(m.data), _hash_array(m.indices), _hash_array(m.indptr))
 
 
 def attach_device(m: csr_matrix, dev_csr, backend) -> None:
@@ -86,8 +103,11 @@ def canonical_csr(counts) -> csr_matrix:
     dtype promotion the reference's first statement performs (ints -> float64)."""
     if issparse(counts):
         m = counts.tocsr()
-        if m is counts:
-            m = m.copy()
+        if m is counts and not (m.dtype in (np.float32, np.float64) and m.has_canonical_format
+                                and m.has_sorted_indices):
+            m = m.copy()  # sum_duplicates / sort_indices below work in place: not on the caller's arrays
+        # (already canonical float CSR: returned as is, no copy - at 6e9 entries the copy alone is
+        #  75 GB of host memory and a single-threaded memcpy; callers only read it)
     else:
         m = csr_matrix(np.asarray(counts))  # dense branch (:97-99,113-114) ends in CSR too
     if m.dtype not in (np.float32, np.float64):

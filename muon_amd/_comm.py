@@ -27,6 +27,9 @@ class LocalComm:
     def sum_scalar(self, x):
         return x
 
+    def all_reduce_max(self, t):
+        return t
+
     def agree(self, flag):
         return bool(flag)
 
@@ -43,9 +46,34 @@ class TorchDistComm:
         self.rank = dist.get_rank(group)
 
     def all_reduce_sum(self, *tensors):
+        """In-place sum over the ranks.  Several tensors travel as ONE message per dtype: a Krylov
+        step of the LSI reduces up to four small Grams, a MOFA iteration four statistics, and on
+        xGMI every collective pays its launch and ring latency whatever its size."""
+        groups = {}
         for t in tensors:
-            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+            groups.setdefault((t.dtype, t.device), []).append(t)
+        for ts in groups.values():
+            if len(ts) == 1:
+                t = ts[0]
+                if t.is_contiguous():
+                    self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+                else:
+                    c = t.contiguous()
+                    self._dist.all_reduce(c, op=self._dist.ReduceOp.SUM, group=self.group)
+                    t.copy_(c)
+                continue
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            self._dist.all_reduce(flat, op=self._dist.ReduceOp.SUM, group=self.group)
+            o = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[o:o + n].view(t.shape))
+                o += n
         return tensors[0] if len(tensors) == 1 else tensors
+
+    def all_reduce_max(self, t):
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
+        return t
 
     def all_gather_rows(self, t):
         """Concatenate row shards of possibly different length along dim 0."""

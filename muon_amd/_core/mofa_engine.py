@@ -97,11 +97,10 @@ class MofaEngine:
     def _global_max(self, groups):
         m = int(groups.max()) if groups.size else 0
         if self.comm.world_size > 1:
-            # max via sum of one-hot is overkill; gather through a small all-reduce of 2^k bins
-            t = torch.zeros(4096, dtype=torch.float64)
-            t[m] = 1
-            t = self._allreduce(t)
-            m = int(torch.nonzero(t).max().item())
+            t = torch.tensor([m], dtype=torch.int64)
+            if getattr(self.be, "name", "") == "hip":
+                t = t.to(self.be.device)
+            m = int(self.comm.all_reduce_max(t).item())
         return m
 
     def _allreduce(self, t: torch.Tensor) -> torch.Tensor:
@@ -482,7 +481,8 @@ class MofaEngine:
             if callback is not None:
                 callback(it, self)
             if it >= min_iterations and len(self.elbo) >= 2:
-                if 100.0 * abs((self.elbo[-1] - self.elbo[-2]) / self.elbo[0]) < tol:
+                # (rank 0 decides: a rank that leaves alone strands the others in their next collective)
+                if self.comm.agree(100.0 * abs((self.elbo[-1] - self.elbo[-2]) / self.elbo[0]) < tol):
                     break
         return len(self.elbo)
 

@@ -150,3 +150,26 @@ def test_k_not_at_a_spectral_gap_is_never_silently_wrong(hip, case):
     np.testing.assert_allclose(sd, ref["stdev"], rtol=1e-5)
     if case == "k_inside_cluster":
         assert info["converged"]  # gap 1.3 %: reachable in f32, and reached
+
+
+def test_two_ranks_on_one_gpu_match_the_single_process_result():
+    """The row-sharded HIP path with real collectives: two processes share cuda:0 (gloo), hold
+    uneven shards, all-reduce the per-peak sums, the Grams and Z = X^T Y, and must reproduce the
+    single-process TF-IDF values and LSI subspace (scripts/dist_gpu_check.py does the comparison)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "scripts", "dist_gpu_check.py")],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "dist gpu check ok" in r.stdout

@@ -179,6 +179,33 @@ def test_resident_copy_is_dropped_when_the_host_matrix_changes():
     np.testing.assert_allclose(ad.uns["lsi"]["stdev"], ref["stdev"], rtol=1e-5)
 
 
+def test_resident_copy_detects_surgical_and_index_edits():
+    # one changed entry, or a rewritten index array, must invalidate the device copy
+    X = planted_topics_csr(400, 300, n_topics=5, density=0.1, seed=6, dtype=np.float32)
+    for edit in ("one_value", "indices", "indptr"):
+        be = _CountingBackend()
+        ad = AnnData(X.copy())
+        ac.pp.tfidf(ad, backend=be)
+        assert be.uploads == 1
+        m = ad.X
+        if edit == "one_value":
+            m.data[m.nnz // 3 + 1] += 0.5
+        elif edit == "indices":
+            lo, hi = m.indptr[7], m.indptr[8]
+            m.indices[lo:hi] = m.indices[lo:hi][::-1].copy()  # same buffer, other content
+            m.has_sorted_indices = False
+        else:
+            m.indptr[5] -= 1  # moves one entry from row 4 to row 5 (still a valid CSR)
+            m.has_sorted_indices = False
+        ac.tl.lsi(ad, n_comps=5, backend=be)
+        assert be.uploads == 2, edit
+    be = _CountingBackend()
+    ad = AnnData(X.copy())
+    ac.pp.tfidf(ad, backend=be)
+    ac.tl.lsi(ad, n_comps=5, backend=be)  # untouched: the copy is reused
+    assert be.uploads == 1
+
+
 def _device_tfidf(X):
     T = tfidf_oracle.canonical(tfidf_oracle.tfidf(X)).astype(np.float32)
     return T, BE.upload_csr(T.indptr, T.indices, T.data, T.shape)
