@@ -26,6 +26,10 @@ Workloads (--workload):
   c3shard            125 000 cells x 200 000 peaks PER GPU (weak scaling; N = 8 is the same 1M x
                      200k matrix)
   c2                 10 000 x 30 000, 3 % nnz (configs[1]; launch/latency bound at this size)
+  c4                 configs[3]/[4]: mu.tl.mofa on rna 100k x 20k dense + atac 100k x 100k sparse, K = 10;
+                     metric = seconds per 100 ELBO iterations (lower is better), --steps = iterations
+                     (default 100), cells sharded over the N GPUs; cpu_baseline = the numpy f64
+                     restatement on a cell sample, extrapolated (scripts/bench_mofa.py)
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run.
 Prints ONE JSON line on rank 0.
@@ -47,6 +51,7 @@ WORKLOADS = {  # cells = TOTAL cells for strong scaling, cells PER GPU for weak 
     "c3": dict(cells=1_000_000, peaks=200_000, scaling="strong"),
     "c3shard": dict(cells=125_000, peaks=200_000, scaling="weak"),
     "c2": dict(cells=10_000, peaks=30_000, scaling="weak"),
+    "c4": None,  # BASELINE.json configs[3]/[4]: mu.tl.mofa, 100 ELBO iterations (scripts/bench_mofa.py)
 }
 
 
@@ -143,6 +148,20 @@ def main():
     ap.add_argument("--no-pack", action="store_true",
                     help="ablation: run the SpMM on plain CSR (k_spmm_rowwave, one wave per row) instead of the row streams")
     args = ap.parse_args()
+
+    if args.workload == "c4":
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("bench_mofa", os.path.join(ROOT, "scripts", "bench_mofa.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        argv = ["--gpus", str(args.gpus), "--iters", str(100 if args.steps == 3 else args.steps),
+                "--warmup", str(max(args.warmup, 3))]
+        if args.cells:
+            argv += ["--cells", str(args.cells)]
+        if args.no_cpu_baseline:
+            argv += ["--no-cpu-baseline"]
+        return mod.main(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -143,10 +143,10 @@ class MofaEngine:
             pres = np.ones(N, dtype=bool)
             if isinstance(v, DeviceCSR):
                 V.kind = "sparse"
-                V.X = v.with_values(v.values.to(T))
-            else:
+                V.X = v.with_values(v.values.to(T, copy=True))  # centring / scaling work in place:
+            else:                                               # never on the caller's tensors
                 V.kind = "dense"
-                V.Y = v.to(T)
+                V.Y = v.to(T, copy=True)
         elif issparse(v):
             m = v.tocsr()[self.perm]
             m.sort_indices()
@@ -188,18 +188,28 @@ class MofaEngine:
         mu = s1 / n
         V.intercepts = mu.clone()  # tools.py:283-286: nanmean per (view, group)
         if not center_groups:
-            mu = torch.zeros_like(mu)
-        yy = s2 - 2 * mu * s1 + n * mu * mu  # sum (y - mu)^2 over observed samples
+            # mofapy2 process_data: without group centring every feature still loses its mean over
+            # ALL observed samples (r01 left such data uncentred)
+            mu = (s1.sum(dim=0) / V.Ngm.to(s1.device).to(T).sum().clamp(min=1.0))[None, :].expand(G, D).contiguous()
+        c1 = s1 - n * mu                     # sum (y - mu)   over the observed samples of a group
+        yy = s2 - 2 * mu * s1 + n * mu * mu  # sum (y - mu)^2
+        # scale_views: the centred view / its nanstd; scale_groups (applied after it): every group's
+        # block / its nanstd, which cancels the view's scalar.  nanstd subtracts the scalar mean of
+        # the block (zero under group centring, not otherwise).
         scale = torch.ones((G,), dtype=T, device=s1.device)
         if scale_groups:
             for g in range(G):
-                var = yy[g].sum() / (V.Ngm[g].item() * D)
+                cnt = V.Ngm[g].item() * D
+                if cnt > 0:
+                    var = yy[g].sum() / cnt - (c1[g].sum() / cnt) ** 2
+                    if var > 0:
+                        scale[g] = 1.0 / math.sqrt(float(var))
+        elif scale_views:
+            cnt = float(V.Ngm.sum().item()) * D
+            if cnt > 0:
+                var = float(yy.sum().item()) / cnt - (float(c1.sum().item()) / cnt) ** 2
                 if var > 0:
-                    scale[g] = 1.0 / math.sqrt(float(var))
-        if scale_views:
-            tot = float((yy * scale[:, None] ** 2).sum().item()) / (float(V.Ngm.sum().item()) * D)
-            if tot > 0:
-                scale = scale / math.sqrt(tot)
+                    scale = scale / math.sqrt(var)
         if scale_groups or scale_views:
             for g, (a, b) in enumerate(self.gslice):
                 if V.kind == "dense":

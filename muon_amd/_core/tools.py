@@ -9,11 +9,12 @@ products, PyTorch-ROCm for the dense blocks.
 
 Deliberate deviations, all explicit:
   * sparse modalities are NOT densified (tools.py:117-141 does ``.todense()``);
-  * only the Gaussian likelihood is implemented; bernoulli / poisson, SVI, MEFISTO
-    (smooth_*), ``spikeslab_factors`` raise NotImplementedError instead of being ignored;
+  * only the Gaussian likelihood is implemented: views whose likelihood the reference's default
+    would GUESS as bernoulli / poisson are modelled as gaussian with a warning; asking for them
+    explicitly, SVI, MEFISTO (smooth_*) and ``spikeslab_factors`` raise NotImplementedError;
   * a bad ``groups_label`` raises ValueError where the reference calls ``sys.exit()`` (:106-113);
-  * the model file ``outfile`` is written as ``.npz`` (no h5py in this image) unless h5py is
-    importable; results are handed to the write-back directly instead of through the file.
+  * the model file is HDF5 (mofapy2's layout) when h5py is importable; otherwise ``outfile`` +
+    ".npz" (NumPy archive, with a warning); results reach the write-back directly, not through it.
 """
 from __future__ import annotations
 
@@ -101,16 +102,27 @@ def _collect_views(mdata, groups_label, use_raw, use_layer, likelihoods, feature
                 x._missing_rows = miss
         views.append(x)
 
-    if likelihoods is None:
+    guessed = likelihoods is None
+    if guessed:
         likelihoods = [_guess_likelihood(v) for v in views]
     assert len(likelihoods) == len(views), "Please specify one likelihood for each view"
     assert set(likelihoods).issubset({"gaussian", "bernoulli", "poisson"}), \
         "Available likelihoods are 'gaussian', 'bernoulli', 'poisson'"
     if any(l != "gaussian" for l in likelihoods):
-        raise NotImplementedError(
-            f"likelihoods {likelihoods}: only 'gaussian' is implemented on the GPU path "
-            "(pass likelihoods='gaussian' to force it)"
-        )
+        if not guessed:
+            raise NotImplementedError(
+                f"likelihoods {likelihoods}: only 'gaussian' is implemented on the GPU path "
+                "(pass likelihoods='gaussian' to force it)"
+            )
+        # The reference's default (likelihoods=None, tools.py:272-280) guesses poisson / bernoulli for
+        # integer / binary data, e.g. raw or binarised ATAC counts.  mofapy2 fits those through
+        # pseudo-data that needs the dense N x D prediction in every iteration, which is what this
+        # path exists to avoid; a drop-in call must still run: the views are modelled as gaussian,
+        # loudly.  (Pass likelihoods explicitly to get the NotImplementedError instead.)
+        warn("mofa: guessed likelihoods " + str(likelihoods) + " are not implemented on the GPU path; "
+             "every view is modelled with a gaussian likelihood (as with likelihoods='gaussian'). "
+             "Transform counts first (e.g. TF-IDF / log-normalisation) for a better fit.")
+        likelihoods = ["gaussian"] * len(views)
 
     obs = mdata.obs.loc[obs_names]
     if groups_label is None:
@@ -316,10 +328,15 @@ def mofa(
 
 def _save_model(outfile, res, view_names, group_names, obs_names, groups, expectations):
     """Model file (tools.py:600-602 ent.save): HDF5 with mofapy2's group layout when h5py is
-    importable, otherwise the same arrays as .npz at the same path."""
+    importable.  Without h5py (this image) the same arrays are written as NumPy .npz - under a name
+    that says so (``outfile`` + ".npz" unless it already ends in .npz): a file called *.hdf5 that no
+    MOFA tool can open helps nobody.  Returns the path written."""
     try:
         import h5py  # noqa: F401
     except Exception:  # noqa: BLE001
+        if not str(outfile).endswith(".npz"):
+            warn(f"h5py is not importable: the model is saved as NumPy archive {outfile}.npz, not as HDF5")
+            outfile = str(outfile) + ".npz"
         try:
             with open(outfile, "wb") as f:
                 np.savez(f, Z=res["Z"], elbo=np.asarray(res["elbo"]), r2=res["r2"],
@@ -328,7 +345,7 @@ def _save_model(outfile, res, view_names, group_names, obs_names, groups, expect
                          **{f"W_{m}": w for m, w in zip(view_names, res["W"])})
         except OSError as e:  # pragma: no cover
             warn(f"Cannot save the model to {outfile}: {e}")
-        return
+        return outfile
     import h5py
 
     with h5py.File(outfile, "w") as f:  # pragma: no cover - h5py absent in the build image
@@ -347,3 +364,4 @@ def _save_model(outfile, res, view_names, group_names, obs_names, groups, expect
         for gi, g in enumerate(group_names):
             ve.create_dataset(g, data=res["r2"][:, gi, :])
         f.create_group("training_stats").create_dataset("elbo", data=np.asarray(res["elbo"]))
+    return outfile

@@ -25,8 +25,15 @@ TOL = {"fast": 5e-4, "medium": 5e-5, "slow": 5e-6}  # % change of the ELBO w.r.t
 
 
 def prepare_views(views, groups, center_groups=True, scale_views=False, scale_groups=False):
-    """What tools.py:283-287 asks mofapy2.process_data to do: per (view, group) feature means
-    removed (stored as intercepts), optional unit-variance scaling.  NaN = missing."""
+    """What tools.py:283-287 asks mofapy2.process_data to do for gaussian views, statement by
+    statement on dense arrays with NaN = missing (mofapy2 is not under /root/reference; this is
+    its published preprocessing, mofapy2/core/utils.py process_data, as of 0.7):
+        centring:     per group, features minus their nanmean   (center_groups=True)
+                      or features minus their nanmean over ALL samples (center_groups=False)
+        scale_views:  the view divided by its nanstd (one scalar)
+        scale_groups: every group's block divided by its nanstd (one scalar per group)
+    in this order.  The per-(view, group) feature means are returned as intercepts
+    (tools.py:283-286)."""
     groups = np.asarray(groups)
     G = int(groups.max()) + 1 if groups.size else 1
     out, intercepts = [], []
@@ -38,18 +45,22 @@ def prepare_views(views, groups, center_groups=True, scale_views=False, scale_gr
             with np.errstate(invalid="ignore"):
                 mu[g] = np.nanmean(Y[idx], axis=0) if idx.any() else 0.0
             mu[g] = np.nan_to_num(mu[g])
-            if center_groups:
-                Y[idx] -= mu[g]
-        if scale_groups:
+        if center_groups:
             for g in range(G):
-                idx = groups == g
-                s = np.nanstd(Y[idx])
-                if s > 0:
-                    Y[idx] /= s
+                Y[groups == g] -= mu[g]
+        else:
+            with np.errstate(invalid="ignore"):
+                Y -= np.nan_to_num(np.nanmean(Y, axis=0))
         if scale_views:
             s = np.nanstd(Y)
             if s > 0:
                 Y /= s
+        if scale_groups:
+            for g in range(G):
+                idx = groups == g
+                s = np.nanstd(Y[idx]) if idx.any() else 0.0
+                if s > 0:
+                    Y[idx] /= s
         out.append(Y)
         intercepts.append(mu)
     return out, intercepts

@@ -17,96 +17,139 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--gpus", type=int, default=1)
-ap.add_argument("--cells", type=int, default=100000)
-ap.add_argument("--rna", type=int, default=20000)
-ap.add_argument("--atac", type=int, default=100000)
-ap.add_argument("--iters", type=int, default=100)
-ap.add_argument("--warmup", type=int, default=3)
-ap.add_argument("--f64", action="store_true", help="float64 like the reference default (use_float32=False)")
-args = ap.parse_args()
 
-world = int(os.environ.get("WORLD_SIZE", "1"))
-rank = int(os.environ.get("RANK", "0"))
-local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-shared_gpu = os.environ.get("MUON_AMD_BENCH_SHARED_GPU") == "1"  # test hook: all ranks on GPU 0 over gloo
-if shared_gpu:
-    local_rank = 0
-torch.cuda.set_device(local_rank)
-comm = None
-if world > 1:
-    import torch.distributed as dist
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+def cpu_baseline(be, rna, atac, n_cells_total, sample_cells, iters):
+    """mofapy2 is not installable here, so the CPU baseline is the numpy f64
+    restatement of the MOFA+ updates (oracle/mofa_oracle.py: checker-side code) on the first
+    `sample_cells` cells with the SAME feature dimensions and K = 10 - the reference's data path
+    (tools.py:117-141 densifies the sparse modality) -, timed per iteration and extrapolated linearly
+    in the number of cells to the full workload; labelled as such."""
+    import scipy.sparse as sp
+    from oracle import mofa_oracle
+
+    n = min(sample_cells, rna.shape[0])
+    y1 = be.to_host(rna[:n]).astype(np.float64)
+    hi = int(atac.indptr[n].item())
+    y2 = sp.csr_matrix((be.to_host(atac.values[:hi]).astype(np.float64), be.to_host(atac.indices[:hi]),
+                        be.to_host(atac.indptr[: n + 1])), shape=(n, atac.shape[1])).toarray()
+    t0, c0 = time.perf_counter(), time.process_time()
+    res = mofa_oracle.run([y1, y2], groups=np.zeros(n, dtype=np.int64), n_factors=10, n_iterations=iters,
+                          convergence_mode="slow", min_iterations=iters + 1)
+    wall, cpu = time.perf_counter() - t0, time.process_time() - c0
+    done = max(len(res["elbo"]), 1)
+    per_iter_full = wall / done * (n_cells_total / n)
+    return {
+        "value": 100 * per_iter_full, "unit": "s", "cores": max(1, int(round(cpu / max(wall, 1e-9)))),
+        "kind": "port",
+        "sample": f"numpy f64 MOFA+ updates (oracle/mofa_oracle.py) on the first {n} cells x ({rna.shape[1]} dense + "
+                  f"{atac.shape[1]} densified) features, K=10, {done} iterations in {wall:.1f} s ({wall / done:.2f} s per "
+                  f"iteration incl. set-up); extrapolated linearly in cells to {n_cells_total} and to 100 iterations; "
+                  f"measured CPU/wall {cpu / max(wall, 1e-9):.1f} (host has {os.cpu_count()} cores)",
+    }
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--cells", type=int, default=100000)
+    ap.add_argument("--rna", type=int, default=20000)
+    ap.add_argument("--atac", type=int, default=100000)
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--f64", action="store_true", help="float64 like the reference default (use_float32=False)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-cells", type=int, default=1500)
+    ap.add_argument("--cpu-sample-iters", type=int, default=4)
+    args = ap.parse_args(argv)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    shared_gpu = os.environ.get("MUON_AMD_BENCH_SHARED_GPU") == "1"  # test hook: all ranks on GPU 0 over gloo
     if shared_gpu:
-        dist.init_process_group("gloo")
-    else:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from muon_amd._comm import TorchDistComm
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
 
-    comm = TorchDistComm()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from muon_amd._comm import TorchDistComm
 
-from muon_amd._atac.preproc import tfidf_device
-from muon_amd._backend import HipBackend
-from muon_amd._core.mofa_engine import MofaEngine
+        comm = TorchDistComm()
 
-be = HipBackend(local_rank)
-T = torch.float64 if args.f64 else torch.float32
-row0 = rank * args.cells // world
-N = (rank + 1) * args.cells // world - row0
-K0 = 10
-g = torch.Generator(device="cuda").manual_seed(0)
-W = torch.randn((args.rna, K0), generator=g, device="cuda") * (torch.rand((args.rna, K0), generator=g, device="cuda") < 0.3)
-gz = torch.Generator(device="cuda").manual_seed(1 + rank)
-Z = torch.randn((N, K0), generator=gz, device="cuda", dtype=torch.float32)
-rna = Z @ W.T
-rna += torch.randn(rna.shape, generator=gz, device="cuda")
-X = be.synth_counts(row0, N, args.atac, 50, 0.03, 0)
-atac = tfidf_device(be, X, args.cells, 3, 1e4, comm=comm)
-eng = MofaEngine(be, [rna, atac], np.zeros(N, dtype=np.int64), 10, dtype=T, seed=1, comm=comm,
-                 row_offset=row0, n_total=args.cells)
-for _ in range(args.warmup):
-    eng.step()
+    from muon_amd._atac.preproc import tfidf_device
+    from muon_amd._backend import HipBackend
+    from muon_amd._core.mofa_engine import MofaEngine
+
+    be = HipBackend(local_rank)
+    T = torch.float64 if args.f64 else torch.float32
+    row0 = rank * args.cells // world
+    N = (rank + 1) * args.cells // world - row0
+    K0 = 10
+    g = torch.Generator(device="cuda").manual_seed(0)
+    W = torch.randn((args.rna, K0), generator=g, device="cuda") * (torch.rand((args.rna, K0), generator=g, device="cuda") < 0.3)
+    gz = torch.Generator(device="cuda").manual_seed(1 + rank)
+    Z = torch.randn((N, K0), generator=gz, device="cuda", dtype=torch.float32)
+    rna = Z @ W.T
+    rna += torch.randn(rna.shape, generator=gz, device="cuda")
+    X = be.synth_counts(row0, N, args.atac, 50, 0.03, 0)
+    atac = tfidf_device(be, X, args.cells, 3, 1e4, comm=comm)
+    eng = MofaEngine(be, [rna, atac], np.zeros(N, dtype=np.int64), 10, dtype=T, seed=1, comm=comm,
+                     row_offset=row0, n_total=args.cells)
+    for _ in range(args.warmup):
+        eng.step()
 
 
-def sync():
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        eng.step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        vb = 8 if args.f64 else 4
+        dense_b = vb * args.cells * args.rna
+        sparse_b = int(atac.nnz * world) * (4 + vb)  # approx.: rank 0's nnz x world
+        alg = 2 * (dense_b + sparse_b)  # two passes over every view per iteration (DESIGN.md 6)
+        per = dt / args.iters
+        mono = bool(np.all(np.diff(eng.elbo) > -1e-5 * abs(eng.elbo[0])))
+        out = {
+            "metric": "seconds per 100 ELBO iterations of mu.tl.mofa (10 factors)",
+            "value": 100 * per, "unit": "s", "n_gpus": world, "steps": args.iters, "warmup": args.warmup,
+            "ms_per_step": per * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if args.f64 else "f32", "data": "synthetic",
+            "config": {"workload": f"c4: rna {args.cells} x {args.rna} dense + atac {args.cells} x {args.atac} sparse "
+                                   f"({atac.nnz} nnz on rank 0), K=10, gaussian likelihoods, {args.iters} iterations",
+                       "parallelism": f"cells row-sharded x{world}" if world > 1 else "1 GPU"},
+            "roofline": {"kernel": "whole iteration (two passes over every view: A = Y (tau o W), B = Y^T Z)",
+                         "bound": "hbm", "achieved": alg / per / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": alg / per / 1e9 / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_iteration": alg},
+            "elbo": {"first": eng.elbo[0], "last": eng.elbo[-1], "monotone": mono},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(be, rna, atac, args.cells, args.cpu_sample_cells, args.cpu_sample_iters)
+        print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+        torch.distributed.destroy_process_group()
 
 
-sync()
-t0 = time.perf_counter()
-for _ in range(args.iters):
-    eng.step()
-sync()
-dt = time.perf_counter() - t0
-if world > 1:
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t.item())
-if rank == 0:
-    vb = 8 if args.f64 else 4
-    dense_b = vb * args.cells * args.rna
-    sparse_b = int(atac.nnz * world) * (4 + vb)  # approx.: rank 0's nnz x world
-    alg = 2 * (dense_b + sparse_b)  # two passes over every view per iteration
-    per = dt / args.iters
-    mono = bool(np.all(np.diff(eng.elbo) > -1e-5 * abs(eng.elbo[0])))
-    print(json.dumps({
-        "metric": "seconds per 100 ELBO iterations of mu.tl.mofa (10 factors)",
-        "value": 100 * per, "unit": "s", "n_gpus": world, "steps": args.iters, "warmup": args.warmup,
-        "ms_per_step": per * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64" if args.f64 else "f32", "data": "synthetic",
-        "config": {"workload": f"c4: rna {args.cells} x {args.rna} dense + atac {args.cells} x {args.atac} sparse "
-                               f"({atac.nnz} nnz on rank 0), K=10, gaussian likelihoods, {args.iters} iterations",
-                   "parallelism": f"cells row-sharded x{world}" if world > 1 else "1 GPU"},
-        "roofline": {"kernel": "whole iteration (two passes over every view: A = Y (tau o W), B = Y^T Z)",
-                     "bound": "hbm", "achieved": alg / per / 1e9, "peak": 8000.0, "unit": "GB/s",
-                     "frac": alg / per / 1e9 / 8000.0, "traffic": None,
-                     "algorithmic_bytes_per_iteration": alg},
-        "elbo": {"first": eng.elbo[0], "last": eng.elbo[-1], "monotone": mono},
-    }))
-if world > 1:
-    torch.distributed.barrier()
-    torch.distributed.destroy_process_group()
+if __name__ == "__main__":
+    main()
