@@ -185,6 +185,8 @@ int mu_csr_tpack_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int
  * accumulated in column order with one fmaf chain per dense column, whatever the layout =>
  * bit-reproducible and layout-independent. */
 int mu_spmm_stream_k(int64_t n_rows);
+/* diagnostics (scripts/tpack_probe.py): see csrc/tpack.hip */
+int mu_csr_tpack_phase_cycles(unsigned long long* h_out6, int reset);
 int mu_csr_stream_len(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr, int64_t* d_len,
                       void* stream);
 int mu_csr_stream_fill(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "mu_csr_tpack_count_sp": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_csr_tpack_fill_csr": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_stream_k": (C.c_int, [_i64]),
+    "mu_csr_tpack_phase_cycles": (C.c_int, [_vp, _i32]),
     "mu_csr_stream_len": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "mu_csr_stream_fill": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_csr_tpack_fill_stream": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

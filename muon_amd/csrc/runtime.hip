@@ -29,13 +29,14 @@ int mu_num_cus() {
 
 // tuning / ablation knobs (tests and bench only)
 static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "spmm_waves", "spmm_pipe",
-                                        "tpack_abl", "tpack_c", "gram_wg", "tpack_v2", "pack_wg"};
-constexpr int kTuneN = 9;
-static int g_tune[kTuneN] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                                        "tpack_abl", "tpack_c", "gram_wg", "tpack_v2", "pack_wg",
+                                        "tpack_dbg", "tpack_rows"};
+constexpr int kTuneN = 11;
+static int g_tune[kTuneN] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 extern "C" {
 
-int mu_version(void) { return 103; }
+int mu_version(void) { return 200; }
 
 int mu_tune_set(const char* key, int value) {
   MU_REQUIRE(key, "null key");

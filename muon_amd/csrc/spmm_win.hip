@@ -329,6 +329,12 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
         request_window<k>(off[k], entb, __ballot(off[k] < (unsigned)bcast_i<k>((int)endv)));
         if ((c0 | c1 | c2 | c3) & 16u) again |= 1u << k;  // a window used up: maybe more in this slab
       }
+      if constexpr (MODE & 1024) {  // real stage A, synthetic 12-entry window for stage B
+        w.a = ((lane * 37 + k * 13 + (int)s0) & (kSlabCols - 1)) << kRowShift;
+        w.vv = 1.0f;
+        w.any16 = 0x0fffu;
+      }
+      if constexpr (MODE & 2048) w.any16 = (w.any16 & 0xf000u) ? 0xffffu : (w.any16 & 0x0f00u) ? 0x0fffu : w.any16;
       return w;
     };
     // Stage B: the LDS gathers and FMAs of the window.
@@ -378,6 +384,38 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
       __builtin_amdgcn_s_setprio(0);
     };
 
+    // Slots 0-7 of a main pass in two halves: the eight LDS reads go out BEFORE stage A of the next
+    // pass, whose scalar work then runs under their latency; the FMAs and the upper half follow.
+    struct Low8 { Quad<NB> r0, r1; };
+    auto b_issue = [&](const Win& w) -> Low8 {
+      Low8 r;
+      r.r0 = quad_read<0, NB>(qbase, w.a);
+      r.r1 = quad_read<4, NB>(qbase, w.a);
+      return r;
+    };
+    auto b_finish = [&](auto kc, const Win& w, const Low8& r) {
+      constexpr int k = decltype(kc)::value;
+      __builtin_amdgcn_s_setprio(1);
+      quad_fma<0, NB>(r.r0, w.vv, acc[k]);
+      quad_fma<4, NB>(r.r1, w.vv, acc[k]);
+      if (w.any16 & 0xf000u) {
+        const Quad<NB> q0 = quad_read<8, NB>(qbase, w.a);
+        const Quad<NB> q1 = quad_read<12, NB>(qbase, w.a);
+        quad_fma<8, NB>(q0, w.vv, acc[k]);
+        quad_fma<12, NB>(q1, w.vv, acc[k]);
+      } else if (w.any16 & 0x0c00u) {
+        const Quad<NB> q = quad_read<8, NB>(qbase, w.a);
+        quad_fma<8, NB>(q, w.vv, acc[k]);
+      } else if (w.any16 & 0x0300u) {
+        const Pair<NB> q = pair_read<8, NB>(qbase, w.a);
+        pair_fma<8, NB>(q, w.vv, acc[k]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    };
+    // (measured r02p: 4.80 / 4.89 ms against 4.54 / 4.75 unsplit on X Q / X^T Y at 125k x 200k: the
+    //  eight results held across stage A cost more than the latency they hide; kept as ablation 4096)
+    constexpr bool kSplit = kDeep && (MODE & 4096) && !(MODE & (1 | 64));
+
     if constexpr (MODE & 64) {
       static_for<K>([&](auto kc) {
         if constexpr (decltype(kc)::value < kMyPieces) next_piece(decltype(kc)::value);
@@ -394,11 +432,14 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
       static_for<K>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         Win wn = w;
+        Low8 low;
+        if constexpr (kSplit) low = b_issue(w);
         if constexpr (k + 1 < K) {
           if constexpr (k + 1 < kMyPieces) next_piece(k + 1);
           wn = stage_a(std::integral_constant<int, k + 1>{}, std::false_type{});
         }
-        stage_b(kc, w);
+        if constexpr (kSplit) b_finish(kc, w, low);
+        else stage_b(kc, w);
         w = wn;
       });
     }
@@ -576,6 +617,10 @@ int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
   const int mode = mu_tune_get("spmm_mode");
 #define MU_ARGS B, st, n_pos, n_cols, d_sptr, ent, d_perm, d_Q, d_Y
   if (mode != 0) {
+    if (mode == 4096 && K == 8) return launch<8, 4096>(MU_ARGS);
+    if (mode == 4096 && K == 7) return launch<7, 4096>(MU_ARGS);
+    if (mode == 1024 + 64 && K == 8) return launch<8, 1024 + 64>(MU_ARGS);
+    if (mode == 2048 + 64 && K == 8) return launch<8, 2048 + 64>(MU_ARGS);
     switch ((mode & 0x7f) + 100 * K + (mode & 128 ? 100 : 0)) {  // (128 = stage B alone: ids 9xx)
       case 801: return launch<8, 1>(MU_ARGS);
       case 809: return launch<8, 9>(MU_ARGS);

@@ -372,6 +372,11 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
 // tile), i.e. the place walk of tile t has already seen tile t+1's entries of that row: it counts
 // them into a second, 16-bit bucket array, and tile t+1 starts with its counts done.  Only the
 // first tile (and a tile that follows an empty one) needs an explicit count walk.
+// cycle accounting of the fill's phases (tune tpack_dbg = 1; read with mu_csr_tpack_phase_cycles):
+// header + scan, count walk, per-column prefix over waves, place walk, write-out - per workgroup,
+// measured by wave 0 between the barriers, summed over workgroups and tiles
+__device__ unsigned long long g_t_phase[8];
+
 constexpr int kF3Cols = 640;  // u32 cursors 40 KiB + u16 counts 20 KiB + 80 KiB staging fit 160 KiB
 constexpr int64_t kF3MaxRows = 16ll * 65535;  // a wave's count of one column fits 16 bits
 
@@ -475,7 +480,7 @@ __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cb
   }
 }
 
-__global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n_cols, int C,
+__global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n_cols, int C, int dbg,
                                                        const int64_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ indices,
                                                        const float* __restrict__ values,
@@ -506,6 +511,15 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
   const uint32_t* base_g = base + (int64_t)g * n_cols;
   const uint32_t* base_n = (g + 1 < G) ? base + (int64_t)(g + 1) * n_cols : nullptr;
   bool have = false;  // wcnt_all holds the counts of the tile about to be processed (uniform)
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto mark = [&](int i) {
+    if (dbg) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      ph[i] += t - t_prev;
+      t_prev = t;
+    }
+  };
 
   for (int64_t cb = 0; cb < n_cols; cb += C) {
     const int32_t cbase = (int32_t)cb;
@@ -543,10 +557,12 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
       have = false;    // (the counts of an empty tile are zeros: wcnt_all stays clear)
       continue;
     }
+    mark(0);
     if (!have)
       f3_walk<0>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs, wcur_all[wave],
                  wcnt_all[wave], &dummy_all[wave][threadIdx.x & 63], gdst, stage, staged, ent);
     __syncthreads();
+    mark(1);
     // per column: exclusive prefix of the wave counts = first slot of every wave inside the run;
     // the counts are consumed (zeroed) for the next tile
     if (threadIdx.x < kF3Cols) {
@@ -561,10 +577,13 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
       }
     }
     __syncthreads();
+    mark(2);
     f3_walk<1>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs, wcur_all[wave],
                wcnt_all[wave], &dummy_all[wave][threadIdx.x & 63], gdst, stage, staged, ent);
     have = true;
+    mark(3);
     __syncthreads();
+    mark(4);
     if (staged) {
       const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
       for (int cl = grp; cl < cend - cbase; cl += kTThreads / 16) {
@@ -574,7 +593,10 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
       }
     }
     __syncthreads();
+    mark(5);
   }
+  if (dbg && threadIdx.x == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_t_phase[i], ph[i]);
 }
 
 struct TWork {
@@ -673,7 +695,7 @@ static int tpack_fill_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const in
     if (mu_tune_get("tpack_c") > 0) C = mu_tune_get("tpack_c");
     if (n_rows <= kF3MaxRows && !mu_tune_get("tpack_v2")) {
       if (C > kF3Cols) C = kF3Cols;
-      hipLaunchKernelGGL(k_t_fill3, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C, d_indptr,
+      hipLaunchKernelGGL(k_t_fill3, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C, mu_tune_get("tpack_dbg"), d_indptr,
                          d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt, w.coltot, out);
     } else {
       hipLaunchKernelGGL(k_t_fill2, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,
@@ -696,6 +718,21 @@ int mu_csr_tpack_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int
   const TOut out{nullptr, d_t_indices, d_t_values};
   return tpack_fill_impl(n_rows, n_cols, nnz, d_indptr, d_indices, d_values, d_t_indptr, nullptr, out,
                          d_work, (hipStream_t)stream);
+}
+
+/* tune tpack_dbg = 1: cycles (s_memtime) of the phases of the third-generation fill, summed over
+ * workgroups and tiles: 0 header + scan, 1 count walk, 2 per-column prefix, 3 place walk (this wave),
+ * 4 waiting for the other waves' place walks, 5 write-out.  reset != 0 clears the counters first. */
+int mu_csr_tpack_phase_cycles(unsigned long long* h_out6, int reset) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (reset) {
+    MU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_t_phase), z, sizeof(z)));
+    return MU_OK;
+  }
+  MU_CHECK_HIP(hipDeviceSynchronize());
+  MU_CHECK_HIP(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_t_phase), sizeof(z)));
+  for (int i = 0; i < 6; ++i) h_out6[i] = z[i];
+  return MU_OK;
 }
 
 /* the same with the row stream of X^T as the target (csrc/spmm_win.hip): output row c goes to

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Timing of the transpose-pack on the bench matrix: third-generation fill (count rides on the
-previous tile's place walk) against the two-walk kernel, with its ablations and tile widths."""
+"""Timing of the transposition (csrc/tpack.hip) on the bench matrix: the third-generation fill at
+several tile widths and its per-phase cycle accounting (tune tpack_dbg)."""
+import ctypes
 import os
 import sys
 
@@ -15,34 +16,34 @@ cells = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 125
 X = be.synth_counts(0, cells, 200000, 50, 0.03, 0)
 T = tfidf_device(be, X, cells, 3, 1e4)
 SORT = "--natural" not in sys.argv
+NAMES = ["header+scan", "count walk", "prefix", "place walk", "wait others", "write-out"]
 
 
-def t(label):
+def t(label, dbg=False):
     be.transpose_stream(T, sort_rows=SORT)
     torch.cuda.synchronize()
+    if dbg:
+        be.tune("tpack_dbg", 1)
+        be.lib.mu_csr_tpack_phase_cycles(None, 1)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(3):
         be.transpose_stream(T, sort_rows=SORT)
     e.record()
     torch.cuda.synchronize()
-    print(f"{label}: {s.elapsed_time(e) / 3:.2f} ms (count + layout + scan + fill + pads; sorted layout = {SORT})", flush=True)
+    print(f"{label}: {s.elapsed_time(e) / 3:.2f} ms (count + layout + scan + fill; sorted layout = {SORT})", flush=True)
+    if dbg:
+        out = (ctypes.c_ulonglong * 6)()
+        be.lib.mu_csr_tpack_phase_cycles(ctypes.cast(out, ctypes.c_void_p), 0)
+        be.tune("tpack_dbg", 0)
+        tot = sum(out)
+        print("   phase share of the fill (wave 0 of every workgroup): " +
+              ", ".join(f"{n} {100.0 * v / tot:.1f} %" for n, v in zip(NAMES, out)), flush=True)
 
 
 t("v3 full")
-for c in (384, 512, 640):
+t("v3 full, phases", dbg=True)
+for c in (256, 384, 512, 640):
     be.tune("tpack_c", c)
-    t(f"v3 C={c}")
+    t(f"v3 C={c}", dbg=(c == 256))
 be.tune("tpack_c", 0)
-be.tune("tpack_v2", 1)
-t("v2 full")
-for abl, name in ((1, "v2 no count walk"), (2, "v2 no place walk"), (4, "v2 no write-out"), (3, "v2 no walks"),
-                  (7, "v2 setup/scans/barriers only")):
-    be.tune("tpack_abl", abl)
-    t(name)
-be.tune("tpack_abl", 0)
-for c in (640, 768):
-    be.tune("tpack_c", c)
-    t(f"v2 C={c}")
-be.tune("tpack_c", 0)
-be.tune("tpack_v2", 0)
