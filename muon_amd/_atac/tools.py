@@ -197,9 +197,11 @@ def _lsi_device(
     # has not converged by then is a hard one and keeps the larger space (measured on a 1.3 % gap:
     # 45 products with 3 blocks, > 120 with 2).
     early_cap = None
+    # (stored entries per rank, averaged over the ranks: every rank must take the same decisions)
+    nnz_rank = comm.sum_scalar(int(getattr(X, "nnz", 0))) / max(getattr(comm, "world_size", 1), 1)
     if max_blocks is None:
         max_blocks = keep_blocks + 2
-        if int(getattr(X, "nnz", 0)) <= 500_000_000:
+        if nnz_rank <= 500_000_000:
             early_cap = keep_blocks + 1
     max_blocks = max(int(max_blocks), keep_blocks + 1)
     if X.values.dtype != torch.float32:
@@ -301,7 +303,7 @@ def _lsi_device(
 
     it = 0          # Krylov expansions done
     beta_hat = 0.0
-    big_products = int(getattr(X, "nnz", 0)) > 500_000_000
+    big_products = nnz_rank > 500_000_000
     restarts = 0
     converged = n_iter is not None
     limit = n_iter if n_iter is not None else max_iter

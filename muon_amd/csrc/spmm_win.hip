@@ -226,7 +226,7 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
   const int lane = threadIdx.x & 63;
   const int wave = uniform32(threadIdx.x >> 6);
   const int sub = lane & 15, g = lane >> 4;
-  const int g8 = g * 8;
+  const unsigned gmask = (g & 1) ? 0xffff0000u : 0x0000ffffu;  // this group's lanes inside its ballot word
   const int sub_off = sub * (4 * NB);  // this lane's byte offset inside a Q row
   const int64_t rb0 = (int64_t)blockIdx.x * (4 * W * K);
   const int64_t rb1 = (rb0 + 4 * W * K) < n_pos ? (rb0 + 4 * W * K) : n_pos;
@@ -316,18 +316,21 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
       const bool valid = col < s_hi;  // sorted rows: a prefix; padding lanes hold INT_MAX
       const unsigned long long m = __ballot(valid);
       const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
-      const unsigned c0 = __popc(mlo & 0xffffu), c1 = __popc(mlo >> 16);
-      const unsigned c2 = __popc(mhi & 0xffffu), c3 = __popc(mhi >> 16);
-      const unsigned packed = (c0 << 3) | (c1 << 11) | (c2 << 19) | (c3 << 27);  // wave-uniform: 8 * count, a byte per group
       const unsigned mm = mlo | mhi;
       Win w;
       w.any16 = (mm | (mm >> 16)) & 0xffffu;  // bit e: some group has entry e
       w.a = (col & (kSlabCols - 1)) << kRowShift;  // always inside the slab buffer, valid or not
       w.vv = valid ? __builtin_bit_cast(float, valbits) : 0.f;
       if constexpr (!(MODE & 8)) {
-        off[k] += (packed >> g8) & 0xffu;  // 8 bytes per consumed pair
+        // entries consumed by this lane's group: the bits of its 16 lanes in the ballot, counted on
+        // the vector side (a wave issues one scalar instruction per ~5 cycles and nothing else
+        // meanwhile: the r02k version - four s_bcnt1 and a packed byte per group - was 14 SALU)
+        const unsigned mine = (lane & 32) ? mhi : mlo;
+        const unsigned cnt = (unsigned)__popc(mine & gmask);
+        off[k] += cnt << 3;  // 8 bytes per consumed pair
         request_window<k>(off[k], entb, __ballot(off[k] < (unsigned)bcast_i<k>((int)endv)));
-        if ((c0 | c1 | c2 | c3) & 16u) again |= 1u << k;  // a window used up: maybe more in this slab
+        // a window used up (some group has all 16 bits set): maybe more in this slab
+        if (__ballot(cnt == 16u)) again |= 1u << k;
       }
       if constexpr (MODE & 1024) {  // real stage A, synthetic 12-entry window for stage B
         w.a = ((lane * 37 + k * 13 + (int)s0) & (kSlabCols - 1)) << kRowShift;
@@ -350,6 +353,7 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
         // any16 set => every lower bit set), 8 entries per row and slab on the bench matrices.
         // Slots 0-7 go out as one batch of eight reads, the upper half as one more batch sized by
         // the highest slot in use: two round trips for almost every pass (r01: three to six).
+        // (twelve reads in flight for the passes that use slots 8-11: hipcc spills at K >= 7)
         if (w.any16 & 0x00f0u) {
           const Quad<NB> r0 = quad_read<0, NB>(qbase, w.a);
           const Quad<NB> r1 = quad_read<4, NB>(qbase, w.a);
