@@ -31,7 +31,9 @@ inline int64_t t_slabs(int64_t n_cols) { return (n_cols + kTSlab - 1) / kTSlab; 
 // of tiles whose 64-lane row loads are mostly outside the slab (c3full: 1.2 s -> see DESIGN.md 4.1).
 inline int t_grid(int64_t nnz) {
   const int64_t cus = mu_num_cus();
-  int64_t rounds = (nnz + 3200000ll * cus - 1) / (3200000ll * cus);
+  // (tune tpack_rows: stored entries per row block in units of 1e5; 0 = 32)
+  const int64_t per_block = 100000ll * (mu_tune_get("tpack_rows") > 0 ? mu_tune_get("tpack_rows") : 32);
+  int64_t rounds = (nnz + per_block * cus - 1) / (per_block * cus);
   if (rounds < 1) rounds = 1;
   if (rounds > 64) rounds = 64;
   return (int)(cus * rounds);

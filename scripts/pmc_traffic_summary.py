@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Turn the two PMC passes of scripts/pmc_traffic.sh into the per-shape entry of
-profiles/r01_spmm_traffic.json: HBM bytes per SpMM launch = FETCH_SIZE x2 (gfx950 tallies 128-byte
+profiles/r02_spmm_traffic.json: HBM bytes per SpMM launch = FETCH_SIZE x2 (gfx950 tallies 128-byte
 requests as 64 B; checked against the 4 GiB calibration copy of the same pass) + WRITE_SIZE, KiB."""
 import csv
 import glob
@@ -29,7 +29,7 @@ res = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     per, meta = load(counter)
     ids = sorted(per)
-    spmm = [i for i in ids if "k_spmm_pcr64" in meta[i][0]]
+    spmm = [i for i in ids if "k_spmm_win" in meta[i][0]]
     xq_key = meta[spmm[0]]  # (kernel instance, grid): the first product of scripts/spmm_probe.py is X * Q
     xq = [per[i] for i in spmm if meta[i] == xq_key]
     xt = [per[i] for i in spmm if meta[i] != xq_key]
@@ -51,8 +51,8 @@ entry = {
 }
 print(json.dumps(entry, indent=1))
 if "--update" in sys.argv:
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_spmm_traffic.json")
-    d = json.load(open(path))
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_spmm_traffic.json")
+    d = json.load(open(path)) if os.path.exists(path) else {}
     old = d.get(f"{cells}x{peaks}", {})
     if "algorithmic_bytes_per_launch" in old:
         entry["algorithmic_bytes_per_launch"] = old["algorithmic_bytes_per_launch"]

@@ -47,3 +47,7 @@ for c in (256, 384, 512, 640):
     be.tune("tpack_c", c)
     t(f"v3 C={c}", dbg=(c == 256))
 be.tune("tpack_c", 0)
+for rows in (8, 16, 24, 48):
+    be.tune("tpack_rows", rows)
+    t(f"v3 {rows}e5 entries per row block", dbg=(rows == 16))
+be.tune("tpack_rows", 0)
