@@ -237,13 +237,14 @@ class HipBackend:
             raise NotImplementedError("row stream: the rows of one workgroup span 4 GiB or more")
         return sptr
 
-    def stream(self, X: DeviceCSR, sort_rows: bool = True) -> DeviceStream:
+    def stream(self, X: DeviceCSR, sort_rows: bool = True, K: Optional[int] = None) -> DeviceStream:
         """Row stream of X for the SpMM of the iteration (a streaming copy, once per lsi call)."""
         n, d = X.shape
         assert X.values.dtype == torch.float32
-        perm, K, n_pos = None, max(1, int(self.lib.mu_spmm_stream_k(n))), n
+        want_k = K
+        perm, K, n_pos = None, max(1, int(want_k or self.lib.mu_spmm_stream_k(n))), n
         if sort_rows and n > 0:
-            perm, _inv, K = self.launch_layout(X.indptr[1:] - X.indptr[:-1])
+            perm, _inv, K = self.launch_layout(X.indptr[1:] - X.indptr[:-1], want_k)
             n_pos = int(perm.numel())
         lens = self.empty((max(n_pos, 1),), torch.int64)[:n_pos]
         with torch.cuda.device(self.device):
@@ -255,7 +256,7 @@ class HipBackend:
                                               _p(sptr), _p(ent), st))
         return DeviceStream(sptr, ent, (n, d), X.nnz, perm, K)
 
-    def transpose_stream(self, X: DeviceCSR, sort_rows: bool = True, before_fill=None) -> DeviceStream:
+    def transpose_stream(self, X: DeviceCSR, sort_rows: bool = True, before_fill=None, K: Optional[int] = None) -> DeviceStream:
         """Row stream of X^T straight from the CSR of X (no CSR of X^T; stable: cells ascending inside
         every row).  ``before_fill``: called once the count phase is done and before the fill is queued."""
         n, d = X.shape
@@ -267,10 +268,11 @@ class HipBackend:
             st = self._stream()
             check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
                                               _p(work), wb, st))
-            perm, inv, K, n_pos = None, None, max(1, int(self.lib.mu_spmm_stream_k(d))), d
+            want_k = K
+            perm, inv, K, n_pos = None, None, max(1, int(want_k or self.lib.mu_spmm_stream_k(d))), d
             lens = col_nnz[:d]
             if sort_rows and d > 0:
-                perm, inv, K = self.launch_layout(lens)
+                perm, inv, K = self.launch_layout(lens, want_k)
                 n_pos = int(perm.numel())
                 plens = torch.zeros((n_pos,), dtype=torch.int64, device=self.device)
                 plens[inv.long()] = lens
@@ -284,14 +286,14 @@ class HipBackend:
                                                     _p(sptr), _p(inv), _p(ent), _p(work), wb, st))
         return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K)
 
-    def launch_layout(self, lens: torch.Tensor):
+    def launch_layout(self, lens: torch.Tensor, K: Optional[int] = None):
         """Where the rows go in a row stream (include/muon_amd.h): sorted by length (descending,
         stable) and dealt round robin - row-set q of the sorted order goes to workgroup q % n_wg,
         inside it to wave (q // n_wg) % 16 and row-set slot (q // n_wg) // 16 - so that the four rows
         a wave advances in lock step have similar lengths and every workgroup and wave gets the same
         mix.  Returns (perm int32[n_pos], inv int32[n], K)."""
         n = int(lens.numel())
-        K = max(1, int(self.lib.mu_spmm_stream_k(n)))
+        K = max(1, int(K or self.lib.mu_spmm_stream_k(n)))
         per_wg = 64 * K
         n_wg = max(1, (n + per_wg - 1) // per_wg)
         # One workgroup per CU runs at a time (128 KiB of LDS) and the dealt workgroups take equally

@@ -20,6 +20,7 @@ ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--modes", default="1,9,32,64,96")
 ap.add_argument("--no-packed", action="store_true")
 ap.add_argument("--B", type=int, default=64)
+ap.add_argument("--ks", default="", help="also time layouts dealt for these K (row-sets per wave)")
 ap.add_argument("--calibrate", action="store_true",
                 help="run a 4 GiB device copy first (known HBM byte count for PMC calibration)")
 args = ap.parse_args()
@@ -90,3 +91,11 @@ for M, D, tag in ((Ts, Q, "X*Q "), (Tts, Yn, "Xt*Y")):
             print("   cycles per pass and wave: " + ", ".join(f"{n} {float(tt[:, i].mean()) / passes:7.1f}" for i, n in enumerate(names))
                   + f"; sum {float(tt.sum(dim=1).mean()) / passes:7.1f}", flush=True)
     be.tune("spmm_mode", 0)
+
+for K in [int(k) for k in args.ks.split(",") if k]:
+    A = be.stream(T, K=K)
+    bench(f"X*Q  stream K={K} ({A.n_pos // (64 * K)} workgroups)", A, Q)
+    del A
+    At = be.transpose_stream(T, K=K)
+    bench(f"Xt*Y stream K={K} ({At.n_pos // (64 * K)} workgroups)", At, Yn)
+    del At
