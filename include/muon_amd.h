@@ -231,6 +231,12 @@ int mu_gram_cross_f32(int64_t n_rows, int B, const float* d_A, const float* d_Bm
 int mu_dense_apply_f32(int64_t n_rows, int B, const float* d_A, const float* d_M,
                        const float* d_bias, float* d_Out, void* stream);
 
+/* M[B x B] (f32) = R^-1, upper triangular, zero outside the leading w x w block, for G = R^T R (f64,
+ * B x B, B <= 64): the small step of CholeskyQR on the device (one wave, LDS resident) instead of two
+ * host round trips.  A pivot that is not safely positive sets *d_flag to 1 (never cleared here) and is
+ * clamped: the output stays finite, the caller redoes the step on the host. */
+int mu_chol_rinv_f64(int B, int w, const double* d_G, float* d_M, int* d_flag, void* stream);
+
 /* standard normal fill, counter based (seed, element index) -> reproducible */
 int mu_randn_f32(int64_t count, uint64_t seed, float* d_out, void* stream);
 

@@ -74,10 +74,23 @@ def _ritz_subspace_sine(Ga, Cx, Gb, Wa, Wb) -> float:
     return float(np.sqrt(max(np.linalg.eigvalsh((S + S.T) / 2)[-1], 0.0)))
 
 
-def _orthonormalize(backend, Z: torch.Tensor, w: int, passes: int = 2):
-    """CholeskyQR(passes) in place on the replicated d x B block; returns the first Gram (host
-    f64), whose trace tells how much of the block survived the projection before it."""
+class _RedoOnHost(Exception):
+    """The device-side Cholesky met a pivot that was not safely positive."""
+
+
+def _orthonormalize(backend, Z: torch.Tensor, w: int, passes: int = 2, flag=None):
+    """CholeskyQR(passes) in place on the replicated d x B block; returns the first Gram, whose
+    trace tells how much of the block survived the projection before it.  With ``flag`` (an int32
+    device scalar) the B x B Cholesky and the inverse of its factor run on the device
+    (mu_chol_rinv_f64) and the Gram comes back as a device tensor: no host round trip."""
     first = None
+    if flag is not None:
+        for _ in range(passes):
+            G, _cs = backend.gram(Z)
+            if first is None:
+                first = G
+            backend.apply(Z, backend.chol_rinv(G, w, flag), out=Z)
+        return Z, first
     for _ in range(passes):
         G, _cs = backend.gram(Z)
         Gh = G.cpu().numpy()
@@ -150,7 +163,12 @@ def _single_threaded_host_blas():
 def lsi_device(backend, X, n_comps: int = 50, scale_embeddings: bool = True, *args, **kwargs):
     """See ``_lsi_device`` (same arguments); runs it with the host BLAS pinned to the calling thread."""
     with _single_threaded_host_blas():
-        return _lsi_device(backend, X, n_comps, scale_embeddings, *args, **kwargs)
+        try:
+            return _lsi_device(backend, X, n_comps, scale_embeddings, *args, **kwargs)
+        except _RedoOnHost:
+            # a block with (numerically) dependent columns: the host path truncates those directions
+            kwargs["device_qr"] = False
+            return _lsi_device(backend, X, n_comps, scale_embeddings, *args, **kwargs)
 
 
 def _lsi_device(
@@ -170,6 +188,7 @@ def _lsi_device(
     return_info: bool = False,
     pack: Optional[bool] = None,
     max_blocks: Optional[int] = None,
+    device_qr: Optional[bool] = None,
 ):
     """Truncated SVD of a device-resident CSR (row shard) by block Lanczos on X^T X with full
     reorthogonalisation and Rayleigh-Ritz over the whole block Krylov space.
@@ -239,10 +258,17 @@ def _lsi_device(
     # 3 err_j < angle_tol (default 3e-5, i.e. err_j < 1e-5, ten times under the 1e-4 parity target), when s_j stagnates
     # at the f32 noise floor, or when the Krylov space is exhausted.  The test sits right after
     # Y_j = X Q_j, so no product is wasted.
+    # CholeskyQR with the B x B factorisation on the device wherever the Krylov space cannot run out
+    # of independent directions (it can on matrices with a few thousand rows or columns: the host
+    # path detects that and truncates)
+    if device_qr is None:
+        device_qr = hasattr(backend, "chol_rinv") and min(n_obs, d) >= 8192
+    qr_flag = backend.zeros((1,), torch.int32) if device_qr else None
+    pending_g1 = None  # first Gram of the last orthonormalisation, still on the device
     Q0 = backend.randn(d, B, seed)
     if w < B:
         Q0[:, w:] = 0
-    Q0, _ = _orthonormalize(backend, Q0, w, passes=2)
+    Q0, _ = _orthonormalize(backend, Q0, w, passes=2, flag=qr_flag)
     Qs, Ys, css = [Q0], [], []
     Tb, Mb = {}, {}  # (i, j), i <= j  ->  w x w f64 host blocks
 
@@ -261,10 +287,20 @@ def _lsi_device(
         cross = [backend.gram_cross(Ys[i], Ys[j]) for i in range(j)]
         comm.all_reduce_sum(Gj, cs, *cross)
         mq = [backend.gram(Qs[j])[0]] + [backend.gram_cross(Qs[i], Qs[j]) for i in range(j)]
-        return backend.fetch_async([Gj, cs] + cross + mq)
+        extra = [pending_g1, qr_flag] if (device_qr and pending_g1 is not None) else []
+        return backend.fetch_async([Gj, cs] + cross + mq + extra), bool(extra)
 
-    def collect_block_grams(j, handle):
+    def collect_block_grams(j, handle_extra):
+        nonlocal beta_hat, pending_g1
+        handle, has_extra = handle_extra
         got = handle.wait()
+        if has_extra:
+            if int(got[-1].reshape(-1)[0]) != 0:
+                raise _RedoOnHost()
+            # ||B_{j+1}||_2 <= sqrt(||B^T B||_F): the safe side of the estimate, without an eigensolve
+            beta_hat = float(np.sqrt(np.linalg.norm(got[-2][:w, :w])))
+            pending_g1 = None
+            got = got[:-2]
         Tb[(j, j)] = got[0][:w, :w]
         css.append(got[1][:w])
         for i in range(j):
@@ -406,7 +442,7 @@ def _lsi_device(
             expect_final = False
         if w < B:
             Z[:, w:] = 0
-        before = float(np.trace(backend.gram(Z)[0].cpu().numpy()[:w, :w]))
+        before = None if device_qr else float(np.trace(backend.gram(Z)[0].cpu().numpy()[:w, :w]))
         # the next block is the part of A Q_j outside the WHOLE space built so far - also when that
         # space is about to be compressed: the residuals of all its Ritz vectors lie in this block
         Z = _project_out(backend, Z, Qs, passes=1)  # (the second pass follows the normalisation below)
@@ -422,13 +458,16 @@ def _lsi_device(
             C = np.zeros((keep, k))
             C[:k, :k] = np.eye(k)  # the kept Ritz vectors are the leading columns of the new blocks
             restarts += 1
-        Z, G1 = _orthonormalize(backend, Z, w, passes=2)
-        # ||B_{j+1}||_2 <= sqrt(||B^T B||_F): the safe side of the estimate, without an eigensolve
-        beta_hat = float(np.sqrt(np.linalg.norm(G1[:w, :w])))
-        if comm.agree(np.trace(G1[:w, :w]) <= 1e-12 * max(before, 1e-300)):
-            converged = True  # nothing left outside the Krylov space: the Ritz pairs are exact
-            bound = floor = 0.0
-            break
+        Z, G1 = _orthonormalize(backend, Z, w, passes=2, flag=qr_flag)
+        if device_qr:
+            pending_g1 = G1  # read with the Grams of the next step (no host round trip here)
+        else:
+            # ||B_{j+1}||_2 <= sqrt(||B^T B||_F): the safe side of the estimate, without an eigensolve
+            beta_hat = float(np.sqrt(np.linalg.norm(G1[:w, :w])))
+            if comm.agree(np.trace(G1[:w, :w]) <= 1e-12 * max(before, 1e-300)):
+                converged = True  # nothing left outside the Krylov space: the Ritz pairs are exact
+                bound = floor = 0.0
+                break
         Z = _project_out(backend, Z, Qs, passes=1)  # the normalisation amplified what the f32 projection left
         Qs.append(Z)
         it += 1

@@ -425,6 +425,16 @@ class HipBackend:
             check(self.lib.mu_dense_apply_f32(n, B, _p(A), _p(M), _p(bias), _p(out), self._stream()))
         return out
 
+    def chol_rinv(self, G: torch.Tensor, w: int, flag: torch.Tensor) -> torch.Tensor:
+        """R^-1 (f32, B x B, upper) of the leading w x w block of the f64 Gram G = R^T R, on the
+        device; ``flag`` (int32[1]) is set when a pivot was not safely positive."""
+        B = G.shape[0]
+        assert G.dtype == torch.float64 and G.is_contiguous() and flag.dtype == torch.int32
+        M = self.empty((B, B), torch.float32)
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_chol_rinv_f64(B, int(w), _p(G), _p(M), _p(flag), self._stream()))
+        return M
+
     def randn(self, rows: int, B: int, seed: int) -> torch.Tensor:
         out = self.empty((rows, B), torch.float32)
         with torch.cuda.device(self.device):

@@ -270,6 +270,70 @@ __global__ __launch_bounds__(256) void k_randn(int64_t count, uint64_t seed, flo
   }
 }
 
+// ---------------------------------------------------------------------------------
+// CholeskyQR's small step on the device: M = R^-1 (upper triangular, f32, zero outside the leading
+// w x w block) for the Gram G = R^T R of a block (f64, B x B, B <= 64).  One wave, LDS-resident:
+// the host version (numpy cholesky + inv) costs two device -> host round trips per
+// orthonormalisation, which is what a 10k x 30k lsi() spends 20 % of its time in.
+// A pivot that is not safely positive (a block with dependent columns: Krylov space exhausted)
+// sets *flag and is clamped, so that nothing non-finite is produced; the caller checks the flag
+// with its next host read and redoes the call on the host path.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_chol_rinv(int B, int w, const double* __restrict__ G,
+                                                  float* __restrict__ M, int* __restrict__ flag) {
+  __shared__ double L[64][65];
+  __shared__ double X[64][65];
+  const int lane = threadIdx.x;
+  double dmax = 0.0;
+  for (int i = 0; i < w; ++i) {
+    if (lane < w) L[i][lane] = G[(int64_t)i * B + lane];
+    const double d = G[(int64_t)i * B + i];
+    dmax = d > dmax ? d : dmax;
+  }
+  __syncthreads();
+  const double tiny = dmax > 0.0 ? dmax * 1e-13 : 1.0;
+  bool bad = false;
+  // left-looking Cholesky, lane i owns row i of L
+  for (int k = 0; k < w; ++k) {
+    double s = 0.0;
+    if (lane >= k && lane < w) {
+      s = L[lane][k];
+      for (int p = 0; p < k; ++p) s -= L[lane][p] * L[k][p];
+    }
+    double piv = __shfl(s, k, 64);
+    if (!(piv > tiny)) {  // also catches NaN
+      bad = true;
+      piv = tiny;
+    }
+    const double r = sqrt(piv);
+    __syncthreads();
+    if (lane == k) L[k][k] = r;
+    else if (lane > k && lane < w) L[lane][k] = s / r;
+    __syncthreads();
+  }
+  // X = L^-1 (lower): lane j owns column j, forward substitution
+  if (lane < w) {
+    for (int i = 0; i < w; ++i) {
+      double x = 0.0;
+      if (i >= lane) {
+        x = (i == lane) ? 1.0 : 0.0;
+        for (int p = lane; p < i; ++p) x -= L[i][p] * X[p][lane];
+        x /= L[i][i];
+      }
+      X[i][lane] = x;
+    }
+  }
+  __syncthreads();
+  // M = R^-1 = (L^-1)^T: M[r][c] = X[c][r] for r <= c < w
+  for (int r = 0; r < B; ++r) {
+    if (lane < B) {
+      const bool in = (r < w) && (lane < w) && (r <= lane);
+      M[(int64_t)r * B + lane] = in ? (float)X[lane][r] : 0.f;
+    }
+  }
+  if (bad && lane == 0) *flag = 1;
+}
+
 extern "C" {
 
 size_t mu_gram_worksize(int64_t n_rows, int B) {
@@ -376,6 +440,14 @@ int mu_randn_f32(int64_t count, uint64_t seed, float* d_out, void* stream) {
   const int64_t cap = (int64_t)mu_num_cus() * 16;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(k_randn, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, count, seed, d_out);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_chol_rinv_f64(int B, int w, const double* d_G, float* d_M, int* d_flag, void* stream) {
+  MU_REQUIRE(B >= 1 && B <= 64 && w >= 0 && w <= B, "B must be 1..64 and 0 <= w <= B");
+  MU_REQUIRE(d_G && d_M && d_flag, "null pointer");
+  hipLaunchKernelGGL(k_chol_rinv, dim3(1), dim3(64), 0, (hipStream_t)stream, B, w, d_G, d_M, d_flag);
   MU_CHECK_LAUNCH();
   return MU_OK;
 }

@@ -426,3 +426,31 @@ def test_spmm_stream_narrow_blocks(hip, B, n, d, dens):
     refz = m.T.astype(np.float64) @ Yn.astype(np.float64)
     scalez = np.abs(m.T).astype(np.float64) @ np.abs(Yn).astype(np.float64) + 1e-30
     assert Z.shape == (d, B) and np.max(np.abs(Z - refz) / scalez) < 2e-6
+
+
+@pytest.mark.parametrize("B,w", [(64, 64), (64, 50), (32, 32), (16, 7), (64, 1)])
+def test_chol_rinv_on_device_matches_numpy(hip, B, w):
+    """CholeskyQR's B x B step on the device: M = R^-1 of the leading w x w block of G = R^T R."""
+    rng = np.random.default_rng(B * 100 + w)
+    A = rng.standard_normal((4 * B, B))
+    G = A.T @ A
+    flag = hip.zeros((1,), torch.int32)
+    M = hip.to_host(hip.chol_rinv(hip.to_device(G), w, flag)).astype(np.float64)
+    R = np.linalg.cholesky(G[:w, :w]).T
+    ref = np.zeros((B, B))
+    ref[:w, :w] = np.linalg.inv(R)
+    assert int(flag.item()) == 0
+    assert np.allclose(M, ref, rtol=0, atol=2e-6 * np.abs(ref).max())
+    assert np.all(M[np.tril_indices(B, -1)] == 0) and np.all(M[w:] == 0) and np.all(M[:, w:] == 0)
+    # the product it is used for: (A M)^T (A M) = I on the leading block
+    QtQ = (A[:, :] @ M).T @ (A @ M)
+    assert np.allclose(QtQ[:w, :w], np.eye(w), atol=1e-4)
+
+
+def test_chol_rinv_flags_a_semidefinite_gram(hip):
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((200, 64))
+    A[:, 40] = A[:, 3] * 2.0 - A[:, 17]  # a dependent column: the Gram is singular
+    flag = hip.zeros((1,), torch.int32)
+    M = hip.to_host(hip.chol_rinv(hip.to_device(A.T @ A), 64, flag))
+    assert int(flag.item()) == 1 and np.all(np.isfinite(M))
