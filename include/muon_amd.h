@@ -150,12 +150,6 @@ size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz);
 int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
                        const int32_t* d_indices, int64_t* d_col_nnz, void* d_work,
                        size_t work_bytes, void* stream);
-/* Same with the row / slab pointers handed in: d_slab_ptr = the head of the work buffer a
- * mu_csr_row_col_sums call filled for this very (d_indptr, d_indices) - both passes cut the rows at
- * multiples of 8192 columns - or NULL to search them here. */
-int mu_csr_tpack_count_sp(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
-                          const int32_t* d_indices, int64_t* d_col_nnz, const int64_t* d_slab_ptr,
-                          void* d_work, size_t work_bytes, void* stream);
 /* The same transposition written as a plain CSR of X^T (t_indptr int64[n_cols + 1] = exclusive scan
  * of col_nnz, t_indices int32[nnz] = cell ids ascending inside every row, t_values f32[nnz]): step 3
  * of the sequence above with the CSR arrays as the target (the fast stable transpose). */

@@ -636,13 +636,6 @@ size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz) {
 int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
                        const int32_t* d_indices, int64_t* d_col_nnz, void* d_work,
                        size_t work_bytes, void* stream) {
-  return mu_csr_tpack_count_sp(n_rows, n_cols, nnz, d_indptr, d_indices, d_col_nnz, nullptr, d_work,
-                               work_bytes, stream);
-}
-
-int mu_csr_tpack_count_sp(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
-                          const int32_t* d_indices, int64_t* d_col_nnz, const int64_t* d_slab_ptr,
-                          void* d_work, size_t work_bytes, void* stream) {
   MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
   MU_REQUIRE(n_rows < ((int64_t)1 << 31), "row ids must fit int32");
   if (n_cols == 0) return MU_OK;
@@ -658,15 +651,11 @@ int mu_csr_tpack_count_sp(int64_t n_rows, int64_t n_cols, int64_t nnz, const int
     int64_t blocks = (total + 255) / 256;
     const int64_t cap = (int64_t)mu_num_cus() * 32;
     if (blocks > cap) blocks = cap;
-    // (the TF-IDF sum pass searches the same 8192-column slab pointers for the same pattern)
-    const int64_t* sp = d_slab_ptr ? d_slab_ptr : w.sp;
-    if (!d_slab_ptr) {
-      hipLaunchKernelGGL(k_t_slab_ptr, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, S, d_indptr,
-                         d_indices, w.sp);
-      MU_CHECK_LAUNCH();
-    }
+    hipLaunchKernelGGL(k_t_slab_ptr, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, S, d_indptr,
+                       d_indices, w.sp);
+    MU_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_t_count, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, S, d_indptr,
-                       d_indices, sp, w.cnt);
+                       d_indices, w.sp, w.cnt);
     MU_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(k_t_base, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, n_cols, G,
