@@ -231,7 +231,10 @@ def tfidf(
         # of the transpose, which the device turns into the CSR of X instead of a
         # single-threaded scipy tocsr() on the host
         n_r, n_c = counts.shape
-        X = backend.transpose(backend.upload_csr(counts.indptr, counts.indices, counts.data, (n_c, n_r)))
+        Xc = backend.upload_csr(counts.indptr, counts.indices, counts.data, (n_c, n_r))
+        # f32: the tile-staged transposition of csrc/tpack.hip (3x the rate of the general kernel)
+        fast = counts.dtype == np.float32 and hasattr(backend, "transpose_csr") and counts.nnz > 0
+        X = backend.transpose_csr(Xc) if fast else backend.transpose(Xc)
         host = None
     else:
         host = canonical_csr(counts)

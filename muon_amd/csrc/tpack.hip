@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_count(int64_t n_rows, int64_t n
 }
 
 // cnt[g][c] <- sum_{g' < g} cnt[g'][c];  coltot[c] = sum_g cnt[g][c] (also handed to the caller,
-// who sorts the output rows by it and lays them out: muon_amd/_backend.py packed_layout)
+// who sorts the output rows by it and lays them out: muon_amd/_backend.py launch_layout)
 __global__ __launch_bounds__(256) void k_t_base(int64_t n_cols, int G, uint32_t* __restrict__ cnt,
                                                 int64_t* __restrict__ coltot,
                                                 int64_t* __restrict__ col_nnz) {
