@@ -349,27 +349,43 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
       if constexpr (MODE & 1) {
         acc[k][0] += w.vv + (float)w.a;
       } else if constexpr (kDeep) {
+        // (MODE 8192 / 8192 + 32768, timing only: the reads with lanes 32-63 / the odd groups
+        // switched off in EXEC - does the LDS pipe charge for inactive quarter-waves?)
+        auto qrd = [&](auto ec) {
+          Quad<NB> r;
+          if constexpr (MODE & 8192) {
+            asm volatile("s_mov_b64 exec, %0" ::"s"((MODE & 32768) ? 0x0000ffff0000ffffull : 0x00000000ffffffffull) : "memory");
+            r = quad_read<decltype(ec)::value, NB>(qbase, w.a);
+            asm volatile("s_mov_b64 exec, -1" ::: "memory");
+          } else {
+            r = quad_read<decltype(ec)::value, NB>(qbase, w.a);
+          }
+          return r;
+        };
         // A pass is a chain of LDS round trips; sorted rows fill the window from slot 0 (bit e of
         // any16 set => every lower bit set), 8 entries per row and slab on the bench matrices.
         // Slots 0-7 go out as one batch of eight reads, the upper half as one more batch sized by
         // the highest slot in use: two round trips for almost every pass (r01: three to six).
         // (twelve reads in flight for the passes that use slots 8-11: hipcc spills at K >= 7)
         if (w.any16 & 0x00f0u) {
-          const Quad<NB> r0 = quad_read<0, NB>(qbase, w.a);
-          const Quad<NB> r1 = quad_read<4, NB>(qbase, w.a);
+          const Quad<NB> r0 = qrd(std::integral_constant<int, 0>{});
+          const Quad<NB> r1 = qrd(std::integral_constant<int, 4>{});
           quad_fma<0, NB>(r0, w.vv, acc[k]);
           quad_fma<4, NB>(r1, w.vv, acc[k]);
+          // (hipcc otherwise sinks the second quad into a block shared with the branch below - one
+          //  quad of reads, its FMAs, then the next quad: two LDS round trips instead of one)
+          asm volatile("; eight reads in flight" ::: "memory");
         } else if (w.any16 & 0x000fu) {
-          const Quad<NB> r = quad_read<0, NB>(qbase, w.a);
+          const Quad<NB> r = qrd(std::integral_constant<int, 0>{});
           quad_fma<0, NB>(r, w.vv, acc[k]);
         }
         if (w.any16 & 0xf000u) {
-          const Quad<NB> r0 = quad_read<8, NB>(qbase, w.a);
-          const Quad<NB> r1 = quad_read<12, NB>(qbase, w.a);
+          const Quad<NB> r0 = qrd(std::integral_constant<int, 8>{});
+          const Quad<NB> r1 = qrd(std::integral_constant<int, 12>{});
           quad_fma<8, NB>(r0, w.vv, acc[k]);
           quad_fma<12, NB>(r1, w.vv, acc[k]);
         } else if (w.any16 & 0x0c00u) {
-          const Quad<NB> r = quad_read<8, NB>(qbase, w.a);
+          const Quad<NB> r = qrd(std::integral_constant<int, 8>{});
           quad_fma<8, NB>(r, w.vv, acc[k]);
         } else if (w.any16 & 0x0300u) {
           const Pair<NB> r = pair_read<8, NB>(qbase, w.a);
@@ -419,6 +435,7 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
     // (measured r02p: 4.80 / 4.89 ms against 4.54 / 4.75 unsplit on X Q / X^T Y at 125k x 200k: the
     //  eight results held across stage A cost more than the latency they hide; kept as ablation 4096)
     constexpr bool kSplit = kDeep && (MODE & 4096) && !(MODE & (1 | 64));
+    constexpr bool kPipeB = (MODE & 16384) && !(MODE & (1 | 64 | 4096));
 
     if constexpr (MODE & 64) {
       static_for<K>([&](auto kc) {
@@ -430,6 +447,39 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
         t_b += now() - t2;
       });
     } else {
+      if constexpr (kPipeB) {
+        // Stage B as a software pipeline ACROSS passes: the gathers of a pass are three batches of
+        // four window slots (0-3, 4-7, 8-11; 12-15 on demand), and a batch's LDS reads are issued two
+        // batches before its FMAs - the reads of pass k+1's first two batches go out between the
+        // FMAs of pass k, behind stage A(k+1).  A pass no longer is a chain of three LDS round trips.
+        next_piece(0);
+        Win wk = stage_a(std::integral_constant<int, 0>{}, std::false_type{});
+        Quad<NB> b0 = quad_read<0, NB>(qbase, wk.a);
+        Quad<NB> b1 = quad_read<4, NB>(qbase, wk.a);
+        static_for<K>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          Win wn = wk;
+          if constexpr (k + 1 < K) {
+            if constexpr (k + 1 < kMyPieces) next_piece(k + 1);
+            wn = stage_a(std::integral_constant<int, k + 1>{}, std::false_type{});
+          }
+          const bool n2 = (wk.any16 & 0x0f00u) != 0;
+          __builtin_amdgcn_s_setprio(1);
+          Quad<NB> b2;
+          quad_fma<0, NB>(b0, wk.vv, acc[k]);
+          if (n2) b2 = quad_read<8, NB>(qbase, wk.a);
+          quad_fma<4, NB>(b1, wk.vv, acc[k]);
+          if constexpr (k + 1 < K) b0 = quad_read<0, NB>(qbase, wn.a);
+          if (n2) quad_fma<8, NB>(b2, wk.vv, acc[k]);
+          if constexpr (k + 1 < K) b1 = quad_read<4, NB>(qbase, wn.a);
+          if (wk.any16 & 0xf000u) {
+            const Quad<NB> r = quad_read<12, NB>(qbase, wk.a);
+            quad_fma<12, NB>(r, wk.vv, acc[k]);
+          }
+          __builtin_amdgcn_s_setprio(0);
+          wk = wn;
+        });
+      } else {
       // A(k+1) is issued before B(k): the scalar part of the next pass runs under this pass' gathers
       next_piece(0);
       Win w = stage_a(std::integral_constant<int, 0>{}, std::false_type{});
@@ -446,6 +496,7 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
         else stage_b(kc, w);
         w = wn;
       });
+      }
     }
 #pragma unroll
     for (int u = K; u < kMyPieces; ++u) next_piece(u);  // K < kMyPieces: the pieces left over
@@ -621,6 +672,10 @@ int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
   const int mode = mu_tune_get("spmm_mode");
 #define MU_ARGS B, st, n_pos, n_cols, d_sptr, ent, d_perm, d_Q, d_Y
   if (mode != 0) {
+    if (mode == 128 + 8192 && K == 8) return launch<8, 128 + 8192>(MU_ARGS);
+    if (mode == 128 + 8192 + 32768 && K == 8) return launch<8, 128 + 8192 + 32768>(MU_ARGS);
+    if (mode == 16384 && K == 8) return launch<8, 16384>(MU_ARGS);
+    if (mode == 16384 && K == 7) return launch<7, 16384>(MU_ARGS);
     if (mode == 4096 && K == 8) return launch<8, 4096>(MU_ARGS);
     if (mode == 4096 && K == 7) return launch<7, 4096>(MU_ARGS);
     if (mode == 1024 + 64 && K == 8) return launch<8, 1024 + 64>(MU_ARGS);

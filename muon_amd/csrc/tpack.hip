@@ -382,6 +382,13 @@ __device__ unsigned long long g_t_phase[8];
 constexpr int kF3Cols = 640;  // u32 cursors 40 KiB + u16 counts 20 KiB + 80 KiB staging fit 160 KiB
 constexpr int64_t kF3MaxRows = 16ll * 65535;  // a wave's count of one column fits 16 bits
 
+// 16-bit count i of a wave's count row += 1, as a 32-bit LDS atomic on the word that holds it
+// (neighbouring columns of one row share a word: the atomic serialises them)
+__device__ __forceinline__ void cnt_add(uint16_t* wcnt, int i) {
+  __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(wcnt) + (i >> 1), 1u << ((i & 1) * 16), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int PHASE>
 __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, int first,
                                            int64_t row0, int32_t cbase, int32_t cend, int32_t cend2,
@@ -403,19 +410,18 @@ __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, 
       const bool valid = c < cend;  // sorted rows: a prefix of the 64 loaded entries
       const int n = __popcll(__ballot(valid));
       if (PHASE == 0) {
-        if (valid) wcnt[c - cbase] += (uint16_t)1;  // columns inside one row are distinct
+        if (valid) cnt_add(wcnt, c - cbase);
       } else {
-        // Both bucket updates of the visit - the cursor of this tile for the lanes inside it, the
-        // count of the next tile for the lanes just past it - are issued together and waited for
-        // once; lanes that take part in neither go to a private dummy slot instead of being masked
-        // off (the two masked read-modify-write sequences cost two LDS round trips per visit).
+        // Both bucket updates of the visit are LDS atomics (columns inside one row are distinct, so
+        // they never collide inside a wave - the atomic is there for the single round trip): the
+        // cursor of this tile for the lanes inside it (ds_add_rtn_u32, the one result the visit waits
+        // for) and the count of the next tile for the lanes just past it (ds_add_u32, not waited for).
+        // (r01/r02: read-modify-write pairs through a dummy slot for idle lanes - four LDS
+        //  instructions and two results to wait for.)
         const bool nxt = !valid && c < cend2;
-        uint32_t* pc = valid ? &wcur[c - cbase] : dummy;
-        uint16_t* pn = nxt ? &wcnt[c - cend] : reinterpret_cast<uint16_t*>(dummy) + 1;
-        const uint32_t k = *pc;   // absolute slot in the staging buffer (run-relative when not staged)
-        const uint16_t t = *pn;
-        *pc = k + 1u;
-        *pn = (uint16_t)(t + 1);
+        uint32_t k = 0;   // absolute slot in the staging buffer (run-relative when not staged)
+        if (valid) k = __hip_atomic_fetch_add(&wcur[c - cbase], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (nxt) cnt_add(wcnt, c - cend);
         if (valid) {
           const unsigned long long e = (unsigned long long)(unsigned)(row0 + first + j) |
                                        ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32);
@@ -438,7 +444,7 @@ __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, 
           ws += 64;
           const int p = ws + lane;
           c = (p < e0) ? indices_b[p] : 0x7fffffff;
-          if (c < cend2) wcnt[c - cend] += (uint16_t)1;
+          if (c < cend2) cnt_add(wcnt, c - cend);
         }
       }
       break;

@@ -21,6 +21,7 @@ ap.add_argument("--modes", default="1,9,32,64,96")
 ap.add_argument("--no-packed", action="store_true")
 ap.add_argument("--B", type=int, default=64)
 ap.add_argument("--ks", default="", help="also time layouts dealt for these K (row-sets per wave)")
+ap.add_argument("--k-modes", default="", help="ablation modes to time on the --ks layouts as well")
 ap.add_argument("--calibrate", action="store_true",
                 help="run a 4 GiB device copy first (known HBM byte count for PMC calibration)")
 args = ap.parse_args()
@@ -78,7 +79,7 @@ bench("X*Q  stream      ", Ts, Q)
 bench("Xt*Y stream      ", Tts, Yn)
 names = ["wait window", "stage A", "stage B", "barrier+dma wait", "dma issue"]
 for M, D, tag in ((Ts, Q, "X*Q "), (Tts, Yn, "Xt*Y")):
-    if M.k != 8 and not all(int(m) in (4096,) for m in args.modes.split(",") if m):
+    if M.k != 8 and not all(int(m) in (4096, 16384) for m in args.modes.split(",") if m):
         continue
     for mode in [int(m) for m in args.modes.split(",") if m]:
         be.tune("spmm_mode", mode)
@@ -93,9 +94,16 @@ for M, D, tag in ((Ts, Q, "X*Q "), (Tts, Yn, "Xt*Y")):
     be.tune("spmm_mode", 0)
 
 for K in [int(k) for k in args.ks.split(",") if k]:
-    A = be.stream(T, K=K)
-    bench(f"X*Q  stream K={K} ({A.n_pos // (64 * K)} workgroups)", A, Q)
-    del A
-    At = be.transpose_stream(T, K=K)
-    bench(f"Xt*Y stream K={K} ({At.n_pos // (64 * K)} workgroups)", At, Yn)
-    del At
+    for mode in [0] + [int(m) for m in args.k_modes.split(",") if m]:
+        be.tune("spmm_mode", mode)
+        A = be.stream(T, K=K)
+        bench(f"X*Q  stream K={K} mode {mode} ({A.n_pos // (64 * K)} workgroups)", A, Q)
+        if mode:
+            print("   vs mode 0:", "bit-identical" if torch.equal(be.spmm(A, Q), Yn) else "DIFFERS", flush=True)
+        del A
+        At = be.transpose_stream(T, K=K)
+        bench(f"Xt*Y stream K={K} mode {mode} ({At.n_pos // (64 * K)} workgroups)", At, Yn)
+        if mode:
+            print("   vs mode 0:", "bit-identical" if torch.equal(be.spmm(At, Yn), Zn) else "DIFFERS", flush=True)
+        del At
+    be.tune("spmm_mode", 0)
