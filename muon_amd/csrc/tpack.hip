@@ -25,14 +25,17 @@ constexpr int kTThreads = 1024;
 constexpr int kTWaves = kTThreads / 64;
 
 inline int64_t t_slabs(int64_t n_cols) { return (n_cols + kTSlab - 1) / kTSlab; }
-// Row blocks (= workgroups of the count and fill sweeps): one per CU (the staged fill needs 140 KiB
-// of LDS), and more rounds of them for big inputs so that a block stays near 3.2e6 stored entries -
-// with bigger blocks the staging tile forces narrow slabs (64 columns at 1e6 rows), i.e. thousands
-// of tiles whose 64-lane row loads are mostly outside the slab (c3full: 1.2 s -> see DESIGN.md 4.1).
-inline int t_grid(int64_t nnz) {
+// Row blocks (= workgroups of the count and fill sweeps): one per CU at a time (the staged fill needs
+// 156 KiB of LDS), in as many rounds as it takes for the expected tile of a block - its rows x the
+// widest tile, kF3Cols columns - to fill ~93 % of the staging buffer (~4.2e6 stored entries per block
+// at 200k columns; measured at 1e6 x 200k: 1024-column tiles with 1.9e6-entry blocks 110 ms, 640 columns
+// with 3.2e6-entry blocks 89 ms).
+inline int t_grid(int64_t nnz, int64_t n_cols) {
   const int64_t cus = mu_num_cus();
-  // (tune tpack_rows: stored entries per row block in units of 1e5; 0 = 32)
-  const int64_t per_block = 100000ll * (mu_tune_get("tpack_rows") > 0 ? mu_tune_get("tpack_rows") : 32);
+  // (tune tpack_rows: stored entries per row block in units of 1e5 instead)
+  int64_t per_block = (int64_t)(0.93 * 14336 / 640 * (double)(n_cols > 0 ? n_cols : 1));  // kF3Cap / kF3Cols
+  if (per_block < 100000) per_block = 100000;
+  if (mu_tune_get("tpack_rows") > 0) per_block = 100000ll * mu_tune_get("tpack_rows");
   int64_t rounds = (nnz + per_block * cus - 1) / (per_block * cus);
   if (rounds < 1) rounds = 1;
   if (rounds > 64) rounds = 64;
@@ -379,7 +382,8 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
 // measured by wave 0 between the barriers, summed over workgroups and tiles
 __device__ unsigned long long g_t_phase[8];
 
-constexpr int kF3Cols = 640;  // u32 cursors 40 KiB + u16 counts 20 KiB + 80 KiB staging fit 160 KiB
+constexpr int kF3Cols = 640;   // 16-bit cursors and counts 40 KiB + 112 KiB staging + 7.5 KiB per-column state fit 160 KiB
+constexpr int kF3Cap = 14336;  // staged pairs of the third-generation fill
 constexpr int64_t kF3MaxRows = 16ll * 65535;  // a wave's count of one column fits 16 bits
 
 // 16-bit count i of a wave's count row += 1, as a 32-bit LDS atomic on the word that holds it
@@ -389,12 +393,21 @@ __device__ __forceinline__ void cnt_add(uint16_t* wcnt, int i) {
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// 16-bit cursor i of a wave's cursor row: fetch and add 1, same packing (the neighbour's half of the
+// returned word is whatever it was at the time - only this lane's half is looked at)
+__device__ __forceinline__ uint32_t cur_fetch_inc(uint16_t* wcur, int i) {
+  const int sh = (i & 1) * 16;
+  const uint32_t old = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(wcur) + (i >> 1), 1u << sh,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return (old >> sh) & 0xffffu;
+}
+
 template <int PHASE>
 __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, int first,
                                            int64_t row0, int32_t cbase, int32_t cend, int32_t cend2,
                                            const int32_t* __restrict__ indices_b,
-                                           const float* __restrict__ values_b, uint32_t* wcur,
-                                           uint16_t* wcnt, uint32_t* dummy, const int64_t* gdst,
+                                           const float* __restrict__ values_b, uint16_t* wcur,
+                                           uint16_t* wcnt, uint32_t* wcur32, const int64_t* gdst,
                                            unsigned long long* stage, bool staged,
                                            const TOut& ent) {
   const int lane = threadIdx.x & 63;
@@ -420,7 +433,12 @@ __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, 
         //  instructions and two results to wait for.)
         const bool nxt = !valid && c < cend2;
         uint32_t k = 0;   // absolute slot in the staging buffer (run-relative when not staged)
-        if (valid) k = __hip_atomic_fetch_add(&wcur[c - cbase], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (valid) {
+          // staged: 16-bit absolute staging slots; a tile that does not fit the staging buffer keeps
+          // 32-bit run-relative cursors in the (then unused) staging memory
+          k = staged ? cur_fetch_inc(wcur, c - cbase)
+                     : __hip_atomic_fetch_add(&wcur32[c - cbase], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         if (nxt) cnt_add(wcnt, c - cend);
         if (valid) {
           const unsigned long long e = (unsigned long long)(unsigned)(row0 + first + j) |
@@ -459,7 +477,7 @@ __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cb
                                         const int64_t* __restrict__ indptr,
                                         const int32_t* __restrict__ indices,
                                         const float* __restrict__ values, int64_t* __restrict__ curs,
-                                        uint32_t* wcur, uint16_t* wcnt, uint32_t* dummy,
+                                        uint16_t* wcur, uint16_t* wcnt, uint32_t* wcur32,
                                         const int64_t* gdst, unsigned long long* stage, bool staged,
                                         const TOut& ent) {
   const int lane = threadIdx.x & 63;
@@ -476,12 +494,12 @@ __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cb
     f2_load<PHASE>(ba, cur, end, 0, indices_b, values_b);
     for (int first = 0; first < nr; first += 2 * kF2Rows) {
       if (first + kF2Rows < nr) f2_load<PHASE>(bb, cur, end, first + kF2Rows, indices_b, values_b);
-      f3_process<PHASE>(ba, cur, end, first, sb, cbase, cend, cend2, indices_b, values_b, wcur, wcnt, dummy,
+      f3_process<PHASE>(ba, cur, end, first, sb, cbase, cend, cend2, indices_b, values_b, wcur, wcnt, wcur32,
                         gdst, stage, staged, ent);
       if (first + kF2Rows < nr) {
         if (first + 2 * kF2Rows < nr) f2_load<PHASE>(ba, cur, end, first + 2 * kF2Rows, indices_b, values_b);
         f3_process<PHASE>(bb, cur, end, first + kF2Rows, sb, cbase, cend, cend2, indices_b, values_b, wcur,
-                          wcnt, dummy, gdst, stage, staged, ent);
+                          wcnt, wcur32, gdst, stage, staged, ent);
       }
     }
     if (PHASE == 1 && lane < nr) curs[sb + lane] = wg_base + (int64_t)cur;
@@ -498,12 +516,13 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
                                                        const uint32_t* __restrict__ base,
                                                        const int64_t* __restrict__ coltot,
                                                        TOut ent) {
-  __shared__ unsigned long long stage[kF2Cap];     // 80 KiB
-  __shared__ uint32_t wcur_all[kTWaves][kF3Cols];  // 40 KiB: per (wave, column) cursor of this tile
-  __shared__ uint16_t wcnt_all[kTWaves][kF3Cols];  // 20 KiB: per (wave, column) count of the tile in the making
-  __shared__ uint32_t dummy_all[kTWaves][64];      // where the bucket updates of idle lanes go
-  __shared__ uint32_t lcount[kF3Cols], lpos[kF3Cols];
+  __shared__ unsigned long long stage[kF3Cap];     // 112 KiB
+  __shared__ uint16_t wcur_all[kTWaves][kF3Cols];  // 32 KiB: per (wave, column) cursor of this tile
+  __shared__ uint16_t wcnt_all[kTWaves][kF3Cols];  // 32 KiB: per (wave, column) count of the tile in the making
+  __shared__ uint16_t lcount[kF3Cols], lpos[kF3Cols];  // staged tiles only (<= kF3Cap pairs)
   __shared__ int64_t gdst[kF3Cols];
+  static_assert(sizeof(uint32_t) * kTWaves * kF3Cols <= sizeof(unsigned long long) * kF3Cap, "direct-mode cursors live in the staging buffer");
+  uint32_t(*wcur32_all)[kF3Cols] = reinterpret_cast<uint32_t(*)[kF3Cols]>(stage);
   __shared__ uint32_t wsum[kTWaves];
   __shared__ int64_t s_r[2];
   const int g = blockIdx.x, G = gridDim.x;
@@ -542,7 +561,6 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
         mine = b1 - b0;
         gdst[threadIdx.x] = cptr[inv ? (int64_t)inv[c] : c] + (int64_t)b0;
       }
-      lcount[threadIdx.x] = mine;
     }
     uint32_t incl = mine;
 #pragma unroll
@@ -558,8 +576,12 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
       if (w < wave) wpre += t;
       total += t;
     }
-    if (threadIdx.x < kF3Cols) lpos[threadIdx.x] = wpre + incl - mine;
-    const bool staged = total <= (uint32_t)kF2Cap;
+    const bool staged = total <= (uint32_t)kF3Cap;
+    if (threadIdx.x < kF3Cols && staged) {  // (16 bits are enough for a staged tile)
+      lcount[threadIdx.x] = (uint16_t)mine;
+      lpos[threadIdx.x] = (uint16_t)(wpre + incl - mine);
+    }
+    const uint32_t my_lpos = wpre + incl - mine;
     __syncthreads();
     if (total == 0) {  // uniform: nothing here, so nobody counted the next tile either
       have = false;    // (the counts of an empty tile are zeros: wcnt_all stays clear)
@@ -568,7 +590,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
     mark(0);
     if (!have)
       f3_walk<0>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs, wcur_all[wave],
-                 wcnt_all[wave], &dummy_all[wave][threadIdx.x & 63], gdst, stage, staged, ent);
+                 wcnt_all[wave], wcur32_all[wave], gdst, stage, staged, ent);
     __syncthreads();
     mark(1);
     // per column: exclusive prefix of the wave counts = first slot of every wave inside the run;
@@ -576,18 +598,19 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
     if (threadIdx.x < kF3Cols) {
       // a staged tile's cursors are absolute staging slots (no lpos lookup in the walk), a direct
       // one's are relative to the column's run in the output
-      uint32_t run = staged ? lpos[threadIdx.x] : 0u;
+      uint32_t run = staged ? my_lpos : 0u;
       for (int w = 0; w < kTWaves; ++w) {
         const uint32_t t = wcnt_all[w][threadIdx.x];
         wcnt_all[w][threadIdx.x] = (uint16_t)0;
-        wcur_all[w][threadIdx.x] = run;
+        if (staged) wcur_all[w][threadIdx.x] = (uint16_t)run;
+        else wcur32_all[w][threadIdx.x] = run;
         run += t;
       }
     }
     __syncthreads();
     mark(2);
     f3_walk<1>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs, wcur_all[wave],
-               wcnt_all[wave], &dummy_all[wave][threadIdx.x & 63], gdst, stage, staged, ent);
+               wcnt_all[wave], wcur32_all[wave], gdst, stage, staged, ent);
     have = true;
     mark(3);
     __syncthreads();
@@ -621,7 +644,7 @@ inline TWork carve(void* work, int64_t n_rows, int64_t n_cols, int64_t nnz) {
   t.sp = (int64_t*)w;
   w += al((size_t)(n_rows * (S + 1)) * sizeof(int64_t));
   t.cnt = (uint32_t*)w;
-  w += al((size_t)t_grid(nnz) * (size_t)n_cols * sizeof(uint32_t));
+  w += al((size_t)t_grid(nnz, n_cols) * (size_t)n_cols * sizeof(uint32_t));
   t.coltot = (int64_t*)w;
   w += al((size_t)n_cols * sizeof(int64_t));
   t.curs = (int64_t*)w;
@@ -635,7 +658,7 @@ extern "C" {
 size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz) {
   const int64_t S = t_slabs(n_cols);
   return al((size_t)(n_rows * (S + 1)) * sizeof(int64_t)) +
-         al((size_t)t_grid(nnz) * (size_t)n_cols * sizeof(uint32_t)) +
+         al((size_t)t_grid(nnz, n_cols) * (size_t)n_cols * sizeof(uint32_t)) +
          al((size_t)n_cols * sizeof(int64_t)) + al((size_t)(n_rows + 1) * sizeof(int64_t)) + 256;
 }
 
@@ -649,7 +672,7 @@ int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_
   MU_REQUIRE(work_bytes >= mu_csr_tpack_worksize(n_rows, n_cols, nnz), "work buffer too small");
   hipStream_t st = (hipStream_t)stream;
   const int64_t S = t_slabs(n_cols);
-  const int G = t_grid(nnz);
+  const int G = t_grid(nnz, n_cols);
   const TWork w = carve(d_work, n_rows, n_cols, nnz);
   MU_CHECK_HIP(hipMemsetAsync(w.cnt, 0, (size_t)G * (size_t)n_cols * sizeof(uint32_t), st));
   if (n_rows > 0) {
@@ -678,19 +701,20 @@ int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_
 static int tpack_fill_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
                            const int32_t* d_indices, const float* d_values, const int64_t* d_cptr,
                            const int32_t* d_inv, TOut out, void* d_work, hipStream_t st) {
-  const int G = t_grid(nnz);
+  const int G = t_grid(nnz, n_cols);
   const TWork w = carve(d_work, n_rows, n_cols, nnz);
   if (n_rows > 0) {
     // slab width: the expected tile (nnz / G rows x C columns) fills ~93 % of the staging buffer
     // (measured best on the bench matrix: fewer, fuller tiles; a tile that overflows takes the
     //  direct-store path)
     const double per_col = (double)nnz / (double)G / (double)n_cols;  // pairs of a tile per column
-    int64_t C = per_col > 0 ? (int64_t)(0.93 * kF2Cap / per_col) : kF2Cols;
+    const bool v3 = n_rows <= kF3MaxRows && !mu_tune_get("tpack_v2");
+    int64_t C = per_col > 0 ? (int64_t)(0.93 * (v3 ? kF3Cap : kF2Cap) / per_col) : kF2Cols;
     C = (C / 32) * 32;
     if (C < 32) C = 32;
-    if (C > kF2Cols) C = kF2Cols;
+    if (C > (v3 ? kF3Cols : kF2Cols)) C = v3 ? kF3Cols : kF2Cols;
     if (mu_tune_get("tpack_c") > 0) C = mu_tune_get("tpack_c");
-    if (n_rows <= kF3MaxRows && !mu_tune_get("tpack_v2")) {
+    if (v3) {
       if (C > kF3Cols) C = kF3Cols;
       hipLaunchKernelGGL(k_t_fill3, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C, mu_tune_get("tpack_dbg"), d_indptr,
                          d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt, w.coltot, out);
