@@ -341,8 +341,9 @@ class MofaEngine:
             for g in range(G):
                 Gw[m, g] = self._tn(Wm.EW, TW[g])
                 dw2[m, g] = (Wm.tau[g][:, None] * Wm.EW2).sum(dim=0)
-            # (f32: hipBLASLt's N x D by D x K kernel already streams Y at 6 TB/s (1.3 ms vs 3.2 ms for
-            #  mu_skinny_nn); f64: rocBLAS needs 26 ms, mu_skinny_nn 4.6)
+            # (f32: hipBLASLt streams Y at 5.1 TB/s when the K x D operand is the transposed one -
+            #  1.57 ms at 1e5 x 2e4 against 2.27 ms with tau o W stored D x K and 3.1 ms for
+            #  mu_skinny_nn, scripts/probes/skinny_nn_probe.py; f64: rocBLAS needs 26 ms, mu_skinny_nn 4.6)
             if V.kind == "dense" and K <= 16 and self.T == torch.float64 and hasattr(self.be, "skinny_nn"):
                 for g, (a, b) in enumerate(self.gslice):
                     T16 = torch.zeros((V.D, 16), dtype=self.T, device=dev)
@@ -350,7 +351,7 @@ class MofaEngine:
                     A[m, a:b] = self.be.skinny_nn(V.Y[a:b], T16)[:, :K]
             elif V.kind == "dense":
                 for g, (a, b) in enumerate(self.gslice):
-                    A[m, a:b] = V.Y[a:b] @ TW[g]
+                    A[m, a:b] = V.Y[a:b] @ TW[g].T.contiguous().T
             else:
                 Bp = _pad_block(G * K)
                 TWs = torch.zeros((V.D, Bp), dtype=self.T, device=dev)
