@@ -264,6 +264,34 @@ int mu_mofa_update_z(int dtype, int64_t N, int K, int M, int G, const void* d_A,
                      const int32_t* d_grp, const void* d_Gw, const void* d_dw2, const void* d_alphaz,
                      void* d_EZ, void* d_EZ2, void* d_sig2, void* stream);
 
+/* ---- MOFA+ small nodes and the ELBO, fused (tools.py:585 ent.run(): mofapy2's Tau, AlphaW, ThetaW,
+ * AlphaZ node updates and calculateELBO()).  Arithmetic in f64 for both storage types; every entry
+ * ADDS its ELBO terms to the device scalar *d_elbo.  d_work: mu_mofa_elbo_work_doubles(K) doubles. */
+size_t mu_mofa_elbo_work_doubles(int K);
+/* tau node of one view and the likelihood term.  yy[G][D] = sum_n (y - mean)^2 over the observed
+ * samples of the group, Ngm[G] their number, EW / EW2[D][K], B[G][D][K], Gz[G][K][K], Z2[G][K] as
+ * in mu_mofa_update_w.  Out tau[G][D] = <tau>, ltau[G][D] = <ln tau>. */
+int mu_mofa_tau_elbo(int dtype, int64_t D, int K, int G, const void* d_yy, const void* d_Ngm,
+                     const void* d_EW, const void* d_EW2, const void* d_B, const void* d_Gz,
+                     const void* d_Z2, double a0, double b0, void* d_tau, void* d_ltau, double* d_elbo,
+                     double* d_work, void* stream);
+/* ARD precision (ard != 0: alpha[K], lalpha[K] = <ln alpha>) and sparsity level (spikeslab != 0:
+ * lth[K] = <ln theta>, l1mth[K] = <ln(1 - theta)>) of one view's weights from EWh2, gamma, sig2
+ * [D][K] (outputs of mu_mofa_update_w), and the ELBO terms of the W, alpha_w and theta nodes.
+ * a_alpha = a0 + D / 2; (th_a0, th_b0): the Beta prior of theta. */
+int mu_mofa_w_elbo(int dtype, int64_t D, int K, int ard, int spikeslab, const void* d_EWh2,
+                   const void* d_gamma, const void* d_sig2, double a_alpha, double a0, double b0,
+                   double th_a0, double th_b0, void* d_alpha, void* d_lalpha, void* d_lth, void* d_l1mth,
+                   double* d_elbo, double* d_work, void* stream);
+/* d_out[0][K] = sum_n <z_nk^2>, d_out[1][K] = sum_n ln sig2_nk over the rows [n0, n1) (one group's
+ * samples on this rank; the caller adds the ranks up), then with zs[G][2][K] and the group sizes
+ * Ng[G] (f64): the ARD precision of the factors (ard != 0: alpha_z, lalpha_z [G][K]) and the ELBO
+ * terms of the Z and alpha_z nodes. */
+int mu_mofa_z_sums(int dtype, int64_t n0, int64_t n1, int K, const void* d_EZ2, const void* d_sig2,
+                   double* d_out, double* d_work, void* stream);
+int mu_mofa_z_elbo(int dtype, int K, int G, int ard, const double* d_zs, const double* d_Ng, double a0,
+                   double b0, void* d_alpha_z, void* d_lalpha_z, double* d_elbo, void* stream);
+
 /* ---- synthetic planted-topic counts (bench / tests only) ------ */
 /* Pass 1: nnz of every row for rows [row0, row0+n_rows) of the global matrix.
  * Pass 2 (after scanning the counts into indptr): fills indices / values (f32 counts).*/

@@ -481,6 +481,39 @@ class HipBackend:
                                             _p(dw2), _p(alphaz), _p(EZ), _p(EZ2), _p(sig2),
                                             self._stream()))
 
+    def mofa_elbo_work(self, K: int) -> torch.Tensor:
+        return self.empty((int(self.lib.mu_mofa_elbo_work_doubles(int(K))),), torch.float64)
+
+    def mofa_tau_elbo(self, yy, Ngm, EW, EW2, B, Gz, Z2, a0, b0, tau, ltau, elbo, work):
+        """tau / <ln tau> of one view from the sufficient statistics; adds the likelihood and tau-node
+        terms to the f64 device scalar ``elbo`` (include/muon_amd.h)."""
+        G, D, K = B.shape
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_mofa_tau_elbo(_dt(EW), D, K, G, _p(yy), _p(Ngm), _p(EW), _p(EW2), _p(B), _p(Gz),
+                                            _p(Z2), float(a0), float(b0), _p(tau), _p(ltau), _p(elbo),
+                                            _p(work), self._stream()))
+
+    def mofa_w_elbo(self, EWh2, gamma, sig2, ard, spikeslab, a_alpha, a0, b0, th_a0, th_b0, alpha, lalpha,
+                    lth, l1mth, elbo, work):
+        D, K = EWh2.shape
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_mofa_w_elbo(_dt(EWh2), D, K, int(bool(ard)), int(bool(spikeslab)), _p(EWh2),
+                                          _p(gamma), _p(sig2), float(a_alpha), float(a0), float(b0),
+                                          float(th_a0), float(th_b0), _p(alpha), _p(lalpha), _p(lth),
+                                          _p(l1mth), _p(elbo), _p(work), self._stream()))
+
+    def mofa_z_sums(self, EZ2, sig2, n0, n1, out, work):
+        K = EZ2.shape[1]
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_mofa_z_sums(_dt(EZ2), int(n0), int(n1), K, _p(EZ2), _p(sig2), _p(out), _p(work),
+                                          self._stream()))
+
+    def mofa_z_elbo(self, zs, Ng, ard, a0, b0, alpha_z, lalpha_z, elbo):
+        G, _two, K = zs.shape
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_mofa_z_elbo(_dt(alpha_z), K, G, int(bool(ard)), _p(zs), _p(Ng), float(a0),
+                                          float(b0), _p(alpha_z), _p(lalpha_z), _p(elbo), self._stream()))
+
     # -- synthetic data (bench / tests) ---------------------------------------------
     def synth_counts(self, row0: int, n_rows: int, n_cols: int, n_topics: int = 50,
                      density: float = 0.03, seed: int = 0) -> DeviceCSR:

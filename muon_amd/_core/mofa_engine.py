@@ -262,8 +262,12 @@ class MofaEngine:
         self.lalpha_z = torch.zeros((G, K), dtype=T, device=dev)
         # constants of the Gamma updates, resident so that an iteration has no host -> device copies
         self.Ng_d = self.Ng.to(dev).to(T)
+        self._Ng64 = self.Ng.to(dev).to(torch.float64).contiguous()
+        self._zs = torch.zeros((G, 2, K), dtype=torch.float64, device=dev)
+        self._elbo_work = self.be.mofa_elbo_work(K)
         for V, w in zip(self.views, self.W):
-            V.Ngm_d = V.Ngm.to(dev).to(T)
+            V.Ngm_d = V.Ngm.to(dev).to(T).contiguous()
+            V.yy = V.yy.contiguous()
             w.a_alpha = torch.tensor(A0 + 0.5 * V.D, dtype=T, device=dev)
 
     # -- sufficient statistics --------------------------------------------------------------
@@ -368,84 +372,27 @@ class MofaEngine:
                               az.contiguous(), self.EZ, self.EZ2, self.sig2z)
         self._stats = {}  # <Z> changed: statistics are stale
 
-    def _gamma_kl(self, a0, b0, a, b, ex, elx):
-        lp = a0 * math.log(b0) - math.lgamma(a0) + (a0 - 1.0) * elx - b0 * ex
-        lq = a * torch.log(b) - torch.lgamma(a) + (a - 1.0) * elx - b * ex
-        return lp - lq
-
     def _update_rest_and_elbo(self):
-        K, G = self.K, self.G
-        o = self.opts
+        """tau, alpha_w, theta, alpha_z and the ELBO: csrc/mofa_elbo.hip (one pass per array and a
+        one-workgroup finish per node; the same equations as tensor operations - ~250 launches per
+        iteration - are tests/cpu_backend.py's versions of these entry points)."""
+        o, be = self.opts, self.be
         elbo = torch.zeros((), dtype=torch.float64, device=self.EZ.device)
+        work = self._elbo_work
         for m, (V, Wm) in enumerate(zip(self.views, self.W)):
             Gz, Z2, B = self._zstats(m)
-            EW, EW2 = Wm.EW, Wm.EW2
-            Ngm = V.Ngm_d
-            for g in range(G):
-                S = (V.yy[g] - 2.0 * (EW * B[g]).sum(dim=1) + ((EW @ Gz[g]) * EW).sum(dim=1)
-                     + EW2 @ Z2[g] - (EW ** 2) @ torch.diagonal(Gz[g]))
-                a = A0 + 0.5 * Ngm[g]
-                b = B0 + 0.5 * S
-                Wm.tau[g] = a / b
-                Wm.ltau[g] = torch.digamma(a) - torch.log(b)
-                elbo += (0.5 * Ngm[g] * (Wm.ltau[g] - math.log(2 * math.pi)) - 0.5 * Wm.tau[g] * S).sum().double()
-                elbo += self._gamma_kl(A0, B0, a, b, Wm.tau[g], Wm.ltau[g]).sum().double()
-            D = V.D
-            if o["ard_weights"]:
-                a = Wm.a_alpha
-                b = B0 + 0.5 * Wm.EWh2.sum(dim=0)
-                Wm.alpha.copy_(a / b)
-                Wm.lalpha.copy_(torch.digamma(a) - torch.log(b))
-            if o["spikeslab_weights"]:
-                sg = Wm.gamma.sum(dim=0)
-                a = TH_A0 + sg
-                b = TH_B0 + D - sg
-                Wm.lth.copy_(torch.digamma(a) - torch.digamma(a + b))
-                Wm.l1mth.copy_(torch.digamma(b) - torch.digamma(a + b))
-            # ELBO terms of the W, alpha_w and theta nodes
-            aw = Wm.alpha if o["ard_weights"] else torch.ones_like(Wm.alpha)
-            law = Wm.lalpha if o["ard_weights"] else torch.zeros_like(Wm.lalpha)
-            gam = Wm.gamma
-            elbo += (0.5 * law - 0.5 * aw * Wm.EWh2).sum().double()
-            elbo += (gam * 0.5 * torch.log(Wm.sig2) + (1 - gam) * 0.5 * torch.log(1.0 / aw) + 0.5).sum().double()
-            if o["spikeslab_weights"]:
-                elbo += (gam * Wm.lth + (1 - gam) * Wm.l1mth).sum().double()
-                ent = -(torch.xlogy(gam, gam) + torch.xlogy(1 - gam, 1 - gam))
-                elbo += torch.nan_to_num(ent).sum().double()
-                sg = gam.sum(dim=0)
-                a = TH_A0 + sg
-                b = TH_B0 + D - sg
-                lb = torch.lgamma(a) + torch.lgamma(b) - torch.lgamma(a + b)
-                lb0 = math.lgamma(TH_A0) + math.lgamma(TH_B0) - math.lgamma(TH_A0 + TH_B0)
-                elbo += ((lb - lb0) + (TH_A0 - a) * Wm.lth + (TH_B0 - b) * Wm.l1mth).sum().double()
-            if o["ard_weights"]:
-                a = Wm.a_alpha
-                b = B0 + 0.5 * Wm.EWh2.sum(dim=0)
-                elbo += self._gamma_kl(A0, B0, a, b, aw, law).sum().double()
-        # factors: ARD per group
-        z2g = torch.stack([self.EZ2[a:b].sum(dim=0) for a, b in self.gslice])
-        if self.comm.world_size > 1:
-            self.comm.all_reduce_sum(z2g)
-        Ng = self.Ng_d
-        if o["ard_factors"]:
-            a = (A0 + 0.5 * Ng)[:, None].expand(G, K)
-            b = B0 + 0.5 * z2g
-            self.alpha_z.copy_(a / b)
-            self.lalpha_z.copy_(torch.digamma(a) - torch.log(b))
-        az = self.alpha_z if o["ard_factors"] else torch.ones_like(self.alpha_z)
-        laz = self.lalpha_z if o["ard_factors"] else torch.zeros_like(self.lalpha_z)
-        zpart = torch.zeros((), dtype=torch.float64, device=self.EZ.device)
+            be.mofa_tau_elbo(V.yy, V.Ngm_d, Wm.EW, Wm.EW2, B, Gz, Z2, A0, B0, Wm.tau, Wm.ltau, elbo, work)
+            be.mofa_w_elbo(Wm.EWh2, Wm.gamma, Wm.sig2, o["ard_weights"], o["spikeslab_weights"],
+                           A0 + 0.5 * V.D, A0, B0, TH_A0, TH_B0, Wm.alpha, Wm.lalpha, Wm.lth, Wm.l1mth,
+                           elbo, work)
+        # factors: per-group column sums of <z^2> and ln sig2 over this rank's samples, added up over
+        # the ranks in one collective; the ARD update and the ELBO terms follow from the global sums
+        zs = self._zs
         for g, (a_, b_) in enumerate(self.gslice):
-            zpart += (0.5 * laz[g] - 0.5 * az[g] * self.EZ2[a_:b_] + 0.5 * torch.log(self.sig2z[a_:b_]) + 0.5).sum().double()
+            be.mofa_z_sums(self.EZ2, self.sig2z, a_, b_, zs[g], work)
         if self.comm.world_size > 1:
-            zpart = zpart.reshape(1)
-            self.comm.all_reduce_sum(zpart)
-            zpart = zpart.reshape(())
-        elbo += zpart
-        if o["ard_factors"]:
-            a = (A0 + 0.5 * Ng)[:, None].expand(G, K)
-            b = B0 + 0.5 * z2g
-            elbo += self._gamma_kl(A0, B0, a, b, az, laz).sum().double()
+            self.comm.all_reduce_sum(zs)
+        be.mofa_z_elbo(zs, self._Ng64, o["ard_factors"], A0, B0, self.alpha_z, self.lalpha_z, elbo)
         return elbo
 
     # -- driver --------------------------------------------------------------------------------

@@ -80,6 +80,11 @@ SIGNATURES = {
     "mu_skinny_tn": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_mofa_update_w": (C.c_int, [_i32, _i64, _i32, _i32] + [_vp] * 7 + [_i32] + [_vp] * 6),
     "mu_mofa_update_z": (C.c_int, [_i32, _i64, _i32, _i32, _i32] + [_vp] * 10),
+    "mu_mofa_elbo_work_doubles": (_sz, [_i32]),
+    "mu_mofa_tau_elbo": (C.c_int, [_i32, _i64, _i32, _i32] + [_vp] * 7 + [_dbl, _dbl] + [_vp] * 5),
+    "mu_mofa_w_elbo": (C.c_int, [_i32, _i64, _i32, _i32, _i32] + [_vp] * 3 + [_dbl] * 5 + [_vp] * 7),
+    "mu_mofa_z_sums": (C.c_int, [_i32, _i64, _i64, _i32] + [_vp] * 5),
+    "mu_mofa_z_elbo": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _dbl, _dbl] + [_vp] * 4),
     "mu_synth_row_nnz": (C.c_int, [_i64, _i64, _i64, _i32, _dbl, _u64, _vp, _vp]),
     "mu_synth_fill": (C.c_int, [_i64, _i64, _i64, _i32, _dbl, _u64, _vp, _vp, _vp, _vp]),
 }

@@ -148,6 +148,87 @@ class CpuTestBackend:
             EWh2[:, k] = gam * (mu * mu + s2) + (1 - gam) / alpha[k]
             sig2[:, k] = s2
 
+    # tau / alpha / theta nodes and the ELBO: the equations of csrc/mofa_elbo.hip as tensor operations
+    # (f64 arithmetic, like the kernels)
+    def mofa_elbo_work(self, K):
+        return torch.zeros((1,), dtype=torch.float64)
+
+    @staticmethod
+    def _gamma_kl(a0, b0, a, b, ex, elx):
+        import math
+
+        lp = a0 * math.log(b0) - math.lgamma(a0) + (a0 - 1.0) * elx - b0 * ex
+        lq = a * torch.log(b) - torch.lgamma(a) + (a - 1.0) * elx - b * ex
+        return lp - lq
+
+    def mofa_tau_elbo(self, yy, Ngm, EW, EW2, B, Gz, Z2, a0, b0, tau, ltau, elbo, work):
+        import math
+
+        G = B.shape[0]
+        f = torch.float64
+        W, W2 = EW.to(f), EW2.to(f)
+        for g in range(G):
+            Gg = Gz[g].to(f)
+            S = (yy[g].to(f) - 2.0 * (W * B[g].to(f)).sum(dim=1) + ((W @ Gg) * W).sum(dim=1)
+                 + W2 @ Z2[g].to(f) - (W ** 2) @ torch.diagonal(Gg))
+            n = Ngm[g].to(f)
+            a = a0 + 0.5 * n
+            b = b0 + 0.5 * S
+            t, lt = a / b, torch.digamma(a) - torch.log(b)
+            tau[g] = t.to(tau.dtype)
+            ltau[g] = lt.to(tau.dtype)
+            elbo += (0.5 * n * (lt - math.log(2 * math.pi)) - 0.5 * t * S).sum()
+            elbo += self._gamma_kl(a0, b0, a, b, t, lt).sum()
+
+    def mofa_w_elbo(self, EWh2, gamma, sig2, ard, spikeslab, a_alpha, a0, b0, th_a0, th_b0, alpha, lalpha,
+                    lth, l1mth, elbo, work):
+        import math
+
+        f = torch.float64
+        D, K = EWh2.shape
+        H, gam, s2 = EWh2.to(f), gamma.to(f), sig2.to(f)
+        aw, law = torch.ones(K, dtype=f), torch.zeros(K, dtype=f)
+        if ard:
+            a = torch.tensor(float(a_alpha), dtype=f)
+            b = b0 + 0.5 * H.sum(dim=0)
+            aw, law = a / b, torch.digamma(a) - torch.log(b)
+            alpha.copy_(aw.to(alpha.dtype))
+            lalpha.copy_(law.to(alpha.dtype))
+            elbo += self._gamma_kl(a0, b0, a, b, aw, law).sum()
+        elbo += (0.5 * law - 0.5 * aw * H).sum()
+        elbo += (gam * 0.5 * torch.log(s2) + (1 - gam) * 0.5 * torch.log(1.0 / aw) + 0.5).sum()
+        if spikeslab:
+            sg = gam.sum(dim=0)
+            a = th_a0 + sg
+            b = th_b0 + D - sg
+            lt = torch.digamma(a) - torch.digamma(a + b)
+            l1 = torch.digamma(b) - torch.digamma(a + b)
+            lth.copy_(lt.to(lth.dtype))
+            l1mth.copy_(l1.to(lth.dtype))
+            elbo += (gam * lt + (1 - gam) * l1).sum()
+            elbo += torch.nan_to_num(-(torch.xlogy(gam, gam) + torch.xlogy(1 - gam, 1 - gam))).sum()
+            lb = torch.lgamma(a) + torch.lgamma(b) - torch.lgamma(a + b)
+            lb0 = math.lgamma(th_a0) + math.lgamma(th_b0) - math.lgamma(th_a0 + th_b0)
+            elbo += ((lb - lb0) + (th_a0 - a) * lt + (th_b0 - b) * l1).sum()
+
+    def mofa_z_sums(self, EZ2, sig2, n0, n1, out, work):
+        out[0] = EZ2[n0:n1].to(torch.float64).sum(dim=0)
+        out[1] = torch.log(sig2[n0:n1].to(torch.float64)).sum(dim=0)
+
+    def mofa_z_elbo(self, zs, Ng, ard, a0, b0, alpha_z, lalpha_z, elbo):
+        f = torch.float64
+        G, _two, K = zs.shape
+        n = Ng.to(f)[:, None]
+        az, laz = torch.ones((G, K), dtype=f), torch.zeros((G, K), dtype=f)
+        if ard:
+            a = (a0 + 0.5 * n).expand(G, K)
+            b = b0 + 0.5 * zs[:, 0]
+            az, laz = a / b, torch.digamma(a) - torch.log(b)
+            alpha_z.copy_(az.to(alpha_z.dtype))
+            lalpha_z.copy_(laz.to(alpha_z.dtype))
+            elbo += self._gamma_kl(a0, b0, a, b, az, laz).sum()
+        elbo += (0.5 * laz * n - 0.5 * az * zs[:, 0] + 0.5 * zs[:, 1] + 0.5 * n).sum()
+
     def mofa_update_z(self, A, pres, grp, Gw, dw2, alphaz, EZ, EZ2, sig2):
         M, N, K = A.shape
         g = grp.long()

@@ -109,3 +109,71 @@ class TestWrapperOnGpu:
         m = MuData({"y1": p, "y2": q})
         mu.tl.mofa(m, n_factors=10, use_obs="union", likelihoods="gaussian")
         assert m.obsm["X_mofa"].shape == (100, 10) and np.all(np.isfinite(m.obsm["X_mofa"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("K,G,ard,ss", [(10, 1, True, True), (10, 2, True, False), (20, 2, False, True), (3, 3, False, False)])
+def test_fused_small_nodes_match_tensor_formulas(hip, dtype, K, G, ard, ss):
+    """csrc/mofa_elbo.hip against the same equations as tensor operations (tests/cpu_backend.py):
+    tau / <ln tau>, alpha_w, theta, alpha_z and every ELBO term."""
+    from tests.cpu_backend import CpuTestBackend
+
+    cpu = CpuTestBackend()
+    g = torch.Generator().manual_seed(5)
+    D, N = 1234, 777
+    r = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64)
+    EW = (r(D, K) - 0.5).to(dtype)
+    EW2 = (EW.double() ** 2 + 0.1 * r(D, K)).to(dtype)
+    Zm = r(G, 50, K) - 0.5
+    Gz = torch.einsum("gnk,gnl->gkl", Zm, Zm).to(dtype)
+    Z2 = (Zm ** 2).sum(dim=1).add(0.3).to(dtype)
+    B = (4 * (r(G, D, K) - 0.5)).to(dtype)
+    yy = (60 + 30 * r(G, D)).to(dtype)
+    Ngm = torch.randint(40, 51, (G,), generator=g).to(dtype)
+    gamma = r(D, K)
+    gamma[:5] = 1.0
+    gamma[5:9] = 0.0
+    gamma = gamma.to(dtype)
+    EWh2 = (0.2 + r(D, K)).to(dtype)
+    sig2 = (0.01 + r(D, K)).to(dtype)
+    EZ2 = (0.1 + r(N, K)).to(dtype)
+    sig2z = (0.01 + r(N, K)).to(dtype)
+    cuts = [0] + sorted(torch.randint(1, N, (G - 1,), generator=g).tolist()) + [N]
+    Ng = torch.tensor([cuts[i + 1] - cuts[i] for i in range(G)], dtype=torch.float64)
+
+    def run(be, dev):
+        to = lambda t: t.to(dev).contiguous()
+        out = {"tau": torch.zeros((G, D), dtype=dtype, device=dev), "ltau": torch.zeros((G, D), dtype=dtype, device=dev)}
+        for n in ("alpha", "lalpha", "lth", "l1mth"):
+            out[n] = torch.full((K,), 0.25, dtype=dtype, device=dev)
+        out["alpha_z"] = torch.ones((G, K), dtype=dtype, device=dev)
+        out["lalpha_z"] = torch.zeros((G, K), dtype=dtype, device=dev)
+        parts = []
+        work = be.mofa_elbo_work(K)
+        e = torch.zeros((), dtype=torch.float64, device=dev)
+        be.mofa_tau_elbo(to(yy), to(Ngm), to(EW), to(EW2), to(B), to(Gz), to(Z2), 1e-14, 1e-14, out["tau"], out["ltau"], e, work)
+        parts.append(float(e))
+        e = torch.zeros((), dtype=torch.float64, device=dev)
+        be.mofa_w_elbo(to(EWh2), to(gamma), to(sig2), ard, ss, 1e-14 + 0.5 * D, 1e-14, 1e-14, 1.0, 1.0,
+                       out["alpha"], out["lalpha"], out["lth"], out["l1mth"], e, work)
+        parts.append(float(e))
+        zs = torch.zeros((G, 2, K), dtype=torch.float64, device=dev)
+        for i in range(G):
+            be.mofa_z_sums(to(EZ2), to(sig2z), cuts[i], cuts[i + 1], zs[i], work)
+        e = torch.zeros((), dtype=torch.float64, device=dev)
+        be.mofa_z_elbo(zs, to(Ng), ard, 1e-14, 1e-14, out["alpha_z"], out["lalpha_z"], e)
+        parts.append(float(e))
+        return {k: v.cpu() for k, v in out.items()}, parts, zs.cpu()
+
+    ref, pref, zref = run(cpu, torch.device("cpu"))
+    got, pgot, zgot = run(hip, hip.device)
+    tol = 1e-10 if dtype == torch.float64 else 2e-6
+    assert torch.allclose(zgot, zref, rtol=1e-12, atol=0)
+    for n in ref:
+        assert torch.allclose(got[n].double(), ref[n].double(), rtol=tol, atol=tol), n
+    for a, b in zip(pgot, pref):
+        assert abs(a - b) <= 1e-9 * max(1.0, abs(b)), (pgot, pref)
+    # the partial sums are folded in a fixed order
+    _again, p2, _z = run(hip, hip.device)
+    assert p2 == pgot
