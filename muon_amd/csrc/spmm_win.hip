@@ -588,9 +588,24 @@ __global__ __launch_bounds__(256) void k_stream_fill(int64_t n_pos, const int32_
     if (row < 0) continue;
     const int64_t lo = uniform64(indptr[row]), hi = uniform64(indptr[row + 1]);
     const int64_t o0 = uniform64(sptr[pos]);
-    for (int64_t j = lane; j < hi - lo; j += 64)
-      ent[o0 + j] = (unsigned long long)(unsigned)indices[lo + j] |
-                    ((unsigned long long)__builtin_bit_cast(unsigned, values[lo + j]) << 32);
+    // four independent chunks per iteration: the copy runs on a few waves per CU next to the
+    // transposition's fill (backend.stream_both) and lives on loads in flight
+    const int64_t len = hi - lo;
+    for (int64_t j = lane; j < len; j += 256) {
+      int32_t c[4];
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = j + 64 * u < len;
+        c[u] = ok ? indices[lo + j + 64 * u] : 0;
+        v[u] = ok ? values[lo + j + 64 * u] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j + 64 * u < len)
+          ent[o0 + j + 64 * u] = (unsigned long long)(unsigned)c[u] |
+                                 ((unsigned long long)__builtin_bit_cast(unsigned, v[u]) << 32);
+    }
   }
 }
 
