@@ -258,12 +258,15 @@ __global__ __launch_bounds__(64) void k_mofa_z_finish(int K, int G, int ard, con
   }
 }
 
-inline int blocks_for(int64_t items, int per_block) {
+inline int blocks_for(int64_t items, int per_block, int cap = kEBlocksMax) {
   int64_t b = (items + per_block - 1) / per_block;
   if (b < 1) b = 1;
-  if (b > kEBlocksMax) b = kEBlocksMax;
+  if (b > cap) b = cap;
   return (int)b;
 }
+// the finish kernels add the partials up one after the other (fixed order): few, fat workgroups for
+// the column sums (512 partials made the one-workgroup finish 0.15 ms, ten times the pass itself)
+constexpr int kEColBlocks = 48;
 
 template <typename T>
 int run_tau(int64_t D, int K, int G, const void* yy, const void* Ngm, const void* EW, const void* EW2,
@@ -287,7 +290,7 @@ int run_w(int64_t D, int K, int ard, int spikeslab, const void* EWh2, const void
           double a_alpha, double a0, double b0, double th_a0, double th_b0, void* alpha, void* lalpha,
           void* lth, void* l1mth, double* elbo, double* work, hipStream_t st) {
   const int KP = K <= 16 ? 16 : 32;
-  const int nb = blocks_for(D, kET / KP);
+  const int nb = blocks_for(D, kET / KP, kEColBlocks);
   if (K <= 16)
     hipLaunchKernelGGL((k_mofa_w_colsums<T, 16>), dim3(nb), dim3(kET), 0, st, D, K, (const T*)EWh2,
                        (const T*)gamma, (const T*)sig2, work);
@@ -305,7 +308,7 @@ template <typename T>
 int run_z_sums(int64_t n0, int64_t n1, int K, const void* EZ2, const void* sig2, double* out, double* work,
                hipStream_t st) {
   const int KP = K <= 16 ? 16 : 32;
-  const int nb = blocks_for(n1 - n0, kET / KP);
+  const int nb = blocks_for(n1 - n0, kET / KP, kEColBlocks);
   if (K <= 16)
     hipLaunchKernelGGL((k_mofa_z_colsums<T, 16>), dim3(nb), dim3(kET), 0, st, n0, n1, K, (const T*)EZ2,
                        (const T*)sig2, work);

@@ -30,9 +30,9 @@ int mu_num_cus() {
 // tuning / ablation knobs (tests and bench only)
 static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "spmm_waves", "spmm_pipe",
                                         "tpack_abl", "tpack_c", "gram_wg", "tpack_v2", "pack_wg",
-                                        "tpack_dbg", "tpack_rows"};
-constexpr int kTuneN = 11;
-static int g_tune[kTuneN] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                                        "tpack_dbg", "tpack_rows", "tpack_narrow"};
+constexpr int kTuneN = sizeof(kTuneKeys) / sizeof(kTuneKeys[0]);
+static int g_tune[kTuneN] = {};
 
 extern "C" {
 

@@ -16,6 +16,8 @@
 //      writes every column's run with consecutive lanes (k_t_fill3 / k_t_fill2 below; the first
 //      generation, a bitmap-rank fill with one 8-byte store per pair, ran at the fabric's
 //      partial-write rate and is gone)
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -33,7 +35,7 @@ inline int64_t t_slabs(int64_t n_cols) { return (n_cols + kTSlab - 1) / kTSlab; 
 inline int t_grid(int64_t nnz, int64_t n_cols) {
   const int64_t cus = mu_num_cus();
   // (tune tpack_rows: stored entries per row block in units of 1e5 instead)
-  int64_t per_block = (int64_t)(0.93 * 14336 / 640 * (double)(n_cols > 0 ? n_cols : 1));  // kF3Cap / kF3Cols
+  int64_t per_block = (int64_t)(0.93 * 14336 / 640 * (double)(n_cols > 0 ? n_cols : 1));  // kF3CapNarrow / kF3Cols
   if (per_block < 100000) per_block = 100000;
   if (mu_tune_get("tpack_rows") > 0) per_block = 100000ll * mu_tune_get("tpack_rows");
   int64_t rounds = (nnz + per_block * cus - 1) / (per_block * cus);
@@ -382,8 +384,12 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
 // measured by wave 0 between the barriers, summed over workgroups and tiles
 __device__ unsigned long long g_t_phase[8];
 
-constexpr int kF3Cols = 640;   // 16-bit cursors and counts 40 KiB + 112 KiB staging + 7.5 KiB per-column state fit 160 KiB
-constexpr int kF3Cap = 14336;  // staged pairs of the third-generation fill
+// Two builds of the third-generation fill.  NARROW: 16-bit cursors packed in pairs (20 KiB) leave
+// room for 112 KiB of staging - more rows per block, fewer rounds of blocks: 86.5 instead of 88.9 ms
+// at 1e6 x 200k.  The packing costs a shift and a mask per visit, so an input that is one round of
+// blocks either way (125k x 200k: 12.9 against 12.3 ms) takes the 32-bit build with 80 KiB of staging.
+constexpr int kF3Cols = 640;
+constexpr int kF3CapNarrow = 14336, kF3CapWide = 10240;  // staged pairs
 constexpr int64_t kF3MaxRows = 16ll * 65535;  // a wave's count of one column fits 16 bits
 
 // 16-bit count i of a wave's count row += 1, as a 32-bit LDS atomic on the word that holds it
@@ -402,7 +408,7 @@ __device__ __forceinline__ uint32_t cur_fetch_inc(uint16_t* wcur, int i) {
   return (old >> sh) & 0xffffu;
 }
 
-template <int PHASE>
+template <int PHASE, bool NARROW>
 __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, int first,
                                            int64_t row0, int32_t cbase, int32_t cend, int32_t cend2,
                                            const int32_t* __restrict__ indices_b,
@@ -434,10 +440,12 @@ __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, 
         const bool nxt = !valid && c < cend2;
         uint32_t k = 0;   // absolute slot in the staging buffer (run-relative when not staged)
         if (valid) {
-          // staged: 16-bit absolute staging slots; a tile that does not fit the staging buffer keeps
-          // 32-bit run-relative cursors in the (then unused) staging memory
-          k = staged ? cur_fetch_inc(wcur, c - cbase)
-                     : __hip_atomic_fetch_add(&wcur32[c - cbase], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          // NARROW, staged: 16-bit absolute staging slots; a tile that does not fit the staging
+          // buffer keeps 32-bit run-relative cursors in the (then unused) staging memory.  Wide
+          // build: one 32-bit cursor array for both cases.
+          k = (NARROW && staged)
+                  ? cur_fetch_inc(wcur, c - cbase)
+                  : __hip_atomic_fetch_add(&wcur32[c - cbase], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (nxt) cnt_add(wcnt, c - cend);
         if (valid) {
@@ -471,7 +479,7 @@ __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, 
   }
 }
 
-template <int PHASE>
+template <int PHASE, bool NARROW>
 __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cbase, int32_t cend,
                                         int32_t cend2, int64_t wg_base,
                                         const int64_t* __restrict__ indptr,
@@ -494,11 +502,11 @@ __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cb
     f2_load<PHASE>(ba, cur, end, 0, indices_b, values_b);
     for (int first = 0; first < nr; first += 2 * kF2Rows) {
       if (first + kF2Rows < nr) f2_load<PHASE>(bb, cur, end, first + kF2Rows, indices_b, values_b);
-      f3_process<PHASE>(ba, cur, end, first, sb, cbase, cend, cend2, indices_b, values_b, wcur, wcnt, wcur32,
+      f3_process<PHASE, NARROW>(ba, cur, end, first, sb, cbase, cend, cend2, indices_b, values_b, wcur, wcnt, wcur32,
                         gdst, stage, staged, ent);
       if (first + kF2Rows < nr) {
         if (first + 2 * kF2Rows < nr) f2_load<PHASE>(ba, cur, end, first + 2 * kF2Rows, indices_b, values_b);
-        f3_process<PHASE>(bb, cur, end, first + kF2Rows, sb, cbase, cend, cend2, indices_b, values_b, wcur,
+        f3_process<PHASE, NARROW>(bb, cur, end, first + kF2Rows, sb, cbase, cend, cend2, indices_b, values_b, wcur,
                           wcnt, wcur32, gdst, stage, staged, ent);
       }
     }
@@ -506,6 +514,7 @@ __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cb
   }
 }
 
+template <bool NARROW>
 __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n_cols, int C, int dbg,
                                                        const int64_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ indices,
@@ -516,13 +525,17 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
                                                        const uint32_t* __restrict__ base,
                                                        const int64_t* __restrict__ coltot,
                                                        TOut ent) {
-  __shared__ unsigned long long stage[kF3Cap];     // 112 KiB
-  __shared__ uint16_t wcur_all[kTWaves][kF3Cols];  // 32 KiB: per (wave, column) cursor of this tile
-  __shared__ uint16_t wcnt_all[kTWaves][kF3Cols];  // 32 KiB: per (wave, column) count of the tile in the making
+  constexpr int kF3Cap = NARROW ? kF3CapNarrow : kF3CapWide;
+  typedef typename std::conditional<NARROW, uint16_t, uint32_t>::type CurT;
+  __shared__ unsigned long long stage[kF3Cap];     // 112 / 80 KiB
+  __shared__ CurT wcur_all[kTWaves][kF3Cols];      // 20 / 40 KiB: per (wave, column) cursor of this tile
+  __shared__ uint16_t wcnt_all[kTWaves][kF3Cols];  // 20 KiB: per (wave, column) count of the tile in the making
   __shared__ uint16_t lcount[kF3Cols], lpos[kF3Cols];  // staged tiles only (<= kF3Cap pairs)
   __shared__ int64_t gdst[kF3Cols];
   static_assert(sizeof(uint32_t) * kTWaves * kF3Cols <= sizeof(unsigned long long) * kF3Cap, "direct-mode cursors live in the staging buffer");
-  uint32_t(*wcur32_all)[kF3Cols] = reinterpret_cast<uint32_t(*)[kF3Cols]>(stage);
+  // 32-bit cursors: the wide build's own array; the narrow build's direct-mode cursors (staging memory)
+  uint32_t(*wcur32_all)[kF3Cols] = NARROW ? reinterpret_cast<uint32_t(*)[kF3Cols]>(stage)
+                                          : reinterpret_cast<uint32_t(*)[kF3Cols]>(&wcur_all[0][0]);
   __shared__ uint32_t wsum[kTWaves];
   __shared__ int64_t s_r[2];
   const int g = blockIdx.x, G = gridDim.x;
@@ -589,8 +602,9 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
     }
     mark(0);
     if (!have)
-      f3_walk<0>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs, wcur_all[wave],
-                 wcnt_all[wave], wcur32_all[wave], gdst, stage, staged, ent);
+      f3_walk<0, NARROW>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs,
+                         reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_all[wave], wcur32_all[wave], gdst, stage,
+                         staged, ent);
     __syncthreads();
     mark(1);
     // per column: exclusive prefix of the wave counts = first slot of every wave inside the run;
@@ -602,15 +616,16 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
       for (int w = 0; w < kTWaves; ++w) {
         const uint32_t t = wcnt_all[w][threadIdx.x];
         wcnt_all[w][threadIdx.x] = (uint16_t)0;
-        if (staged) wcur_all[w][threadIdx.x] = (uint16_t)run;
+        if (NARROW && staged) wcur_all[w][threadIdx.x] = (CurT)run;
         else wcur32_all[w][threadIdx.x] = run;
         run += t;
       }
     }
     __syncthreads();
     mark(2);
-    f3_walk<1>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs, wcur_all[wave],
-               wcnt_all[wave], wcur32_all[wave], gdst, stage, staged, ent);
+    f3_walk<1, NARROW>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs,
+                       reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_all[wave], wcur32_all[wave], gdst, stage,
+                       staged, ent);
     have = true;
     mark(3);
     __syncthreads();
@@ -709,15 +724,25 @@ static int tpack_fill_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const in
     //  direct-store path)
     const double per_col = (double)nnz / (double)G / (double)n_cols;  // pairs of a tile per column
     const bool v3 = n_rows <= kF3MaxRows && !mu_tune_get("tpack_v2");
-    int64_t C = per_col > 0 ? (int64_t)(0.93 * (v3 ? kF3Cap : kF2Cap) / per_col) : kF2Cols;
+    // more than one round of row blocks (or one round of blocks too big for 512-column tiles in the
+    // small staging buffer): the bigger staging buffer pays
+    bool narrow = G > mu_num_cus() || per_col > 0.93 * kF3CapWide / 512;
+    if (mu_tune_get("tpack_narrow") > 0) narrow = mu_tune_get("tpack_narrow") == 1;  // tests: 1 narrow, 2 wide
+    int64_t C = per_col > 0 ? (int64_t)(0.93 * (v3 ? (narrow ? kF3CapNarrow : kF3CapWide) : kF2Cap) / per_col) : kF2Cols;
     C = (C / 32) * 32;
     if (C < 32) C = 32;
     if (C > (v3 ? kF3Cols : kF2Cols)) C = v3 ? kF3Cols : kF2Cols;
     if (mu_tune_get("tpack_c") > 0) C = mu_tune_get("tpack_c");
     if (v3) {
       if (C > kF3Cols) C = kF3Cols;
-      hipLaunchKernelGGL(k_t_fill3, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C, mu_tune_get("tpack_dbg"), d_indptr,
-                         d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt, w.coltot, out);
+      if (narrow)
+        hipLaunchKernelGGL(k_t_fill3<true>, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,
+                           mu_tune_get("tpack_dbg"), d_indptr, d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt,
+                           w.coltot, out);
+      else
+        hipLaunchKernelGGL(k_t_fill3<false>, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,
+                           mu_tune_get("tpack_dbg"), d_indptr, d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt,
+                           w.coltot, out);
     } else {
       hipLaunchKernelGGL(k_t_fill2, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,
                          mu_tune_get("tpack_abl"), d_indptr, d_indices, d_values, w.curs, d_cptr, d_inv,

@@ -352,6 +352,37 @@ def test_transpose_stream_tile_overflow_falls_back(hip):
         _check_stream(hip, Ps, mt)
 
 
+@pytest.mark.parametrize("build", [1, 2])
+def test_transpose_stream_both_cursor_widths(hip, build):
+    """The fill exists with packed 16-bit cursors (inputs of more than one round of row blocks) and
+    with 32-bit ones; small inputs only reach the second by themselves.  Both builds, forced: ragged
+    rows with bursts, narrow tiles, and a tile that overflows the staging buffer (direct stores with
+    the 32-bit cursors kept in the staging memory in the packed build)."""
+    rng = np.random.default_rng(5 + build)
+    cases = [(_heavy_rows_csr(2000, 20000, 0.004, rng, bursts=True), 0),
+             (_heavy_rows_csr(5000, 700, 0.03, rng, bursts=True), 64),
+             (_heavy_rows_csr(300, 9000, 0.01, rng, bursts=True), 32)]
+    dense = sp.random(60000, 100, density=0.95, format="csr", random_state=rng, dtype=np.float32)
+    big = sp.hstack([dense, sp.csr_matrix((60000, 100), dtype=np.float32)], format="csr")
+    big.sort_indices()
+    cases.append((big, 0))
+    for m, C in cases:
+        mt = m.T.tocsr()
+        mt.sort_indices()
+        sptr, ent = _stream_ref(mt)
+        try:
+            hip.tune("tpack_narrow", build)
+            hip.tune("tpack_c", C)
+            P = hip.transpose_stream(_up(hip, m), sort_rows=False)
+            Ps = hip.transpose_stream(_up(hip, m))
+        finally:
+            hip.tune("tpack_narrow", 0)
+            hip.tune("tpack_c", 0)
+        assert np.array_equal(hip.to_host(P.sptr), sptr)
+        assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
+        _check_stream(hip, Ps, mt)
+
+
 @pytest.mark.parametrize("C", [32, 64, 0])
 def test_transpose_stream_count_rides_on_previous_tile(hip, C):
     """Third-generation fill: the place walk of a tile counts the next tile's entries.  Narrow tiles
