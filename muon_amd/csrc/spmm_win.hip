@@ -37,6 +37,7 @@
 #include <type_traits>
 #include <utility>
 #include "common.hpp"
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"  // 32-bit LDS addresses made from integers
 
 namespace {
 
