@@ -544,7 +544,7 @@ def lsi(data, scale_embeddings=True, n_comps=50, *, comm=None, n_iter: Optional[
     Xd = resident(X, backend)  # still on the device from tfidf(): no PCIe upload
     if Xd is None:
         host = canonical_csr(X)
-        Xd = backend.upload_csr(host.indptr, host.indices, host.data.astype(np.float32, copy=False), host.shape)
+        Xd = backend.upload_csr(host.indptr, host.indices, host.data, host.shape, values_dtype=np.float32)
     out_dtype = X.dtype if X.dtype in (np.float32, np.float64) else np.float64
 
     U, stdev, V, info = lsi_device(backend, Xd, n_comps=n_comps, scale_embeddings=scale_embeddings,

@@ -102,17 +102,69 @@ class HipBackend:
     def zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
-    def to_device(self, arr) -> torch.Tensor:
-        return torch.as_tensor(np.ascontiguousarray(arr)).to(self.device, non_blocking=False)
+    def to_device(self, arr, dtype=None) -> torch.Tensor:
+        """Host array -> device tensor (optionally converted to ``dtype`` on the way).  Big arrays -
+        the CSR of a whole experiment is tens of GB - go through pinned staging buffers filled by a
+        few host threads while the previous chunk is on the bus (scripts/probes/upload_probe.py);
+        a pageable ``.to(device)`` stages the same bytes on one thread."""
+        a = np.asarray(arr)
+        want = np.dtype(dtype) if dtype is not None else a.dtype
+        if a.nbytes >= self._UPLOAD_PIPELINE_MIN and a.ndim == 1:
+            return self._upload_pipelined(a, want)
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=want)).to(self.device, non_blocking=False)
+
+    _UPLOAD_PIPELINE_MIN = 256 << 20
+    _UPLOAD_CHUNK = 64 << 20      # bytes per staging buffer
+    _UPLOAD_THREADS = 4
+
+    def _upload_pipelined(self, a: np.ndarray, want: np.dtype) -> torch.Tensor:
+        from concurrent.futures import ThreadPoolExecutor
+
+        tdt = torch.from_numpy(np.empty(0, dtype=want)).dtype
+        n = a.shape[0]
+        out = torch.empty((n,), dtype=tdt, device=self.device)
+        per = max(1, self._UPLOAD_CHUNK // want.itemsize)
+        st = self.__dict__.get("_upload_state")
+        if st is None or st["dtype"] != tdt:
+            bufs = [torch.empty((per,), dtype=tdt).pin_memory() for _ in range(3)]
+            st = self._upload_state = {"dtype": tdt, "bufs": bufs, "np": [b.numpy() for b in bufs],
+                                       "stream": torch.cuda.Stream(self.device),
+                                       "pool": ThreadPoolExecutor(self._UPLOAD_THREADS)}
+        bufs, nps, copy_stream, pool = st["bufs"], st["np"], st["stream"], st["pool"]
+        events = [None, None, None]
+        T = self._UPLOAD_THREADS
+
+        def fill(dst, src):
+            np.copyto(dst, src, casting="unsafe")  # (memcpy or a converting loop; releases the GIL)
+
+        for i, lo in enumerate(range(0, n, per)):
+            hi = min(n, lo + per)
+            b = i % 3
+            if events[b] is not None:
+                events[b].synchronize()  # the bus is done with this staging buffer
+            m = hi - lo
+            cuts = [m * t // T for t in range(T + 1)]
+            list(pool.map(lambda t: fill(nps[b][cuts[t]:cuts[t + 1]], a[lo + cuts[t]:lo + cuts[t + 1]]), range(T)))
+            with torch.cuda.stream(copy_stream):
+                out[lo:hi].copy_(bufs[b][:m], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            events[b] = ev
+        torch.cuda.current_stream(self.device).wait_stream(copy_stream)
+        copy_stream.synchronize()  # the staging buffers are reused by the next call
+        return out
 
     def to_host(self, t: torch.Tensor) -> np.ndarray:
         return t.detach().cpu().numpy()
 
-    def upload_csr(self, indptr, indices, values, shape) -> DeviceCSR:
+    def upload_csr(self, indptr, indices, values, shape, values_dtype=None) -> DeviceCSR:
+        """Host CSR -> HBM.  Index arrays become int64 / int32 and the values ``values_dtype`` on the
+        way (scipy keeps int64 column indices beyond 2^31 stored entries; a separate ``astype`` of
+        such an array is a single-threaded pass over tens of GB)."""
         return DeviceCSR(
-            self.to_device(np.asarray(indptr, dtype=np.int64)),
-            self.to_device(np.asarray(indices, dtype=np.int32)),
-            self.to_device(values),
+            self.to_device(indptr, np.int64),
+            self.to_device(indices, np.int32),
+            self.to_device(values, values_dtype),
             (int(shape[0]), int(shape[1])),
         )
 

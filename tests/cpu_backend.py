@@ -24,8 +24,8 @@ class CpuTestBackend:
     def zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype)
 
-    def to_device(self, arr):
-        return torch.as_tensor(np.ascontiguousarray(arr)).clone()
+    def to_device(self, arr, dtype=None):
+        return torch.as_tensor(np.ascontiguousarray(arr, dtype=dtype)).clone()
 
     def to_host(self, t):
         return t.detach().numpy().copy()
@@ -39,10 +39,9 @@ class CpuTestBackend:
 
         return _Done()
 
-    def upload_csr(self, indptr, indices, values, shape):
-        return DeviceCSR(self.to_device(np.asarray(indptr, dtype=np.int64)),
-                         self.to_device(np.asarray(indices, dtype=np.int32)),
-                         self.to_device(values), (int(shape[0]), int(shape[1])))
+    def upload_csr(self, indptr, indices, values, shape, values_dtype=None):
+        return DeviceCSR(self.to_device(indptr, np.int64), self.to_device(indices, np.int32),
+                         self.to_device(values, values_dtype), (int(shape[0]), int(shape[1])))
 
     @staticmethod
     def _sp(X):

@@ -485,3 +485,25 @@ def test_chol_rinv_flags_a_semidefinite_gram(hip):
     flag = hip.zeros((1,), torch.int32)
     M = hip.to_host(hip.chol_rinv(hip.to_device(A.T @ A), 64, flag))
     assert int(flag.item()) == 1 and np.all(np.isfinite(M))
+
+
+def test_pipelined_upload_matches_plain_copy(hip):
+    """Big host arrays reach HBM through pinned staging buffers filled by host threads, converted on
+    the way (int64 -> int32 column indices, f64 -> f32 values): forced here with small buffers so that
+    the three staging buffers are reused several times and the last chunk is ragged."""
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 2**31 - 1, 1_000_003).astype(np.int64)
+    v = rng.standard_normal(777_777)
+    keep = (hip._UPLOAD_PIPELINE_MIN, hip._UPLOAD_CHUNK)
+    try:
+        hip._UPLOAD_PIPELINE_MIN, hip._UPLOAD_CHUNK = 1 << 16, 1 << 18
+        hip.__dict__.pop("_upload_state", None)
+        got_a = hip.to_device(a, np.int32)
+        got_v = hip.to_device(v, np.float32)
+        got_same = hip.to_device(v)
+    finally:
+        hip._UPLOAD_PIPELINE_MIN, hip._UPLOAD_CHUNK = keep
+        hip.__dict__.pop("_upload_state", None)
+    assert got_a.dtype == torch.int32 and np.array_equal(hip.to_host(got_a), a.astype(np.int32))
+    assert got_v.dtype == torch.float32 and np.array_equal(hip.to_host(got_v), v.astype(np.float32))
+    assert got_same.dtype == torch.float64 and np.array_equal(hip.to_host(got_same), v)
