@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Multi-rank GPU path against the single-process result, on ONE GPU (all ranks on cuda:0, gloo):
-tfidf + lsi of a row-sharded matrix must give the single-process values / subspace.
+tfidf + lsi of a row-sharded matrix must give the single-process values / subspace, mofa on
+row-sharded samples the single-process ELBO trace, factors and weights.
 
   python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 scripts/dist_gpu_check.py
 """
@@ -42,5 +43,35 @@ if rank == 0:
     print(f"ranks {world}: tfidf max rel diff {dv:.2e}, subspace angle vs single process {ang:.2e}, stdev rel diff {ds:.2e}, "
           f"|U| max diff {du:.2e}, iterations {info['iterations']} / {inff['iterations']}")
     assert dv < 1e-6 and ang < 1e-4 and ds < 1e-5
+
+# MOFA: two views (dense + sparse), two groups, samples sharded by rows; the sufficient statistics,
+# the factor column sums and the ELBO part of the samples are the collectives (float64 engine)
+import scipy.sparse as sp
+
+from muon_amd._core.mofa_engine import MofaEngine
+
+rng = np.random.default_rng(0)
+N = 3000
+Z0 = rng.standard_normal((N, 4))
+y1 = Z0 @ rng.standard_normal((300, 4)).T + rng.standard_normal((N, 300))
+y2 = Z0 @ rng.standard_normal((500, 4)).T + rng.standard_normal((N, 500))
+y2[np.abs(y2) < 0.8] = 0
+groups = np.sort(rng.integers(0, 2, N))
+a, b = (0, 1300) if rank == 0 else (1300, N)
+if world == 1:
+    a, b = 0, N
+eng = MofaEngine(be, [y1[a:b], sp.csr_matrix(y2[a:b])], groups[a:b], 6, seed=1, comm=comm, row_offset=a, n_total=N)
+eng.run(12, "slow")
+res = eng.results(sort_factors=False)
+Zall = comm.all_gather_rows(torch.from_numpy(res["Z"]))
+if rank == 0:
+    one = MofaEngine(be, [y1, sp.csr_matrix(y2)], groups, 6, seed=1)
+    one.run(12, "slow")
+    ref = one.results(sort_factors=False)
+    de = float(np.max(np.abs((np.asarray(res["elbo"]) - np.asarray(ref["elbo"])) / np.asarray(ref["elbo"]))))
+    dz = float(np.max(np.abs(Zall.numpy() - ref["Z"])))
+    dw = max(float(np.max(np.abs(x - y))) for x, y in zip(res["W"], ref["W"]))
+    print(f"mofa ranks {world}: ELBO trace max rel diff {de:.2e}, |Z| diff {dz:.2e}, |W| diff {dw:.2e}")
+    assert de < 1e-9 and dz < 1e-7 and dw < 1e-7
     print("dist gpu check ok")
 dist.barrier()
