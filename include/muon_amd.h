@@ -193,6 +193,13 @@ int mu_csr_tpack_fill_stream(int64_t n_rows, int64_t n_cols, int64_t nnz, const 
 int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, const void* d_ent,
                        const int32_t* d_perm, int k_layout, const float* d_Q, int B, float* d_Y,
                        void* stream);
+/* The same row stream (f32 stored values) against an f64 dense block, f64 accumulation and product,
+ * B = 16 / 32: mofapy2's default precision (tools.py:308 use_float32=False).  accumulate != 0 adds to
+ * d_Y - an f64-valued matrix is the sum of two f32-valued ones (v = fl32(v) + fl32(v - fl32(v)), exact
+ * to 2^-48), i.e. two streams and two launches; data that is exact in f32 (counts) needs one. */
+int mu_spmm_stream_f64(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, const void* d_ent,
+                       const int32_t* d_perm, int k_layout, const double* d_Q, int B, double* d_Y,
+                       int accumulate, void* stream);
 
 
 /* Tuning / ablation knobs (tests and bench only; all default to 0 = what ships):

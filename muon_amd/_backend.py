@@ -61,6 +61,20 @@ class DeviceStream:
         return int(self.sptr.numel()) - 1
 
 
+@dataclass
+class SplitStream:
+    """An f64-valued matrix as row streams: v = hi + lo with hi = fl32(v), lo = fl32(v - hi) (exact to
+    2^-48); ``lo`` is None when every value is exact in f32 (counts, f32 input).  SpMM-only, against
+    f64 dense blocks."""
+
+    hi: DeviceStream
+    lo: Optional[DeviceStream]
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+
 def _dt(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
         return F32
@@ -338,6 +352,18 @@ class HipBackend:
                                                     _p(sptr), _p(inv), _p(ent), _p(work), wb, st))
         return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K)
 
+    def split_streams(self, X: DeviceCSR):
+        """(row streams of X, row streams of X^T) for an f64-valued CSR: see SplitStream."""
+        assert X.values.dtype == torch.float64
+        hi = X.values.to(torch.float32)
+        rest = X.values - hi.to(torch.float64)
+        Xh = X.with_values(hi)
+        s_hi, t_hi = self.stream(Xh), self.transpose_stream(Xh)
+        if bool((rest != 0).any().item()):
+            Xl = X.with_values(rest.to(torch.float32))
+            return SplitStream(s_hi, self.stream(Xl)), SplitStream(t_hi, self.transpose_stream(Xl))
+        return SplitStream(s_hi, None), SplitStream(t_hi, None)
+
     def launch_layout(self, lens: torch.Tensor, K: Optional[int] = None):
         """Where the rows go in a row stream (include/muon_amd.h): sorted by length (descending,
         stable) and dealt round robin - row-set q of the sorted order goes to workgroup q % n_wg,
@@ -422,18 +448,32 @@ class HipBackend:
     def tune(self, key: str, value: int) -> None:
         check(self.lib.mu_tune_set(key.encode(), int(value)))
 
-    def spmm(self, X, Q: torch.Tensor, out=None) -> torch.Tensor:
+    def spmm(self, X, Q: torch.Tensor, out=None, accumulate: bool = False) -> torch.Tensor:
         n, d = X.shape
         B = Q.shape[1]
         assert Q.shape[0] == d and Q.dtype in (torch.float32, torch.float64) and Q.is_contiguous()
+        if isinstance(X, SplitStream):
+            # f64 values as two f32 streams: X Q = X_hi Q + X_lo Q, accumulated in f64
+            out = self.spmm(X.hi, Q, out=out)
+            if X.lo is not None:
+                self.spmm(X.lo, Q, out=out, accumulate=True)
+            return out
         if isinstance(X, DeviceStream):
-            if Q.dtype != torch.float32 or B not in (16, 32, 64):
-                raise TypeError("the row-stream SpMM needs an f32 dense block of width 16, 32 or 64")
+            wide = Q.dtype == torch.float64
+            if B not in ((16, 32) if wide else (16, 32, 64)):
+                raise TypeError("the row-stream SpMM needs a dense block of width 16, 32 or 64 (f64: 16 or 32)")
+            if accumulate and not wide:
+                raise TypeError("accumulating row-stream products exist for f64 blocks only")
             if out is None:
+                assert not accumulate
                 out = self.empty((n, B), Q.dtype)
             with torch.cuda.device(self.device):
-                check(self.lib.mu_spmm_stream_f32(X.n_pos, d, _p(X.sptr), _p(X.ent), _p(X.perm), X.k,
-                                                  _p(Q), B, _p(out), self._stream()))
+                if wide:
+                    check(self.lib.mu_spmm_stream_f64(X.n_pos, d, _p(X.sptr), _p(X.ent), _p(X.perm), X.k,
+                                                      _p(Q), B, _p(out), int(bool(accumulate)), self._stream()))
+                else:
+                    check(self.lib.mu_spmm_stream_f32(X.n_pos, d, _p(X.sptr), _p(X.ent), _p(X.perm), X.k,
+                                                      _p(Q), B, _p(out), self._stream()))
             return out
         if X.values.dtype != Q.dtype:
             raise TypeError("spmm needs values and dense block of one dtype")

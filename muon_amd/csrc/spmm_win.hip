@@ -56,62 +56,69 @@ __device__ __forceinline__ float bcast_f(float x) {
   return __builtin_bit_cast(float, bcast_i<E>(__builtin_bit_cast(int, x)));
 }
 
-// NB = dense columns a lane owns (B = 16 NB): 4 (ds_read_b128), 2 (b64), 1 (b32)
-template <int NB> struct Vec;
-template <> struct Vec<4> { typedef float type __attribute__((ext_vector_type(4))); };
-template <> struct Vec<2> { typedef float type __attribute__((ext_vector_type(2))); };
-template <> struct Vec<1> { typedef float type __attribute__((ext_vector_type(1))); };
+// NB = dense columns a lane owns (B = 16 NB): 4 (ds_read_b128), 2 (b64), 1 (b32) in f32.
+// DT = type of the dense operand and the product: float, or double (MOFA's default precision: the
+// stored values stay f32 - the window machinery is untouched - and every FMA widens its value, a
+// lane's columns are NB doubles: B = 16 reads ds_read_b64, B = 32 ds_read_b128)
+template <int NB, typename DT = float> struct Vec;
+template <> struct Vec<4, float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct Vec<2, float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Vec<1, float> { typedef float type __attribute__((ext_vector_type(1))); };
+template <> struct Vec<2, double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct Vec<1, double> { typedef double type __attribute__((ext_vector_type(1))); };
+__device__ __forceinline__ float mu_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double mu_fma(double a, double b, double c) { return fma(a, b, c); }
 
-template <int NB> struct Quad { typename Vec<NB>::type q0, q1, q2, q3; };
+template <int NB, typename DT = float> struct Quad { typename Vec<NB, DT>::type q0, q1, q2, q3; };
 
 // Entries E..E+3 of every group's window: four independent LDS reads.  `base` is the LDS byte
 // address of the slab buffer plus this lane's column offset; slots a group does not use carry
 // v = 0 (a read of some row of the slab and FMAs with zero).
-template <int E, int NB>
-__device__ __forceinline__ Quad<NB> quad_read(unsigned base, int a) {
-  typedef __attribute__((address_space(3))) const typename Vec<NB>::type* lds_p;
+template <int E, int NB, typename DT = float>
+__device__ __forceinline__ Quad<NB, DT> quad_read(unsigned base, int a) {
+  typedef __attribute__((address_space(3))) const typename Vec<NB, DT>::type* lds_p;
   const unsigned a0 = (unsigned)bcast_i<E>(a) + base, a1 = (unsigned)bcast_i<E + 1>(a) + base;
   const unsigned a2 = (unsigned)bcast_i<E + 2>(a) + base, a3 = (unsigned)bcast_i<E + 3>(a) + base;
-  Quad<NB> r;
+  Quad<NB, DT> r;
   r.q0 = *(lds_p)(a0);
   r.q1 = *(lds_p)(a1);
   r.q2 = *(lds_p)(a2);
   r.q3 = *(lds_p)(a3);
   return r;
 }
-template <int E, int NB>
-__device__ __forceinline__ void quad_fma(const Quad<NB>& r, float v, typename Vec<NB>::type& acc) {
-  const float v0 = bcast_f<E>(v), v1 = bcast_f<E + 1>(v);
-  const float v2 = bcast_f<E + 2>(v), v3 = bcast_f<E + 3>(v);
+template <int E, int NB, typename DT = float>
+__device__ __forceinline__ void quad_fma(const Quad<NB, DT>& r, float v, typename Vec<NB, DT>::type& acc) {
+  const DT v0 = (DT)bcast_f<E>(v), v1 = (DT)bcast_f<E + 1>(v);
+  const DT v2 = (DT)bcast_f<E + 2>(v), v3 = (DT)bcast_f<E + 3>(v);
 #pragma unroll
-  for (int c = 0; c < NB; ++c) acc[c] = fmaf(v0, r.q0[c], acc[c]);
+  for (int c = 0; c < NB; ++c) acc[c] = mu_fma(v0, r.q0[c], acc[c]);
 #pragma unroll
-  for (int c = 0; c < NB; ++c) acc[c] = fmaf(v1, r.q1[c], acc[c]);
+  for (int c = 0; c < NB; ++c) acc[c] = mu_fma(v1, r.q1[c], acc[c]);
 #pragma unroll
-  for (int c = 0; c < NB; ++c) acc[c] = fmaf(v2, r.q2[c], acc[c]);
+  for (int c = 0; c < NB; ++c) acc[c] = mu_fma(v2, r.q2[c], acc[c]);
 #pragma unroll
-  for (int c = 0; c < NB; ++c) acc[c] = fmaf(v3, r.q3[c], acc[c]);
+  for (int c = 0; c < NB; ++c) acc[c] = mu_fma(v3, r.q3[c], acc[c]);
 }
 
 // Entries E, E+1 only: the upper half of the window is used by few groups (8 entries per row and
 // slab on the bench matrices), so it is gated pair by pair instead of quad by quad.
-template <int NB> struct Pair { typename Vec<NB>::type q0, q1; };
-template <int E, int NB>
-__device__ __forceinline__ Pair<NB> pair_read(unsigned base, int a) {
-  typedef __attribute__((address_space(3))) const typename Vec<NB>::type* lds_p;
+template <int NB, typename DT = float> struct Pair { typename Vec<NB, DT>::type q0, q1; };
+template <int E, int NB, typename DT = float>
+__device__ __forceinline__ Pair<NB, DT> pair_read(unsigned base, int a) {
+  typedef __attribute__((address_space(3))) const typename Vec<NB, DT>::type* lds_p;
   const unsigned a0 = (unsigned)bcast_i<E>(a) + base, a1 = (unsigned)bcast_i<E + 1>(a) + base;
-  Pair<NB> r;
+  Pair<NB, DT> r;
   r.q0 = *(lds_p)(a0);
   r.q1 = *(lds_p)(a1);
   return r;
 }
-template <int E, int NB>
-__device__ __forceinline__ void pair_fma(const Pair<NB>& r, float v, typename Vec<NB>::type& acc) {
-  const float v0 = bcast_f<E>(v), v1 = bcast_f<E + 1>(v);
+template <int E, int NB, typename DT = float>
+__device__ __forceinline__ void pair_fma(const Pair<NB, DT>& r, float v, typename Vec<NB, DT>::type& acc) {
+  const DT v0 = (DT)bcast_f<E>(v), v1 = (DT)bcast_f<E + 1>(v);
 #pragma unroll
-  for (int c = 0; c < NB; ++c) acc[c] = fmaf(v0, r.q0[c], acc[c]);
+  for (int c = 0; c < NB; ++c) acc[c] = mu_fma(v0, r.q0[c], acc[c]);
 #pragma unroll
-  for (int c = 0; c < NB; ++c) acc[c] = fmaf(v1, r.q1[c], acc[c]);
+  for (int c = 0; c < NB; ++c) acc[c] = mu_fma(v1, r.q1[c], acc[c]);
 }
 
 // one LDS-DMA piece: 64 lanes x 16 B land contiguously at the wave-uniform LDS byte address
@@ -199,18 +206,21 @@ struct Win {      // what stage A of a pass hands to stage B
 // (results are then wrong on purpose): 1 no LDS gathers / FMAs, 8 no window requests (and no
 // overflow passes), 32 window slots 0-7 as two batches of four LDS reads (r01), 64 per-wave cycle
 // accounting instead of the product.
-template <int K, int MODE, int NB>
+template <int K, int MODE, int NB, typename DT>
 __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
                                               const int64_t* __restrict__ sptr,
                                               const unsigned long long* __restrict__ ent,
                                               const int32_t* __restrict__ perm,
-                                              const float* __restrict__ Q, float* __restrict__ Y) {
+                                              const DT* __restrict__ Q, DT* __restrict__ Y,
+                                              int accumulate) {
   static_assert(K >= 1 && K <= kKMax, "K out of range");
+  static_assert(sizeof(DT) == 4 || MODE == 0, "the timing ablations exist for f32 only");
   constexpr int W = kWaves;
-  typedef typename Vec<NB>::type acc_t;
-  constexpr int kRowBytes = 64 * NB;                         // one Q row: 16 NB floats
+  typedef typename Vec<NB, DT>::type acc_t;
+  constexpr int kRowBytes = 16 * NB * (int)sizeof(DT);       // one Q row: 16 NB elements (64 .. 256 B)
   constexpr int kSlabBytes = kSlabCols * kRowBytes;          // 64 / 32 / 16 KiB
-  constexpr int kRowShift = NB == 4 ? 8 : (NB == 2 ? 7 : 6);
+  constexpr int kRowShift = kRowBytes == 256 ? 8 : (kRowBytes == 128 ? 7 : 6);
+  static_assert(kRowBytes <= 256, "a Q row is at most 256 bytes");
   constexpr int kPieces = kSlabBytes / 1024;                 // 1 KiB LDS-DMA pieces per slab
   constexpr int kMyPieces = kPieces / W;                     // per wave and slab: 4 / 2 / 1
   static_assert(kPieces % W == 0, "every wave issues the same number of DMA pieces");
@@ -228,11 +238,11 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
   const int wave = uniform32(threadIdx.x >> 6);
   const int sub = lane & 15, g = lane >> 4;
   const unsigned gmask = (g & 1) ? 0xffff0000u : 0x0000ffffu;  // this group's lanes inside its ballot word
-  const int sub_off = sub * (4 * NB);  // this lane's byte offset inside a Q row
+  const int sub_off = sub * (NB * (int)sizeof(DT));  // this lane's byte offset inside a Q row
   const int64_t rb0 = (int64_t)blockIdx.x * (4 * W * K);
   const int64_t rb1 = (rb0 + 4 * W * K) < n_pos ? (rb0 + 4 * W * K) : n_pos;
   const float4* __restrict__ Q4 = reinterpret_cast<const float4*>(Q);
-  const int64_t q4_total = n_cols * (4 * NB);
+  const int64_t q4_total = n_cols * (kRowBytes / 16);
   const int ncols32 = (int)n_cols;
   const unsigned qs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&qs[0][0]);
   // the rows of this workgroup are contiguous in the stream: cursors are byte offsets from here
@@ -251,7 +261,7 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
     static_for<K>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
 #pragma unroll
-      for (int c = 0; c < NB; ++c) acc[k][c] = 0.f;
+      for (int c = 0; c < NB; ++c) acc[k][c] = (DT)0;
       off[k] = (unsigned)bcast_i<k>((int)lo) + (unsigned)sub * 8u;
       const bool in = off[k] < (unsigned)bcast_i<k>((int)endv);
       const unsigned long long e = in ? *reinterpret_cast<const unsigned long long*>(entb + off[k]) : 0ull;
@@ -261,7 +271,7 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
 
   auto dma_one = [&](int64_t s0, int buf, int u) {           // 1 KiB piece u of this wave
     const int piece = wave + u * W;
-    int64_t i = s0 * (4 * NB) + piece * 64 + lane;           // float4 index into Q
+    int64_t i = s0 * (kRowBytes / 16) + piece * 64 + lane;   // float4 index into Q
     if (i >= q4_total) i = q4_total - 1;                     // tail / past the end: clamp (never consumed)
     dma_piece(Q4 + i, qs_lds + (unsigned)buf * (unsigned)kSlabBytes + (unsigned)piece * 1024u);
   };
@@ -348,18 +358,18 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
       // first (measured on X Q / X^T Y at 125k x 200k: -6.5 % / -2.8 %)
       __builtin_amdgcn_s_setprio(1);
       if constexpr (MODE & 1) {
-        acc[k][0] += w.vv + (float)w.a;
+        acc[k][0] += (DT)(w.vv + (float)w.a);
       } else if constexpr (kDeep) {
         // (MODE 8192 / 8192 + 32768, timing only: the reads with lanes 32-63 / the odd groups
         // switched off in EXEC - does the LDS pipe charge for inactive quarter-waves?)
         auto qrd = [&](auto ec) {
-          Quad<NB> r;
+          Quad<NB, DT> r;
           if constexpr (MODE & 8192) {
             asm volatile("s_mov_b64 exec, %0" ::"s"((MODE & 32768) ? 0x0000ffff0000ffffull : 0x00000000ffffffffull) : "memory");
-            r = quad_read<decltype(ec)::value, NB>(qbase, w.a);
+            r = quad_read<decltype(ec)::value, NB, DT>(qbase, w.a);
             asm volatile("s_mov_b64 exec, -1" ::: "memory");
           } else {
-            r = quad_read<decltype(ec)::value, NB>(qbase, w.a);
+            r = quad_read<decltype(ec)::value, NB, DT>(qbase, w.a);
           }
           return r;
         };
@@ -369,37 +379,37 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
         // the highest slot in use: two round trips for almost every pass (r01: three to six).
         // (twelve reads in flight for the passes that use slots 8-11: hipcc spills at K >= 7)
         if (w.any16 & 0x00f0u) {
-          const Quad<NB> r0 = qrd(std::integral_constant<int, 0>{});
-          const Quad<NB> r1 = qrd(std::integral_constant<int, 4>{});
-          quad_fma<0, NB>(r0, w.vv, acc[k]);
-          quad_fma<4, NB>(r1, w.vv, acc[k]);
+          const Quad<NB, DT> r0 = qrd(std::integral_constant<int, 0>{});
+          const Quad<NB, DT> r1 = qrd(std::integral_constant<int, 4>{});
+          quad_fma<0, NB, DT>(r0, w.vv, acc[k]);
+          quad_fma<4, NB, DT>(r1, w.vv, acc[k]);
           // (hipcc otherwise sinks the second quad into a block shared with the branch below - one
           //  quad of reads, its FMAs, then the next quad: two LDS round trips instead of one)
           asm volatile("; eight reads in flight" ::: "memory");
         } else if (w.any16 & 0x000fu) {
-          const Quad<NB> r = qrd(std::integral_constant<int, 0>{});
-          quad_fma<0, NB>(r, w.vv, acc[k]);
+          const Quad<NB, DT> r = qrd(std::integral_constant<int, 0>{});
+          quad_fma<0, NB, DT>(r, w.vv, acc[k]);
         }
         if (w.any16 & 0xf000u) {
-          const Quad<NB> r0 = qrd(std::integral_constant<int, 8>{});
-          const Quad<NB> r1 = qrd(std::integral_constant<int, 12>{});
-          quad_fma<8, NB>(r0, w.vv, acc[k]);
-          quad_fma<12, NB>(r1, w.vv, acc[k]);
+          const Quad<NB, DT> r0 = qrd(std::integral_constant<int, 8>{});
+          const Quad<NB, DT> r1 = qrd(std::integral_constant<int, 12>{});
+          quad_fma<8, NB, DT>(r0, w.vv, acc[k]);
+          quad_fma<12, NB, DT>(r1, w.vv, acc[k]);
         } else if (w.any16 & 0x0c00u) {
-          const Quad<NB> r = qrd(std::integral_constant<int, 8>{});
-          quad_fma<8, NB>(r, w.vv, acc[k]);
+          const Quad<NB, DT> r = qrd(std::integral_constant<int, 8>{});
+          quad_fma<8, NB, DT>(r, w.vv, acc[k]);
         } else if (w.any16 & 0x0300u) {
-          const Pair<NB> r = pair_read<8, NB>(qbase, w.a);
-          pair_fma<8, NB>(r, w.vv, acc[k]);
+          const Pair<NB, DT> r = pair_read<8, NB, DT>(qbase, w.a);
+          pair_fma<8, NB, DT>(r, w.vv, acc[k]);
         }
       } else {
-        if (w.any16 & 0x000fu) { const Quad<NB> r = quad_read<0, NB>(qbase, w.a); quad_fma<0, NB>(r, w.vv, acc[k]); }
-        if (w.any16 & 0x00f0u) { const Quad<NB> r = quad_read<4, NB>(qbase, w.a); quad_fma<4, NB>(r, w.vv, acc[k]); }
+        if (w.any16 & 0x000fu) { const Quad<NB, DT> r = quad_read<0, NB, DT>(qbase, w.a); quad_fma<0, NB, DT>(r, w.vv, acc[k]); }
+        if (w.any16 & 0x00f0u) { const Quad<NB, DT> r = quad_read<4, NB, DT>(qbase, w.a); quad_fma<4, NB, DT>(r, w.vv, acc[k]); }
         if (w.any16 & 0xff00u) {
-          { const Pair<NB> r = pair_read<8, NB>(qbase, w.a); pair_fma<8, NB>(r, w.vv, acc[k]); }
-          if (w.any16 & 0x0c00u) { const Pair<NB> r = pair_read<10, NB>(qbase, w.a); pair_fma<10, NB>(r, w.vv, acc[k]); }
-          if (w.any16 & 0x3000u) { const Pair<NB> r = pair_read<12, NB>(qbase, w.a); pair_fma<12, NB>(r, w.vv, acc[k]); }
-          if (w.any16 & 0xc000u) { const Pair<NB> r = pair_read<14, NB>(qbase, w.a); pair_fma<14, NB>(r, w.vv, acc[k]); }
+          { const Pair<NB, DT> r = pair_read<8, NB, DT>(qbase, w.a); pair_fma<8, NB, DT>(r, w.vv, acc[k]); }
+          if (w.any16 & 0x0c00u) { const Pair<NB, DT> r = pair_read<10, NB, DT>(qbase, w.a); pair_fma<10, NB, DT>(r, w.vv, acc[k]); }
+          if (w.any16 & 0x3000u) { const Pair<NB, DT> r = pair_read<12, NB, DT>(qbase, w.a); pair_fma<12, NB, DT>(r, w.vv, acc[k]); }
+          if (w.any16 & 0xc000u) { const Pair<NB, DT> r = pair_read<14, NB, DT>(qbase, w.a); pair_fma<14, NB, DT>(r, w.vv, acc[k]); }
         }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -407,29 +417,29 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
 
     // Slots 0-7 of a main pass in two halves: the eight LDS reads go out BEFORE stage A of the next
     // pass, whose scalar work then runs under their latency; the FMAs and the upper half follow.
-    struct Low8 { Quad<NB> r0, r1; };
+    struct Low8 { Quad<NB, DT> r0, r1; };
     auto b_issue = [&](const Win& w) -> Low8 {
       Low8 r;
-      r.r0 = quad_read<0, NB>(qbase, w.a);
-      r.r1 = quad_read<4, NB>(qbase, w.a);
+      r.r0 = quad_read<0, NB, DT>(qbase, w.a);
+      r.r1 = quad_read<4, NB, DT>(qbase, w.a);
       return r;
     };
     auto b_finish = [&](auto kc, const Win& w, const Low8& r) {
       constexpr int k = decltype(kc)::value;
       __builtin_amdgcn_s_setprio(1);
-      quad_fma<0, NB>(r.r0, w.vv, acc[k]);
-      quad_fma<4, NB>(r.r1, w.vv, acc[k]);
+      quad_fma<0, NB, DT>(r.r0, w.vv, acc[k]);
+      quad_fma<4, NB, DT>(r.r1, w.vv, acc[k]);
       if (w.any16 & 0xf000u) {
-        const Quad<NB> q0 = quad_read<8, NB>(qbase, w.a);
-        const Quad<NB> q1 = quad_read<12, NB>(qbase, w.a);
-        quad_fma<8, NB>(q0, w.vv, acc[k]);
-        quad_fma<12, NB>(q1, w.vv, acc[k]);
+        const Quad<NB, DT> q0 = quad_read<8, NB, DT>(qbase, w.a);
+        const Quad<NB, DT> q1 = quad_read<12, NB, DT>(qbase, w.a);
+        quad_fma<8, NB, DT>(q0, w.vv, acc[k]);
+        quad_fma<12, NB, DT>(q1, w.vv, acc[k]);
       } else if (w.any16 & 0x0c00u) {
-        const Quad<NB> q = quad_read<8, NB>(qbase, w.a);
-        quad_fma<8, NB>(q, w.vv, acc[k]);
+        const Quad<NB, DT> q = quad_read<8, NB, DT>(qbase, w.a);
+        quad_fma<8, NB, DT>(q, w.vv, acc[k]);
       } else if (w.any16 & 0x0300u) {
-        const Pair<NB> q = pair_read<8, NB>(qbase, w.a);
-        pair_fma<8, NB>(q, w.vv, acc[k]);
+        const Pair<NB, DT> q = pair_read<8, NB, DT>(qbase, w.a);
+        pair_fma<8, NB, DT>(q, w.vv, acc[k]);
       }
       __builtin_amdgcn_s_setprio(0);
     };
@@ -455,8 +465,8 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
         // FMAs of pass k, behind stage A(k+1).  A pass no longer is a chain of three LDS round trips.
         next_piece(0);
         Win wk = stage_a(std::integral_constant<int, 0>{}, std::false_type{});
-        Quad<NB> b0 = quad_read<0, NB>(qbase, wk.a);
-        Quad<NB> b1 = quad_read<4, NB>(qbase, wk.a);
+        Quad<NB, DT> b0 = quad_read<0, NB, DT>(qbase, wk.a);
+        Quad<NB, DT> b1 = quad_read<4, NB, DT>(qbase, wk.a);
         static_for<K>([&](auto kc) {
           constexpr int k = decltype(kc)::value;
           Win wn = wk;
@@ -466,16 +476,16 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
           }
           const bool n2 = (wk.any16 & 0x0f00u) != 0;
           __builtin_amdgcn_s_setprio(1);
-          Quad<NB> b2;
-          quad_fma<0, NB>(b0, wk.vv, acc[k]);
-          if (n2) b2 = quad_read<8, NB>(qbase, wk.a);
-          quad_fma<4, NB>(b1, wk.vv, acc[k]);
-          if constexpr (k + 1 < K) b0 = quad_read<0, NB>(qbase, wn.a);
-          if (n2) quad_fma<8, NB>(b2, wk.vv, acc[k]);
-          if constexpr (k + 1 < K) b1 = quad_read<4, NB>(qbase, wn.a);
+          Quad<NB, DT> b2;
+          quad_fma<0, NB, DT>(b0, wk.vv, acc[k]);
+          if (n2) b2 = quad_read<8, NB, DT>(qbase, wk.a);
+          quad_fma<4, NB, DT>(b1, wk.vv, acc[k]);
+          if constexpr (k + 1 < K) b0 = quad_read<0, NB, DT>(qbase, wn.a);
+          if (n2) quad_fma<8, NB, DT>(b2, wk.vv, acc[k]);
+          if constexpr (k + 1 < K) b1 = quad_read<4, NB, DT>(qbase, wn.a);
           if (wk.any16 & 0xf000u) {
-            const Quad<NB> r = quad_read<12, NB>(qbase, wk.a);
-            quad_fma<12, NB>(r, wk.vv, acc[k]);
+            const Quad<NB, DT> r = quad_read<12, NB, DT>(qbase, wk.a);
+            quad_fma<12, NB, DT>(r, wk.vv, acc[k]);
           }
           __builtin_amdgcn_s_setprio(0);
           wk = wn;
@@ -533,12 +543,12 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
     float dep = 0.f;  // (keeps the FMAs of stage B alive)
     static_for<K>([&](auto kc) {
 #pragma unroll
-      for (int c = 0; c < NB; ++c) dep += acc[decltype(kc)::value][c];
+      for (int c = 0; c < NB; ++c) dep += (float)acc[decltype(kc)::value][c];
     });
     if (__ballot(dep == 1.2345e-30f)) t_b += 1;
     if (lane < 5) {
       const unsigned t = lane == 0 ? t_wait : lane == 1 ? t_a : lane == 2 ? t_b : lane == 3 ? t_bar : t_dma;
-      Y[((int64_t)blockIdx.x * W + wave) * (16 * NB) + lane] = (float)t;
+      Y[((int64_t)blockIdx.x * W + wave) * (16 * NB) + lane] = (DT)t;
     }
     return;
   }
@@ -547,18 +557,20 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
     const int64_t p = rb0 + ((int64_t)wave * K + k) * 4 + g;
     if (p < rb1) {
       const int64_t out = perm ? (int64_t)perm[p] : p;  // position -> row of the product (-1: none)
-      if (out >= 0) *reinterpret_cast<acc_t*>(Y + out * (16 * NB) + sub * NB) = acc[k];
+      if (out >= 0) {
+        acc_t* y = reinterpret_cast<acc_t*>(Y + out * (16 * NB) + sub * NB);
+        *y = accumulate ? (*y + acc[k]) : acc[k];
+      }
     }
   });
 }
 
-#define MU_KARGS                                                                                  \
-  int64_t n_pos, int64_t n_cols, const int64_t *__restrict__ sptr,                                \
-      const unsigned long long *__restrict__ ent, const int32_t *__restrict__ perm,               \
-      const float *__restrict__ Q, float *__restrict__ Y
-template <int K, int MODE, int NB>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(55))) void k_spmm_win(MU_KARGS) {
-  spmm_win_body<K, MODE, NB>(n_pos, n_cols, sptr, ent, perm, Q, Y);
+template <int K, int MODE, int NB, typename DT = float>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(55))) void k_spmm_win(
+    int64_t n_pos, int64_t n_cols, const int64_t* __restrict__ sptr,
+    const unsigned long long* __restrict__ ent, const int32_t* __restrict__ perm,
+    const DT* __restrict__ Q, DT* __restrict__ Y, int accumulate) {
+  spmm_win_body<K, MODE, NB, DT>(n_pos, n_cols, sptr, ent, perm, Q, Y, accumulate);
 }
 
 // ---- the row stream ------------------------------------------------------------------------
@@ -627,13 +639,29 @@ int launch(int B, hipStream_t st, int64_t n_pos, int64_t n_cols, const int64_t* 
   const int64_t wgs = (n_pos + 64 * K - 1) / (64 * K);
   if (B == 64)
     hipLaunchKernelGGL((k_spmm_win<K, MODE, 4>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos, n_cols,
-                       sptr, ent, perm, Q, Y);
+                       sptr, ent, perm, Q, Y, 0);
   else if (B == 32)
     hipLaunchKernelGGL((k_spmm_win<K, MODE, 2>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos, n_cols,
-                       sptr, ent, perm, Q, Y);
+                       sptr, ent, perm, Q, Y, 0);
   else
     hipLaunchKernelGGL((k_spmm_win<K, MODE, 1>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos, n_cols,
-                       sptr, ent, perm, Q, Y);
+                       sptr, ent, perm, Q, Y, 0);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+// f32 stored values, f64 dense operand and product (B = 16 / 32)
+template <int K>
+int launch_f64(int B, hipStream_t st, int64_t n_pos, int64_t n_cols, const int64_t* sptr,
+               const unsigned long long* ent, const int32_t* perm, const double* Q, double* Y,
+               int accumulate) {
+  const int64_t wgs = (n_pos + 64 * K - 1) / (64 * K);
+  if (B == 32)
+    hipLaunchKernelGGL((k_spmm_win<K, 0, 2, double>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos,
+                       n_cols, sptr, ent, perm, Q, Y, accumulate);
+  else
+    hipLaunchKernelGGL((k_spmm_win<K, 0, 1, double>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos,
+                       n_cols, sptr, ent, perm, Q, Y, accumulate);
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
@@ -722,6 +750,30 @@ int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
     case 6: return launch<6, 0>(MU_ARGS);
     case 7: return launch<7, 0>(MU_ARGS);
     default: return launch<8, 0>(MU_ARGS);
+  }
+#undef MU_ARGS
+}
+
+int mu_spmm_stream_f64(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, const void* d_ent,
+                       const int32_t* d_perm, int k_layout, const double* d_Q, int B, double* d_Y,
+                       int accumulate, void* stream) {
+  MU_REQUIRE(B == 16 || B == 32, "B must be 16 or 32");
+  MU_REQUIRE(n_pos >= 0 && n_cols > 0 && n_cols < ((int64_t)1 << 31), "shape out of range");
+  if (n_pos == 0) return MU_OK;
+  MU_REQUIRE(d_sptr && d_ent && d_Q && d_Y, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned long long* ent = (const unsigned long long*)d_ent;
+  const int K = (k_layout >= 1 && k_layout <= kKMax) ? k_layout : pick_k(n_pos);
+#define MU_ARGS B, st, n_pos, n_cols, d_sptr, ent, d_perm, d_Q, d_Y, accumulate
+  switch (K) {
+    case 1: return launch_f64<1>(MU_ARGS);
+    case 2: return launch_f64<2>(MU_ARGS);
+    case 3: return launch_f64<3>(MU_ARGS);
+    case 4: return launch_f64<4>(MU_ARGS);
+    case 5: return launch_f64<5>(MU_ARGS);
+    case 6: return launch_f64<6>(MU_ARGS);
+    case 7: return launch_f64<7>(MU_ARGS);
+    default: return launch_f64<8>(MU_ARGS);
   }
 #undef MU_ARGS
 }

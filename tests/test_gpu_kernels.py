@@ -507,3 +507,36 @@ def test_pipelined_upload_matches_plain_copy(hip):
     assert got_a.dtype == torch.int32 and np.array_equal(hip.to_host(got_a), a.astype(np.int32))
     assert got_v.dtype == torch.float32 and np.array_equal(hip.to_host(got_v), v.astype(np.float32))
     assert got_same.dtype == torch.float64 and np.array_equal(hip.to_host(got_same), v)
+
+
+@pytest.mark.parametrize("B", [16, 32])
+def test_stream_spmm_with_f64_blocks(hip, B):
+    """The row-stream SpMM against f64 dense blocks (MOFA's default precision): f32 stored values,
+    f64 FMAs.  Values that are exact in f32 need one stream; arbitrary f64 values are split into
+    hi + lo streams and the second product accumulates - both against scipy in f64, both directions."""
+    rng = np.random.default_rng(40 + B)
+    m = _heavy_rows_csr(3000, 2500, 0.02, rng).astype(np.float64)
+    Q = rng.standard_normal((2500, B))
+    Y = rng.standard_normal((3000, B))
+    X32 = _up(hip, m)  # f32-exact values
+    assert X32.values.dtype == torch.float64
+    Xs, Xt = hip.split_streams(X32)
+    assert Xs.lo is None and Xt.lo is None
+    got = hip.to_host(hip.spmm(Xs, hip.to_device(Q)))
+    ref = m @ Q
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+    got = hip.to_host(hip.spmm(Xt, hip.to_device(Y)))
+    ref = m.T @ Y
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+    m2 = m.copy()
+    m2.data = m2.data * np.pi + rng.standard_normal(m2.nnz) * 1e-9  # not exact in f32
+    Xs, Xt = hip.split_streams(_up(hip, m2))
+    assert Xs.lo is not None
+    got = hip.to_host(hip.spmm(Xs, hip.to_device(Q)))
+    ref = m2 @ Q
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+    got = hip.to_host(hip.spmm(Xt, hip.to_device(Y)))
+    ref = m2.T @ Y
+    assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
+    # bit-reproducible like the f32 kernel
+    assert torch.equal(hip.spmm(Xt, hip.to_device(Y)), hip.spmm(Xt, hip.to_device(Y)))

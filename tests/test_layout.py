@@ -88,7 +88,7 @@ def test_stream_spmm_isa_keeps_out_of_the_asm_owned_registers(tmp_path):
     # production instances only (MODE = 0, the second template argument); the timing ablations never
     # feed results to anybody
     kernels = [(n, b) for n, b in kernels if re.search(r"k_spmm_winILi\d+ELi0ELi", n)]
-    assert len(kernels) == 24  # K = 1..8 x B = 64 / 32 / 16
+    assert len(kernels) == 40  # K = 1..8 x (f32: B = 64 / 32 / 16; f64 blocks: B = 32 / 16)
     reg = re.compile(r"\bv(\d+)\b|v\[(\d+):(\d+)\]")
     for name, body in kernels:
         assert "scratch_" not in body, name
