@@ -231,6 +231,11 @@ int mu_gram_cross_f32(int64_t n_rows, int B, const float* d_A, const float* d_Bm
  * (v_mfma_f32_16x16x4_f32).  Out may alias A. */
 int mu_dense_apply_f32(int64_t n_rows, int B, const float* d_A, const float* d_M,
                        const float* d_bias, float* d_Out, void* stream);
+/* Z[n_rows x B] -= A[n_rows x B] * C[B x B] with C in f64 as mu_gram_cross_f32 leaves it (rounded to
+ * f32 for the MFMA): one block of the Gram-Schmidt projection that keeps a new Krylov block
+ * orthogonal to the basis (the reorthogonalisation inside ARPACK's dsaupd, tools.py:53). */
+int mu_dense_project_out_f32(int64_t n_rows, int B, const float* d_A, const double* d_C, float* d_Z,
+                             void* stream);
 
 /* M[B x B] (f32) = R^-1, upper triangular, zero outside the leading w x w block, for G = R^T R (f64,
  * B x B, B <= 64): the small step of CholeskyQR on the device (one wave, LDS resident) instead of two

@@ -107,7 +107,7 @@ def _project_out(backend, Z: torch.Tensor, blocks, passes: int = 2) -> torch.Ten
     for _ in range(passes):
         for Qi in blocks:
             C = backend.gram_cross(Qi, Z)  # Q_i^T Z, B x B, f64
-            Z -= backend.apply(Qi, C.to(torch.float32).contiguous())
+            backend.project_out_block(Qi, C, Z)  # Z -= Q_i C
     return Z
 
 

@@ -517,6 +517,15 @@ class HipBackend:
             check(self.lib.mu_dense_apply_f32(n, B, _p(A), _p(M), _p(bias), _p(out), self._stream()))
         return out
 
+    def project_out_block(self, Q: torch.Tensor, C: torch.Tensor, Z: torch.Tensor) -> torch.Tensor:
+        """Z -= Q C in place (C: the f64 B x B coefficients Q^T Z of gram_cross)."""
+        n, B = Q.shape
+        assert Z.shape == Q.shape and C.shape == (B, B) and C.dtype == torch.float64 and C.is_contiguous()
+        assert Q.dtype == torch.float32 and Z.dtype == torch.float32 and Z.is_contiguous() and Q.is_contiguous()
+        with torch.cuda.device(self.device):
+            check(self.lib.mu_dense_project_out_f32(n, B, _p(Q), _p(C), _p(Z), self._stream()))
+        return Z
+
     def chol_rinv(self, G: torch.Tensor, w: int, flag: torch.Tensor) -> torch.Tensor:
         """R^-1 (f32, B x B, upper) of the leading w x w block of the f64 Gram G = R^T R, on the
         device; ``flag`` (int32[1]) is set when a pivot was not safely positive."""

@@ -74,6 +74,7 @@ SIGNATURES = {
     "mu_gram_f32": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_gram_cross_f32": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_dense_apply_f32": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mu_dense_project_out_f32": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp]),
     "mu_chol_rinv_f64": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp]),
     "mu_randn_f32": (C.c_int, [_i64, _u64, _vp, _vp]),
     "mu_skinny_tn_worksize": (_sz, [_i32, _i64, _i64]),

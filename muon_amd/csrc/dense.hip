@@ -260,6 +260,48 @@ __global__ __launch_bounds__(256) void k_dense_apply(int64_t n_rows, const float
   }
 }
 
+// Z <- Z - A * C with the B x B coefficients in f64 (the output of mu_gram_cross_f32): one block of a
+// Gram-Schmidt projection.  Same arithmetic as k_dense_apply into a temporary followed by a
+// subtraction (the product is rounded to f32, then subtracted), without the temporary, the
+// conversion of C and the subtraction as separate launches.
+template <int B>
+__global__ __launch_bounds__(256) void k_dense_project(int64_t n_rows, const float* __restrict__ A,
+                                                       const double* __restrict__ C,
+                                                       float* __restrict__ Z) {
+  constexpr int T = B / 16;
+  constexpr int KS = B / 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane >> 4, lc = lane & 15;
+  float bm[KS][T];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int t = 0; t < T; ++t) bm[ks][t] = (float)C[(4 * ks + lr) * B + 16 * t + lc];
+  const int64_t n_tiles = (n_rows + 15) / 16;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t r0 = tile * 16;
+    const int64_t arow = r0 + lc;
+    float a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = (arow < n_rows) ? A[arow * B + 4 * ks + lr] : 0.f;
+    f4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bm[ks][t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t orow = r0 + 4 * lr + r;
+        if (orow < n_rows) Z[orow * B + 16 * t + lc] -= acc[t][r];
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_randn(int64_t count, uint64_t seed, float* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -426,6 +468,32 @@ int mu_dense_apply_f32(int64_t n_rows, int B, const float* d_A, const float* d_M
       break;
     default:
       hipLaunchKernelGGL(k_dense_apply<16>, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, d_A, d_M, d_bias, d_Out);
+      break;
+  }
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_dense_project_out_f32(int64_t n_rows, int B, const float* d_A, const double* d_C, float* d_Z,
+                             void* stream) {
+  MU_REQUIRE(B == 16 || B == 32 || B == 64, "B must be 16, 32 or 64");
+  MU_REQUIRE(n_rows >= 0, "negative size");
+  if (n_rows == 0) return MU_OK;
+  MU_REQUIRE(d_A && d_C && d_Z, "null pointer");
+  MU_REQUIRE(d_A != d_Z, "the projected block must not alias the basis block");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t blocks = (((n_rows + 15) / 16) + 3) / 4;
+  const int64_t cap = (int64_t)mu_num_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  switch (B) {
+    case 64:
+      hipLaunchKernelGGL(k_dense_project<64>, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, d_A, d_C, d_Z);
+      break;
+    case 32:
+      hipLaunchKernelGGL(k_dense_project<32>, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, d_A, d_C, d_Z);
+      break;
+    default:
+      hipLaunchKernelGGL(k_dense_project<16>, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, d_A, d_C, d_Z);
       break;
   }
   MU_CHECK_LAUNCH();

@@ -119,6 +119,10 @@ class CpuTestBackend:
             return out
         return r
 
+    def project_out_block(self, Q, C, Z):
+        Z -= self.apply(Q, C.to(torch.float32).contiguous())
+        return Z
+
     def randn(self, rows, B, seed):
         g = torch.Generator().manual_seed(int(seed))
         return torch.randn((rows, B), generator=g, dtype=torch.float32)

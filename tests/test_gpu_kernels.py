@@ -540,3 +540,15 @@ def test_stream_spmm_with_f64_blocks(hip, B):
     assert np.max(np.abs(got - ref)) <= 1e-12 * np.max(np.abs(ref))
     # bit-reproducible like the f32 kernel
     assert torch.equal(hip.spmm(Xt, hip.to_device(Y)), hip.spmm(Xt, hip.to_device(Y)))
+
+
+@pytest.mark.parametrize("B", [16, 32, 64])
+def test_project_out_block_equals_apply_and_subtract(hip, B):
+    rng = np.random.default_rng(B)
+    n = 2049
+    Q = hip.to_device(rng.standard_normal((n, B)).astype(np.float32))
+    Z = hip.to_device(rng.standard_normal((n, B)).astype(np.float32))
+    C = hip.gram_cross(Q, Z)
+    want = Z - hip.apply(Q, C.to(torch.float32).contiguous())
+    got = hip.project_out_block(Q, C, Z.clone())
+    assert torch.equal(got, want)
