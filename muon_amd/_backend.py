@@ -55,6 +55,7 @@ class DeviceStream:
     nnz: int
     perm: Optional[torch.Tensor] = None
     k: int = 0
+    waves: int = 16   # waves a workgroup's row-sets are dealt to: 16, or 12 (wave-specialised SpMM)
 
     @property
     def n_pos(self) -> int:
@@ -291,38 +292,41 @@ class HipBackend:
         """The row-stream SpMM exists for f32 values and B in (16, 32, 64)."""
         return X.values.dtype == torch.float32 and B in (16, 32, 64) and X.shape[0] > 0 and X.shape[1] > 0
 
-    def _stream_sptr(self, lens_by_pos: torch.Tensor, K: int):
+    def _stream_sptr(self, lens_by_pos: torch.Tensor, K: int, waves: int = 16):
         n_pos = int(lens_by_pos.numel())
         sptr = self.zeros((n_pos + 1,), torch.int64)
         with torch.cuda.device(self.device):
             check(self.lib.mu_exclusive_scan_i64(n_pos, _p(lens_by_pos), _p(sptr), self._stream()))
         # cursors are 32-bit byte offsets from the first pair of the workgroup's 64 K rows
-        per_wg = 64 * K
+        per_wg = 4 * waves * K
         span = sptr[per_wg::per_wg] - sptr[:-per_wg:per_wg] if n_pos > per_wg else sptr[-1:] - sptr[:1]
         if span.numel() and int(span.max().item()) * 8 >= (1 << 32) - 256:
             raise NotImplementedError("row stream: the rows of one workgroup span 4 GiB or more")
         return sptr
 
-    def stream(self, X: DeviceCSR, sort_rows: bool = True, K: Optional[int] = None) -> DeviceStream:
-        """Row stream of X for the SpMM of the iteration (a streaming copy, once per lsi call)."""
+    def stream(self, X: DeviceCSR, sort_rows: bool = True, K: Optional[int] = None, waves: int = 16) -> DeviceStream:
+        """Row stream of X for the SpMM of the iteration (a streaming copy, once per lsi call).
+        ``waves=12``: laid out for the wave-specialised kernel (csrc/spmm_ws.hip: 12 gather waves)."""
         n, d = X.shape
         assert X.values.dtype == torch.float32
-        want_k = K
+        want_k = self._ws_k() if waves == 12 else K
+        assert waves == 16 or sort_rows
         perm, K, n_pos = None, max(1, int(want_k or self.lib.mu_spmm_stream_k(n))), n
         if sort_rows and n > 0:
-            perm, _inv, K = self.launch_layout(X.indptr[1:] - X.indptr[:-1], want_k)
+            perm, _inv, K = self.launch_layout(X.indptr[1:] - X.indptr[:-1], want_k, waves)
             n_pos = int(perm.numel())
         lens = self.empty((max(n_pos, 1),), torch.int64)[:n_pos]
         with torch.cuda.device(self.device):
             st = self._stream()
             check(self.lib.mu_csr_stream_len(n_pos, _p(perm), _p(X.indptr), _p(lens), st))
-            sptr = self._stream_sptr(lens, K)
+            sptr = self._stream_sptr(lens, K, waves)
             ent = self.empty((max(X.nnz, 1),), torch.int64)
             check(self.lib.mu_csr_stream_fill(n_pos, _p(perm), _p(X.indptr), _p(X.indices), _p(X.values),
                                               _p(sptr), _p(ent), st))
-        return DeviceStream(sptr, ent, (n, d), X.nnz, perm, K)
+        return DeviceStream(sptr, ent, (n, d), X.nnz, perm, K, waves)
 
-    def transpose_stream(self, X: DeviceCSR, sort_rows: bool = True, before_fill=None, K: Optional[int] = None) -> DeviceStream:
+    def transpose_stream(self, X: DeviceCSR, sort_rows: bool = True, before_fill=None, K: Optional[int] = None,
+                         waves: int = 16) -> DeviceStream:
         """Row stream of X^T straight from the CSR of X (no CSR of X^T; stable: cells ascending inside
         every row).  ``before_fill``: called once the count phase is done and before the fill is queued."""
         n, d = X.shape
@@ -334,23 +338,24 @@ class HipBackend:
             st = self._stream()
             check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
                                               _p(work), wb, st))
-            want_k = K
+            want_k = self._ws_k() if waves == 12 else K
+            assert waves == 16 or sort_rows
             perm, inv, K, n_pos = None, None, max(1, int(want_k or self.lib.mu_spmm_stream_k(d))), d
             lens = col_nnz[:d]
             if sort_rows and d > 0:
-                perm, inv, K = self.launch_layout(lens, want_k)
+                perm, inv, K = self.launch_layout(lens, want_k, waves)
                 n_pos = int(perm.numel())
                 plens = torch.zeros((n_pos,), dtype=torch.int64, device=self.device)
                 plens[inv.long()] = lens
             else:
                 plens = lens.contiguous()
-            sptr = self._stream_sptr(plens, K)
+            sptr = self._stream_sptr(plens, K, waves)
             ent = self.empty((max(X.nnz, 1),), torch.int64)
             if before_fill is not None:
                 before_fill()
             check(self.lib.mu_csr_tpack_fill_stream(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
                                                     _p(sptr), _p(inv), _p(ent), _p(work), wb, st))
-        return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K)
+        return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K, waves)
 
     def split_streams(self, X: DeviceCSR):
         """(row streams of X, row streams of X^T) for an f64-valued CSR: see SplitStream."""
@@ -364,7 +369,11 @@ class HipBackend:
             return SplitStream(s_hi, self.stream(Xl)), SplitStream(t_hi, self.transpose_stream(Xl))
         return SplitStream(s_hi, None), SplitStream(t_hi, None)
 
-    def launch_layout(self, lens: torch.Tensor, K: Optional[int] = None):
+    def _ws_k(self) -> int:
+        """Row-sets per gather wave of the wave-specialised SpMM (12 gather waves x 4 rows each)."""
+        return int(self.lib.mu_spmm_ws_rows_per_wg()) // 48
+
+    def launch_layout(self, lens: torch.Tensor, K: Optional[int] = None, waves: int = 16):
         """Where the rows go in a row stream (include/muon_amd.h): sorted by length (descending,
         stable) and dealt round robin - row-set q of the sorted order goes to workgroup q % n_wg,
         inside it to wave (q // n_wg) % 16 and row-set slot (q // n_wg) // 16 - so that the four rows
@@ -372,7 +381,8 @@ class HipBackend:
         mix.  Returns (perm int32[n_pos], inv int32[n], K)."""
         n = int(lens.numel())
         K = max(1, int(K or self.lib.mu_spmm_stream_k(n)))
-        per_wg = 64 * K
+        W = int(waves)
+        per_wg = 4 * W * K
         n_wg = max(1, (n + per_wg - 1) // per_wg)
         # One workgroup per CU runs at a time (128 KiB of LDS) and the dealt workgroups take equally
         # long, so the launch proceeds in rounds of n_cus workgroups: a last round that is 3/4 empty
@@ -387,8 +397,8 @@ class HipBackend:
         i = torch.arange(n, device=lens.device)
         q, j = i // 4, i % 4
         b, t = q % n_wg, q // n_wg
-        w, k = t % 16, t // 16
-        pos = ((b * 16 + w) * K + k) * 4 + j
+        w, k = t % W, t // W
+        pos = ((b * W + w) * K + k) * 4 + j
         perm = torch.full((n_pos,), -1, dtype=torch.int32, device=lens.device)
         perm[pos] = order.to(torch.int32)
         inv = torch.empty((n,), dtype=torch.int32, device=lens.device)
@@ -467,6 +477,13 @@ class HipBackend:
             if out is None:
                 assert not accumulate
                 out = self.empty((n, B), Q.dtype)
+            if X.waves == 12:
+                if wide or B != 64:
+                    raise TypeError("a stream laid out for the wave-specialised SpMM serves f32 blocks of width 64")
+                with torch.cuda.device(self.device):
+                    check(self.lib.mu_spmm_ws_f32(X.n_pos, d, _p(X.sptr), _p(X.ent), _p(X.perm), _p(Q), B, _p(out),
+                                                  self._stream()))
+                return out
             with torch.cuda.device(self.device):
                 if wide:
                     check(self.lib.mu_spmm_stream_f64(X.n_pos, d, _p(X.sptr), _p(X.ent), _p(X.perm), X.k,
