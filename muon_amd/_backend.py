@@ -12,6 +12,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
+import contextlib
 import os
 
 import numpy as np
@@ -76,6 +77,9 @@ class SplitStream:
         return self.hi.shape
 
 
+_NULL_CTX = contextlib.nullcontext()
+
+
 def _dt(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
         return F32
@@ -109,7 +113,19 @@ class HipBackend:
 
     # -- plumbing -------------------------------------------------------------
     def _stream(self):
+        """Raw handle of torch's current stream on this device (a few hundred of these per small lsi()
+        call: the raw-handle query is ~10x cheaper than building a torch.cuda.Stream object)."""
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if raw is not None:
+            return raw(self.device.index)
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _dev_ctx(self):
+        """Context that makes this backend's device current - a no-op object when it already is (the
+        usual case: one process per GPU), instead of two device switches per kernel launch."""
+        if torch.cuda.current_device() == self.device.index:
+            return _NULL_CTX
+        return torch.cuda.device(self.device)
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -190,7 +206,7 @@ class HipBackend:
         colsum = self.empty((d,), torch.float64)
         wb = int(self.lib.mu_csr_row_col_sums_worksize(n, d))
         work = self.empty((wb,), torch.uint8)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_csr_row_col_sums(_dt(X.values), n, d, _p(X.indptr), _p(X.indices),
                                                _p(X.values), _p(rowsum), _p(colsum), _p(work), wb,
                                                self._stream()))
@@ -201,7 +217,7 @@ class HipBackend:
     def idf(self, colsum: torch.Tensor, n_obs: float, flags: int, dtype) -> torch.Tensor:
         d = colsum.numel()
         out = self.empty((d,), dtype)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_tfidf_idf(_dt(out), d, float(n_obs), _p(colsum), flags, _p(out),
                                         self._stream()))
         return out
@@ -213,7 +229,7 @@ class HipBackend:
         n, d = X.shape
         kept = self.__dict__.pop("_sweep_work", None)
         key = (X.indptr.data_ptr(), X.indices.data_ptr(), n, d)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             if self.__dict__.get("_scale_gather"):  # comparison / tests: the per-lane gather kernel
                 check(self.lib.mu_tfidf_scale(_dt(X.values), n, _p(X.indptr), _p(X.indices),
                                               _p(X.values), _p(rowsum), _p(idf), float(scale), flags,
@@ -235,7 +251,7 @@ class HipBackend:
         n = X.shape[0]
         row_nnz = self.empty((n,), torch.int64)
         new_indptr = self.empty((n + 1,), torch.int64)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             st = self._stream()
             check(self.lib.mu_csr_count_nonzero(_dt(X.values), n, _p(X.indptr), _p(X.values),
                                                 _p(row_nnz), st))
@@ -249,7 +265,7 @@ class HipBackend:
         return DeviceCSR(new_indptr, new_indices, new_values, X.shape)
 
     def binarize_values(self, values: torch.Tensor) -> None:
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_binarize_values(_dt(values), values.numel(), _p(values),
                                               self._stream()))
 
@@ -262,7 +278,7 @@ class HipBackend:
         t_values = torch.empty_like(X.values)
         wb = int(self.lib.mu_csr_transpose_worksize(n, d, nnz))
         work = self.empty((wb,), torch.uint8)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_csr_transpose(_dt(X.values), n, d, nnz, _p(X.indptr), _p(X.indices),
                                             _p(X.values), _p(t_indptr), _p(t_indices),
                                             _p(t_values), _p(work), wb, self._stream()))
@@ -279,7 +295,7 @@ class HipBackend:
         t_values = self.empty((max(X.nnz, 1),), torch.float32)[:X.nnz]
         wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
         work = self.empty((wb,), torch.uint8)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             st = self._stream()
             check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
                                               _p(work), wb, st))
@@ -295,7 +311,7 @@ class HipBackend:
     def _stream_sptr(self, lens_by_pos: torch.Tensor, K: int, waves: int = 16):
         n_pos = int(lens_by_pos.numel())
         sptr = self.zeros((n_pos + 1,), torch.int64)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_exclusive_scan_i64(n_pos, _p(lens_by_pos), _p(sptr), self._stream()))
         # cursors are 32-bit byte offsets from the first pair of the workgroup's 64 K rows
         per_wg = 4 * waves * K
@@ -316,7 +332,7 @@ class HipBackend:
             perm, _inv, K = self.launch_layout(X.indptr[1:] - X.indptr[:-1], want_k, waves)
             n_pos = int(perm.numel())
         lens = self.empty((max(n_pos, 1),), torch.int64)[:n_pos]
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             st = self._stream()
             check(self.lib.mu_csr_stream_len(n_pos, _p(perm), _p(X.indptr), _p(lens), st))
             sptr = self._stream_sptr(lens, K, waves)
@@ -334,7 +350,7 @@ class HipBackend:
         col_nnz = self.empty((max(d, 1),), torch.int64)
         wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
         work = self.empty((wb,), torch.uint8)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             st = self._stream()
             check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
                                               _p(work), wb, st))
@@ -480,11 +496,11 @@ class HipBackend:
             if X.waves == 12:
                 if wide or B != 64:
                     raise TypeError("a stream laid out for the wave-specialised SpMM serves f32 blocks of width 64")
-                with torch.cuda.device(self.device):
+                with self._dev_ctx():
                     check(self.lib.mu_spmm_ws_f32(X.n_pos, d, _p(X.sptr), _p(X.ent), _p(X.perm), _p(Q), B, _p(out),
                                                   self._stream()))
                 return out
-            with torch.cuda.device(self.device):
+            with self._dev_ctx():
                 if wide:
                     check(self.lib.mu_spmm_stream_f64(X.n_pos, d, _p(X.sptr), _p(X.ent), _p(X.perm), X.k,
                                                       _p(Q), B, _p(out), int(bool(accumulate)), self._stream()))
@@ -497,7 +513,7 @@ class HipBackend:
         if out is None:
             out = self.empty((n, B), Q.dtype)
         fn = self.lib.mu_spmm_f32 if Q.dtype == torch.float32 else self.lib.mu_spmm_f64
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(fn(n, d, _p(X.indptr), _p(X.indices), _p(X.values), _p(Q), B, _p(out), 0,
                      self._stream()))
         return out
@@ -509,7 +525,7 @@ class HipBackend:
         cs = self.empty((B,), torch.float64)
         wb = int(self.lib.mu_gram_worksize(n, B))
         work = self.empty((wb,), torch.uint8)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_gram_f32(n, B, _p(A), _p(G), _p(cs), _p(work), wb, self._stream()))
         return G, cs
 
@@ -521,7 +537,7 @@ class HipBackend:
         Cm = self.empty((B, B), torch.float64)
         wb = int(self.lib.mu_gram_worksize(n, B))
         work = self.empty((wb,), torch.uint8)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_gram_cross_f32(n, B, _p(A), _p(Bm), _p(Cm), _p(work), wb, self._stream()))
         return Cm
 
@@ -530,7 +546,7 @@ class HipBackend:
         assert M.shape == (B, B) and M.dtype == torch.float32 and M.is_contiguous()
         if out is None:
             out = torch.empty_like(A)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_dense_apply_f32(n, B, _p(A), _p(M), _p(bias), _p(out), self._stream()))
         return out
 
@@ -539,7 +555,7 @@ class HipBackend:
         n, B = Q.shape
         assert Z.shape == Q.shape and C.shape == (B, B) and C.dtype == torch.float64 and C.is_contiguous()
         assert Q.dtype == torch.float32 and Z.dtype == torch.float32 and Z.is_contiguous() and Q.is_contiguous()
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_dense_project_out_f32(n, B, _p(Q), _p(C), _p(Z), self._stream()))
         return Z
 
@@ -549,13 +565,13 @@ class HipBackend:
         B = G.shape[0]
         assert G.dtype == torch.float64 and G.is_contiguous() and flag.dtype == torch.int32
         M = self.empty((B, B), torch.float32)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_chol_rinv_f64(B, int(w), _p(G), _p(M), _p(flag), self._stream()))
         return M
 
     def randn(self, rows: int, B: int, seed: int) -> torch.Tensor:
         out = self.empty((rows, B), torch.float32)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_randn_f32(rows * B, int(seed) & (2**64 - 1), _p(out), self._stream()))
         return out
 
@@ -565,7 +581,7 @@ class HipBackend:
         n, D = Y.shape
         assert T16.shape == (D, 16) and T16.dtype == Y.dtype and T16.is_contiguous() and Y.stride(1) == 1
         out = self.empty((n, 16), Y.dtype)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_skinny_nn(_dt(Y), n, D, Y.stride(0) if n > 1 else D, _p(Y), _p(T16), _p(out),
                                         self._stream()))
         return out
@@ -577,7 +593,7 @@ class HipBackend:
         out = self.empty((D, 16), Y.dtype)
         wb = int(self.lib.mu_skinny_tn_worksize(_dt(Y), n, D))
         work = self.empty((wb,), torch.uint8)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_skinny_tn(_dt(Y), n, D, Y.stride(0) if n > 1 else D, _p(Y), _p(Z16), _p(out),
                                         _p(work), wb, self._stream()))
         return out
@@ -585,7 +601,7 @@ class HipBackend:
     # -- MOFA+ coordinate updates (reference tools.py:585 -> mofapy2 node updates) -----------
     def mofa_update_w(self, B, tau, Gz, Z2, alpha, lth, l1mth, spikeslab, EW, EW2, gamma, EWh2, sig2):
         G, D, K = B.shape
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_mofa_update_w(_dt(EW), D, K, G, _p(B), _p(tau), _p(Gz), _p(Z2),
                                             _p(alpha), _p(lth), _p(l1mth), int(bool(spikeslab)),
                                             _p(EW), _p(EW2), _p(gamma), _p(EWh2), _p(sig2),
@@ -594,7 +610,7 @@ class HipBackend:
     def mofa_update_z(self, A, pres, grp, Gw, dw2, alphaz, EZ, EZ2, sig2):
         M, N, K = A.shape
         G = alphaz.shape[0]
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_mofa_update_z(_dt(EZ), N, K, M, G, _p(A), _p(pres), _p(grp), _p(Gw),
                                             _p(dw2), _p(alphaz), _p(EZ), _p(EZ2), _p(sig2),
                                             self._stream()))
@@ -606,7 +622,7 @@ class HipBackend:
         """tau / <ln tau> of one view from the sufficient statistics; adds the likelihood and tau-node
         terms to the f64 device scalar ``elbo`` (include/muon_amd.h)."""
         G, D, K = B.shape
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_mofa_tau_elbo(_dt(EW), D, K, G, _p(yy), _p(Ngm), _p(EW), _p(EW2), _p(B), _p(Gz),
                                             _p(Z2), float(a0), float(b0), _p(tau), _p(ltau), _p(elbo),
                                             _p(work), self._stream()))
@@ -614,7 +630,7 @@ class HipBackend:
     def mofa_w_elbo(self, EWh2, gamma, sig2, ard, spikeslab, a_alpha, a0, b0, th_a0, th_b0, alpha, lalpha,
                     lth, l1mth, elbo, work):
         D, K = EWh2.shape
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_mofa_w_elbo(_dt(EWh2), D, K, int(bool(ard)), int(bool(spikeslab)), _p(EWh2),
                                           _p(gamma), _p(sig2), float(a_alpha), float(a0), float(b0),
                                           float(th_a0), float(th_b0), _p(alpha), _p(lalpha), _p(lth),
@@ -622,13 +638,13 @@ class HipBackend:
 
     def mofa_z_sums(self, EZ2, sig2, n0, n1, out, work):
         K = EZ2.shape[1]
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_mofa_z_sums(_dt(EZ2), int(n0), int(n1), K, _p(EZ2), _p(sig2), _p(out), _p(work),
                                           self._stream()))
 
     def mofa_z_elbo(self, zs, Ng, ard, a0, b0, alpha_z, lalpha_z, elbo):
         G, _two, K = zs.shape
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             check(self.lib.mu_mofa_z_elbo(_dt(alpha_z), K, G, int(bool(ard)), _p(zs), _p(Ng), float(a0),
                                           float(b0), _p(alpha_z), _p(lalpha_z), _p(elbo), self._stream()))
 
@@ -637,7 +653,7 @@ class HipBackend:
                      density: float = 0.03, seed: int = 0) -> DeviceCSR:
         row_nnz = self.empty((n_rows,), torch.int64)
         indptr = self.empty((n_rows + 1,), torch.int64)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             st = self._stream()
             check(self.lib.mu_synth_row_nnz(row0, n_rows, n_cols, n_topics, density, seed,
                                             _p(row_nnz), st))
