@@ -327,6 +327,7 @@ __global__ __launch_bounds__(64) void k_chol_rinv(int B, int w, const double* __
   __shared__ double X[64][65];
   const int lane = threadIdx.x;
   double dmax = 0.0;
+#pragma unroll 8
   for (int i = 0; i < w; ++i) {
     if (lane < w) L[i][lane] = G[(int64_t)i * B + lane];
     const double d = G[(int64_t)i * B + i];
@@ -339,8 +340,22 @@ __global__ __launch_bounds__(64) void k_chol_rinv(int B, int w, const double* __
   for (int k = 0; k < w; ++k) {
     double s = 0.0;
     if (lane >= k && lane < w) {
-      s = L[lane][k];
-      for (int p = 0; p < k; ++p) s -= L[lane][p] * L[k][p];
+      // (eight products per trip, their LDS reads issued together: one read-wait-FMA per trip made
+      //  this kernel 158 us, a chain of 4000 LDS round trips)
+      double s0 = L[lane][k], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int p = 0;
+      for (; p + 8 <= k; p += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a[u] = L[lane][p + u];
+          b[u] = L[k][p + u];
+        }
+        s0 -= a[0] * b[0]; s1 -= a[1] * b[1]; s2 -= a[2] * b[2]; s3 -= a[3] * b[3];
+        s0 -= a[4] * b[4]; s1 -= a[5] * b[5]; s2 -= a[6] * b[6]; s3 -= a[7] * b[7];
+      }
+      for (; p < k; ++p) s0 -= L[lane][p] * L[k][p];
+      s = (s0 + s1) + (s2 + s3);
     }
     double piv = __shfl(s, k, 64);
     if (!(piv > tiny)) {  // also catches NaN
@@ -358,9 +373,20 @@ __global__ __launch_bounds__(64) void k_chol_rinv(int B, int w, const double* __
     for (int i = 0; i < w; ++i) {
       double x = 0.0;
       if (i >= lane) {
-        x = (i == lane) ? 1.0 : 0.0;
-        for (int p = lane; p < i; ++p) x -= L[i][p] * X[p][lane];
-        x /= L[i][i];
+        double x0 = (i == lane) ? 1.0 : 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+        int p = lane;
+        for (; p + 8 <= i; p += 8) {
+          double a[8], b[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            a[u] = L[i][p + u];
+            b[u] = X[p + u][lane];
+          }
+          x0 -= a[0] * b[0]; x1 -= a[1] * b[1]; x2 -= a[2] * b[2]; x3 -= a[3] * b[3];
+          x0 -= a[4] * b[4]; x1 -= a[5] * b[5]; x2 -= a[6] * b[6]; x3 -= a[7] * b[7];
+        }
+        for (; p < i; ++p) x0 -= L[i][p] * X[p][lane];
+        x = ((x0 + x1) + (x2 + x3)) / L[i][i];
       }
       X[i][lane] = x;
     }
