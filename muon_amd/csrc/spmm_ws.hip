@@ -36,13 +36,15 @@ constexpr int kKC = 5;                        // row-sets per gather wave (hipcc
 constexpr int kRS = kGather * kKC / kWindow;  // row-sets per window wave: 15
 constexpr int kSetsPerWg = kGather * kKC;     // 60 row-sets = 240 rows
 constexpr int kNX = 126 - 2 * kRS;            // asm-owned v[96 .. 125]
-constexpr int kRing = 7;                       // slots per ring: the 5 windows of a slab, its end marker, one overflow window
-constexpr int kAhead = 4;                      // windows of the NEXT slab a window wave prepares before the slab barrier
+constexpr int kRing = 5;                       // slots per ring: the 5 windows of a slab
+constexpr int kAhead = 3;                      // windows of the NEXT slab a window wave prepares before the slab barrier
 constexpr int kPadCol = 0x7fffffff;
 constexpr int kRowBytes = 256, kRowShift = 8, kSlabBytes = kSlabCols * kRowBytes;  // 64 KiB
 constexpr int kPiecesPerWave = kSlabBytes / 1024 / kWindow;                           // 16
 constexpr int kWaitMain = (kRS - 1) + kPiecesPerWave;                                 // 30
-constexpr unsigned kHdrExtra = 1u << 16, kHdrEnd = 1u << 17;  // header: any16 | flags | row-set << 20
+// header of an entry: any16 | flags | row-set << 20 | sequence tag << 24 (the tag - entry number mod 128,
+// plus 1 - is what tells a gather wave that the slot holds the entry it waits for: no separate counter)
+constexpr unsigned kHdrExtra = 1u << 16, kHdrMore = 1u << 17;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -183,10 +185,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 struct Rings {
-  unsigned vbits[kGather][kRing][64];       // per lane: value bits of the window entry
-  unsigned short rowoff[kGather][kRing][64];  // per lane: row of the slab (LDS byte offset >> 8)
+  uint2 slot[kGather][kRing][64];   // per lane: (LDS byte offset inside the slab, value bits)
   unsigned hdr[kGather][kRing];
-  unsigned prod[kGather];           // entries published
   unsigned cons[kGather];           // entries taken
 };
 
@@ -227,10 +227,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(48))) void k_s
   const int64_t q4_total = n_cols * (kRowBytes / 16);
   const int ncols32 = (int)n_cols;
   const unsigned qs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&qs[0][0]);
-  if (threadIdx.x < kGather) {
-    rings.prod[threadIdx.x] = 0u;
-    rings.cons[threadIdx.x] = 0u;
-  }
+  if (threadIdx.x < kGather) rings.cons[threadIdx.x] = 0u;
+  if (threadIdx.x < kGather * kRing) (&rings.hdr[0][0])[threadIdx.x] = 0u;  // no tag is 0
 
   if (wave >= kGather) {
     // ------------------------------------------------------------------ window wave
@@ -319,20 +317,20 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(48))) void k_s
     auto publish = [&](int ci, int a, int vbits, unsigned hdr) {
       const int c = 3 * pw + ci;
       const unsigned sl = slot_of[ci];
-      rings.vbits[c][sl][lane] = (unsigned)vbits;
-      rings.rowoff[c][sl][lane] = (unsigned short)((unsigned)a >> kRowShift);
-      if (lane == 0) {
-        rings.hdr[c][sl] = hdr;
-        lds_store_relaxed(&rings.prod[c], nseq[ci] + 1u);
-      }
+      rings.slot[c][sl][lane] = make_uint2((unsigned)a, (unsigned)vbits);
+      asm volatile("" ::: "memory");  // (data, then the tagged header: the LDS keeps a wave's order)
+      if (lane == 0) lds_store_relaxed(&rings.hdr[c][sl], hdr | (((nseq[ci] & 0x7fu) + 1u) << 24));
       nseq[ci] += 1u;
       slot_of[ci] = (sl + 1u == (unsigned)kRing) ? 0u : sl + 1u;
     };
 
     unsigned again = 0, again_next = 0;
-    auto stage_a = [&](auto rc, auto slowc, unsigned extra, int s_hi, unsigned& ag) {
+    // `rest`: overflow windows of this slab still to come behind this entry, as a row-set mask (the last
+    // window of a slab and every overflow window say whether the gather wave has more to take)
+    auto stage_a = [&](auto rc, auto slowc, unsigned extra, int s_hi, unsigned& ag, unsigned rest) {
       constexpr int r = decltype(rc)::value;
       constexpr bool SLOW = decltype(slowc)::value;
+      constexpr unsigned kMine = (1u << (r % 3)) * 0x1249u;  // row-sets r % 3, + 3, + 6, + 9, + 12
       int col, valbits;
       if constexpr (SLOW) wait_window<r, 0>(col, valbits);
       else wait_window<r, kWaitMain>(col, valbits);
@@ -348,7 +346,55 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(48))) void k_s
       off[r] += cnt << 3;
       request_window<r>(off[r], entb, __ballot(off[r] < end_of(rc)));
       if (__ballot(cnt == 16u)) ag |= 1u << r;
-      publish(r % 3, a, vb, any16 | extra | ((unsigned)(r / 3) << 20));
+      unsigned more = 0u;
+      if constexpr (SLOW || r / 3 == kKC - 1) more = ((ag | rest) & kMine) ? kHdrMore : 0u;
+      publish(r % 3, a, vb, any16 | extra | more | ((unsigned)(r / 3) << 20));
+    };
+    // Three row-sets (one per gather wave of this window wave) at once.  A row-set's stage A is a chain
+    // of ~12 dependent vector <-> scalar steps (compare, ballot, count, cursor, compare, mask); in the
+    // single-role kernel four waves per SIMD cover each other's chains, a window wave is alone on its
+    // SIMD with this work, so it interleaves three independent chains itself.  The three windows are
+    // waited for before any of the three new requests goes out: counts 30, 29, 28.
+    auto stage_a3 = [&](auto r0c, int s_hi, unsigned& ag) {
+      constexpr int r0 = decltype(r0c)::value;
+      static_assert(r0 % 3 == 0, "a group is row-sets 3q, 3q + 1, 3q + 2");
+      int col[3], valbits[3];
+      wait_window<r0, kWaitMain>(col[0], valbits[0]);
+      wait_window<r0 + 1, kWaitMain - 1>(col[1], valbits[1]);
+      wait_window<r0 + 2, kWaitMain - 2>(col[2], valbits[2]);
+      unsigned any16[3], cnt[3];
+      int a[3], vb[3];
+      unsigned long long rq[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const bool valid = col[i] < s_hi;
+        const unsigned long long m = __ballot(valid);
+        const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+        const unsigned mm = mlo | mhi;
+        any16[i] = (mm | (mm >> 16)) & 0xffffu;
+        a[i] = (col[i] & (kSlabCols - 1)) << kRowShift;
+        vb[i] = valid ? valbits[i] : 0;
+        const unsigned mine = (lane & 32) ? mhi : mlo;
+        cnt[i] = (unsigned)__popc(mine & gmask);
+      }
+      off[r0] += cnt[0] << 3;
+      off[r0 + 1] += cnt[1] << 3;
+      off[r0 + 2] += cnt[2] << 3;
+      rq[0] = __ballot(off[r0] < end_of(std::integral_constant<int, r0>{}));
+      rq[1] = __ballot(off[r0 + 1] < end_of(std::integral_constant<int, r0 + 1>{}));
+      rq[2] = __ballot(off[r0 + 2] < end_of(std::integral_constant<int, r0 + 2>{}));
+      request_window<r0>(off[r0], entb, rq[0]);
+      request_window<r0 + 1>(off[r0 + 1], entb, rq[1]);
+      request_window<r0 + 2>(off[r0 + 2], entb, rq[2]);
+      if (__ballot(cnt[0] == 16u)) ag |= 1u << r0;
+      if (__ballot(cnt[1] == 16u)) ag |= 1u << (r0 + 1);
+      if (__ballot(cnt[2] == 16u)) ag |= 1u << (r0 + 2);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        unsigned more = 0u;
+        if constexpr (r0 / 3 == kKC - 1) more = (ag & ((1u << i) * 0x1249u)) ? kHdrMore : 0u;
+        publish(i, a[i], vb[i], any16[i] | more | ((unsigned)(r0 / 3) << 20));
+      }
     };
     auto slab_hi = [&](int64_t s0) -> int {
       return ((int)s0 + kSlabCols) < ncols32 ? ((int)s0 + kSlabCols) : ncols32;
@@ -357,42 +403,39 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(48))) void k_s
     // barrier that ends the slab before it: the gather waves find windows waiting when they come out
     // of the barrier.  VMEM order per slab: R0 .. R11 | barrier | D0 .. D15 R12 .. R17 - still 33
     // younger operations between a request and its use, whatever the row-set.
-    constexpr int kHead = 3 * kAhead;  // 12
+    constexpr int kHead = 3 * kAhead;  // 9
     static_assert(kHead <= kRS, "head of a slab");
-    static_for<kHead>([&](auto rc) { stage_a(rc, std::false_type{}, 0u, slab_hi(0), again); });
+    static_for<kHead / 3>([&](auto qc) { stage_a3(std::integral_constant<int, 3 * decltype(qc)::value>{}, slab_hi(0), again); });
     int buf = 0;
     for (int64_t s0 = 0; s0 < n_cols; s0 += kSlabCols, buf ^= 1) {
       const int s_hi = slab_hi(s0);
       if (s0 > 0) {
         unsigned tb0 = 0;
         if constexpr (DBG) tb0 = now();
-        // this slab's pieces went out one iteration ago, followed by 6 + 12 requests
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kRS) : "memory");
+        // this slab's pieces went out one iteration ago, followed by the head's requests
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(kHead) : "memory");
         __syncthreads();  // end of the previous slab
         if constexpr (DBG) tm[4] += now() - tb0;
       }
       unsigned tq0 = 0, tq1 = 0;
       if constexpr (DBG) tq1 = now();
-      static_for<kRS - kHead>([&](auto rc) {
-        stage_a(std::integral_constant<int, decltype(rc)::value + kHead>{}, std::false_type{}, 0u, s_hi, again);
+      static_for<(kRS - kHead) / 3>([&](auto qc) {
+        stage_a3(std::integral_constant<int, kHead + 3 * decltype(qc)::value>{}, s_hi, again);
       });
-      unsigned n_extra[3] = {0u, 0u, 0u};
       if (again) {
         do {
           const unsigned pend = again;
           again = 0;
           static_for<kRS>([&](auto rc) {
             if (pend & (1u << decltype(rc)::value)) {
-              // (the first overflow window of a ring in a slab has its slot; more of them look first)
-              if (n_extra[decltype(rc)::value % 3]++ > 0) make_room(decltype(rc)::value % 3, 2u);
-              stage_a(rc, std::true_type{}, kHdrExtra, s_hi, again);
+              constexpr int r = decltype(rc)::value;
+              make_room(r % 3, 1u);  // (rare: one LDS round trip)
+              stage_a(rc, std::true_type{}, kHdrExtra, s_hi, again, pend & ~((2u << r) - 1u));
             }
           });
         } while (again);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-#pragma unroll
-      for (int ci = 0; ci < 3; ++ci) publish(ci, 0, 0, kHdrEnd);
       // The next slab's pieces go out AFTER the overflow windows: those end in a full drain
       // (s_waitcnt vmcnt(0): an overflow request is younger than the counted waits assume), and with 15
       // row-sets per window wave most slabs have one - behind the DMA burst that drain waited for the
@@ -408,7 +451,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(48))) void k_s
 #pragma unroll
         for (int ci = 0; ci < 3; ++ci)
           if (!room_from_peek(peek, ci, (unsigned)kAhead)) make_room(ci, (unsigned)kAhead);
-        static_for<kHead>([&](auto rc) { stage_a(rc, std::false_type{}, 0u, slab_hi(s0 + kSlabCols), again_next); });
+        static_for<kHead / 3>([&](auto qc) {
+          stage_a3(std::integral_constant<int, 3 * decltype(qc)::value>{}, slab_hi(s0 + kSlabCols), again_next);
+        });
         again = again_next;
       }
       if constexpr (DBG) tm[2] += now() - tq2;
@@ -435,25 +480,27 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(48))) void k_s
   // The next window is read while the current one is being worked on: counter, header and data in
   // one round trip, issued before stage B; they are valid if the counter says published (the LDS
   // executes a wave's reads in order: counter first), otherwise the read is repeated.
-  struct Pre { unsigned pr, x, y, hdr; };
+  struct Pre { unsigned x, y, hdr; };
   unsigned slot_c = 0;  // slot of the entry to take next
   auto issue = [&]() -> Pre {
     Pre p;
-    p.pr = lds_load_relaxed(&rings.prod[c]);
-    p.x = *reinterpret_cast<const volatile unsigned short*>(&rings.rowoff[c][slot_c][lane]);
-    p.y = *reinterpret_cast<const volatile unsigned*>(&rings.vbits[c][slot_c][lane]);
-    p.hdr = *reinterpret_cast<const volatile unsigned*>(&rings.hdr[c][slot_c]);
+    // header first, then the data: if the header carries the expected tag, the data read behind it is
+    // the entry's (the window wave wrote data, then header; both sides execute in order)
+    p.hdr = lds_load_relaxed(&rings.hdr[c][slot_c]);
+    const volatile unsigned* sp = reinterpret_cast<const volatile unsigned*>(&rings.slot[c][slot_c][lane]);
+    p.x = sp[0];
+    p.y = sp[1];
     asm volatile("" ::: "memory");
     return p;
   };
   auto finish = [&](Pre p, int& a, float& vv) -> unsigned {
     unsigned tt0 = 0;
     if constexpr (DBG) tt0 = nowc();
-    while ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)p.pr) - nget) <= 0) {
+    while (((unsigned)__builtin_amdgcn_readfirstlane((int)p.hdr) >> 24) != (nget & 0x7fu) + 1u) {
       __builtin_amdgcn_s_sleep(2);
       p = issue();
     }
-    a = (int)(p.x << kRowShift);
+    a = (int)p.x;
     vv = __builtin_bit_cast(float, p.y);
     ++nget;
     slot_c = (slot_c + 1u == (unsigned)kRing) ? 0u : slot_c + 1u;
@@ -465,12 +512,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(48))) void k_s
   int buf = 0;
   for (int64_t s0 = 0; s0 < n_cols; s0 += kSlabCols, buf ^= 1) {
     const unsigned qbase = qs_lds + (unsigned)buf * (unsigned)kSlabBytes + (unsigned)sub_off;
+    unsigned more = 0u;
     static_for<kKC>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       int a;
       float vv;
       const unsigned hdr = finish(pre, a, vv);
       pre = issue();
+      if constexpr (k == kKC - 1) more = hdr & kHdrMore;
       unsigned tb0 = 0;
       if constexpr (DBG) tb0 = nowc();
       __builtin_amdgcn_s_setprio(1);
@@ -481,13 +530,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(48))) void k_s
         tc[1] += nowc() - tb0;
       }
     });
-    while (true) {
+    while (more) {
       int a;
       float vv;
       const unsigned hdr = finish(pre, a, vv);
       pre = issue();
-      if (hdr & kHdrEnd) break;
-      const int k = (int)(hdr >> 20);
+      more = hdr & kHdrMore;
+      const int k = (int)((hdr >> 20) & 7u);
       static_for<kKC>([&](auto kc) {
         if (k == decltype(kc)::value) stage_b(qbase, a, vv, hdr & 0xffffu, acc[decltype(kc)::value]);
       });
