@@ -1,23 +1,29 @@
 // Row-stream SpMM, wave-specialised (B = 64, f32): Y[n x 64] = X * Q with X a row stream
 // (csrc/spmm_win.hip has the format and the single-role kernel this one grew out of).
+// EXPERIMENT, opt-in (HipBackend.stream(..., waves=12)): bit-identical to k_spmm_win and 17 % slower
+// (5.7 against 4.8 ms at 122 880 x 200 000); DESIGN.md 4.2 and profiles/r02_spmm_ws_accounting.txt.
 //
 // Why.  In k_spmm_win every wave runs stage A (window cut, cursor update, next request: a chain of
 // scalar work and waits) and then stage B (the LDS gathers and FMAs) of a pass, and the 16 waves of
 // the CU's one workgroup move through a slab together, so the gather pipes idle while waves are in
-// stage A or at the slab barrier: 4.65 ms at 125k x 200k against 3.1 ms for stage B alone, and
-// stage B alone runs as fast on 12 waves as on 16 (spmm_mode 128 / 128 + 65536: the LDS and VALU
-// pipes bound it, not the number of waves).  Here 4 "window" waves of the workgroup do stage A for 12
-// "gather" waves and hand the prepared windows - per lane the LDS offset and the value of one entry,
-// plus the slot mask - over through small rings in LDS:
-//   * gather wave c owns kKC = 6 row-sets of 4 rows (accumulators in registers) and per slab takes
-//     its 6 windows, then any overflow windows (rows with more than 16 entries in the slab; tagged
-//     with their row-set), then an end marker, from ring c;
-//   * window wave p serves gather waves 3p .. 3p+2 round robin: 18 row-sets, i.e. 18 window
-//     requests in flight (asm-owned v[90 .. 125]) and 16 of the next slab's 64 LDS-DMA pieces,
-//     D0 .. D15 R0 .. R17 per slab, so a window is waited for with the exact count 33;
-//   * ring protocol: 4 slots per gather wave, producer sequence / consumer sequence counters in LDS
-//     (release / acquire at workgroup scope; LDS operations of one wave execute in order); the slab
-//     barrier stays - one per slab for all 16 waves - so nothing outlives a slab but the requests.
+// stage A or at the slab barrier: 4.8 ms against 3.25 ms for stage B alone, and stage B alone runs
+// as fast on 12 waves as on 16 (spmm_mode 128 / 128 + 65536: the LDS and VALU pipes bound it, not the
+// number of waves).  Here 4 "window" waves of the workgroup do stage A for 12 "gather" waves and hand
+// the prepared windows - per lane the LDS offset and the value of one entry, plus a header word with
+// the slot mask - over through small rings in LDS:
+//   * gather wave c owns kKC = 5 row-sets of 4 rows (accumulators in registers) and per slab takes its
+//     5 windows, then any overflow windows (rows with more than 16 entries in the slab; tagged with
+//     their row-set and announced by the "more" bit of the entry before), from ring c;
+//   * window wave p serves gather waves 3p .. 3p+2: 15 row-sets in groups of three whose stage A
+//     chains are interleaved, 15 window requests in flight (asm-owned v[96 .. 125]; hipcc cannot be
+//     held below v96) and 16 of the next slab's 64 LDS-DMA pieces; VMEM order per slab
+//     R9 .. R14 | D0 .. D15 | R0 .. R8, so a window is waited for with the exact counts 30 / 29 / 28;
+//   * ring protocol: 5 slots per gather wave, an entry is one ds_write_b64 per lane and one tagged
+//     header word (sequence number mod 128, plus 1) - the LDS executes a wave's operations in order,
+//     so "data, then header" / "header, then data" need no s_waitcnt; the gather wave's count of taken
+//     entries is the only counter, looked at once per slab (before the windows of the NEXT slab's head
+//     are published ahead of the slab barrier) and before an overflow window;
+//   * the slab barrier stays - one per slab for all 16 waves.
 // Results are bit-identical to k_spmm_win (a row's entries are accumulated in column order).
 #include <cstdlib>
 #include <type_traits>
