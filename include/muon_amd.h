@@ -194,9 +194,11 @@ int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
                        const int32_t* d_perm, int k_layout, const float* d_Q, int B, float* d_Y,
                        void* stream);
 /* Wave-specialised build of the same product for B = 64 (csrc/spmm_ws.hip: 4 window waves prepare the
- * windows of 12 gather waves).  The stream must be laid out for it: mu_spmm_ws_rows_per_wg() rows per
- * workgroup, row-set q of a workgroup = gather wave q / 6, its row-set q % 6.  Bit-identical results. */
+ * windows of the gather waves).  The stream must be laid out for it: mu_spmm_ws_rows_per_wg() rows per
+ * workgroup dealt to mu_spmm_ws_gather_waves() waves (row-set q of a workgroup = gather wave q / K, its
+ * row-set q % K, K = rows per workgroup / 4 / gather waves).  Bit-identical results. */
 int mu_spmm_ws_rows_per_wg(void);
+int mu_spmm_ws_gather_waves(void);
 int mu_spmm_ws_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, const void* d_ent,
                    const int32_t* d_perm, const float* d_Q, int B, float* d_Y, void* stream);
 /* The same row stream (f32 stored values) against an f64 dense block, f64 accumulation and product,

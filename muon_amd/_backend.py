@@ -56,7 +56,7 @@ class DeviceStream:
     nnz: int
     perm: Optional[torch.Tensor] = None
     k: int = 0
-    waves: int = 16   # waves a workgroup's row-sets are dealt to: 16, or 12 (wave-specialised SpMM)
+    waves: int = 16   # waves a workgroup's row-sets are dealt to: 16, or the gather waves of csrc/spmm_ws.hip
 
     @property
     def n_pos(self) -> int:
@@ -322,11 +322,11 @@ class HipBackend:
 
     def stream(self, X: DeviceCSR, sort_rows: bool = True, K: Optional[int] = None, waves: int = 16) -> DeviceStream:
         """Row stream of X for the SpMM of the iteration (a streaming copy, once per lsi call).
-        ``waves=12``: laid out for the wave-specialised kernel (csrc/spmm_ws.hip: 12 gather waves)."""
+        ``waves=self.ws_waves()``: laid out for the wave-specialised kernel (csrc/spmm_ws.hip)."""
         n, d = X.shape
         assert X.values.dtype == torch.float32
-        want_k = self._ws_k() if waves == 12 else K
-        assert waves == 16 or sort_rows
+        want_k = self._ws_k() if waves != 16 else K
+        assert waves in (16, self.ws_waves()) and (waves == 16 or sort_rows)
         perm, K, n_pos = None, max(1, int(want_k or self.lib.mu_spmm_stream_k(n))), n
         if sort_rows and n > 0:
             perm, _inv, K = self.launch_layout(X.indptr[1:] - X.indptr[:-1], want_k, waves)
@@ -354,8 +354,8 @@ class HipBackend:
             st = self._stream()
             check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
                                               _p(work), wb, st))
-            want_k = self._ws_k() if waves == 12 else K
-            assert waves == 16 or sort_rows
+            want_k = self._ws_k() if waves != 16 else K
+            assert waves in (16, self.ws_waves()) and (waves == 16 or sort_rows)
             perm, inv, K, n_pos = None, None, max(1, int(want_k or self.lib.mu_spmm_stream_k(d))), d
             lens = col_nnz[:d]
             if sort_rows and d > 0:
@@ -385,9 +385,14 @@ class HipBackend:
             return SplitStream(s_hi, self.stream(Xl)), SplitStream(t_hi, self.transpose_stream(Xl))
         return SplitStream(s_hi, None), SplitStream(t_hi, None)
 
+    def ws_waves(self) -> int:
+        """Gather waves per workgroup of the wave-specialised SpMM (csrc/spmm_ws.hip): pass it as
+        ``waves=`` to stream() / transpose_stream() to lay an operand out for that kernel."""
+        return int(self.lib.mu_spmm_ws_gather_waves())
+
     def _ws_k(self) -> int:
-        """Row-sets per gather wave of the wave-specialised SpMM (12 gather waves x 4 rows each)."""
-        return int(self.lib.mu_spmm_ws_rows_per_wg()) // 48
+        """Row-sets per gather wave of the wave-specialised SpMM."""
+        return int(self.lib.mu_spmm_ws_rows_per_wg()) // (4 * self.ws_waves())
 
     def launch_layout(self, lens: torch.Tensor, K: Optional[int] = None, waves: int = 16):
         """Where the rows go in a row stream (include/muon_amd.h): sorted by length (descending,
@@ -493,7 +498,7 @@ class HipBackend:
             if out is None:
                 assert not accumulate
                 out = self.empty((n, B), Q.dtype)
-            if X.waves == 12:
+            if X.waves != 16:
                 if wide or B != 64:
                     raise TypeError("a stream laid out for the wave-specialised SpMM serves f32 blocks of width 64")
                 with self._dev_ctx():

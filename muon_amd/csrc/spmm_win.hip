@@ -310,9 +310,9 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
         Win ws;
         ws.a = ((lane * 37 + k * 13 + (int)s0) & (kSlabCols - 1)) << kRowShift;
         ws.vv = 1.0f;
-        // (+ 65536: the windows of waves 12-15 are empty - stage B alone on 12 of the 16 waves, what the
-        //  twelve "gather" waves of a wave-specialised kernel could deliver)
-        ws.any16 = ((MODE & 65536) && wave >= 12) ? 0u : 0x0fffu;
+        // (+ 65536 / 131072: the windows of waves 12-15 / 8-15 are empty - stage B alone on 12 / 8 of the
+        //  16 waves, what that many "gather" waves of a wave-specialised kernel could deliver)
+        ws.any16 = (((MODE & 65536) && wave >= 12) || ((MODE & 131072) && wave >= 8)) ? 0u : 0x0fffu;
         if constexpr (MODE & 64) t_a -= now();
         return ws;
       }
@@ -719,6 +719,7 @@ int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
 #define MU_ARGS B, st, n_pos, n_cols, d_sptr, ent, d_perm, d_Q, d_Y
   if (mode != 0) {
     if (mode == 128 + 65536 && K == 8) return launch<8, 128 + 65536>(MU_ARGS);
+    if (mode == 128 + 131072 && K == 8) return launch<8, 128 + 131072>(MU_ARGS);
     if (mode == 128 + 8192 && K == 8) return launch<8, 128 + 8192>(MU_ARGS);
     if (mode == 128 + 8192 + 32768 && K == 8) return launch<8, 128 + 8192 + 32768>(MU_ARGS);
     if (mode == 16384 && K == 8) return launch<8, 16384>(MU_ARGS);

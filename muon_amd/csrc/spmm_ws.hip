@@ -25,6 +25,10 @@
 //     are published ahead of the slab barrier) and before an overflow window;
 //   * the slab barrier stays - one per slab for all 16 waves.
 // Results are bit-identical to k_spmm_win (a row's entries are accumulated in column order).
+// (Also measured: 8 window + 8 gather waves x 6 row-sets, one gather wave per window wave - the window
+//  waves then have time to spare, but eight waves gather 16 % slower than twelve (spmm_mode 128 +
+//  131072) and a slab took 8.7k cycles for 192 rows: 8.5 ms.  Twelve gather waves need more than four
+//  window waves' worth of instruction issue, and sixteen is all a CU's one workgroup has.)
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -573,6 +577,7 @@ extern "C" {
 /* rows per workgroup of the wave-specialised kernel: the layout (muon_amd/_backend.py
  * launch_layout(waves = 12, K = 6)) deals row-sets to 12 gather waves x 6 row-sets */
 int mu_spmm_ws_rows_per_wg(void) { return 4 * kSetsPerWg; }
+int mu_spmm_ws_gather_waves(void) { return kGather; }
 
 int mu_spmm_ws_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, const void* d_ent,
                    const int32_t* d_perm, const float* d_Q, int B, float* d_Y, void* stream) {

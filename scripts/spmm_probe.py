@@ -97,7 +97,8 @@ for M, D, tag in ((Ts, Q, "X*Q "), (Tts, Yn, "Xt*Y")):
 if args.ws:
     # wave-specialised kernel (csrc/spmm_ws.hip): its own layout (12 gather waves x 6 row-sets)
     WSR = int(be.lib.mu_spmm_ws_rows_per_wg())
-    A = be.stream(T, waves=12)
+    WG = be.ws_waves()
+    A = be.stream(T, waves=WG)
     got = be.spmm(A, Q)
     torch.cuda.synchronize()
     print("X*Q  wave-specialised vs single-role:", "bit-identical" if torch.equal(got, Yn) else "DIFFERS", flush=True)
@@ -108,12 +109,12 @@ if args.ws:
     nwg = A.n_pos // WSR
     tt = t.reshape(-1)[: nwg * 16 * 64].reshape(nwg, 16, 64)[:, :, :6].double()
     slabs = (A.shape[1] + 255) // 256
-    print("   window waves, cycles per slab: " + ", ".join(f"{n} {float(tt[:, 12:, i].mean()) / slabs:7.0f}" for i, n in enumerate(
+    print("   window waves, cycles per slab: " + ", ".join(f"{n} {float(tt[:, WG:, i].mean()) / slabs:7.0f}" for i, n in enumerate(
         ["DMA issue", "tail row-sets + end", "head of next slab", "-", "slab end", "-"])), flush=True)
-    print("   gather waves, cycles per slab: " + ", ".join(f"{n} {float(tt[:, :12, i].mean()) / slabs:7.0f}" for i, n in
+    print("   gather waves, cycles per slab: " + ", ".join(f"{n} {float(tt[:, :WG, i].mean()) / slabs:7.0f}" for i, n in
         ((0, "waiting for windows"), (1, "stage B"), (4, "barrier"))), flush=True)
     del A, got, t
-    At = be.transpose_stream(T, waves=12)
+    At = be.transpose_stream(T, waves=WG)
     got = be.spmm(At, Yn)
     torch.cuda.synchronize()
     print("Xt*Y wave-specialised vs single-role:", "bit-identical" if torch.equal(got, Zn) else "DIFFERS", flush=True)

@@ -567,8 +567,8 @@ def test_wave_specialised_spmm_is_bit_identical(hip):
         Q = hip.randn(d, 64, 3)
         Y = hip.randn(n, 64, 4)
         ref = hip.spmm(hip.stream(X), Q)
-        A = hip.stream(X, waves=12)
-        assert A.waves == 12 and A.n_pos % int(hip.lib.mu_spmm_ws_rows_per_wg()) == 0
+        A = hip.stream(X, waves=hip.ws_waves())
+        assert A.waves == hip.ws_waves() and A.n_pos % int(hip.lib.mu_spmm_ws_rows_per_wg()) == 0
         assert torch.equal(hip.spmm(A, Q), ref)
         reft = hip.spmm(hip.transpose_stream(X), Y)
-        assert torch.equal(hip.spmm(hip.transpose_stream(X, waves=12), Y), reft)
+        assert torch.equal(hip.spmm(hip.transpose_stream(X, waves=hip.ws_waves()), Y), reft)

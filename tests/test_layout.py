@@ -109,7 +109,7 @@ def test_stream_spmm_isa_keeps_out_of_the_asm_owned_registers(tmp_path):
 
 def test_wave_specialised_kernel_keeps_its_window_registers(tmp_path):
     """csrc/spmm_ws.hip: the window waves' requests in flight live in v96 .. v125, written by inline asm
-    while the wave runs; hipcc must stay below (amdgpu_num_vgpr(48) = v0 .. v95) and must not spill."""
+    while the wave runs; hipcc must stay below and must not spill."""
     import re
     import shutil
     import subprocess
