@@ -1,5 +1,9 @@
-import sys, os
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python
+"""mu_chol_rinv_f64 (the B x B step of CholeskyQR on the device): time per call and error against numpy."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, numpy as np
 from muon_amd._backend import HipBackend
 be = HipBackend(0)
