@@ -317,6 +317,7 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
         return ws;
       }
       int col, valbits;
+      if constexpr (MODE & 262144) __builtin_amdgcn_s_setprio(2);  // (timing: stage A above the gathers)
       unsigned tw0 = 0;
       if constexpr (MODE & 64) tw0 = now();
       if constexpr (SLOW) wait_window<k, 0>(col, valbits);
@@ -718,6 +719,8 @@ int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
   const int mode = mu_tune_get("spmm_mode");
 #define MU_ARGS B, st, n_pos, n_cols, d_sptr, ent, d_perm, d_Q, d_Y
   if (mode != 0) {
+    if (mode == 262144 && K == 8) return launch<8, 262144>(MU_ARGS);
+    if (mode == 262144 && K == 7) return launch<7, 262144>(MU_ARGS);
     if (mode == 128 + 65536 && K == 8) return launch<8, 128 + 65536>(MU_ARGS);
     if (mode == 128 + 131072 && K == 8) return launch<8, 128 + 131072>(MU_ARGS);
     if (mode == 128 + 8192 && K == 8) return launch<8, 128 + 8192>(MU_ARGS);

@@ -80,7 +80,7 @@ bench("X*Q  stream      ", Ts, Q)
 bench("Xt*Y stream      ", Tts, Yn)
 names = ["wait window", "stage A", "stage B", "barrier+dma wait", "dma issue"]
 for M, D, tag in ((Ts, Q, "X*Q "), (Tts, Yn, "Xt*Y")):
-    if M.k != 8 and not all(int(m) in (4096, 16384) for m in args.modes.split(",") if m):
+    if M.k != 8 and not all(int(m) in (4096, 16384, 262144) for m in args.modes.split(",") if m):
         continue
     for mode in [int(m) for m in args.modes.split(",") if m]:
         be.tune("spmm_mode", mode)
