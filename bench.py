@@ -9,13 +9,20 @@ left in HBM at the end.
 roofline: the dominant kernel is the row-stream SpMM (both X*Q and X^T*Y).  `achieved` =
 algorithmic bytes per launch (8 B per stored entry + row pointers + the two dense blocks,
 SURVEY.md 8d / DESIGN.md 4) / mean launch time from HIP events recorded on the launch stream
-inside the timed region.  `traffic` = HBM bytes per launch from rocprofv3 PMC counters
+inside the timed region.  `traffic` = HBM-side bytes per launch from rocprofv3 PMC counters
 (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction) for the default workload, read
-from profiles/r02_spmm_traffic.json; null for any other shape.
+from the newest profiles/r*_spmm_traffic.json - a builder-run measurement, NOT a counter of this
+run: the top-level `traffic_source` says so; null for any other shape.  `lds_frac` = the kernel's
+own bound: every stored entry gathers a 256-byte Q row from LDS (256 B/clk/CU), so a launch
+cannot take less than nnz / (CUs x clock) whatever the HBM does.
 
 parity: the CPU leg's f32 ARPACK result on its sample is kept, the GPU path runs tfidf + lsi on the
 same sample, and the largest principal angle between the two top-k right singular subspaces and
 the largest relative difference of the singular values go into the JSON line (`parity`).
+
+secondary: the default run (c3, one GPU) also carries the two other single-GPU configurations of
+BASELINE.json as complete sub-records (ms, roofline, cpu_baseline, parity): `c2` (configs[0]/[1]) and
+`c4` (configs[3], mu.tl.mofa).  --no-secondary skips them.
 
 Workloads (--workload):
   c3 (default)       BASELINE.json configs[2], the shape the metric is quoted on: 1 000 000 cells x
@@ -25,16 +32,20 @@ Workloads (--workload):
                      N = 1 (~170 GB of the 288 GB).
   c3shard            125 000 cells x 200 000 peaks PER GPU (weak scaling; N = 8 is the same 1M x
                      200k matrix)
-  c2                 10 000 x 30 000, 3 % nnz (configs[1]; launch/latency bound at this size)
+  c2                 10 000 x 30 000, 3 % nnz (configs[0]/[1]; launch/latency bound at this size);
+                     cpu_baseline = the scipy path on the SAME 10 000 cells
   c4                 configs[3]/[4]: mu.tl.mofa on rna 100k x 20k dense + atac 100k x 100k sparse, K = 10;
                      metric = seconds per 100 ELBO iterations (lower is better), --steps = iterations
                      (default 100), cells sharded over the N GPUs; cpu_baseline = the numpy f64
                      restatement on a cell sample, extrapolated (scripts/bench_mofa.py)
 
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under torch.distributed.run.
-Prints ONE JSON line on rank 0.
+Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 either run it under
+torch.distributed.run (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env) or
+just call `python bench.py --gpus N`: it then starts its own N ranks (torch.distributed.run on
+127.0.0.1 with a free port).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -47,6 +58,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+LDS_BYTES_PER_CLK_CU = 256.0  # ds_read_b128, conflict free (same guide, LDS table)
+SHADER_CLOCK_HZ = 2.4e9
 WORKLOADS = {  # cells = TOTAL cells for strong scaling, cells PER GPU for weak scaling
     "c3": dict(cells=1_000_000, peaks=200_000, scaling="strong"),
     "c3shard": dict(cells=125_000, peaks=200_000, scaling="weak"),
@@ -76,7 +89,7 @@ class TimedBackend:
         e.record()
         B = Q.shape[1]
         n, d = X.shape
-        self.events.append((s, e, 8 * X.nnz + 8 * (n + 1) + 4 * B * (n + d), n))
+        self.events.append((s, e, 8 * X.nnz + 8 * (n + 1) + 4 * B * (n + d), n, 4.0 * B * X.nnz))
         return r
 
 
@@ -98,13 +111,11 @@ def cpu_baseline(be, peaks, density, seed, sample_cells, n_comps):
     t2 = time.perf_counter()
     # threads the timed legs could use: scipy's sparse kernels and ARPACK's matvec loop are serial
     # (measured: user+sys CPU time / wall time of the two legs)
-    cpu = time.process_time()
     tfidf_oracle.tfidf(m[:2000])
     w0 = time.perf_counter()
     c0 = time.process_time()
     tfidf_oracle.tfidf(m[:2000])
     busy = (time.process_time() - c0) / max(time.perf_counter() - w0, 1e-9)
-    del cpu
     # parity of the product path on the same sample (tolerances of BASELINE.json north_star)
     T = tfidf_device(be, Xs, sample_cells, 3, 1e4)
     _U, stdev, V, info = lsi_device(be, T, n_comps=n_comps, n_obs=sample_cells, return_info=True)
@@ -132,10 +143,181 @@ def cpu_baseline(be, peaks, density, seed, sample_cells, n_comps):
     }, parity
 
 
+def newest_traffic_profile():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_spmm_traffic.json")))
+    return files[-1] if files else None
+
+
+def run_lsi(args, workload, rank, world, local_rank, comm, steps, warmup, cpu_sample_cells):
+    """tfidf + lsi on one workload; returns the JSON object on rank 0 (None elsewhere)."""
+    from muon_amd._atac.preproc import tfidf_device
+    from muon_amd._atac.tools import lsi_device
+    from muon_amd._backend import HipBackend
+
+    wl = dict(WORKLOADS[workload])
+    if args.cells and workload == args.workload:
+        wl["cells"] = args.cells
+    if args.peaks and workload == args.workload:
+        wl["peaks"] = args.peaks
+    d = wl["peaks"]
+    if wl["scaling"] == "strong":
+        n_global = wl["cells"]
+        row0 = rank * n_global // world
+        n_local = (rank + 1) * n_global // world - row0
+    else:
+        n_local = wl["cells"]
+        n_global = n_local * world
+        row0 = rank * n_local
+
+    be = TimedBackend(HipBackend(local_rank))
+    X = be.synth_counts(row0, n_local, d, 50, args.density, args.seed)
+    nnz_local = X.nnz
+    tf_vals = torch.empty_like(X.values)
+    flags = 3  # log_tf | log_idf (reference defaults)
+    info = {}
+
+    def step():
+        T = tfidf_device(be, X, n_global, flags, 1e4, comm=comm, out=tf_vals)
+        U, stdev, V, inf = lsi_device(be, T, n_comps=args.n_comps, n_obs=n_global, comm=comm,
+                                      return_info=True, pack=False if args.no_pack else None)
+        info.update(inf)
+        return U, stdev, V
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    be.events.clear()
+    be.enabled = True
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    be.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel: the row-stream SpMM (both X*Q and X^T*Y run through it)
+    ms = [s.elapsed_time(e) for s, e, _, _, _ in be.events]
+    byt = [b for _, _, b, _, _ in be.events]
+    avg_ms = float(np.mean(ms))
+    achieved = float(np.mean(byt)) / (avg_ms * 1e-3) / 1e9
+    spmm_total_ms = float(np.sum(ms))
+    n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+    lds_floor_ms = float(np.mean([g for *_, g in be.events])) / (LDS_BYTES_PER_CLK_CU * n_cus * SHADER_CLOCK_HZ) * 1e3
+
+    traffic = traffic_detail = traffic_source = None
+    tpath = newest_traffic_profile()
+    tj = None
+    if not args.cells and not args.peaks and not args.no_pack and tpath:
+        with open(tpath) as f:
+            tj = json.load(f).get(f"{n_local}x{d}")  # measured per shape of the rank-0 shard
+    if tj:
+        # bytes per launch, like algorithmic_bytes_per_launch: the two directions weighted as launched
+        n_xq = sum(1 for _, _, _, rows, _ in be.events if rows == n_local)
+        n_xt = len(be.events) - n_xq
+        traffic = (tj["spmm_xq_bytes_per_launch"] * n_xq + tj["spmm_xty_bytes_per_launch"] * n_xt) / max(len(be.events), 1)
+        traffic_source = (f"profiles/{os.path.basename(tpath)}: builder-run rocprofv3 --pmc FETCH_SIZE (x2 gfx950 "
+                          "correction, calibrated on a copy) + WRITE_SIZE, separate passes - not a counter of this run")
+        traffic_detail = {"x_q": tj["spmm_xq_bytes_per_launch"], "xt_y": tj["spmm_xty_bytes_per_launch"],
+                          "vs_algorithmic": traffic / tj["algorithmic_bytes_per_launch"]}
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "cells/sec for TF-IDF+LSI(k=50)",
+            "value": n_global * steps / dt,
+            "unit": "cells/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": wl["scaling"],
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{workload}: planted-topic CSR, {n_global} cells x {d} peaks in total, "
+                            f"{n_local} cells on rank 0 ({wl['scaling']} scaling), {nnz_local} nnz on rank 0 "
+                            f"({nnz_local / n_local / d:.4f} dense), tfidf + lsi(n_comps={args.n_comps})",
+                "parallelism": f"cells row-sharded x{world}" if world > 1 else "1 GPU",
+                "lsi": {"block": info.get("block"), "iterations": info.get("iterations"),
+                        "converged": info.get("converged"), "spmm_per_step": len(ms) // max(steps, 1),
+                        "spmm_unused": info.get("spmm_unused"), "angle_bound": info.get("angle_bound"),
+                        "lanczos_bounds": [float(f"{b:.3g}") for b in info.get("bounds", [])]},
+            },
+            "roofline": {
+                "kernel": ("k_spmm_rowwave (CSR SpMM, f32, B=64: one wave per row, Q rows gathered through L2)"
+                           if args.no_pack else
+                           "k_spmm_win (row-stream SpMM, f32, B=64: Q column slabs in LDS via LDS-DMA, one "
+                           "counted-vmcnt window request per row-set and slab, DPP broadcast)"),
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "frac_of_measured_peak": achieved / 6300.0,  # the guide's achievable HBM rate (SURVEY 8d)
+                "lds_floor_ms": lds_floor_ms,  # B x 4 bytes gathered from LDS per stored entry at 256 B/clk/CU
+                "lds_frac": lds_floor_ms / avg_ms,
+                "traffic": traffic,
+                "traffic_detail": traffic_detail,
+                "avg_launch_ms": avg_ms,
+                "launches": len(ms),
+                "share_of_step": spmm_total_ms / (dt * 1e3),
+                "algorithmic_bytes_per_launch": float(np.mean(byt)),
+            },
+            "traffic_source": traffic_source,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"], out["parity"] = cpu_baseline(be._be, d, args.density, args.seed,
+                                                              min(cpu_sample_cells, n_global), args.n_comps)
+    del X, tf_vals, be
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_c4(args, steps, warmup):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mofa", os.path.join(ROOT, "scripts", "bench_mofa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = ["--gpus", str(args.gpus), "--iters", str(steps), "--warmup", str(max(warmup, 3))]
+    if args.cells and args.workload == "c4":
+        argv += ["--cells", str(args.cells)]
+    if args.no_cpu_baseline:
+        argv += ["--no-cpu-baseline"]
+    return mod.run(argv, init_dist=False)
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 3; c4: 100 iterations)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--cells", type=int, default=None, help="override cells (total if strong, per GPU if weak)")
@@ -145,30 +327,20 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-sample-cells", type=int, default=12000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default workload on one GPU: do not append the c2 / c4 sub-records")
     ap.add_argument("--no-pack", action="store_true",
                     help="ablation: run the SpMM on plain CSR (k_spmm_rowwave, one wave per row) instead of the row streams")
     args = ap.parse_args()
 
-    if args.workload == "c4":
-        import importlib.util
-
-        spec = importlib.util.spec_from_file_location("bench_mofa", os.path.join(ROOT, "scripts", "bench_mofa.py"))
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        argv = ["--gpus", str(args.gpus), "--iters", str(100 if args.steps == 3 else args.steps),
-                "--warmup", str(max(args.warmup, 3))]
-        if args.cells:
-            argv += ["--cells", str(args.cells)]
-        if args.no_cpu_baseline:
-            argv += ["--no-cpu-baseline"]
-        return mod.main(argv)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # test hook (not a measurement mode): all ranks on GPU 0 over gloo, to exercise the multi-rank
     # GPU path on a one-GPU box
     shared_gpu = os.environ.get("MUON_AMD_BENCH_SHARED_GPU") == "1"
@@ -188,131 +360,26 @@ def main():
 
         comm = TorchDistComm()
 
-    from muon_amd._atac.preproc import tfidf_device
-    from muon_amd._atac.tools import lsi_device
-    from muon_amd._backend import HipBackend
-
-    wl = dict(WORKLOADS[args.workload])
-    if args.cells:
-        wl["cells"] = args.cells
-    if args.peaks:
-        wl["peaks"] = args.peaks
-    d = wl["peaks"]
-    if wl["scaling"] == "strong":
-        n_global = wl["cells"]
-        row0 = rank * n_global // world
-        n_local = (rank + 1) * n_global // world - row0
+    if args.workload == "c4":
+        out = run_c4(args, args.steps or 100, args.warmup)
     else:
-        n_local = wl["cells"]
-        n_global = n_local * world
-        row0 = rank * n_local
-
-    be = TimedBackend(HipBackend(local_rank))
-    X = be.synth_counts(row0, n_local, d, 50, args.density, args.seed)
-    nnz_local = X.nnz
-    tf_vals = torch.empty_like(X.values)
-    flags = 3  # log_tf | log_idf (reference defaults)
-
-    info = {}
-
-    def step():
-        T = tfidf_device(be, X, n_global, flags, 1e4, comm=comm, out=tf_vals)
-        U, stdev, V, inf = lsi_device(be, T, n_comps=args.n_comps, n_obs=n_global, comm=comm,
-                                      return_info=True, pack=False if args.no_pack else None)
-        info.update(inf)
-        return U, stdev, V
-
-    def sync():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    be.events.clear()
-    be.enabled = True
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    be.enabled = False
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # dominant kernel: the CSR SpMM (both X*Q and X^T*Y run through it)
-    ms = [s.elapsed_time(e) for s, e, _, _ in be.events]
-    byt = [b for _, _, b, _ in be.events]
-    avg_ms = float(np.mean(ms))
-    achieved = float(np.mean(byt)) / (avg_ms * 1e-3) / 1e9
-    spmm_total_ms = float(np.sum(ms))
-
-    traffic = None
-    traffic_detail = None
-    tpath = os.path.join(ROOT, "profiles", "r02_spmm_traffic.json")
-    tj = None
-    if not args.cells and not args.peaks and not args.no_pack and os.path.exists(tpath):
-        with open(tpath) as f:
-            tj = json.load(f).get(f"{n_local}x{d}")  # measured per shape of the rank-0 shard
-    if tj:
-        # bytes per launch, like algorithmic_bytes_per_launch: the two directions weighted as launched
-        n_xq = sum(1 for _, _, _, rows in be.events if rows == n_local)
-        n_xt = len(be.events) - n_xq
-        traffic = (tj["spmm_xq_bytes_per_launch"] * n_xq + tj["spmm_xty_bytes_per_launch"] * n_xt) / max(len(be.events), 1)
-        traffic_detail = {"x_q": tj["spmm_xq_bytes_per_launch"], "xt_y": tj["spmm_xty_bytes_per_launch"],
-                          "vs_algorithmic": traffic / tj["algorithmic_bytes_per_launch"],
-                          "source": "profiles/r02_spmm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 "
-                                    "correction + WRITE_SIZE, separate passes)"}
-
-    if rank == 0:
-        out = {
-            "metric": "cells/sec for TF-IDF+LSI(k=50)",
-            "value": n_global * args.steps / dt,
-            "unit": "cells/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": wl["scaling"],
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{args.workload}: planted-topic CSR, {n_global} cells x {d} peaks in total, "
-                            f"{n_local} cells on rank 0 ({wl['scaling']} scaling), {nnz_local} nnz on rank 0 "
-                            f"({nnz_local / n_local / d:.4f} dense), tfidf + lsi(n_comps={args.n_comps})",
-                "parallelism": f"cells row-sharded x{world}" if world > 1 else "1 GPU",
-                "lsi": {"block": info.get("block"), "iterations": info.get("iterations"),
-                        "converged": info.get("converged"), "spmm_per_step": len(ms) // max(args.steps, 1),
-                        "spmm_unused": info.get("spmm_unused"), "angle_bound": info.get("angle_bound"),
-                        "lanczos_bounds": [float(f"{b:.3g}") for b in info.get("bounds", [])]},
-            },
-            "roofline": {
-                "kernel": ("k_spmm_rowwave (CSR SpMM, f32, B=64: one wave per row, Q rows gathered through L2)"
-                           if args.no_pack else
-                           "k_spmm_win (row-stream SpMM, f32, B=64: Q column slabs in LDS via LDS-DMA, one "
-                           "counted-vmcnt window request per row-set and slab, DPP broadcast)"),
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "frac_of_measured_peak": achieved / 6300.0,  # the guide's achievable HBM rate
-                "traffic": traffic,
-                "traffic_detail": traffic_detail,
-                "avg_launch_ms": avg_ms,
-                "launches": len(ms),
-                "share_of_step": spmm_total_ms / (dt * 1e3),
-                "algorithmic_bytes_per_launch": float(np.mean(byt)),
-            },
-        }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(be._be, d, args.density, args.seed,
-                                                              args.cpu_sample_cells, args.n_comps)
+        out = run_lsi(args, args.workload, rank, world, local_rank, comm, args.steps or 3, args.warmup,
+                      args.cpu_sample_cells)
+        default_line = (args.workload == "c3" and world == 1 and not (args.cells or args.peaks or args.no_pack
+                                                                       or args.no_secondary))
+        if default_line and out is not None:
+            # the other single-GPU configurations of BASELINE.json, as complete sub-records
+            sec = {}
+            try:
+                sec["c2"] = run_lsi(args, "c2", rank, world, local_rank, comm, 20, 3, 10_000)
+            except Exception as e:  # noqa: BLE001  (the headline line must survive a failing extra)
+                sec["c2"] = {"error": repr(e)}
+            try:
+                sec["c4"] = run_c4(args, 100, 3)
+            except Exception as e:  # noqa: BLE001
+                sec["c4"] = {"error": repr(e)}
+            out["secondary"] = sec
+    if rank == 0 and out is not None:
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

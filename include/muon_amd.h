@@ -193,14 +193,6 @@ int mu_csr_tpack_fill_stream(int64_t n_rows, int64_t n_cols, int64_t nnz, const 
 int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, const void* d_ent,
                        const int32_t* d_perm, int k_layout, const float* d_Q, int B, float* d_Y,
                        void* stream);
-/* Wave-specialised build of the same product for B = 64 (csrc/spmm_ws.hip: 4 window waves prepare the
- * windows of the gather waves).  The stream must be laid out for it: mu_spmm_ws_rows_per_wg() rows per
- * workgroup dealt to mu_spmm_ws_gather_waves() waves (row-set q of a workgroup = gather wave q / K, its
- * row-set q % K, K = rows per workgroup / 4 / gather waves).  Bit-identical results. */
-int mu_spmm_ws_rows_per_wg(void);
-int mu_spmm_ws_gather_waves(void);
-int mu_spmm_ws_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, const void* d_ent,
-                   const int32_t* d_perm, const float* d_Q, int B, float* d_Y, void* stream);
 /* The same row stream (f32 stored values) against an f64 dense block, f64 accumulation and product,
  * B = 16 / 32: mofapy2's default precision (tools.py:308 use_float32=False).  accumulate != 0 adds to
  * d_Y - an f64-valued matrix is the sum of two f32-valued ones (v = fl32(v) + fl32(v - fl32(v)), exact

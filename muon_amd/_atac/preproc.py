@@ -23,22 +23,43 @@ DEVICE_ATTR = "_muon_amd_device"
 _HASH_CHUNK = 1 << 26  # 64 MiB per task
 
 
-def _hash_array(a: np.ndarray) -> int:
-    """xxh3-64 over ALL bytes of ``a`` (chunks hashed on a thread pool - the C extension releases
-    the GIL -, digests combined in order): ~10 GB/s per thread, i.e. milliseconds for the matrices
-    that travel through the AnnData API and comparable to the PCIe upload it saves at 1e9 entries."""
-    import xxhash
+def _digest_fn():
+    """xxh3-64 when the ``xxhash`` package is there (~10 GB/s per thread), else blake2b from the
+    standard library (~1 GB/s per thread; both release the GIL on large buffers).  Logged once."""
+    global _DIGEST
+    if _DIGEST is None:
+        try:
+            import xxhash
 
+            _DIGEST = xxhash.xxh3_64_intdigest
+        except ImportError:
+            import hashlib
+            import logging
+
+            logging.getLogger("muon_amd").info(
+                "xxhash is not installed: fingerprints of resident matrices use hashlib.blake2b (slower)")
+            _DIGEST = lambda buf: int.from_bytes(hashlib.blake2b(buf, digest_size=8).digest(), "little")  # noqa: E731
+    return _DIGEST
+
+
+_DIGEST = None
+
+
+def _hash_array(a: np.ndarray) -> int:
+    """64-bit digest over ALL bytes of ``a`` (chunks hashed on a thread pool, digests combined in
+    order): milliseconds for the matrices that travel through the AnnData API and comparable to the
+    PCIe upload it saves at 1e9 entries."""
+    digest = _digest_fn()
     b = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
     if b.size <= _HASH_CHUNK:
-        return xxhash.xxh3_64_intdigest(b)
+        return digest(b)
     from concurrent.futures import ThreadPoolExecutor
     import os
 
     cuts = list(range(0, b.size, _HASH_CHUNK))
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
-        parts = list(ex.map(lambda o: xxhash.xxh3_64_intdigest(b[o:o + _HASH_CHUNK]), cuts))
-    return xxhash.xxh3_64_intdigest(np.asarray(parts, dtype=np.uint64))
+        parts = list(ex.map(lambda o: digest(b[o:o + _HASH_CHUNK]), cuts))
+    return digest(np.asarray(parts, dtype=np.uint64).view(np.uint8))
 
 
 def _fingerprint(m: csr_matrix):

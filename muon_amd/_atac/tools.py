@@ -2,17 +2,20 @@
 
 Host side mirrors /root/reference/muon/_atac/tools.py:29-71 (signature, write-back into
 ``obsm["X_lsi"]``, ``uns["lsi"]["stdev"]``, ``varm["LSI"]``).  The truncated SVD itself is
-NOT ARPACK (tools.py:53 -> scipy svds): it is a block subspace iteration built on the CSR
-SpMM kernel, judged against the reference by the principal angle between the spans of the
-top-k right singular vectors.
+NOT ARPACK (tools.py:53 -> scipy svds): it is a block Lanczos process on X^T X with full
+re-orthogonalisation, thick restarts and Rayleigh-Ritz over the whole block Krylov space,
+built on the row-stream SpMM kernel and judged against the reference by the largest principal
+angle between the spans of the top-k right singular vectors.
 
-  Q0 = randn(d, B)                          B = 16/32/64 >= n_comps + oversample
-  repeat:  Y = X Q ; Z = X^T Y ; (all-reduce Z over row shards) ; Q = orth(Z)
-  finally: Y = X Q ; G = Y^T Y = W S^2 W^T ; V = Q W ; U = Y W S^-1
+  Q_0 = CholeskyQR2(randn(d, B))            B = 16/32/64 >= n_comps + oversample (wider: several blocks)
+  step j:  Y_j = X Q_j                      (SpMM; cells row-sharded over the ranks)
+           T = [Y_i^T Y_j], M = [Q_i^T Q_j] (f64 Grams on the matrix cores; T all-reduced)
+           Ritz pairs of (T, M)             (<= 192 x 192: device Jacobi when available, else host LAPACK)
+           stop on the Lanczos residual bound of the top-k subspace (Davis-Kahan), else
+           Z = X^T Y_j (SpMM, all-reduce), Z <- (I - K K^T) Z, Q_{j+1} = CholeskyQR2(Z)
+  finally: V = sum_i Q_i c_i ;  U = sum_i Y_i c_i S^-1 (scaling of tools.py:60-63 folded in)
 
-orth() is CholeskyQR2: B x B Gram on the f64 matrix cores, Cholesky of the tiny Gram on
-the host, triangular apply on the f32 matrix cores.  Everything of size nnz, n x B or d x B
-stays in HBM; only B x B matrices cross PCIe.
+Everything of size nnz, n x B or d x B stays in HBM; only B x B blocks cross PCIe.
 """
 from __future__ import annotations
 
@@ -57,21 +60,6 @@ def _chol_inverse(G: np.ndarray, w: int):
         Rinv = V / np.sqrt(lam)
     M[:w, :w] = Rinv
     return M
-
-
-def _ritz_subspace_sine(Ga, Cx, Gb, Wa, Wb) -> float:
-    """sin of the largest principal angle between span(Qa Wa) and span(Qb Wb), from the f64 Grams
-    Ga = Qa^T Qa, Cx = Qa^T Qb, Gb = Qb^T Qb (exact for the stored f32 columns, orthonormal or not)."""
-    A = Wa.T @ Ga @ Wa          # (Qa Wa)^T (Qa Wa)
-    Bm = Wb.T @ Gb @ Wb
-    Cm = Wa.T @ Cx @ Wb
-    La = np.linalg.cholesky((A + A.T) / 2)
-    Lb = np.linalg.cholesky((Bm + Bm.T) / 2)
-    M = np.linalg.solve(La, Cm)            # La^-1 Cm
-    M = np.linalg.solve(Lb, M.T).T         # La^-1 Cm Lb^-T: cosines are its singular values
-    # sin^2 = eigenvalues of I - M^T M (symmetric PSD); take the largest
-    S = np.eye(M.shape[1]) - M.T @ M
-    return float(np.sqrt(max(np.linalg.eigvalsh((S + S.T) / 2)[-1], 0.0)))
 
 
 class _RedoOnHost(Exception):
@@ -249,15 +237,16 @@ def _lsi_device(
     # monomial: the error drops like 1 / T_j(gamma) (Chebyshev) instead of gamma^-j.  Everything the
     # Ritz step needs (Y_i) is a by-product of the iteration; U = X V comes from the Y_i as well.
     #
-    # Stopping rule (n_iter=None).  s_j = sin of the largest principal angle between consecutive
-    # top-k Ritz subspaces (in the M inner product, from the f64 Grams: exact for the stored f32
-    # columns) measures the error of the PREVIOUS subspace; the error of the current one is
-    # err_j ~ s_j rho_j with the contraction rho_j estimated by the last measured one,
-    # s_j / s_{j-1}, but not below 1.5 x the asymptotic Chebyshev rate computed from the Ritz values
-    # (theta_k against the largest unwanted one) nor below 1e-3, nor above 0.9.  Stop when
-    # 3 err_j < angle_tol (default 3e-5, i.e. err_j < 1e-5, ten times under the 1e-4 parity target), when s_j stagnates
-    # at the f32 noise floor, or when the Krylov space is exhausted.  The test sits right after
-    # Y_j = X Q_j, so no product is wasted.
+    # Stopping rule (n_iter=None), evaluated right after Y_j = X Q_j so that no product is wasted: the
+    # Lanczos residual estimate of every top-k Ritz pair, ||r_i|| <= ||B_{j+1}|| ||c_i[last block]||
+    # (valid across thick restarts: Krylov-Schur form), is turned into an angle by Davis-Kahan,
+    # sin(angle_i) <~ ||r_i|| / (theta_i - theta_{k+1}); `bound` is the root sum of squares over the k
+    # vectors and `floor` = 2^-24 theta_1 / gap what f32 storage of the blocks leaves.  Stop when
+    # bound < angle_tol (3e-5), when four expansions bought < 30 % (the f32 floor of an ill-conditioned
+    # subspace), when the gap is zero and the top-k Ritz VALUES have settled to `tol` (relative change
+    # over one expansion: all that can be said about k beyond the rank / sigma_k = sigma_k+1), when the
+    # Krylov space is exhausted, or at max_iter.  `converged` = hypot(bound, floor) < 1e-4: a statement
+    # about the angle, not about having stopped.
     # CholeskyQR with the B x B factorisation on the device wherever the Krylov space cannot run out
     # of independent directions (it can on matrices with a few thousand rows or columns: the host
     # path detects that and truncates)
@@ -427,7 +416,15 @@ def _lsi_device(
                 stop = True
             elif len(bounds) >= 6 and bound > 0.7 * bounds[-5] and bound < 1e-2:
                 stop = True  # four expansions bought < 30 %: the f32 floor of an ill-conditioned subspace
-            stop = bool(comm.agree(stop))  # ranks must leave the loop together
+            elif not np.isfinite(bound) and gap <= 0 and len(history) >= 2 and it >= 2:
+                # no gap behind sigma_k (k beyond the rank, sigma_k = sigma_k+1): no angle can be promised;
+                # stop once the Ritz VALUES have settled to `tol` instead of running to max_iter
+                prev, cur = history[-2] ** 2, lam
+                if np.max(np.abs(cur - prev)) <= tol * max(lam_all[0], 1e-300):
+                    stop = True
+            # ranks must leave the loop together AND speculate together (expect_final gates a product
+            # with its all-reduce): one broadcast carries both of rank 0's decisions
+            stop, expect_final = comm.agree(stop, expect_final)
         host["ritz_ms"] += 1e3 * (time.perf_counter() - t_r)
         if stop:
             # "converged" is a statement about the ANGLE, not about having stopped: the Lanczos bound

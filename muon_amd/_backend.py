@@ -56,7 +56,6 @@ class DeviceStream:
     nnz: int
     perm: Optional[torch.Tensor] = None
     k: int = 0
-    waves: int = 16   # waves a workgroup's row-sets are dealt to: 16, or the gather waves of csrc/spmm_ws.hip
 
     @property
     def n_pos(self) -> int:
@@ -156,14 +155,22 @@ class HipBackend:
         out = torch.empty((n,), dtype=tdt, device=self.device)
         per = max(1, self._UPLOAD_CHUNK // want.itemsize)
         st = self.__dict__.get("_upload_state")
-        if st is None or st["dtype"] != tdt:
-            bufs = [torch.empty((per,), dtype=tdt).pin_memory() for _ in range(3)]
-            st = self._upload_state = {"dtype": tdt, "bufs": bufs, "np": [b.numpy() for b in bufs],
-                                       "stream": torch.cuda.Stream(self.device),
+        if st is None:
+            # staging is raw bytes: int32 / float32 / int64 uploads of one call sequence share the three
+            # pinned buffers, the copy stream and the thread pool (they were keyed by dtype
+            # and rebuilt - 3 x 64 MiB of pinning - whenever the dtype changed)
+            bufs = [torch.empty((self._UPLOAD_CHUNK,), dtype=torch.uint8).pin_memory() for _ in range(3)]
+            st = self._upload_state = {"bufs": bufs, "stream": torch.cuda.Stream(self.device),
                                        "pool": ThreadPoolExecutor(self._UPLOAD_THREADS)}
-        bufs, nps, copy_stream, pool = st["bufs"], st["np"], st["stream"], st["pool"]
+        copy_stream, pool = st["stream"], st["pool"]
+        bufs = [b[: per * want.itemsize].view(tdt) for b in st["bufs"]]
+        nps = [b.numpy() for b in bufs]
         events = [None, None, None]
         T = self._UPLOAD_THREADS
+        cur = torch.cuda.current_stream(self.device)
+        # `out` comes from the caching allocator on the CURRENT stream: the block may still be in use
+        # by kernels queued there; the copies run on a private stream, so order them behind those
+        copy_stream.wait_stream(cur)
 
         def fill(dst, src):
             np.copyto(dst, src, casting="unsafe")  # (memcpy or a converting loop; releases the GIL)
@@ -181,7 +188,8 @@ class HipBackend:
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
             events[b] = ev
-        torch.cuda.current_stream(self.device).wait_stream(copy_stream)
+        cur.wait_stream(copy_stream)
+        out.record_stream(copy_stream)
         copy_stream.synchronize()  # the staging buffers are reused by the next call
         return out
 
@@ -308,41 +316,39 @@ class HipBackend:
         """The row-stream SpMM exists for f32 values and B in (16, 32, 64)."""
         return X.values.dtype == torch.float32 and B in (16, 32, 64) and X.shape[0] > 0 and X.shape[1] > 0
 
-    def _stream_sptr(self, lens_by_pos: torch.Tensor, K: int, waves: int = 16):
+    def _stream_sptr(self, lens_by_pos: torch.Tensor, K: int):
         n_pos = int(lens_by_pos.numel())
         sptr = self.zeros((n_pos + 1,), torch.int64)
         with self._dev_ctx():
             check(self.lib.mu_exclusive_scan_i64(n_pos, _p(lens_by_pos), _p(sptr), self._stream()))
         # cursors are 32-bit byte offsets from the first pair of the workgroup's 64 K rows
-        per_wg = 4 * waves * K
+        per_wg = 64 * K
         span = sptr[per_wg::per_wg] - sptr[:-per_wg:per_wg] if n_pos > per_wg else sptr[-1:] - sptr[:1]
         if span.numel() and int(span.max().item()) * 8 >= (1 << 32) - 256:
             raise NotImplementedError("row stream: the rows of one workgroup span 4 GiB or more")
         return sptr
 
-    def stream(self, X: DeviceCSR, sort_rows: bool = True, K: Optional[int] = None, waves: int = 16) -> DeviceStream:
-        """Row stream of X for the SpMM of the iteration (a streaming copy, once per lsi call).
-        ``waves=self.ws_waves()``: laid out for the wave-specialised kernel (csrc/spmm_ws.hip)."""
+    def stream(self, X: DeviceCSR, sort_rows: bool = True, K: Optional[int] = None) -> DeviceStream:
+        """Row stream of X for the SpMM of the iteration (a streaming copy, once per lsi call)."""
         n, d = X.shape
         assert X.values.dtype == torch.float32
-        want_k = self._ws_k() if waves != 16 else K
-        assert waves in (16, self.ws_waves()) and (waves == 16 or sort_rows)
+        want_k = K
         perm, K, n_pos = None, max(1, int(want_k or self.lib.mu_spmm_stream_k(n))), n
         if sort_rows and n > 0:
-            perm, _inv, K = self.launch_layout(X.indptr[1:] - X.indptr[:-1], want_k, waves)
+            perm, _inv, K = self.launch_layout(X.indptr[1:] - X.indptr[:-1], want_k)
             n_pos = int(perm.numel())
         lens = self.empty((max(n_pos, 1),), torch.int64)[:n_pos]
         with self._dev_ctx():
             st = self._stream()
             check(self.lib.mu_csr_stream_len(n_pos, _p(perm), _p(X.indptr), _p(lens), st))
-            sptr = self._stream_sptr(lens, K, waves)
+            sptr = self._stream_sptr(lens, K)
             ent = self.empty((max(X.nnz, 1),), torch.int64)
             check(self.lib.mu_csr_stream_fill(n_pos, _p(perm), _p(X.indptr), _p(X.indices), _p(X.values),
                                               _p(sptr), _p(ent), st))
-        return DeviceStream(sptr, ent, (n, d), X.nnz, perm, K, waves)
+        return DeviceStream(sptr, ent, (n, d), X.nnz, perm, K)
 
-    def transpose_stream(self, X: DeviceCSR, sort_rows: bool = True, before_fill=None, K: Optional[int] = None,
-                         waves: int = 16) -> DeviceStream:
+    def transpose_stream(self, X: DeviceCSR, sort_rows: bool = True, before_fill=None,
+                         K: Optional[int] = None) -> DeviceStream:
         """Row stream of X^T straight from the CSR of X (no CSR of X^T; stable: cells ascending inside
         every row).  ``before_fill``: called once the count phase is done and before the fill is queued."""
         n, d = X.shape
@@ -354,24 +360,23 @@ class HipBackend:
             st = self._stream()
             check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
                                               _p(work), wb, st))
-            want_k = self._ws_k() if waves != 16 else K
-            assert waves in (16, self.ws_waves()) and (waves == 16 or sort_rows)
+            want_k = K
             perm, inv, K, n_pos = None, None, max(1, int(want_k or self.lib.mu_spmm_stream_k(d))), d
             lens = col_nnz[:d]
             if sort_rows and d > 0:
-                perm, inv, K = self.launch_layout(lens, want_k, waves)
+                perm, inv, K = self.launch_layout(lens, want_k)
                 n_pos = int(perm.numel())
                 plens = torch.zeros((n_pos,), dtype=torch.int64, device=self.device)
                 plens[inv.long()] = lens
             else:
                 plens = lens.contiguous()
-            sptr = self._stream_sptr(plens, K, waves)
+            sptr = self._stream_sptr(plens, K)
             ent = self.empty((max(X.nnz, 1),), torch.int64)
             if before_fill is not None:
                 before_fill()
             check(self.lib.mu_csr_tpack_fill_stream(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
                                                     _p(sptr), _p(inv), _p(ent), _p(work), wb, st))
-        return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K, waves)
+        return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K)
 
     def split_streams(self, X: DeviceCSR):
         """(row streams of X, row streams of X^T) for an f64-valued CSR: see SplitStream."""
@@ -385,16 +390,7 @@ class HipBackend:
             return SplitStream(s_hi, self.stream(Xl)), SplitStream(t_hi, self.transpose_stream(Xl))
         return SplitStream(s_hi, None), SplitStream(t_hi, None)
 
-    def ws_waves(self) -> int:
-        """Gather waves per workgroup of the wave-specialised SpMM (csrc/spmm_ws.hip): pass it as
-        ``waves=`` to stream() / transpose_stream() to lay an operand out for that kernel."""
-        return int(self.lib.mu_spmm_ws_gather_waves())
-
-    def _ws_k(self) -> int:
-        """Row-sets per gather wave of the wave-specialised SpMM."""
-        return int(self.lib.mu_spmm_ws_rows_per_wg()) // (4 * self.ws_waves())
-
-    def launch_layout(self, lens: torch.Tensor, K: Optional[int] = None, waves: int = 16):
+    def launch_layout(self, lens: torch.Tensor, K: Optional[int] = None):
         """Where the rows go in a row stream (include/muon_amd.h): sorted by length (descending,
         stable) and dealt round robin - row-set q of the sorted order goes to workgroup q % n_wg,
         inside it to wave (q // n_wg) % 16 and row-set slot (q // n_wg) // 16 - so that the four rows
@@ -402,7 +398,7 @@ class HipBackend:
         mix.  Returns (perm int32[n_pos], inv int32[n], K)."""
         n = int(lens.numel())
         K = max(1, int(K or self.lib.mu_spmm_stream_k(n)))
-        W = int(waves)
+        W = 16  # waves of a workgroup
         per_wg = 4 * W * K
         n_wg = max(1, (n + per_wg - 1) // per_wg)
         # One workgroup per CU runs at a time (128 KiB of LDS) and the dealt workgroups take equally
@@ -498,13 +494,6 @@ class HipBackend:
             if out is None:
                 assert not accumulate
                 out = self.empty((n, B), Q.dtype)
-            if X.waves != 16:
-                if wide or B != 64:
-                    raise TypeError("a stream laid out for the wave-specialised SpMM serves f32 blocks of width 64")
-                with self._dev_ctx():
-                    check(self.lib.mu_spmm_ws_f32(X.n_pos, d, _p(X.sptr), _p(X.ent), _p(X.perm), _p(Q), B, _p(out),
-                                                  self._stream()))
-                return out
             with self._dev_ctx():
                 if wide:
                     check(self.lib.mu_spmm_stream_f64(X.n_pos, d, _p(X.sptr), _p(X.ent), _p(X.perm), X.k,

@@ -30,8 +30,8 @@ class LocalComm:
     def all_reduce_max(self, t):
         return t
 
-    def agree(self, flag):
-        return bool(flag)
+    def agree(self, *flags):
+        return bool(flags[0]) if len(flags) == 1 else tuple(bool(f) for f in flags)
 
 
 class TorchDistComm:
@@ -96,16 +96,18 @@ class TorchDistComm:
         return float(t.item())
 
 
-    def agree(self, flag):
-        """Rank 0's decision, for every rank: stop / restart / convergence tests are taken from host
-        LAPACK results that need not be bit-identical across ranks (different BLAS builds or CPUs),
-        and a rank that leaves a loop alone strands the others in their next collective."""
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    def agree(self, *flags):
+        """Rank 0's decisions, for every rank (one broadcast for all the flags of a step): stop /
+        restart / speculation / convergence tests are taken from host LAPACK results that need not be
+        bit-identical across ranks (different BLAS builds or CPUs), and a rank that leaves a loop - or
+        queues a product with its collective - alone strands the others in their next collective."""
+        t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32)
         if self._dist.get_backend(self.group) == "nccl":
             t = t.cuda()
         self._dist.broadcast(t, src=self._dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                              group=self.group)
-        return bool(int(t.item()))
+        got = [bool(int(v)) for v in t.tolist()]
+        return got[0] if len(got) == 1 else tuple(got)
 
 
 def default_comm(comm=None):

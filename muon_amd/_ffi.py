@@ -66,9 +66,6 @@ SIGNATURES = {
     "mu_csr_stream_fill": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_csr_tpack_fill_stream": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_stream_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
-    "mu_spmm_ws_rows_per_wg": (C.c_int, []),
-    "mu_spmm_ws_gather_waves": (C.c_int, []),
-    "mu_spmm_ws_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "mu_spmm_stream_f64": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
     "mu_tune_set": (C.c_int, [C.c_char_p, _i32]),
     "mu_tune_get": (C.c_int, [C.c_char_p]),

@@ -1,6 +1,6 @@
 // Row-stream SpMM, wave-specialised (B = 64, f32): Y[n x 64] = X * Q with X a row stream
 // (csrc/spmm_win.hip has the format and the single-role kernel this one grew out of).
-// EXPERIMENT, opt-in (HipBackend.stream(..., waves=12)): bit-identical to k_spmm_win and 17 % slower
+// ARCHIVED EXPERIMENT (r02; not compiled into libmuon_amd.so since r03): bit-identical to k_spmm_win and 17 % slower
 // (5.7 against 4.8 ms at 122 880 x 200 000); DESIGN.md 4.2 and profiles/r02_spmm_ws_accounting.txt.
 //
 // Why.  In k_spmm_win every wave runs stage A (window cut, cursor update, next request: a chain of

@@ -22,7 +22,6 @@ ap.add_argument("--no-packed", action="store_true")
 ap.add_argument("--B", type=int, default=64)
 ap.add_argument("--ks", default="", help="also time layouts dealt for these K (row-sets per wave)")
 ap.add_argument("--k-modes", default="", help="ablation modes to time on the --ks layouts as well")
-ap.add_argument("--ws", action="store_true", help="also time the wave-specialised kernel")
 ap.add_argument("--calibrate", action="store_true",
                 help="run a 4 GiB device copy first (known HBM byte count for PMC calibration)")
 args = ap.parse_args()
@@ -93,33 +92,6 @@ for M, D, tag in ((Ts, Q, "X*Q "), (Tts, Yn, "Xt*Y")):
             print("   cycles per pass and wave: " + ", ".join(f"{n} {float(tt[:, i].mean()) / passes:7.1f}" for i, n in enumerate(names))
                   + f"; sum {float(tt.sum(dim=1).mean()) / passes:7.1f}", flush=True)
     be.tune("spmm_mode", 0)
-
-if args.ws:
-    # wave-specialised kernel (csrc/spmm_ws.hip): its own layout (12 gather waves x 6 row-sets)
-    WSR = int(be.lib.mu_spmm_ws_rows_per_wg())
-    WG = be.ws_waves()
-    A = be.stream(T, waves=WG)
-    got = be.spmm(A, Q)
-    torch.cuda.synchronize()
-    print("X*Q  wave-specialised vs single-role:", "bit-identical" if torch.equal(got, Yn) else "DIFFERS", flush=True)
-    bench(f"X*Q  wave-specialised ({A.n_pos // WSR} workgroups)", A, Q)
-    be.tune("spmm_mode", 64)
-    t = be.spmm(A, Q)
-    be.tune("spmm_mode", 0)
-    nwg = A.n_pos // WSR
-    tt = t.reshape(-1)[: nwg * 16 * 64].reshape(nwg, 16, 64)[:, :, :6].double()
-    slabs = (A.shape[1] + 255) // 256
-    print("   window waves, cycles per slab: " + ", ".join(f"{n} {float(tt[:, WG:, i].mean()) / slabs:7.0f}" for i, n in enumerate(
-        ["DMA issue", "tail row-sets + end", "head of next slab", "-", "slab end", "-"])), flush=True)
-    print("   gather waves, cycles per slab: " + ", ".join(f"{n} {float(tt[:, :WG, i].mean()) / slabs:7.0f}" for i, n in
-        ((0, "waiting for windows"), (1, "stage B"), (4, "barrier"))), flush=True)
-    del A, got, t
-    At = be.transpose_stream(T, waves=WG)
-    got = be.spmm(At, Yn)
-    torch.cuda.synchronize()
-    print("Xt*Y wave-specialised vs single-role:", "bit-identical" if torch.equal(got, Zn) else "DIFFERS", flush=True)
-    bench(f"Xt*Y wave-specialised ({At.n_pos // WSR} workgroups)", At, Yn)
-    del At, got
 
 for K in [int(k) for k in args.ks.split(",") if k]:
     for mode in [0] + [int(m) for m in args.k_modes.split(",") if m]:

@@ -554,21 +554,3 @@ def test_project_out_block_equals_apply_and_subtract(hip, B):
     assert torch.equal(got, want)
 
 
-@pytest.mark.timeout(180)
-def test_wave_specialised_spmm_is_bit_identical(hip):
-    """csrc/spmm_ws.hip (4 window waves hand prepared windows to 12 gather waves through LDS rings;
-    opt-in): same bits as the single-role kernel, on ragged matrices with rows that
-    overflow their windows (more than 16 entries in a 256-column slab), empty rows, and both
-    directions."""
-    rng = np.random.default_rng(77)
-    for n, d, dens in ((700, 3000, 0.03), (5000, 1200, 0.05), (60, 9000, 0.1), (3, 40, 0.5)):
-        m = _heavy_rows_csr(n, d, dens, rng)
-        X = _up(hip, m)
-        Q = hip.randn(d, 64, 3)
-        Y = hip.randn(n, 64, 4)
-        ref = hip.spmm(hip.stream(X), Q)
-        A = hip.stream(X, waves=hip.ws_waves())
-        assert A.waves == hip.ws_waves() and A.n_pos % int(hip.lib.mu_spmm_ws_rows_per_wg()) == 0
-        assert torch.equal(hip.spmm(A, Q), ref)
-        reft = hip.spmm(hip.transpose_stream(X), Y)
-        assert torch.equal(hip.spmm(hip.transpose_stream(X, waves=hip.ws_waves()), Y), reft)

@@ -173,3 +173,27 @@ def test_two_ranks_on_one_gpu_match_the_single_process_result():
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "dist gpu check ok" in r.stdout
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` outside torch.distributed.run (the form the driver uses): bench.py
+    starts its own two ranks (here both on cuda:0 over gloo - the one-GPU test hook) and rank 0 prints
+    one JSON line for the row-sharded workload."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MUON_AMD_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c3shard",
+                        "--cells", "6000", "--peaks", "9000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["lsi"]["converged"]
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["lds_frac"] > 0

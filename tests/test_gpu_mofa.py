@@ -177,3 +177,25 @@ def test_fused_small_nodes_match_tensor_formulas(hip, dtype, K, G, ard, ss):
     # the partial sums are folded in a fixed order
     _again, p2, _z = run(hip, hip.device)
     assert p2 == pgot
+
+
+@pytest.mark.timeout(900)
+def test_engine_matches_oracle_at_the_baseline_feature_dimensions(hip):
+    """BASELINE.json configs[3] at its REAL feature dimensions (20 000 dense + 100 000 sparse features,
+    K = 10) on a 1500-cell sample - what the oracle finishes in seconds: the engine must follow the
+    oracle iteration by iteration from the same initialisation (f64: ELBO 1e-8 relative, <Z>/<W> 1e-6;
+    f32, the timed precision: ELBO 2e-3).  Same code as bench.py's `secondary.c4.parity`."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mofa", os.path.join(root, "scripts", "bench_mofa.py"))
+    bm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bm)
+    n = 1500
+    rna, atac = bm.make_views(hip, 0, n, n, 20_000, 100_000)
+    n, host, dev = bm.sample_views(hip, rna, atac, n)
+    ref, _wall, _cpu, par = bm.oracle_parity(hip, host, dev, n, 3)
+    assert len(ref["elbo"]) == 3
+    assert par["f64"]["elbo_max_rel"] < 1e-8 and par["f64"]["Z_max_abs"] < 1e-6 and par["f64"]["W_max_abs"] < 1e-6
+    assert par["f32"]["elbo_max_rel"] < 2e-3
