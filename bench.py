@@ -193,12 +193,21 @@ def run_lsi(args, workload, rank, world, local_rank, comm, steps, warmup, cpu_sa
     be.events.clear()
     be.enabled = True
     sync()
+    ms0 = torch.cuda.memory_stats(local_rank)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     sync()
     dt = time.perf_counter() - t0
     be.enabled = False
+    ms1 = torch.cuda.memory_stats(local_rank)
+    # device allocations inside the timed region: 0 segments / 0 retries = every buffer of a step came
+    # from the caching allocator (no hipMalloc / hipFree, which synchronise the device)
+    alloc = {"device_mallocs": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+             "device_frees": int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)),
+             "alloc_retries": int(ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0)),
+             "reserved_gb": round(ms1.get("reserved_bytes.all.peak", 0) / 1e9, 1),
+             "allocated_peak_gb": round(ms1.get("allocated_bytes.all.peak", 0) / 1e9, 1)}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -249,6 +258,7 @@ def run_lsi(args, workload, rank, world, local_rank, comm, steps, warmup, cpu_sa
                             f"{n_local} cells on rank 0 ({wl['scaling']} scaling), {nnz_local} nnz on rank 0 "
                             f"({nnz_local / n_local / d:.4f} dense), tfidf + lsi(n_comps={args.n_comps})",
                 "parallelism": f"cells row-sharded x{world}" if world > 1 else "1 GPU",
+                "allocator": alloc,
                 "lsi": {"block": info.get("block"), "iterations": info.get("iterations"),
                         "converged": info.get("converged"), "spmm_per_step": len(ms) // max(steps, 1),
                         "spmm_unused": info.get("spmm_unused"), "angle_bound": info.get("angle_bound"),
