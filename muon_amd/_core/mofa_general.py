@@ -1,0 +1,478 @@
+"""MOFA+ with non-gaussian likelihoods and element-wise missing values.
+
+The reference reaches this through ``likelihoods`` (/root/reference/muon/_core/tools.py:296, guessed
+by mofapy2's ``guess_likelihoods`` when None, :272-280) and through NaN entries of a modality
+(:144-169); the arithmetic is mofapy2's pseudo-data nodes (Seeger bound for poisson counts, Jaakkola
+bound for bernoulli data), which need the dense N x D prediction in every iteration - the reference
+densifies every modality for it (:117-141).
+
+Here every view is a gaussian model on pseudo-data with an ELEMENT-WISE precision (equations:
+oracle/mofa_oracle.py ``run_general``; same schedule and initialisation, so engine and oracle agree
+iteration by iteration), which breaks the per-feature-tau sufficient statistics of ``MofaEngine``:
+
+    W update of view m needs   T_d = sum_n Omega_nd <z_n z_n^T>   (D x K x K)  and  b = R^T <Z>
+    Z update needs             S_n = sum_d Omega_nd <w_d w_d^T>   (N x K x K)  and  a = R <W>
+
+Nothing of size N x D is ever stored: the samples are walked in row chunks (``chunk_elems`` dense
+elements at a time); a sparse modality stays CSR in HBM and only the chunk in flight is densified -
+zeros are data for a count likelihood.  Per chunk the work is dense GEMMs against K- and K^2-column
+blocks plus element-wise transforms: PyTorch-ROCm tensor operations (north_star: "PyTorch-ROCm only
+for the MOFA dense factor blocks").  Three chunk passes per iteration (W statistics, Z update,
+tau / ELBO).  Gaussian models without missing entries keep the two-pass HIP engine (mofa_engine.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+from scipy.sparse import issparse
+
+from .._comm import default_comm
+from .mofa_engine import A0, B0, TH_A0, TH_B0, TOL
+
+LIKELIHOODS = ("gaussian", "poisson", "bernoulli")
+
+
+class _GView:
+    pass
+
+
+def _lambda_jj(x: torch.Tensor) -> torch.Tensor:
+    x = x.abs().clamp(min=1e-8)
+    return torch.tanh(0.5 * x) / (4.0 * x)
+
+
+def _gamma_kl(a0, b0, a, b, ex, elx):
+    lp = a0 * math.log(b0) - math.lgamma(a0) + (a0 - 1.0) * elx - b0 * ex
+    lq = a * torch.log(b) - torch.lgamma(a) + (a - 1.0) * elx - b * ex
+    return lp - lq
+
+
+def _beta_kl(a0, b0, a, b, elx, el1mx):
+    lb = lambda p, q: torch.lgamma(p) + torch.lgamma(q) - torch.lgamma(p + q)  # noqa: E731
+    lb0 = math.lgamma(a0) + math.lgamma(b0) - math.lgamma(a0 + b0)
+    return (lb(a, b) - lb0) + (a0 - a) * elx + (b0 - b) * el1mx
+
+
+class GeneralMofaEngine:
+    """Same driver interface as MofaEngine (step / run / results / elbo)."""
+
+    def __init__(self, backend, views: List, likelihoods: List[str], groups: np.ndarray, n_factors: int, *,
+                 dtype=torch.float64, center_groups=True, scale_views=False, scale_groups=False,
+                 ard_weights=True, ard_factors=True, spikeslab_weights=True, seed=1, comm=None,
+                 row_offset: int = 0, n_total: Optional[int] = None, chunk_elems: int = 1 << 27):
+        assert len(likelihoods) == len(views) and set(likelihoods).issubset(LIKELIHOODS)
+        self.be = backend
+        self.comm = default_comm(comm)
+        self.T = dtype
+        self.K = K = int(n_factors)
+        self.lik = list(likelihoods)
+        self.opts = dict(ard_weights=ard_weights, ard_factors=ard_factors, spikeslab_weights=spikeslab_weights)
+        groups = np.asarray(groups, dtype=np.int64)
+        self.N = N = len(groups)
+        gmax = int(groups.max()) if groups.size else 0
+        if self.comm.world_size > 1:
+            gmax = int(self._allreduce_max(torch.tensor([gmax], dtype=torch.int64)).item())
+        self.G = G = gmax + 1
+        self.perm = np.argsort(groups, kind="stable")
+        gs = groups[self.perm]
+        self.gslice = [(int(np.searchsorted(gs, g, "left")), int(np.searchsorted(gs, g, "right"))) for g in range(G)]
+        self.Ng = self._allreduce(torch.tensor([b - a for a, b in self.gslice], dtype=torch.float64))
+        self.M = len(views)
+        self.chunk_elems = int(chunk_elems)
+        self.views = [self._prepare_view(v, lk, center_groups, scale_views, scale_groups)
+                      for v, lk in zip(views, self.lik)]
+        self.Ds = [v.D for v in self.views]
+        self.dev = self.views[0].dev
+        # initialisation shared with the oracle (oracle/mofa_oracle.py init_state)
+        n_total = N if n_total is None else int(n_total)
+        z0 = np.random.default_rng(seed).standard_normal((n_total, K))[row_offset:row_offset + N]
+        self.EZ = backend.to_device(np.ascontiguousarray(z0[self.perm])).to(dtype)
+        self.EZ2 = self.EZ ** 2 + 1.0
+        self.sig2z = torch.ones_like(self.EZ)
+        c = float(torch.digamma(torch.tensor(1.0, dtype=torch.float64)) - torch.digamma(torch.tensor(2.0, dtype=torch.float64)))
+        self.W = []
+        for D in self.Ds:
+            w = _GView()
+            w.EW = torch.zeros((D, K), dtype=dtype, device=self.dev)
+            w.EW2 = torch.ones((D, K), dtype=dtype, device=self.dev)
+            w.gamma = torch.ones((D, K), dtype=dtype, device=self.dev)
+            w.EWh2 = torch.ones((D, K), dtype=dtype, device=self.dev)
+            w.sig2 = torch.ones((D, K), dtype=dtype, device=self.dev)
+            w.tau = torch.ones((G, D), dtype=dtype, device=self.dev)
+            w.ltau = torch.zeros((G, D), dtype=dtype, device=self.dev)
+            w.alpha = torch.ones((K,), dtype=torch.float64, device=self.dev)
+            w.lalpha = torch.zeros((K,), dtype=torch.float64, device=self.dev)
+            w.lth = torch.full((K,), c, dtype=torch.float64, device=self.dev)
+            w.l1mth = torch.full((K,), c, dtype=torch.float64, device=self.dev)
+            self.W.append(w)
+        self.alpha_z = torch.ones((G, K), dtype=torch.float64, device=self.dev)
+        self.lalpha_z = torch.zeros((G, K), dtype=torch.float64, device=self.dev)
+        self.elbo = []
+
+    # -- collectives ------------------------------------------------------------------------------
+    def _on_comm_device(self, t):
+        if getattr(self.be, "name", "") == "hip" and not t.is_cuda:
+            return t.to(self.be.device)
+        return t
+
+    def _allreduce(self, *ts):
+        if self.comm.world_size > 1:
+            moved = [self._on_comm_device(t) for t in ts]
+            self.comm.all_reduce_sum(*moved)
+            for t, m in zip(ts, moved):
+                if m is not t:
+                    t.copy_(m)
+        return ts[0] if len(ts) == 1 else ts
+
+    def _allreduce_max(self, t):
+        if self.comm.world_size > 1:
+            m = self._on_comm_device(t)
+            self.comm.all_reduce_max(m)
+            t = m.to(t.device)
+        return t
+
+    # -- data ---------------------------------------------------------------------------------------
+    def _rows_per_chunk(self, D):
+        return max(64, self.chunk_elems // max(D, 1))
+
+    def _prepare_view(self, v, lik, center_groups, scale_views, scale_groups):
+        be, T, G, N = self.be, self.T, self.G, self.N
+        V = _GView()
+        V.lik = lik
+        V.D = D = v.shape[1]
+        if issparse(v):
+            m = v.tocsr()[self.perm]
+            m.sort_indices()
+            if np.isnan(m.data).any():
+                raise NotImplementedError("NaN among the stored entries of a sparse modality: densify it "
+                                          "(stored zeros of a sparse matrix are observations)")
+            V.kind = "sparse"
+            V.X = be.upload_csr(m.indptr, m.indices, m.data.astype(np.float64), m.shape)
+            V.X = V.X.with_values(V.X.values.to(T))
+            pres = np.ones(N, dtype=bool)
+            if getattr(v, "_missing_rows", None) is not None:
+                pres = ~np.asarray(v._missing_rows)[self.perm]
+            V.rowmask = be.to_device(pres.astype(np.float64)).to(T)
+            V.mask = None
+            V.dev = V.X.values.device
+        else:
+            a = np.asarray(v, dtype=np.float64)[self.perm]
+            nan = np.isnan(a)
+            V.kind = "dense"
+            V.Y = be.to_device(np.where(nan, 0.0, a)).to(T)
+            V.mask = be.to_device((~nan).astype(np.float64)).to(T) if nan.any() else None
+            V.rowmask = None
+            V.dev = V.Y.device
+        # first / second moments per (group, feature) over the observed entries
+        s1 = torch.zeros((G, D), dtype=torch.float64, device=V.dev)
+        s2 = torch.zeros((G, D), dtype=torch.float64, device=V.dev)
+        cnt = torch.zeros((G, D), dtype=torch.float64, device=V.dev)
+        mx = torch.zeros((D,), dtype=torch.float64, device=V.dev)
+        V.mu = torch.zeros((G, D), dtype=T, device=V.dev)
+        V.scale = torch.ones((G,), dtype=T, device=V.dev)
+        for g, (a0, b0) in enumerate(self.gslice):
+            for lo, hi, Yc, Mc in self._chunks(V, a0, b0, raw=True):
+                Yd = Yc.double()
+                Md = Mc.double() if Mc is not None else None
+                s1[g] += (Yd * Md).sum(dim=0) if Md is not None else Yd.sum(dim=0)
+                s2[g] += (Yd * Yd * Md).sum(dim=0) if Md is not None else (Yd * Yd).sum(dim=0)
+                cnt[g] += Md.sum(dim=0) if Md is not None else float(hi - lo)
+                if hi > lo:
+                    mx = torch.maximum(mx, (Yd * Md if Md is not None else Yd).max(dim=0).values)
+        s1, s2, cnt = self._allreduce(s1, s2, cnt)
+        n = cnt.clamp(min=1.0)
+        V.intercepts = (s1 / n).to(T)  # tools.py:283-286: nanmean per (view, group), whatever the likelihood
+        V.kappa = None
+        if lik == "poisson":
+            V.kappa = (0.25 + 0.17 * self._allreduce_max(mx)).to(T)
+        if lik == "gaussian":
+            mu = s1 / n
+            if not center_groups:
+                mu = (s1.sum(dim=0) / cnt.sum(dim=0).clamp(min=1.0))[None, :].expand(G, D).contiguous()
+            c1 = s1 - cnt * mu
+            yy = s2 - 2 * mu * s1 + cnt * mu * mu
+            scale = torch.ones((G,), dtype=torch.float64, device=V.dev)
+            if scale_groups:
+                for g in range(G):
+                    c = float(cnt[g].sum())
+                    if c > 0:
+                        var = float(yy[g].sum()) / c - (float(c1[g].sum()) / c) ** 2
+                        if var > 0:
+                            scale[g] = 1.0 / math.sqrt(var)
+            elif scale_views:
+                c = float(cnt.sum())
+                if c > 0:
+                    var = float(yy.sum()) / c - (float(c1.sum()) / c) ** 2
+                    if var > 0:
+                        scale = scale / math.sqrt(var)
+            V.mu = mu.to(T)
+            V.scale = scale.to(T)
+        return V
+
+    def _chunks(self, V, a, b, raw=False):
+        """Row chunks [lo, hi) of the samples a..b of a view: (lo, hi, Y, M) with Y the dense chunk
+        (centred / scaled unless ``raw``; unobserved entries 0) and M its 0/1 mask (None: all observed)."""
+        step = self._rows_per_chunk(V.D)
+        for lo in range(a, b, step):
+            hi = min(b, lo + step)
+            if V.kind == "dense":
+                Y = V.Y[lo:hi]
+                M = V.mask[lo:hi] if V.mask is not None else None
+            else:
+                X = V.X
+                p0, p1 = int(X.indptr[lo].item()), int(X.indptr[hi].item())
+                Y = torch.zeros((hi - lo, V.D), dtype=self.T, device=V.dev)
+                if p1 > p0:
+                    rows = torch.repeat_interleave(torch.arange(hi - lo, device=V.dev),
+                                                   (X.indptr[lo + 1:hi + 1] - X.indptr[lo:hi]))
+                    Y[rows, X.indices[p0:p1].long()] = X.values[p0:p1]
+                rm = V.rowmask[lo:hi]
+                M = None if bool((rm == 1).all()) else rm[:, None].expand(hi - lo, V.D)
+            if not raw and V.lik == "gaussian":
+                g = self._group_of(lo)
+                Y = (Y - V.mu[g][None, :]) * V.scale[g]
+                if M is not None:
+                    Y = Y * M
+            yield lo, hi, Y, M
+
+    def _group_of(self, row):
+        for g, (a, b) in enumerate(self.gslice):
+            if a <= row < b:
+                return g
+        raise IndexError(row)
+
+    def _omega_r(self, V, Wm, g, Y, M, Zc, Z2c):
+        """(Omega, R, zeta) of a chunk: the element-wise precision, precision x pseudo-data, prediction."""
+        zeta = Zc @ Wm.EW.T
+        if V.lik == "gaussian":
+            Om = Wm.tau[g][None, :].expand_as(zeta)
+            if M is not None:
+                Om = Om * M
+            return Om, Om * Y, zeta
+        if V.lik == "poisson":
+            rate = torch.nn.functional.softplus(zeta).clamp(min=1e-300 if self.T == torch.float64 else 1e-30)
+            Om = V.kappa[None, :].expand_as(zeta)
+            R = V.kappa[None, :] * zeta - torch.sigmoid(zeta) * (1.0 - Y / rate)
+            if M is not None:
+                Om, R = Om * M, R * M
+            return Om, R, zeta
+        xi2 = zeta ** 2 + Z2c @ Wm.EW2.T - (Zc ** 2) @ (Wm.EW ** 2).T
+        Om = 2.0 * _lambda_jj(torch.sqrt(xi2.clamp(min=0.0)))
+        R = Y - 0.5
+        if M is not None:
+            Om, R = Om * M, R * M
+        return Om, R, zeta
+
+    @staticmethod
+    def _outer_moments(E, E2):
+        """rows -> K^2 columns: <e e^T> with the diagonal replaced by the second moments."""
+        n, K = E.shape
+        P = E[:, :, None] * E[:, None, :]
+        idx = torch.arange(K, device=E.device)
+        P[:, idx, idx] = E2
+        return P.reshape(n, K * K)
+
+    # -- one coordinate-ascent sweep -------------------------------------------------------------------
+    def _update_w(self, m):
+        V, Wm, K = self.views[m], self.W[m], self.K
+        Tm = torch.zeros((V.D, K * K), dtype=self.T, device=self.dev)
+        b = torch.zeros((V.D, K), dtype=self.T, device=self.dev)
+        for g, (a0, b0) in enumerate(self.gslice):
+            for lo, hi, Y, M in self._chunks(V, a0, b0):
+                Zc, Z2c = self.EZ[lo:hi], self.EZ2[lo:hi]
+                Om, R, _ = self._omega_r(V, Wm, g, Y, M, Zc, Z2c)
+                Tm += Om.T @ self._outer_moments(Zc, Z2c)
+                b += R.T @ Zc
+        Tm, b = self._allreduce(Tm, b)
+        Tm = Tm.reshape(V.D, K, K)
+        aw = (Wm.alpha if self.opts["ard_weights"] else torch.ones_like(Wm.alpha)).to(self.T)
+        lth, l1mth = Wm.lth.to(self.T), Wm.l1mth.to(self.T)
+        EW = Wm.EW
+        for k in range(K):
+            t = b[:, k] - (EW * Tm[:, k, :]).sum(dim=1) + EW[:, k] * Tm[:, k, k]
+            prec = Tm[:, k, k] + aw[k]
+            s2 = 1.0 / prec
+            mu = t * s2
+            if self.opts["spikeslab_weights"]:
+                lam = lth[k] - l1mth[k] + 0.5 * torch.log(aw[k]) - 0.5 * torch.log(prec) + 0.5 * t * t * s2
+                gam = torch.sigmoid(lam)
+            else:
+                gam = torch.ones_like(mu)
+            EW[:, k] = gam * mu
+            Wm.EW2[:, k] = gam * (mu * mu + s2)
+            Wm.gamma[:, k] = gam
+            Wm.EWh2[:, k] = gam * (mu * mu + s2) + (1.0 - gam) / aw[k]
+            Wm.sig2[:, k] = s2
+
+    def _update_z(self):
+        K = self.K
+        WW = [self._outer_moments(w.EW, w.EW2) for w in self.W]
+        az = (self.alpha_z if self.opts["ard_factors"] else torch.ones_like(self.alpha_z)).to(self.T)
+        step = min(self._rows_per_chunk(v.D) for v in self.views)
+        for g, (a0, b0) in enumerate(self.gslice):
+            for lo in range(a0, b0, step):
+                hi = min(b0, lo + step)
+                Zc, Z2c = self.EZ[lo:hi], self.EZ2[lo:hi]
+                S = torch.zeros((hi - lo, K * K), dtype=self.T, device=self.dev)
+                a = torch.zeros((hi - lo, K), dtype=self.T, device=self.dev)
+                for m, V in enumerate(self.views):
+                    for l2, h2, Y, M in self._chunks_range(V, lo, hi):
+                        Om, R, _ = self._omega_r(V, self.W[m], g, Y, M, self.EZ[l2:h2], self.EZ2[l2:h2])
+                        S[l2 - lo:h2 - lo] += Om @ WW[m]
+                        a[l2 - lo:h2 - lo] += R @ self.W[m].EW
+                S = S.reshape(hi - lo, K, K)
+                for k in range(K):
+                    num = a[:, k] - (Zc * S[:, k, :]).sum(dim=1) + Zc[:, k] * S[:, k, k]
+                    prec = az[g, k] + S[:, k, k]
+                    Zc[:, k] = num / prec
+                    self.sig2z[lo:hi, k] = 1.0 / prec
+                    Z2c[:, k] = Zc[:, k] ** 2 + 1.0 / prec
+
+    def _chunks_range(self, V, lo, hi):
+        """_chunks restricted to [lo, hi) (a Z-update chunk may span several chunks of a wide view)."""
+        return self._chunks(V, lo, hi)
+
+    def _update_rest_and_elbo(self):
+        o, K, G = self.opts, self.K, self.G
+        f64 = torch.float64
+        lik = torch.zeros((), dtype=f64, device=self.dev)
+        for m, (V, Wm) in enumerate(zip(self.views, self.W)):
+            S = torch.zeros((G, V.D), dtype=f64, device=self.dev)
+            Ngd = torch.zeros((G, V.D), dtype=f64, device=self.dev)
+            part = torch.zeros((), dtype=f64, device=self.dev)
+            W2, Wsq = Wm.EW2, Wm.EW ** 2
+            for g, (a0, b0) in enumerate(self.gslice):
+                for lo, hi, Y, M in self._chunks(V, a0, b0):
+                    Zc, Z2c = self.EZ[lo:hi], self.EZ2[lo:hi]
+                    zeta = Zc @ Wm.EW.T
+                    if V.lik == "gaussian":
+                        res = (Y - zeta) ** 2 + (Z2c @ W2.T - (Zc ** 2) @ Wsq.T)
+                        if M is not None:
+                            res = res * M
+                            Ngd[g] += M.sum(dim=0).to(f64)
+                        else:
+                            Ngd[g] += float(hi - lo)
+                        S[g] += res.sum(dim=0).to(f64)
+                    elif V.lik == "poisson":
+                        rate = torch.nn.functional.softplus(zeta).clamp(min=1e-300 if self.T == f64 else 1e-30)
+                        t = Y * torch.log(rate) - rate
+                        part += ((t * M) if M is not None else t).sum().to(f64)
+                    else:
+                        t = Y * zeta - torch.nn.functional.softplus(zeta)
+                        part += ((t * M) if M is not None else t).sum().to(f64)
+            if V.lik == "gaussian":
+                S, Ngd = self._allreduce(S, Ngd)
+                a = A0 + 0.5 * Ngd
+                b = B0 + 0.5 * S
+                tau, ltau = a / b, torch.digamma(a) - torch.log(b)
+                Wm.tau.copy_(tau.to(self.T))
+                Wm.ltau.copy_(ltau.to(self.T))
+                lik = lik + (0.5 * Ngd * (ltau - math.log(2 * math.pi)) - 0.5 * tau * S).sum()
+                lik = lik + _gamma_kl(A0, B0, a, b, tau, ltau).sum()
+            else:
+                lik = lik + self._allreduce(part)
+            EWh2, gam = Wm.EWh2.to(f64), Wm.gamma.to(f64)
+            if o["ard_weights"]:
+                a = torch.full((K,), A0 + 0.5 * V.D, dtype=f64, device=self.dev)
+                b = B0 + 0.5 * EWh2.sum(dim=0)
+                Wm.alpha, Wm.lalpha = a / b, torch.digamma(a) - torch.log(b)
+            if o["spikeslab_weights"]:
+                sg = gam.sum(dim=0)
+                a, b = TH_A0 + sg, TH_B0 + V.D - sg
+                Wm.lth = torch.digamma(a) - torch.digamma(a + b)
+                Wm.l1mth = torch.digamma(b) - torch.digamma(a + b)
+        # factors: per-group sums over this rank's samples, added up over the ranks
+        zs = torch.zeros((G, 2, K), dtype=f64, device=self.dev)
+        for g, (a0, b0) in enumerate(self.gslice):
+            zs[g, 0] = self.EZ2[a0:b0].to(f64).sum(dim=0)
+            zs[g, 1] = torch.log(self.sig2z[a0:b0].to(f64)).sum(dim=0)
+        zs = self._allreduce(zs)
+        Ng = self.Ng.to(self.dev)
+        if o["ard_factors"]:
+            a = (A0 + 0.5 * Ng)[:, None].expand(G, K)
+            b = B0 + 0.5 * zs[:, 0]
+            self.alpha_z, self.lalpha_z = a / b, torch.digamma(a) - torch.log(b)
+        # ---- prior / entropy terms (the same expressions as oracle run()) ----------------------------------
+        elbo = lik
+        for m, (V, Wm) in enumerate(zip(self.views, self.W)):
+            aw = Wm.alpha if o["ard_weights"] else torch.ones((K,), dtype=f64, device=self.dev)
+            law = Wm.lalpha if o["ard_weights"] else torch.zeros((K,), dtype=f64, device=self.dev)
+            gam, EWh2, sig2 = Wm.gamma.to(f64), Wm.EWh2.to(f64), Wm.sig2.to(f64)
+            elbo = elbo + (0.5 * law - 0.5 * aw * EWh2).sum()
+            elbo = elbo + (gam * 0.5 * torch.log(sig2) + (1 - gam) * 0.5 * torch.log(1.0 / aw) + 0.5).sum()
+            if o["spikeslab_weights"]:
+                elbo = elbo + (gam * Wm.lth + (1 - gam) * Wm.l1mth).sum()
+                ent = -(torch.xlogy(gam, gam) + torch.xlogy(1 - gam, 1 - gam))
+                elbo = elbo + torch.nan_to_num(ent).sum()
+                sg = gam.sum(dim=0)
+                a, b = TH_A0 + sg, TH_B0 + V.D - sg
+                elbo = elbo + _beta_kl(TH_A0, TH_B0, a, b, Wm.lth, Wm.l1mth).sum()
+            if o["ard_weights"]:
+                a = torch.full((K,), A0 + 0.5 * V.D, dtype=f64, device=self.dev)
+                b = B0 + 0.5 * EWh2.sum(dim=0)
+                elbo = elbo + _gamma_kl(A0, B0, a, b, aw, law).sum()
+        az = self.alpha_z if o["ard_factors"] else torch.ones((G, K), dtype=f64, device=self.dev)
+        laz = self.lalpha_z if o["ard_factors"] else torch.zeros((G, K), dtype=f64, device=self.dev)
+        for g in range(G):
+            elbo = elbo + (0.5 * laz[g] * Ng[g] - 0.5 * az[g] * zs[g, 0] + 0.5 * zs[g, 1] + 0.5 * Ng[g]).sum()
+            if o["ard_factors"]:
+                a = (A0 + 0.5 * Ng[g]).expand(K)
+                b = B0 + 0.5 * zs[g, 0]
+                elbo = elbo + _gamma_kl(A0, B0, a, b, az[g], laz[g]).sum()
+        return elbo
+
+    # -- driver ----------------------------------------------------------------------------------------
+    def step(self):
+        for m in range(self.M):
+            self._update_w(m)
+        self._update_z()
+        e = float(self._update_rest_and_elbo().item())
+        self.elbo.append(e)
+        return e
+
+    def run(self, n_iterations=1000, convergence_mode="fast", min_iterations=2, callback=None):
+        tol = TOL[convergence_mode]
+        for it in range(n_iterations):
+            self.step()
+            if callback is not None:
+                callback(it, self)
+            if it >= min_iterations and len(self.elbo) >= 2:
+                if self.comm.agree(100.0 * abs((self.elbo[-1] - self.elbo[-2]) / self.elbo[0]) < tol):
+                    break
+        return len(self.elbo)
+
+    def variance_explained(self):
+        """R2 (%) of every factor alone per (view, group) on the (pseudo-)data of the last sweep."""
+        K, G = self.K, self.G
+        ss = torch.zeros((self.M, G), dtype=torch.float64, device=self.dev)
+        rs = torch.zeros((self.M, G, K), dtype=torch.float64, device=self.dev)
+        for m, (V, Wm) in enumerate(zip(self.views, self.W)):
+            for g, (a0, b0) in enumerate(self.gslice):
+                for lo, hi, Y, M in self._chunks(V, a0, b0):
+                    Zc = self.EZ[lo:hi]
+                    Om, R, _ = self._omega_r(V, Wm, g, Y, M, Zc, self.EZ2[lo:hi])
+                    Yh = torch.where(Om > 0, R / torch.where(Om > 0, Om, torch.ones_like(Om)), torch.zeros_like(R))
+                    obs = (Om > 0).to(self.T) if M is None else M
+                    ss[m, g] += (obs * Yh * Yh).sum().double()
+                    for k in range(K):
+                        res = obs * (Yh - Zc[:, k:k + 1] * Wm.EW[:, k][None, :])
+                        rs[m, g, k] += (res * res).sum().double()
+        ss, rs = self._allreduce(ss, rs)
+        r2 = torch.where(ss[:, :, None] > 0, 100.0 * (1.0 - rs / ss[:, :, None].clamp(min=1e-300)), torch.zeros_like(rs))
+        return r2.cpu().numpy()
+
+    def results(self, sort_factors=True):
+        inv = np.empty_like(self.perm)
+        inv[self.perm] = np.arange(self.N)
+        Z = self.be.to_host(self.EZ)[inv].astype(np.float64)
+        W = [self.be.to_host(w.EW).astype(np.float64) for w in self.W]
+        r2 = self.variance_explained()
+        order = np.arange(self.K)
+        if sort_factors:
+            order = np.argsort(-r2.sum(axis=(0, 1)), kind="stable")
+        return {"Z": Z[:, order], "W": [w[:, order] for w in W], "r2": r2[:, :, order],
+                "elbo": list(self.elbo), "order": order,
+                "intercepts": [self.be.to_host(v.intercepts) for v in self.views]}

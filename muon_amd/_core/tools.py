@@ -108,21 +108,9 @@ def _collect_views(mdata, groups_label, use_raw, use_layer, likelihoods, feature
     assert len(likelihoods) == len(views), "Please specify one likelihood for each view"
     assert set(likelihoods).issubset({"gaussian", "bernoulli", "poisson"}), \
         "Available likelihoods are 'gaussian', 'bernoulli', 'poisson'"
-    if any(l != "gaussian" for l in likelihoods):
-        if not guessed:
-            raise NotImplementedError(
-                f"likelihoods {likelihoods}: only 'gaussian' is implemented on the GPU path "
-                "(pass likelihoods='gaussian' to force it)"
-            )
-        # The reference's default (likelihoods=None, tools.py:272-280) guesses poisson / bernoulli for
-        # integer / binary data, e.g. raw or binarised ATAC counts.  mofapy2 fits those through
-        # pseudo-data that needs the dense N x D prediction in every iteration, which is what this
-        # path exists to avoid; a drop-in call must still run: the views are modelled as gaussian,
-        # loudly.  (Pass likelihoods explicitly to get the NotImplementedError instead.)
-        warn("mofa: guessed likelihoods " + str(likelihoods) + " are not implemented on the GPU path; "
-             "every view is modelled with a gaussian likelihood (as with likelihoods='gaussian'). "
-             "Transform counts first (e.g. TF-IDF / log-normalisation) for a better fit.")
-        likelihoods = ["gaussian"] * len(views)
+    # (r03: poisson / bernoulli views and element-wise NaN run through _core/mofa_general.py - the
+    #  guessed likelihoods are the ones the model is fitted with, as in the reference; r02 fitted
+    #  guessed count likelihoods as gaussian with a warning)
 
     obs = mdata.obs.loc[obs_names]
     if groups_label is None:
@@ -133,6 +121,14 @@ def _collect_views(mdata, groups_label, use_raw, use_layer, likelihoods, feature
         group_names = list(pd.unique(labels))  # order of first appearance (groupby sort=False)
         groups = pd.Index(group_names).get_indexer(labels).astype(np.int64)
     return views, groups, group_names, obs_names, likelihoods
+
+
+def _has_elementwise_nan(v) -> bool:
+    """NaN entries that are not whole missing samples (those are row masks: use_obs='union')."""
+    if issparse(v):
+        return bool(np.isnan(v.data).any())
+    a = np.isnan(np.asarray(v))
+    return bool((a.any(axis=1) & ~a.all(axis=1)).any())
 
 
 def mofa(
@@ -241,19 +237,24 @@ def mofa(
     from .mofa_engine import MofaEngine
 
     logger.info("Building the model...")
-    eng = MofaEngine(
-        backend, views, groups, n_factors,
-        dtype=torch.float32 if use_float32 else torch.float64,
-        center_groups=center_groups, scale_views=scale_views, scale_groups=scale_groups,
-        ard_weights=ard_weights, ard_factors=ard_factors, spikeslab_weights=spikeslab_weights,
-        seed=seed, comm=comm,
-    )
+    kw = dict(dtype=torch.float32 if use_float32 else torch.float64,
+              center_groups=center_groups, scale_views=scale_views, scale_groups=scale_groups,
+              ard_weights=ard_weights, ard_factors=ard_factors, spikeslab_weights=spikeslab_weights,
+              seed=seed, comm=comm)
+    if any(l != "gaussian" for l in lik) or any(_has_elementwise_nan(v) for v in views):
+        # pseudo-data likelihoods / element-wise missing values: element-wise precisions, walked in
+        # row chunks (the sparse modalities stay CSR on the device)
+        from .mofa_general import GeneralMofaEngine
+
+        eng = GeneralMofaEngine(backend, views, list(lik), groups, n_factors, **kw)
+    else:
+        eng = MofaEngine(backend, views, groups, n_factors, **kw)
     logger.info("Running the model...")
     eng.run(n_iterations=n_iterations, convergence_mode=convergence_mode)
     res = eng.results(sort_factors=True)
 
     logger.info("Saving the model...")
-    _save_model(outfile, res, list(mdata.mod.keys()), group_names, obs_used, groups, expectations)
+    written = _save_model(outfile, res, list(mdata.mod.keys()), group_names, obs_used, groups, expectations)
 
     if copy:
         data = data.copy()
@@ -306,6 +307,8 @@ def mofa(
             },
         },
         "elbo": np.asarray(res["elbo"]),
+        # (not in the reference) the file actually written: without h5py the archive is `outfile`.npz
+        "model_file": str(written),
     }
     # Variance explained, R2 in % per factor (tools.py:681-697)
     variance = {m: {} for m in mdata.mod}

@@ -279,3 +279,221 @@ def variance_explained(Y0, mask, gidx, EZ, EW):
                 res = Y0[m][i] - np.outer(EZ[i, k], EW[m][:, k])
                 r2[m, g, k] = 100.0 * (1.0 - (res ** 2).sum() / ss) if ss > 0 else 0.0
     return r2
+
+
+# ------------------------------------------------------------------------------------------------
+# Non-gaussian likelihoods and element-wise missing values (PARITY UNPINNED like the
+# rest of this file: mofapy2 is not under /root/reference).  The reference reaches them through
+# tools.py:272-280 (`guess_likelihoods`) / the `likelihoods` argument (:296) and the NaN handling of
+# :144-169.  Restated here from the published bounds (MOFA, Argelaguet et al. 2018, Methods "Non-
+# gaussian likelihoods", after Seeger & Bouchard 2012 and Jaakkola & Jordan 2000):
+#   every view is a gaussian model on pseudo-data yhat with an element-wise precision Omega,
+#     gaussian   Omega_nd = tau_gd m_nd               R_nd := Omega yhat = tau_gd m_nd y_nd
+#     poisson    Omega_nd = kappa_d m_nd,  kappa_d = 0.25 + 0.17 max_n y_nd   (rate ln(1 + e^zeta))
+#                R_nd = m_nd (kappa_d zeta_nd - sigmoid(zeta_nd) (1 - y_nd / ln(1 + e^zeta_nd)))
+#     bernoulli  Omega_nd = 2 lambda(xi_nd) m_nd,  lambda(x) = tanh(x / 2) / (4 x),  xi^2 = E[(w_d z_n)^2]
+#                R_nd = m_nd (y_nd - 1/2)
+#   with m_nd = 1 where y_nd is observed, zeta = <Z><W>^T.  Expansion points (zeta, xi) are refreshed
+#   from the current expectations before the W update and again before the Z update of an iteration
+#   (any refresh order is a valid coordinate ascent on the bound).  Non-gaussian views are neither
+#   centred nor scaled (process_data touches gaussian views only); tau is a node for gaussian views only.
+#   ELBO data terms: gaussian as above (per element), poisson sum m (y ln rate - rate), bernoulli
+#   sum m (y zeta - ln(1 + e^zeta)), both at zeta = <Z><W>^T after the sweep.
+def _lambda_jj(x):
+    x = np.maximum(np.abs(x), 1e-8)
+    return np.tanh(0.5 * x) / (4.0 * x)
+
+
+def _softplus(x):
+    return np.logaddexp(0.0, x)
+
+
+def _sigmoid(x):
+    return 0.5 * (1.0 + np.tanh(0.5 * x))
+
+
+def _omega_r(lik, Y, Mk, EZ, EZ2, EW, EW2, tau_rows, kappa):
+    """(Omega, R, zeta) of one view for all samples: dense N x D arrays."""
+    zeta = EZ @ EW.T
+    if lik == "gaussian":
+        Om = tau_rows * Mk
+        return Om, Om * Y, zeta
+    if lik == "poisson":
+        rate = np.maximum(_softplus(zeta), 1e-300)
+        Om = kappa[None, :] * Mk
+        return Om, Mk * (kappa[None, :] * zeta - _sigmoid(zeta) * (1.0 - Y / rate)), zeta
+    xi2 = zeta ** 2 + EZ2 @ EW2.T - (EZ ** 2) @ (EW ** 2).T
+    Om = 2.0 * _lambda_jj(np.sqrt(np.maximum(xi2, 0.0))) * Mk
+    return Om, Mk * (Y - 0.5), zeta
+
+
+def run_general(views, likelihoods, groups=None, n_factors=10, n_iterations=1000, convergence_mode="fast",
+                seed=1, ard_weights=True, ard_factors=True, spikeslab_weights=True, center_groups=True,
+                scale_views=False, scale_groups=False, min_iterations=2):
+    """Coordinate-ascent VI with per-view likelihoods in {'gaussian', 'poisson', 'bernoulli'} and
+    element-wise missing values (NaN).  Dense numpy, loops over factors."""
+    M, N = len(views), views[0].shape[0]
+    groups = np.zeros(N, dtype=np.int64) if groups is None else np.asarray(groups, dtype=np.int64)
+    G, K = int(groups.max()) + 1, int(n_factors)
+    Ys, masks, kappas, intercepts = [], [], [], []
+    for m, (Y, lik) in enumerate(zip(views, likelihoods)):
+        Y = np.array(Y, dtype=np.float64, copy=True)
+        if lik == "gaussian":
+            (Y,), (mu,) = prepare_views([Y], groups, center_groups, scale_views, scale_groups)
+        else:
+            mu = np.zeros((G, Y.shape[1]))
+            for g in range(G):
+                with np.errstate(invalid="ignore"):
+                    mu[g] = np.nan_to_num(np.nanmean(Y[groups == g], axis=0)) if (groups == g).any() else 0.0
+        Mk = (~np.isnan(Y)).astype(np.float64)
+        Ys.append(np.nan_to_num(Y))
+        masks.append(Mk)
+        kappas.append(0.25 + 0.17 * (Ys[-1] * Mk).max(axis=0) if lik == "poisson" else None)
+        intercepts.append(mu)
+    Ds = [Y.shape[1] for Y in Ys]
+    st = init_state(N, Ds, G, K, seed)
+    EZ, EZ2 = st["EZ"], st["EZ2"]
+    gidx = [np.nonzero(groups == g)[0] for g in range(G)]
+    Ng = np.array([len(i) for i in gidx], dtype=np.float64)
+    gamma = [np.ones((D, K)) for D in Ds]
+    EWh2 = [np.ones((D, K)) for D in Ds]
+    sig2w = [np.ones((D, K)) for D in Ds]
+    sig2z = np.ones((N, K))
+    pres = [(Mk.sum(axis=1) > 0).astype(np.float64) for Mk in masks]  # sample has any entry in view m
+    elbos = []
+
+    def om_r(m):
+        return _omega_r(likelihoods[m], Ys[m], masks[m], EZ, EZ2, st["EW"][m], st["EW2"][m],
+                        st["tau"][m][groups], kappas[m])
+
+    for it in range(n_iterations):
+        # ---- W ------------------------------------------------------------------------------------
+        for m in range(M):
+            Om, R, _ = om_r(m)
+            EW, EW2 = st["EW"][m], st["EW2"][m]
+            aw = st["alpha_w"][m] if ard_weights else np.ones(K)
+            b = R.T @ EZ                                   # D x K
+            for k in range(K):
+                t = b[:, k].copy()
+                for j in range(K):
+                    if j != k:
+                        t -= EW[:, j] * (Om.T @ (EZ[:, k] * EZ[:, j]))
+                prec = Om.T @ EZ2[:, k] + aw[k]
+                s2 = 1.0 / prec
+                mu = t * s2
+                if spikeslab_weights:
+                    lam = (st["lth"][m][k] - st["l1mth"][m][k] + 0.5 * np.log(aw[k]) - 0.5 * np.log(prec)
+                           + 0.5 * t * t * s2)
+                    gam = 1.0 / (1.0 + np.exp(-lam))
+                else:
+                    gam = np.ones(Ds[m])
+                EW[:, k] = gam * mu
+                EW2[:, k] = gam * (mu * mu + s2)
+                gamma[m][:, k] = gam
+                EWh2[m][:, k] = gam * (mu * mu + s2) + (1.0 - gam) / aw[k]
+                sig2w[m][:, k] = s2
+        # ---- Z ------------------------------------------------------------------------------------
+        OR = [om_r(m) for m in range(M)]
+        az = (st["alpha_z"] if ard_factors else np.ones((G, K)))[groups]  # N x K
+        for k in range(K):
+            num = np.zeros(N)
+            prec = az[:, k].copy()
+            for m in range(M):
+                Om, R, _ = OR[m]
+                EW, EW2 = st["EW"][m], st["EW2"][m]
+                a = R @ EW[:, k]
+                for j in range(K):
+                    if j != k:
+                        a -= EZ[:, j] * (Om @ (EW[:, k] * EW[:, j]))
+                num += a
+                prec += Om @ EW2[:, k]
+            EZ[:, k] = num / prec
+            sig2z[:, k] = 1.0 / prec
+            EZ2[:, k] = EZ[:, k] ** 2 + 1.0 / prec
+        # ---- tau (gaussian views) and the data terms of the ELBO ----------------------------------------
+        lik_sum = 0.0
+        for m in range(M):
+            EW, EW2 = st["EW"][m], st["EW2"][m]
+            zeta = EZ @ EW.T
+            Mk, Y = masks[m], Ys[m]
+            if likelihoods[m] == "gaussian":
+                var = EZ2 @ EW2.T - (EZ ** 2) @ (EW ** 2).T
+                res = Mk * ((Y - zeta) ** 2 + var)
+                for g in range(G):
+                    i = gidx[g]
+                    S = res[i].sum(axis=0)
+                    Ngd = Mk[i].sum(axis=0)
+                    a = A0 + 0.5 * Ngd
+                    b = B0 + 0.5 * S
+                    st["tau"][m][g] = a / b
+                    st["ltau"][m][g] = digamma(a) - np.log(b)
+                    lik_sum += np.sum(0.5 * Ngd * (st["ltau"][m][g] - np.log(2 * np.pi)) - 0.5 * st["tau"][m][g] * S)
+                    lik_sum += np.sum(_gamma_kl(A0, B0, a, b, st["tau"][m][g], st["ltau"][m][g]))
+            elif likelihoods[m] == "poisson":
+                rate = np.maximum(_softplus(zeta), 1e-300)
+                lik_sum += np.sum(Mk * (Y * np.log(rate) - rate))
+            else:
+                lik_sum += np.sum(Mk * (Y * zeta - _softplus(zeta)))
+            if ard_weights:
+                a = A0 + 0.5 * Ds[m]
+                b = B0 + 0.5 * EWh2[m].sum(axis=0)
+                st["alpha_w"][m] = a / b
+                st["lalpha_w"][m] = digamma(a) - np.log(b)
+            if spikeslab_weights:
+                sg = gamma[m].sum(axis=0)
+                a = TH_A0 + sg
+                b = TH_B0 + Ds[m] - sg
+                st["lth"][m] = digamma(a) - digamma(a + b)
+                st["l1mth"][m] = digamma(b) - digamma(a + b)
+        if ard_factors:
+            for g in range(G):
+                a = A0 + 0.5 * Ng[g]
+                b = B0 + 0.5 * EZ2[gidx[g]].sum(axis=0)
+                st["alpha_z"][g] = a / b
+                st["lalpha_z"][g] = digamma(a) - np.log(b)
+        # ---- prior / entropy terms of the ELBO (same as run()) -------------------------------------------
+        elbo = lik_sum
+        for m in range(M):
+            aw = st["alpha_w"][m] if ard_weights else np.ones(K)
+            law = st["lalpha_w"][m] if ard_weights else np.zeros(K)
+            gam = gamma[m]
+            elbo += np.sum(0.5 * law - 0.5 * aw * EWh2[m])
+            elbo += np.sum(gam * 0.5 * np.log(sig2w[m]) + (1 - gam) * 0.5 * np.log(1.0 / aw) + 0.5)
+            if spikeslab_weights:
+                elbo += np.sum(gam * st["lth"][m] + (1 - gam) * st["l1mth"][m])
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    ent = -(gam * np.log(gam) + (1 - gam) * np.log1p(-gam))
+                elbo += np.sum(np.nan_to_num(ent))
+                sg = gam.sum(axis=0)
+                a = TH_A0 + sg; b = TH_B0 + Ds[m] - sg
+                elbo += np.sum(_beta_kl(TH_A0, TH_B0, a, b, st["lth"][m], st["l1mth"][m]))
+            if ard_weights:
+                a = A0 + 0.5 * Ds[m]; b = B0 + 0.5 * EWh2[m].sum(axis=0)
+                elbo += np.sum(_gamma_kl(A0, B0, a, b, aw, law))
+        azg = st["alpha_z"] if ard_factors else np.ones((G, K))
+        laz = st["lalpha_z"] if ard_factors else np.zeros((G, K))
+        for g in range(G):
+            i = gidx[g]
+            elbo += np.sum(0.5 * laz[g] - 0.5 * azg[g] * EZ2[i] + 0.5 * np.log(sig2z[i]) + 0.5)
+            if ard_factors:
+                a = A0 + 0.5 * Ng[g]; b = B0 + 0.5 * EZ2[i].sum(axis=0)
+                elbo += np.sum(_gamma_kl(A0, B0, a, b, azg[g], laz[g]))
+        elbos.append(float(elbo))
+        if it >= min_iterations and len(elbos) >= 2:
+            if 100.0 * abs((elbos[-1] - elbos[-2]) / elbos[0]) < TOL[convergence_mode]:
+                break
+
+    # R2 per factor on the (pseudo-)data the last sweep worked with: yhat = R / Omega where observed
+    r2 = np.zeros((M, G, K))
+    for m in range(M):
+        Om, R, _ = om_r(m)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            Yh = np.where(masks[m] > 0, R / np.where(Om > 0, Om, 1.0), 0.0)
+        for g in range(G):
+            i = gidx[g]
+            ss = (masks[m][i] * Yh[i] ** 2).sum()
+            for k in range(K):
+                res = masks[m][i] * (Yh[i] - np.outer(EZ[i, k], st["EW"][m][:, k]))
+                r2[m, g, k] = 100.0 * (1.0 - (res ** 2).sum() / ss) if ss > 0 else 0.0
+    return {"Z": EZ, "W": st["EW"], "elbo": elbos, "r2": r2, "intercepts": intercepts, "state": st,
+            "iterations": len(elbos), "pres": pres}

@@ -63,9 +63,21 @@ def _worker(rank, world, port, q):
         eng.run(12, "slow")
         res = eng.results(sort_factors=False)
         Zall = comm.all_gather_rows(torch.from_numpy(res["Z"]))
+        # the element-wise-precision engine (poisson counts, sparse; gaussian view with NaN entries)
+        from muon_amd._core.mofa_general import GeneralMofaEngine
+
+        yc = rng.poisson(np.logaddexp(0, Z @ rng.standard_normal((40, 4)).T)).astype(float)
+        yn = y1.copy()
+        yn[rng.random(yn.shape) < 0.1] = np.nan
+        ge = GeneralMofaEngine(be, [yn[a:b], sp.csr_matrix(yc[a:b])], ["gaussian", "poisson"], groups[a:b], 5,
+                               seed=1, comm=comm, row_offset=a, n_total=120, chunk_elems=900)
+        ge.run(6, "slow", min_iterations=100)
+        gres = ge.results(sort_factors=False)
+        gZ = comm.all_gather_rows(torch.from_numpy(gres["Z"]))
         if rank == 0:
             q.put({"tfidf": T.values.numpy(), "U": Uall.numpy(), "stdev": stdev, "V": V.numpy(),
-                   "elbo": res["elbo"], "Z": Zall.numpy(), "W": res["W"], "iters": info["iterations"]})
+                   "elbo": res["elbo"], "Z": Zall.numpy(), "W": res["W"], "iters": info["iterations"],
+                   "g_elbo": gres["elbo"], "g_Z": gZ.numpy(), "g_W": gres["W"], "g_r2": gres["r2"]})
     finally:
         dist.destroy_process_group()
 
@@ -118,3 +130,18 @@ def test_world_size_2_matches_single_process():
     np.testing.assert_allclose(got["Z"], res["Z"], atol=1e-8)
     for a, b in zip(got["W"], res["W"]):
         np.testing.assert_allclose(a, b, atol=1e-8)
+
+    # general engine: the same model on the whole data in one process, and the oracle
+    from muon_amd._core.mofa_general import GeneralMofaEngine
+    from oracle import mofa_oracle
+
+    yc = rng.poisson(np.logaddexp(0, Z @ rng.standard_normal((40, 4)).T)).astype(float)
+    yn = y1.copy()
+    yn[rng.random(yn.shape) < 0.1] = np.nan
+    ref = mofa_oracle.run_general([yn, yc], ["gaussian", "poisson"], groups=groups, n_factors=5, n_iterations=6,
+                                  convergence_mode="slow", min_iterations=100)
+    np.testing.assert_allclose(got["g_elbo"], ref["elbo"], rtol=1e-9)
+    np.testing.assert_allclose(got["g_Z"], ref["Z"], atol=1e-8)
+    for a, b in zip(got["g_W"], ref["W"]):
+        np.testing.assert_allclose(a, b, atol=1e-8)
+    np.testing.assert_allclose(got["g_r2"], ref["r2"], atol=1e-6)

@@ -199,3 +199,34 @@ def test_engine_matches_oracle_at_the_baseline_feature_dimensions(hip):
     assert len(ref["elbo"]) == 3
     assert par["f64"]["elbo_max_rel"] < 1e-8 and par["f64"]["Z_max_abs"] < 1e-6 and par["f64"]["W_max_abs"] < 1e-6
     assert par["f32"]["elbo_max_rel"] < 2e-3
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-9), (torch.float32, 5e-3)])
+def test_general_engine_on_the_gpu_matches_oracle(hip, dt, tol):
+    """SURVEY 8f.3 on the device: gaussian view with element-wise NaN + sparse poisson view (stays CSR
+    in HBM, chunk-wise densified) + bernoulli view, two groups, against oracle.run_general."""
+    from muon_amd._core.mofa_general import GeneralMofaEngine
+    from tests.test_mofa_host import _mixed_views
+
+    _, y1, y2, y3 = _mixed_views(n=400, seed=2)
+    groups = np.random.default_rng(1).integers(0, 2, 400)
+    liks = ["gaussian", "poisson", "bernoulli"]
+    ref = mofa_oracle.run_general([y1, y2, y3], liks, groups=groups, n_factors=5, n_iterations=6,
+                                  convergence_mode="slow", min_iterations=100)
+    eng = GeneralMofaEngine(hip, [y1, sp.csr_matrix(y2), y3], liks, groups, 5, seed=1, dtype=dt, chunk_elems=6000)
+    eng.run(6, "slow", min_iterations=100)
+    res = eng.results(sort_factors=False)
+    np.testing.assert_allclose(res["elbo"], ref["elbo"], rtol=tol)
+    np.testing.assert_allclose(res["Z"], ref["Z"], atol=max(tol * 10, 1e-8))
+
+
+def test_wrapper_fits_count_likelihoods_on_the_gpu():
+    from tests.test_mofa_host import _mixed_views
+
+    _, y1, y2, y3 = _mixed_views(n=300, seed=3)
+    md = MuData({"rna": AnnData(np.nan_to_num(y1)), "counts": AnnData(sp.csr_matrix(y2)), "acc": AnnData(y3)})
+    mu.tl.mofa(md, n_factors=6, n_iterations=25, quiet=True)
+    assert list(md.uns["mofa"]["params"]["data"]["likelihoods"]) == ["gaussian", "poisson", "bernoulli"]
+    assert np.all(np.isfinite(md.obsm["X_mofa"])) and md.obsm["X_mofa"].shape == (300, 6)
+    e = md.uns["mofa"]["elbo"]
+    assert np.all(np.diff(e) > -1e-6 * abs(e[0]))

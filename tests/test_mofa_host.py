@@ -160,14 +160,13 @@ class TestWrapperLikeReference:
             mu.tl.mofa(self.mdata, groups_label="nope", backend=BE)
         with pytest.raises(NotImplementedError):
             mu.tl.mofa(self.mdata, svi_mode=True, backend=BE)
-        # count data with the reference's default likelihoods=None (guessed poisson, tools.py:272-280):
-        # the drop-in call runs as gaussian and says so; asking for poisson explicitly still raises
+        # count data with the reference's default likelihoods=None: guessed poisson (tools.py:272-280)
+        # and fitted as poisson (r02 fell back to gaussian with a warning)
         counts = MuData({"c": AnnData(np.random.default_rng(0).poisson(2, size=(30, 8)).astype(float))})
-        with pytest.warns(UserWarning, match="gaussian likelihood"):
-            mu.tl.mofa(counts, n_factors=2, n_iterations=5, quiet=True, backend=BE)
+        mu.tl.mofa(counts, n_factors=2, n_iterations=5, quiet=True, backend=BE)
         assert counts.obsm["X_mofa"].shape == (30, 2)
-        with pytest.raises(NotImplementedError):
-            mu.tl.mofa(counts, likelihoods="poisson", backend=BE)
+        assert list(counts.uns["mofa"]["params"]["data"]["likelihoods"]) == ["poisson"]
+        mu.tl.mofa(counts, likelihoods="poisson", n_factors=2, n_iterations=3, backend=BE)
 
     def test_use_var_subset_zero_fills(self):
         self.mdata.mod["y1"].var["highly_variable"] = np.arange(90) % 2 == 0
@@ -180,3 +179,83 @@ class TestWrapperLikeReference:
         assert lf.shape == (140, 4) and np.all(lf[~sel] == 0) and np.any(lf[sel] != 0)
         with pytest.warns(UserWarning, match="There is no column"):
             mu.tl.mofa(self.mdata, n_factors=3, use_var="absent", backend=BE)
+
+
+# ---- non-gaussian likelihoods and element-wise missing values ------------------------------
+def _mixed_views(n=150, seed=0):
+    rng = np.random.default_rng(seed)
+    Z = rng.standard_normal((n, 3))
+    W1, W2, W3 = (rng.standard_normal((d, 3)) for d in (40, 60, 50))
+    y1 = Z @ W1.T + 0.5 * rng.standard_normal((n, 40))
+    y2 = rng.poisson(np.logaddexp(0, Z @ W2.T + 1.0)).astype(float)
+    y3 = (rng.random((n, 50)) < 1 / (1 + np.exp(-(Z @ W3.T)))).astype(float)
+    y1[rng.random(y1.shape) < 0.1] = np.nan  # element-wise missing values in the gaussian view
+    return Z, y1, y2, y3
+
+
+@pytest.mark.parametrize("kw", [{}, {"scale_views": True},
+                                {"center_groups": False, "ard_weights": False, "spikeslab_weights": False}])
+def test_general_engine_matches_oracle(kw):
+    """Chunked torch engine (sparse poisson view stays CSR, 3 chunk passes per iteration) against the
+    dense numpy restatement, iteration by iteration: gaussian view with NaN entries + poisson +
+    bernoulli, two groups."""
+    from muon_amd._core.mofa_general import GeneralMofaEngine
+    from oracle import mofa_oracle
+
+    _, y1, y2, y3 = _mixed_views()
+    groups = np.random.default_rng(1).integers(0, 2, 150)
+    liks = ["gaussian", "poisson", "bernoulli"]
+    ref = mofa_oracle.run_general([y1, y2, y3], liks, groups=groups, n_factors=5, n_iterations=8,
+                                  convergence_mode="slow", min_iterations=100, **kw)
+    eng = GeneralMofaEngine(BE, [y1, sp.csr_matrix(y2), y3], liks, groups, 5, seed=1, chunk_elems=1500, **kw)
+    eng.run(8, "slow", min_iterations=100)
+    res = eng.results(sort_factors=False)
+    np.testing.assert_allclose(res["elbo"], ref["elbo"], rtol=1e-10)
+    np.testing.assert_allclose(res["Z"], ref["Z"], atol=1e-9)
+    for a, b in zip(res["W"], ref["W"]):
+        np.testing.assert_allclose(a, b, atol=1e-9)
+    np.testing.assert_allclose(res["r2"], ref["r2"], atol=1e-7)
+    e = np.asarray(ref["elbo"])
+    assert np.all(np.diff(e) > -1e-8 * abs(e[0]))  # the bounds are refreshed consistently: monotone
+
+
+def test_general_oracle_equals_gaussian_oracle_on_complete_data():
+    """run_general with a gaussian likelihood and no missing entry is run(): the element-wise
+    formulation reduces to the sufficient-statistics one."""
+    from oracle import mofa_oracle
+
+    y1, y2 = simple_views()
+    a = mofa_oracle.run([y1, y2], n_factors=6, n_iterations=8, convergence_mode="slow", min_iterations=100)
+    b = mofa_oracle.run_general([y1, y2], ["gaussian", "gaussian"], n_factors=6, n_iterations=8,
+                                convergence_mode="slow", min_iterations=100)
+    np.testing.assert_allclose(a["elbo"], b["elbo"], rtol=1e-12)
+    np.testing.assert_allclose(a["Z"], b["Z"], atol=1e-11)
+
+
+def test_wrapper_fits_guessed_count_likelihoods_and_recovers_planted_factors():
+    """mu.tl.mofa with the reference's default likelihoods=None on count / binary / real-valued
+    modalities (guess: poisson / bernoulli / gaussian, tools.py:272-280): the three planted factors
+    span the leading learnt factors."""
+    from scipy.linalg import subspace_angles
+
+    Z, y1, y2, y3 = _mixed_views(n=300, seed=3)
+    md = MuData({"rna": AnnData(np.nan_to_num(y1)), "counts": AnnData(sp.csr_matrix(y2)), "acc": AnnData(y3)})
+    mu.tl.mofa(md, n_factors=6, n_iterations=60, convergence_mode="slow", quiet=True, backend=BE)
+    assert list(md.uns["mofa"]["params"]["data"]["likelihoods"]) == ["gaussian", "poisson", "bernoulli"]
+    X = md.obsm["X_mofa"]
+    assert X.shape == (300, 6) and md.varm["LFs"].shape == (150, 6)
+    # (count views are not centred - process_data centres gaussian views only -, so one learnt
+    #  factor carries the intercept of the poisson view: the planted three lie in the leading four)
+    ang = np.rad2deg(subspace_angles(Z, X[:, :4]))
+    assert ang.max() < 15.0, ang
+    e = md.uns["mofa"]["elbo"]
+    assert np.all(np.diff(e) > -1e-7 * abs(e[0]))
+
+
+def test_wrapper_elementwise_nan_in_a_dense_modality():
+    y1, y2 = simple_views()
+    y1 = y1.copy()
+    y1[np.random.default_rng(0).random(y1.shape) < 0.05] = np.nan
+    md = MuData({"y1": AnnData(y1), "y2": AnnData(y2)})
+    mu.tl.mofa(md, n_factors=8, n_iterations=30, quiet=True, backend=BE)
+    assert np.all(np.isfinite(md.obsm["X_mofa"])) and md.obsm["X_mofa"].shape == (100, 8)
