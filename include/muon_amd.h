@@ -270,11 +270,29 @@ int mu_mofa_update_w(int dtype, int64_t D, int K, int G, const void* d_B, const 
                      void* d_EWh2, void* d_sig2, void* stream);
 /* Update of the factors, one thread per sample.  A[M][N][K] = Y_m (tau_g o <W_m>) (row n uses its
  * own group's tau), pres[M][N] in {0,1} (sample observed in view m), grp[N] group id,
- * Gw[M][G][K][K] = <W>^T diag(tau_g) <W>, dw2[M][G][K] = sum_d tau_gd <w_dk^2>, alphaz[G][K].
- * In/out EZ[N][K]; out EZ2 = <z^2>, sig2 = posterior variance. */
+ * Gw[M][G][K][K] = <W>^T diag(tau_g) <W>, dw2[M][G][K] = sum_d tau_gd <w_dk^2>, alphaz[G][K],
+ * corr[M][G][K] (nullable): subtracted from A per (view, group) - mu_g^T (tau_g o <W>), the implicit
+ * centring of a sparse view.  In/out EZ[N][K]; out EZ2 = <z^2>, sig2 = posterior variance. */
 int mu_mofa_update_z(int dtype, int64_t N, int K, int M, int G, const void* d_A, const void* d_pres,
                      const int32_t* d_grp, const void* d_Gw, const void* d_dw2, const void* d_alphaz,
-                     void* d_EZ, void* d_EZ2, void* d_sig2, void* stream);
+                     const void* d_corr, void* d_EZ, void* d_EZ2, void* d_sig2, void* stream);
+
+/* The K x K statistics of a factor / weight block E[R][K] (second moments E2) in one pass over rows
+ * r0 .. r1-1 (csrc/mofa_stats.hip; mofapy2 recomputes the same moments inside its node updates,
+ * tools.py:585): with a row weight w (nullable = 1) and an auxiliary row weight a (nullable = 1), both
+ * indexed by the absolute row,
+ *   pad[r][col0 + k] = (scale_out ? w_r : 1) E[r][k]   (leading dimension ld; nullable; the other columns
+ *                      are the caller's - zero padding is written once by the caller)
+ *   out_t[k][r]      = the same value, transposed with leading dimension ld_t (nullable)
+ *   gram[i][j] = sum_r w_r E[r][i] E[r][j],  s2[k] = sum_r w_r E2[r][k],  s1[k] = sum_r a_r w_r E[r][k]
+ * (each nullable).  W side: w = tau_g, a = the feature means of a sparse view -> tau o <W>, Gw, dw2 and the
+ * centring correction; Z side: w = the presence mask -> <Z>, Gz, sum <z^2>, sum <z>.  f64 accumulation,
+ * fixed-order reduction.  d_work: mu_mofa_rowstats_work_doubles(K) doubles. */
+size_t mu_mofa_rowstats_work_doubles(int K);
+int mu_mofa_rowstats(int dtype, int64_t r0, int64_t r1, int K, const void* d_E, const void* d_E2,
+                     const void* d_wgt, const void* d_aux, int scale_out, void* d_out_pad, int ld, int col0,
+                     void* d_out_t, int64_t ld_t, void* d_gram, void* d_s2, void* d_s1, double* d_work,
+                     void* stream);
 
 /* ---- MOFA+ small nodes and the ELBO, fused (tools.py:585 ent.run(): mofapy2's Tau, AlphaW, ThetaW,
  * AlphaZ node updates and calculateELBO()).  Arithmetic in f64 for both storage types; every entry

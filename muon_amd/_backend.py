@@ -601,13 +601,27 @@ class HipBackend:
                                             _p(EW), _p(EW2), _p(gamma), _p(EWh2), _p(sig2),
                                             self._stream()))
 
-    def mofa_update_z(self, A, pres, grp, Gw, dw2, alphaz, EZ, EZ2, sig2):
+    def mofa_update_z(self, A, pres, grp, Gw, dw2, alphaz, EZ, EZ2, sig2, corr=None):
         M, N, K = A.shape
         G = alphaz.shape[0]
         with self._dev_ctx():
             check(self.lib.mu_mofa_update_z(_dt(EZ), N, K, M, G, _p(A), _p(pres), _p(grp), _p(Gw),
-                                            _p(dw2), _p(alphaz), _p(EZ), _p(EZ2), _p(sig2),
+                                            _p(dw2), _p(alphaz), _p(corr), _p(EZ), _p(EZ2), _p(sig2),
                                             self._stream()))
+
+    def mofa_rowstats_work(self, K: int) -> torch.Tensor:
+        return self.empty((int(self.lib.mu_mofa_rowstats_work_doubles(int(K))),), torch.float64)
+
+    def mofa_rowstats(self, E, E2, r0, r1, work, wgt=None, aux=None, scale_out=False, out_pad=None, col0=0,
+                      out_t=None, gram=None, s2=None, s1=None):
+        """One pass over rows r0..r1 of the factor / weight block E (include/muon_amd.h)."""
+        K = E.shape[1]
+        ld = int(out_pad.shape[1]) if out_pad is not None else 0
+        ld_t = int(out_t.shape[1]) if out_t is not None else 0
+        with self._dev_ctx():
+            check(self.lib.mu_mofa_rowstats(_dt(E), int(r0), int(r1), K, _p(E), _p(E2), _p(wgt), _p(aux),
+                                            int(bool(scale_out)), _p(out_pad), ld, int(col0), _p(out_t), ld_t,
+                                            _p(gram), _p(s2), _p(s1), _p(work), self._stream()))
 
     def mofa_elbo_work(self, K: int) -> torch.Tensor:
         return self.empty((int(self.lib.mu_mofa_elbo_work_doubles(int(K))),), torch.float64)

@@ -274,6 +274,35 @@ class MofaEngine:
             V.Ngm_d = V.Ngm.to(dev).to(T).contiguous()
             V.yy = V.yy.contiguous()
             w.a_alpha = torch.tensor(A0 + 0.5 * V.D, dtype=T, device=dev)
+        # fused statistics (csrc/mofa_stats.hip): operands and moments at fixed addresses, the zero
+        # padding of the operand blocks written once
+        self._fused = hasattr(self.be, "mofa_rowstats")
+        if self._fused:
+            M = self.M
+            self._rs_work = self.be.mofa_rowstats_work(K)
+            self._A = torch.zeros((M, self.N, K), dtype=T, device=dev)
+            self._Gw = torch.zeros((M, G, K, K), dtype=T, device=dev)
+            self._dw2 = torch.zeros((M, G, K), dtype=T, device=dev)
+            self._corr = torch.zeros((M, G, K), dtype=T, device=dev)
+            self._pres = torch.stack([v.pres for v in self.views]).contiguous()
+            self._zpad = {}
+            for V in self.views:
+                V.full = bool((V.pres == 1).all().item())
+                if V.kind == "sparse":
+                    V.ld = _pad_block(G * K)
+                    V.TWs = torch.zeros((V.D, V.ld), dtype=T, device=dev)
+                elif K <= 16 and hasattr(self.be, "skinny_tn"):
+                    V.ld = 16
+                    if T == torch.float64 and hasattr(self.be, "skinny_nn"):
+                        V.T16 = [torch.zeros((V.D, 16), dtype=T, device=dev) for _ in range(G)]
+                    else:
+                        V.TWt = [torch.zeros((K, V.D), dtype=T, device=dev) for _ in range(G)]
+                else:
+                    V.ld = 0
+                    V.TWt = [torch.zeros((K, V.D), dtype=T, device=dev) for _ in range(G)]
+                if V.ld and (V.ld, V.kind == "sparse") not in self._zpad:
+                    self._zpad[(V.ld, V.kind == "sparse")] = torch.zeros((self.N, V.ld), dtype=T, device=dev)
+            self._zmom = {}
 
     # -- sufficient statistics --------------------------------------------------------------
     def _zstats(self, m):
@@ -297,7 +326,50 @@ class MofaEngine:
                 dst.copy_(src)
         return buf
 
+    def _z_moments(self, m):
+        """(Gz, Z2, Zs) of view m's presence mask, one pass per group over the factor block
+        (mu_mofa_rowstats); views that observe every sample share one set.  The first call after a Z
+        update also refreshes the padded <Z> operands of the products B = Y^T <Z>."""
+        V, K, G, T, dev = self.views[m], self.K, self.G, self.T, self.EZ.device
+        key = "all" if V.full else m
+        got = self._zmom.get(key)
+        if got is None:
+            Gz = torch.empty((G, K, K), dtype=T, device=dev)
+            Z2 = torch.empty((G, K), dtype=T, device=dev)
+            Zs = torch.empty((G, K), dtype=T, device=dev)
+            pads = list(self._zpad.items()) if not self._zmom else []
+            for g, (a, b) in enumerate(self.gslice):
+                (ld0, st0), pad0 = pads[0] if pads else ((0, False), None)
+                self.be.mofa_rowstats(self.EZ, self.EZ2, a, b, self._rs_work, wgt=None if V.full else V.pres,
+                                      out_pad=pad0, col0=g * K if st0 else 0, gram=Gz[g], s2=Z2[g], s1=Zs[g])
+                for (ld, st), pad in pads[1:]:
+                    c0 = g * K if st else 0
+                    pad[a:b, c0:c0 + K] = self.EZ[a:b]
+            got = self._zmom[key] = (Gz, Z2, Zs)
+        return got
+
+    def _zstats_fused(self, m):
+        V, K, G = self.views[m], self.K, self.G
+        Gz, Z2, Zs = self._z_moments(m)
+        if V.kind == "sparse":
+            out = self.be.spmm(V.Xt, self._zpad[(V.ld, True)])  # D x (G K): X_g^T <Z_g> for every group in one pass
+            B = torch.stack([out[:, g * K:(g + 1) * K] for g in range(G)]) if G > 1 else out[None, :, :K]
+        elif V.ld == 16:
+            Z16 = self._zpad[(16, False)]
+            B = torch.stack([self.be.skinny_tn(V.Y[a:b], Z16[a:b])[:, :K] for a, b in self.gslice])
+        else:
+            B = torch.stack([V.Y[a:b].T @ self.EZ[a:b] for a, b in self.gslice])
+        if self.comm.world_size > 1:
+            B = B.contiguous()
+            Gz, Z2, Zs = Gz.clone(), Z2.clone(), Zs.clone()  # (shared between views: reduce copies)
+            self.comm.all_reduce_sum(Gz, Z2, Zs, B)
+        if V.kind == "sparse":
+            B = B - V.mu[:, :, None] * Zs[:, None, :]  # implicit centring
+        return Gz, Z2, B.contiguous()
+
     def _zstats_fresh(self, m):
+        if getattr(self, "_fused", False):
+            return self._zstats_fused(m)
         V, K, G = self.views[m], self.K, self.G
         Gz = torch.zeros((G, K, K), dtype=self.T, device=self.EZ.device)
         Z2 = torch.zeros((G, K), dtype=self.T, device=self.EZ.device)
@@ -338,7 +410,42 @@ class MofaEngine:
                               Wm.lth, Wm.l1mth, self.opts["spikeslab_weights"], Wm.EW, Wm.EW2,
                               Wm.gamma, Wm.EWh2, Wm.sig2)
 
+    def _update_z_fused(self):
+        """W-side statistics in one pass per (view, group) over the weight block (mu_mofa_rowstats: tau o W
+        as the dense operand, Gw, dw2 and the centring correction), the products A = Y (tau o W), the
+        sample sweep."""
+        K, G, M = self.K, self.G, self.M
+        be, A = self.be, self._A
+        for m, (V, Wm) in enumerate(zip(self.views, self.W)):
+            for g, (a, b) in enumerate(self.gslice):
+                kw = dict(wgt=Wm.tau[g], scale_out=True, gram=self._Gw[m, g], s2=self._dw2[m, g])
+                if V.kind == "sparse":
+                    be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, self._rs_work, aux=V.mu[g], out_pad=V.TWs, col0=g * K,
+                                     s1=self._corr[m, g], **kw)
+                elif hasattr(V, "T16"):
+                    be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, self._rs_work, out_pad=V.T16[g], **kw)
+                    A[m, a:b] = be.skinny_nn(V.Y[a:b], V.T16[g])[:, :K]
+                else:
+                    # (f32: hipBLASLt streams Y at 5.1 TB/s when the K x D operand is the transposed one,
+                    #  scripts/probes/skinny_nn_probe.py: the kernel writes tau o W as K x D)
+                    be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, self._rs_work, out_t=V.TWt[g], **kw)
+                    torch.matmul(V.Y[a:b], V.TWt[g].T, out=A[m, a:b])
+            if V.kind == "sparse":
+                out = be.spmm(V.Xs, V.TWs)  # N x (G K); the centring term goes into the sweep (corr)
+                if G == 1:
+                    A[m].copy_(out[:, :K])
+                else:
+                    for g, (a, b) in enumerate(self.gslice):
+                        A[m, a:b] = out[a:b, g * K:(g + 1) * K]
+        az = self.alpha_z if self.opts["ard_factors"] else torch.ones_like(self.alpha_z)
+        be.mofa_update_z(A, self._pres, self.grp, self._Gw, self._dw2, az.contiguous(), self.EZ, self.EZ2,
+                         self.sig2z, corr=self._corr)
+        self._stats = {}  # <Z> changed: statistics are stale
+        self._zmom = {}
+
     def _update_z(self):
+        if getattr(self, "_fused", False):
+            return self._update_z_fused()
         K, G, M, N = self.K, self.G, self.M, self.N
         dev = self.EZ.device
         A = torch.zeros((M, N, K), dtype=self.T, device=dev)

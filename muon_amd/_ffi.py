@@ -81,7 +81,10 @@ SIGNATURES = {
     "mu_skinny_nn": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mu_skinny_tn": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_mofa_update_w": (C.c_int, [_i32, _i64, _i32, _i32] + [_vp] * 7 + [_i32] + [_vp] * 6),
-    "mu_mofa_update_z": (C.c_int, [_i32, _i64, _i32, _i32, _i32] + [_vp] * 10),
+    "mu_mofa_update_z": (C.c_int, [_i32, _i64, _i32, _i32, _i32] + [_vp] * 11),
+    "mu_mofa_rowstats_work_doubles": (_sz, [_i32]),
+    "mu_mofa_rowstats": (C.c_int, [_i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i64,
+                                   _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_elbo_work_doubles": (_sz, [_i32]),
     "mu_mofa_tau_elbo": (C.c_int, [_i32, _i64, _i32, _i32] + [_vp] * 7 + [_dbl, _dbl] + [_vp] * 5),
     "mu_mofa_w_elbo": (C.c_int, [_i32, _i64, _i32, _i32, _i32] + [_vp] * 3 + [_dbl] * 5 + [_vp] * 7),

@@ -70,17 +70,23 @@ __global__ __launch_bounds__(kMofaThreads) void k_mofa_update_w(
 }
 
 // One thread per sample n.  A[M][N][K], pres[M][N] (1 = sample observed in view m), grp[N],
-// Gw[M][G][K][K] = <W>^T diag(tau_g) <W>, dw2[M][G][K] = sum_d tau_gd <w_dk^2>, alphaz[G][K].
+// Gw[M][G][K][K] = <W>^T diag(tau_g) <W>, dw2[M][G][K] = sum_d tau_gd <w_dk^2>, alphaz[G][K],
+// corr[M][G][K] (nullable) = mu_g^T (tau_g o <W>): the implicit centring of a sparse view, taken off A.
 template <typename T, int KP>
 __global__ __launch_bounds__(kMofaThreads) void k_mofa_update_z(
     int64_t N, int K, int M, int G, const T* __restrict__ A, const T* __restrict__ pres,
     const int32_t* __restrict__ grp, const T* __restrict__ Gw, const T* __restrict__ dw2,
-    const T* __restrict__ alphaz, T* __restrict__ EZ, T* __restrict__ EZ2, T* __restrict__ sig2) {
+    const T* __restrict__ alphaz, const T* __restrict__ corr, T* __restrict__ EZ, T* __restrict__ EZ2,
+    T* __restrict__ sig2) {
   extern __shared__ char smem_raw[];
   T* sGw = reinterpret_cast<T*>(smem_raw);  // M*G*K*K
   T* sdw = sGw + M * G * K * K;              // M*G*K
+  T* sco = sdw + M * G * K;                  // M*G*K
   for (int i = threadIdx.x; i < M * G * K * K; i += kMofaThreads) sGw[i] = Gw[i];
-  for (int i = threadIdx.x; i < M * G * K; i += kMofaThreads) sdw[i] = dw2[i];
+  for (int i = threadIdx.x; i < M * G * K; i += kMofaThreads) {
+    sdw[i] = dw2[i];
+    sco[i] = corr ? corr[i] : (T)0;
+  }
   __syncthreads();
   const int64_t n = (int64_t)blockIdx.x * kMofaThreads + threadIdx.x;
   if (n >= N) return;
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(kMofaThreads) void k_mofa_update_z(
 #pragma unroll
         for (int j = 0; j < KP; ++j)
           if (j < K && j != k) cross += z[j] * gw[j * K + k];
-        num += pm * (A[((int64_t)m * N + n) * K + k] - cross);
+        num += pm * (A[((int64_t)m * N + n) * K + k] - sco[(m * G + g) * K + k] - cross);
         prec += pm * sdw[(m * G + g) * K + k];
       }
       const T s2 = (T)1 / prec;
@@ -129,12 +135,12 @@ static int launch_w(int64_t D, int K, int G, const void* B, const void* tau, con
 
 template <typename T>
 static int launch_z(int64_t N, int K, int M, int G, const void* A, const void* pres,
-                    const int32_t* grp, const void* Gw, const void* dw2, const void* alphaz, void* EZ,
-                    void* EZ2, void* sig2, hipStream_t st) {
+                    const int32_t* grp, const void* Gw, const void* dw2, const void* alphaz,
+                    const void* corr, void* EZ, void* EZ2, void* sig2, hipStream_t st) {
   const unsigned blocks = (unsigned)((N + kMofaThreads - 1) / kMofaThreads);
-  const size_t sh = (size_t)(M * G * K * K + M * G * K) * sizeof(T);
+  const size_t sh = (size_t)(M * G * K * K + 2 * M * G * K) * sizeof(T);
 #define ARGS N, K, M, G, (const T*)A, (const T*)pres, grp, (const T*)Gw, (const T*)dw2, \
-             (const T*)alphaz, (T*)EZ, (T*)EZ2, (T*)sig2
+             (const T*)alphaz, (const T*)corr, (T*)EZ, (T*)EZ2, (T*)sig2
   if (K <= 16) hipLaunchKernelGGL((k_mofa_update_z<T, 16>), dim3(blocks), dim3(kMofaThreads), sh, st, ARGS);
   else hipLaunchKernelGGL((k_mofa_update_z<T, 32>), dim3(blocks), dim3(kMofaThreads), sh, st, ARGS);
 #undef ARGS
@@ -163,19 +169,19 @@ int mu_mofa_update_w(int dtype, int64_t D, int K, int G, const void* d_B, const 
 
 int mu_mofa_update_z(int dtype, int64_t N, int K, int M, int G, const void* d_A, const void* d_pres,
                      const int32_t* d_grp, const void* d_Gw, const void* d_dw2, const void* d_alphaz,
-                     void* d_EZ, void* d_EZ2, void* d_sig2, void* stream) {
+                     const void* d_corr, void* d_EZ, void* d_EZ2, void* d_sig2, void* stream) {
   MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
   MU_REQUIRE(K >= 1 && K <= 32, "1 <= n_factors <= 32");
-  MU_REQUIRE(M >= 1 && G >= 1 && (size_t)(M * G * K * K + M * G * K) * 8 <= 60000,
+  MU_REQUIRE(M >= 1 && G >= 1 && (size_t)(M * G * K * K + 2 * M * G * K) * 8 <= 60000,
              "too many views x groups for one LDS tile");
   if (N == 0) return MU_OK;
   MU_REQUIRE(d_A && d_pres && d_grp && d_Gw && d_dw2 && d_alphaz && d_EZ && d_EZ2 && d_sig2,
              "null pointer");
   if (dtype == MU_DTYPE_F32)
-    return launch_z<float>(N, K, M, G, d_A, d_pres, d_grp, d_Gw, d_dw2, d_alphaz, d_EZ, d_EZ2, d_sig2,
-                           (hipStream_t)stream);
-  return launch_z<double>(N, K, M, G, d_A, d_pres, d_grp, d_Gw, d_dw2, d_alphaz, d_EZ, d_EZ2, d_sig2,
-                          (hipStream_t)stream);
+    return launch_z<float>(N, K, M, G, d_A, d_pres, d_grp, d_Gw, d_dw2, d_alphaz, d_corr, d_EZ, d_EZ2,
+                           d_sig2, (hipStream_t)stream);
+  return launch_z<double>(N, K, M, G, d_A, d_pres, d_grp, d_Gw, d_dw2, d_alphaz, d_corr, d_EZ, d_EZ2,
+                          d_sig2, (hipStream_t)stream);
 }
 
 }  // extern "C"

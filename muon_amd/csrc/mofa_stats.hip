@@ -1,0 +1,139 @@
+// MOFA+: the K x K statistics of a factor / weight block in ONE pass over the block (r03).
+//
+// Between the two passes over the data an iteration needs, per view and group,
+//   W side:  TW = tau_g o <W> (the dense operand of A = Y (tau o W)),  Gw = <W>^T diag(tau_g) <W>,
+//            dw2 = sum_d tau_gd <w_dk^2>,  corr = mu_g^T (tau_g o <W>) (implicit centring of a sparse view)
+//   Z side:  Zst = <Z_g> (the dense operand of B = Y^T Z),  Gz = <Z_g>^T diag(pres) <Z_g>,
+//            Z2 = sum_n pres <z_nk^2>,  Zs = sum_n pres <z_nk>
+// r02 assembled them from ~110 small tensor operations per iteration (zero fills, paddings, slices,
+// element-wise products, reductions, two tall-skinny Gram launches each: ~0.9 of 6.8 ms on
+// BASELINE configs[3]).  Both sides are the same computation on an R x K block E with second moments
+// E2, a row weight w and an auxiliary row weight a:
+//   pad[r, col0 + k] = (scale_out ? w_r : 1) E[r, k]        (and its transpose, optionally)
+//   gram[i, j] = sum_r w_r E[r, i] E[r, j],  s2[k] = sum_r w_r E2[r, k],  s1[k] = sum_r a_r w_r E[r, k]
+// f64 accumulation, fixed-order two-level reduction (bit-reproducible).  These sit where mofapy2's node
+// updates recompute the same moments (/root/reference/muon/_core/tools.py:585 -> ent.run()).
+#include "common.hpp"
+
+namespace {
+
+constexpr int kST = 256;          // threads per block
+constexpr int kSBlocksMax = 512;  // partial blocks
+
+// thread t: column j = t % KP of rows t / KP, t / KP + kST / KP, ...
+template <typename T, int KP>
+__global__ __launch_bounds__(kST) void k_rowstats(int64_t r0, int64_t r1, int K, const T* __restrict__ E,
+                                                  const T* __restrict__ E2, const T* __restrict__ wgt,
+                                                  const T* __restrict__ aux, int scale_out,
+                                                  T* __restrict__ out_pad, int ld, int col0,
+                                                  T* __restrict__ out_t, int64_t ld_t,
+                                                  double* __restrict__ partial) {
+  constexpr int kRows = kST / KP;
+  __shared__ double sh[kST];
+  const int j = threadIdx.x % KP, rr = threadIdx.x / KP;
+  double g[KP];
+#pragma unroll
+  for (int i = 0; i < KP; ++i) g[i] = 0.0;
+  double s2 = 0.0, s1 = 0.0;
+  if (j < K) {
+    for (int64_t r = r0 + (int64_t)blockIdx.x * kRows + rr; r < r1; r += (int64_t)gridDim.x * kRows) {
+      const T w = wgt ? wgt[r] : (T)1;
+      const T a = aux ? aux[r] : (T)1;
+      const T* e = E + r * K;
+      const T ej = e[j];
+      const double wej = (double)w * (double)ej;
+#pragma unroll
+      for (int i = 0; i < KP; ++i)
+        if (i < K) g[i] += wej * (double)e[i];
+      s2 += (double)w * (double)E2[r * K + j];
+      s1 += (double)a * wej;
+      const T o = scale_out ? (T)(w * ej) : ej;
+      if (out_pad) out_pad[r * ld + col0 + j] = o;
+      if (out_t) out_t[(int64_t)j * ld_t + r] = o;
+    }
+  }
+  // block reduction over the kRows row groups, value by value (K + 2 values per column)
+  const int width = K * K + 2 * K;
+  double* dst = partial + (int64_t)blockIdx.x * width;
+  for (int v = 0; v < KP + 2; ++v) {
+    double x = 0.0;
+    if (v < KP) {
+#pragma unroll
+      for (int i = 0; i < KP; ++i)
+        if (i == v) x = g[i];
+    } else {
+      x = v == KP ? s2 : s1;
+    }
+    __syncthreads();
+    sh[threadIdx.x] = x;
+    __syncthreads();
+    if (rr == 0 && j < K && (v >= KP || v < K)) {
+      double s = 0.0;
+      for (int q = 0; q < kRows; ++q) s += sh[q * KP + j];
+      if (v < KP) dst[v * K + j] = s;              // gram[v][j]
+      else dst[K * K + (v - KP) * K + j] = s;      // s2[j], s1[j]
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kST) void k_rowstats_fold(int nb, int K, const double* __restrict__ partial,
+                                                       T* __restrict__ gram, T* __restrict__ s2,
+                                                       T* __restrict__ s1) {
+  const int width = K * K + 2 * K;
+  for (int i = threadIdx.x; i < width; i += kST) {
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += partial[(int64_t)b * width + i];
+    if (i < K * K) { if (gram) gram[i] = (T)s; }
+    else if (i < K * K + K) { if (s2) s2[i - K * K] = (T)s; }
+    else if (s1) s1[i - K * K - K] = (T)s;
+  }
+}
+
+template <typename T>
+int run(int64_t r0, int64_t r1, int K, const void* E, const void* E2, const void* wgt, const void* aux,
+        int scale_out, void* out_pad, int ld, int col0, void* out_t, int64_t ld_t, void* gram, void* s2,
+        void* s1, double* work, hipStream_t st) {
+  const int KP = K <= 16 ? 16 : 32;
+  const int64_t rows = r1 - r0, per = kST / KP;
+  int nb = (int)((rows + per * 8 - 1) / (per * 8));  // >= 8 rows per thread group
+  if (nb < 1) nb = 1;
+  if (nb > kSBlocksMax) nb = kSBlocksMax;
+#define ARGS r0, r1, K, (const T*)E, (const T*)E2, (const T*)wgt, (const T*)aux, scale_out, (T*)out_pad, ld, \
+             col0, (T*)out_t, ld_t, work
+  if (K <= 16) hipLaunchKernelGGL((k_rowstats<T, 16>), dim3(nb), dim3(kST), 0, st, ARGS);
+  else hipLaunchKernelGGL((k_rowstats<T, 32>), dim3(nb), dim3(kST), 0, st, ARGS);
+#undef ARGS
+  MU_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_rowstats_fold<T>, dim3(1), dim3(kST), 0, st, nb, K, work, (T*)gram, (T*)s2, (T*)s1);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mu_mofa_rowstats_work_doubles(int K) {
+  const int k = K > 0 ? K : 1;
+  return (size_t)kSBlocksMax * (size_t)(k * k + 2 * k);
+}
+
+int mu_mofa_rowstats(int dtype, int64_t r0, int64_t r1, int K, const void* d_E, const void* d_E2,
+                     const void* d_wgt, const void* d_aux, int scale_out, void* d_out_pad, int ld, int col0,
+                     void* d_out_t, int64_t ld_t, void* d_gram, void* d_s2, void* d_s1, double* d_work,
+                     void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  MU_REQUIRE(K >= 1 && K <= 32, "1 <= n_factors <= 32");
+  MU_REQUIRE(r0 >= 0 && r1 >= r0, "bad row range");
+  MU_REQUIRE(d_E && d_E2 && d_work, "null pointer");
+  MU_REQUIRE(!d_out_pad || (ld >= col0 + K && col0 >= 0), "padded block too narrow");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MU_DTYPE_F32)
+    return run<float>(r0, r1, K, d_E, d_E2, d_wgt, d_aux, scale_out, d_out_pad, ld, col0, d_out_t, ld_t,
+                      d_gram, d_s2, d_s1, d_work, st);
+  return run<double>(r0, r1, K, d_E, d_E2, d_wgt, d_aux, scale_out, d_out_pad, ld, col0, d_out_t, ld_t,
+                     d_gram, d_s2, d_s1, d_work, st);
+}
+
+}  // extern "C"

@@ -232,9 +232,32 @@ class CpuTestBackend:
             elbo += self._gamma_kl(a0, b0, a, b, az, laz).sum()
         elbo += (0.5 * laz * n - 0.5 * az * zs[:, 0] + 0.5 * zs[:, 1] + 0.5 * n).sum()
 
-    def mofa_update_z(self, A, pres, grp, Gw, dw2, alphaz, EZ, EZ2, sig2):
+    def mofa_rowstats_work(self, K):
+        return torch.zeros((1,), dtype=torch.float64)
+
+    def mofa_rowstats(self, E, E2, r0, r1, work, wgt=None, aux=None, scale_out=False, out_pad=None, col0=0,
+                      out_t=None, gram=None, s2=None, s1=None):
+        K = E.shape[1]
+        e, e2 = E[r0:r1].double(), E2[r0:r1].double()
+        w = wgt[r0:r1].double() if wgt is not None else torch.ones(r1 - r0, dtype=torch.float64)
+        a = aux[r0:r1].double() if aux is not None else torch.ones(r1 - r0, dtype=torch.float64)
+        o = (w[:, None] * e) if scale_out else e
+        if out_pad is not None:
+            out_pad[r0:r1, col0:col0 + K] = o.to(out_pad.dtype)
+        if out_t is not None:
+            out_t[:K, r0:r1] = o.T.to(out_t.dtype)
+        if gram is not None:
+            gram.copy_(((w[:, None] * e).T @ e).to(gram.dtype))
+        if s2 is not None:
+            s2.copy_((w[:, None] * e2).sum(dim=0).to(s2.dtype))
+        if s1 is not None:
+            s1.copy_(((a * w)[:, None] * e).sum(dim=0).to(s1.dtype))
+
+    def mofa_update_z(self, A, pres, grp, Gw, dw2, alphaz, EZ, EZ2, sig2, corr=None):
         M, N, K = A.shape
         g = grp.long()
+        if corr is not None:
+            A = A - corr[:, g, :]  # M x N x K
         for k in range(K):
             num = torch.zeros(N, dtype=EZ.dtype)
             prec = alphaz[g, k].clone()

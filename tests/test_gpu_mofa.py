@@ -230,3 +230,40 @@ def test_wrapper_fits_count_likelihoods_on_the_gpu():
     assert np.all(np.isfinite(md.obsm["X_mofa"])) and md.obsm["X_mofa"].shape == (300, 6)
     e = md.uns["mofa"]["elbo"]
     assert np.all(np.diff(e) > -1e-6 * abs(e[0]))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("K,R", [(10, 5000), (16, 777), (3, 70000), (20, 1234)])
+def test_rowstats_kernel_matches_tensor_formulas(hip, dtype, K, R):
+    """csrc/mofa_stats.hip: padded operand, transposed operand, weighted Gram, second- and first-moment
+    sums of a factor / weight block in one pass, against the same formulas as tensor operations."""
+    g = torch.Generator(device="cuda").manual_seed(K * 1000 + R)
+    E = torch.randn((R, K), generator=g, device="cuda", dtype=dtype)
+    E2 = E ** 2 + torch.rand((R, K), generator=g, device="cuda", dtype=dtype)
+    w = torch.rand((R,), generator=g, device="cuda", dtype=dtype) + 0.5
+    a = torch.randn((R,), generator=g, device="cuda", dtype=dtype)
+    work = hip.mofa_rowstats_work(K)
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    for r0, r1, wgt, aux, scale in ((0, R, w, a, True), (R // 3, R - 5, None, None, False), (7, 7, w, None, True)):
+        ld, col0 = 32, 3
+        pad = torch.full((R, ld), 7.0, device="cuda", dtype=dtype)
+        out_t = torch.full((K, R), 7.0, device="cuda", dtype=dtype)
+        gram = torch.empty((K, K), device="cuda", dtype=dtype)
+        s2 = torch.empty((K,), device="cuda", dtype=dtype)
+        s1 = torch.empty((K,), device="cuda", dtype=dtype)
+        hip.mofa_rowstats(E, E2, r0, r1, work, wgt=wgt, aux=aux, scale_out=scale, out_pad=pad, col0=col0,
+                          out_t=out_t, gram=gram, s2=s2, s1=s1)
+        e, e2 = E[r0:r1].double(), E2[r0:r1].double()
+        ww = wgt[r0:r1].double() if wgt is not None else torch.ones(r1 - r0, device="cuda", dtype=torch.float64)
+        aa = aux[r0:r1].double() if aux is not None else torch.ones(r1 - r0, device="cuda", dtype=torch.float64)
+        o = (ww[:, None] * e) if scale else e
+        want_pad = torch.full((R, ld), 7.0, device="cuda", dtype=torch.float64)
+        want_pad[r0:r1, col0:col0 + K] = o
+        want_t = torch.full((K, R), 7.0, device="cuda", dtype=torch.float64)
+        want_t[:, r0:r1] = o.T
+        scale_g = max(float(((ww[:, None] * e).T @ e).abs().max()), 1.0)
+        assert torch.allclose(pad.double(), want_pad, rtol=tol, atol=tol)
+        assert torch.allclose(out_t.double(), want_t, rtol=tol, atol=tol)
+        assert float((gram.double() - (ww[:, None] * e).T @ e).abs().max()) <= tol * scale_g
+        assert float((s2.double() - (ww[:, None] * e2).sum(0)).abs().max()) <= tol * scale_g
+        assert float((s1.double() - ((aa * ww)[:, None] * e).sum(0)).abs().max()) <= tol * scale_g
