@@ -12,5 +12,6 @@ Everything else of muon (I/O, plotting, clustering, ...) is out of scope; see DE
 from ._containers import AnnData, MuData  # duck-typed stand-ins when anndata/mudata are absent
 from . import atac  # noqa: F401
 from ._core import tools as tl  # noqa: F401
+from ._core import io  # noqa: F401  (arrays of 10x / mtx / snap files -> row-sharded device CSR)
 
 __version__ = "0.1.0"

@@ -1,0 +1,95 @@
+"""on-disk layouts -> (row-sharded) device CSR without a host conversion
+(muon_amd/_core/io.py; reference: muon/_core/io.py:23-72, muon/_atac/io.py:11-22,125).  Host logic on the
+CPU test operator set; the HIP path is exercised by tests/test_gpu_tfidf.py::test_ingest_*."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from muon_amd._core import io as mio
+from tests.cpu_backend import CpuTestBackend
+
+BE = CpuTestBackend()
+
+
+class _FakeComm:
+    def __init__(self, rank, world):
+        self.rank, self.world_size = rank, world
+
+
+def _tenx(n_cells=230, n_feat=90, seed=0):
+    rng = np.random.default_rng(seed)
+    m = sp.random(n_cells, n_feat, density=0.1, format="csr", random_state=rng, dtype=np.float64)
+    m.data = (1 + rng.poisson(0.5, m.nnz)).astype(np.int32)
+    m.sort_indices()
+    ft = np.array([b"Peaks" if j % 3 else b"Gene Expression" for j in range(n_feat)])
+    matrix = {"data": m.data, "indices": m.indices.astype(np.int64), "indptr": m.indptr.astype(np.int64),
+              "shape": np.array([n_feat, n_cells]), "features": {"feature_type": ft}}
+    return m, matrix, ft
+
+
+def _host(X):
+    return sp.csr_matrix((X.values.numpy(), X.indices.numpy(), X.indptr.numpy()), shape=X.shape)
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_10x_arrays_to_row_sharded_device_csr(world):
+    m, matrix, ft = _tenx()
+    peaks = np.array([t == b"Peaks" for t in ft])
+    for rank in range(world):
+        X, keep, (r0, r1) = mio.device_csr_from_10x(matrix, _FakeComm(rank, world), BE)
+        want = m[r0:r1][:, peaks].astype(np.float32)
+        got = _host(X)
+        assert X.values.dtype.is_floating_point and X.indices.dtype.itemsize == 4 and X.indptr.dtype.itemsize == 8
+        assert got.shape == want.shape and (got != want).nnz == 0
+        assert np.array_equal(keep, np.nonzero(peaks)[0])
+    X, keep, _ = mio.device_csr_from_10x(matrix, None, BE, atac_only=False)
+    assert keep is None and (_host(X) != m.astype(np.float32)).nnz == 0
+
+
+def test_unsorted_rows_are_sorted_on_the_device():
+    m, matrix, _ = _tenx(seed=1)
+    idx, dat = matrix["indices"].copy(), matrix["data"].copy()
+    for r in range(m.shape[0]):  # reverse every row: a legal but non-canonical file
+        a, b = matrix["indptr"][r], matrix["indptr"][r + 1]
+        idx[a:b], dat[a:b] = idx[a:b][::-1].copy(), dat[a:b][::-1].copy()
+    X, _, _ = mio.device_csr_from_10x(dict(matrix, indices=idx, data=dat), None, BE, atac_only=False)
+    got = _host(X)
+    assert np.array_equal(got.indices, m.indices) and np.array_equal(got.data, m.data.astype(np.float32))
+
+
+def test_coo_and_csc_layouts():
+    m, _, _ = _tenx(seed=2)
+    coo = m.tocoo()
+    p = np.random.default_rng(0).permutation(coo.nnz)
+    rows = np.concatenate([coo.row[p], coo.row[:5]])  # with duplicates: summed like csr_matrix((v, (i, j)))
+    cols = np.concatenate([coo.col[p], coo.col[:5]])
+    vals = np.concatenate([coo.data[p], coo.data[:5]])
+    X = mio.device_csr_from_coo(rows, cols, vals, m.shape, BE)
+    want = sp.csr_matrix((vals.astype(np.float32), (rows, cols)), shape=m.shape)
+    want.sum_duplicates()
+    assert (_host(X) != want).nnz == 0
+    c = m.tocsc()
+    Y = mio.device_csr_from_csc(c.indptr, c.indices, c.data, m.shape, BE)
+    assert (_host(Y) != m.astype(np.float32)).nnz == 0
+
+
+def test_read_10x_arrays_feeds_tfidf_without_another_upload():
+    from muon_amd import atac as ac
+    from oracle import tfidf_oracle
+
+    m, matrix, ft = _tenx(seed=3)
+    peaks = np.array([t == b"Peaks" for t in ft])
+    ad = mio.read_10x_arrays(matrix, backend=BE, barcodes=[f"c{i}".encode() for i in range(m.shape[0])],
+                             feature_names=[f"f{j}" for j in range(m.shape[1])])
+    assert ad.shape == (m.shape[0], int(peaks.sum())) and ad.X.dtype == np.float32
+    assert list(ad.var_names[:2]) == ["f1", "f2"] and ad.obs_names[0] == "c0"
+    uploads = []
+    orig = BE.upload_csr
+    BE.upload_csr = lambda *a, **k: (uploads.append(1), orig(*a, **k))[1]
+    try:
+        ac.pp.tfidf(ad, backend=BE)
+    finally:
+        BE.upload_csr = orig
+    assert not uploads  # the device copy made by the ingest was used
+    ref = tfidf_oracle.canonical(tfidf_oracle.tfidf(m[:, peaks].astype(np.float32)))
+    assert np.array_equal(ad.X.indices, ref.indices) and np.allclose(ad.X.data, ref.data, rtol=1e-5)
