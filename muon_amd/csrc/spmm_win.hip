@@ -629,6 +629,11 @@ __global__ __launch_bounds__(256) void k_stream_fill(int64_t n_pos, const int32_
 // register budget (K <= kKMax); one workgroup per CU (128 KiB of LDS at B = 64).
 int pick_k(int64_t n_rows) {
   const int64_t cus = mu_num_cus();
+  // Many rounds of workgroups anyway (>= 4 at K = 6): six row-sets per wave.  The windows a workgroup
+  // keeps alive are what the XCD's L2 has to hold between two visits of a row (32 CUs x 64 K rows x 2
+  // lines): at K = 8 they exceed its 4 MiB and the re-requested window tails miss (fabric traffic 2.9x
+  // the algorithmic bytes at 1e6 rows); at K = 6 it is 1.7x for +0.5 % time (r02 K sweep).
+  if (n_rows >= 4 * 64 * 6 * cus) return 6;
   for (int64_t R = 1; R <= 4096; ++R) {
     const int64_t k = (n_rows + 64 * cus * R - 1) / (64 * cus * R);
     if (k <= kKMax) return (int)(k < 1 ? 1 : k);

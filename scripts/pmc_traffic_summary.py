@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Turn the two PMC passes of scripts/pmc_traffic.sh into the per-shape entry of
-profiles/r02_spmm_traffic.json: HBM bytes per SpMM launch = FETCH_SIZE x2 (gfx950 tallies 128-byte
+profiles/r03_spmm_traffic.json (--out NAME): HBM bytes per SpMM launch = FETCH_SIZE x2 (gfx950 tallies 128-byte
 requests as 64 B; checked against the 4 GiB calibration copy of the same pass) + WRITE_SIZE, KiB."""
 import csv
 import glob
@@ -51,7 +51,8 @@ entry = {
 }
 print(json.dumps(entry, indent=1))
 if "--update" in sys.argv:
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_spmm_traffic.json")
+    name = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "r03_spmm_traffic.json"
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)
     d = json.load(open(path)) if os.path.exists(path) else {}
     old = d.get(f"{cells}x{peaks}", {})
     if "algorithmic_bytes_per_launch" in old:
