@@ -121,17 +121,19 @@ __device__ __forceinline__ void pair_fma(const Pair<NB, DT>& r, float v, typenam
   for (int c = 0; c < NB; ++c) acc[c] = mu_fma(v1, r.q1[c], acc[c]);
 }
 
-// one LDS-DMA piece: 64 lanes x 16 B land contiguously at the wave-uniform LDS byte address
-__device__ __forceinline__ void dma_piece(const float4* gsrc, unsigned lds_dst) {
+// one LDS-DMA piece: 64 lanes x 16 B land contiguously at the wave-uniform LDS byte address; the source
+// is base (scalar) + a 32-bit byte offset per lane (r03: the 64-bit per-lane addresses of r02 cost four
+// registers and a 64-bit clamp per piece; the dense operand is < 4 GiB, checked on the host)
+__device__ __forceinline__ void dma_piece(const void* base, unsigned byte_off, unsigned lds_dst) {
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
+      "s_mov_b32 m0, %3\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
+      : "v"(byte_off), "s"(base), "s"(lds_dst)
       : "memory");
 }
 
@@ -233,6 +235,28 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
   constexpr int kWaitMain = (K - 1) + kMyPieces;
   // ... and after the last DMA piece come the requests of passes kMyPieces-1 .. K-1
   constexpr int kWaitSlab = K >= kMyPieces ? (K - kMyPieces + 1) : 0;
+  // r03: overflow passes without drains.  A row with 16 or more entries in one slab is revisited after
+  // the main passes of the slab; its continuation window is the request its main pass issued, so the
+  // revisit of row-set k may leave outstanding what was issued AFTER that request - statically the
+  // requests of passes k+1 .. K-1 and the DMA pieces after pass k (ovf_wait(k); fewer than the truth
+  // when other row-sets were revisited first, i.e. stricter, i.e. safe).  The revisit issues the
+  // row-set's next request out of the counted order: instead of draining everything behind it (r02: a
+  // full memory round trip, exposed, in nearly every slab of every workgroup - 512 rows x P(16+ of
+  // Poisson(8)) = 4 such rows per slab - and the other 15 waves wait for it at the slab barrier), the
+  // wave remembers the row-set (ovf_prev) and its main pass of the NEXT slab waits until everything
+  // issued before that slab has retired: strict_wait(k) = what this slab itself issued before the wait.
+  auto constexpr ovf_wait = [](int k) { return (K - 1 - k) + (kMyPieces > k + 1 ? kMyPieces - (k + 1) : 0); };
+  auto constexpr strict_wait = [](int k) { return k + (k + 1 < kMyPieces ? k + 1 : kMyPieces); };
+  // ... and a revisit at the END of the slab issues the row-set's next request only k + 1 passes before
+  // the next slab needs it (measured: the drain's round trip moved from the barrier into that wait).
+  // Row-sets 0 .. kMid-2 are therefore revisited after pass kMid = K - 3 already (their continuation was
+  // requested two passes earlier and more: landed), the others at the end of the slab (their next
+  // request then has K - 3 passes and more before it is needed).  At the mid point the wave has issued
+  // the requests of passes 0 .. kMid+1 and every DMA piece.
+  constexpr int kMid = (K >= 5 && !(MODE & (64 | 4096 | 16384))) ? K - 3 : -1;
+  constexpr unsigned kEarlyMask = kMid >= 2 ? ((1u << (kMid - 1)) - 1u) : 0u;
+  static_assert(kMid < 0 || kMyPieces <= kMid + 2, "every DMA piece is out at the mid point");
+  auto constexpr mid_wait = [](int k) { return (kMid + 1 - k) + (kMyPieces > k + 1 ? kMyPieces - (k + 1) : 0); };
   __shared__ float4 qs[2][kSlabBytes / 16];  // double buffer; Q row c of a slab at byte c * kRowBytes
   const int lane = threadIdx.x & 63;
   const int wave = uniform32(threadIdx.x >> 6);
@@ -269,11 +293,12 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
     });
   }
 
+  const unsigned q4_last = (unsigned)(q4_total - 1);
   auto dma_one = [&](int64_t s0, int buf, int u) {           // 1 KiB piece u of this wave
     const int piece = wave + u * W;
-    int64_t i = s0 * (kRowBytes / 16) + piece * 64 + lane;   // float4 index into Q
-    if (i >= q4_total) i = q4_total - 1;                     // tail / past the end: clamp (never consumed)
-    dma_piece(Q4 + i, qs_lds + (unsigned)buf * (unsigned)kSlabBytes + (unsigned)piece * 1024u);
+    unsigned i = (unsigned)s0 * (unsigned)(kRowBytes / 16) + (unsigned)(piece * 64 + lane);  // float4 index into Q
+    i = i < q4_last ? i : q4_last;                           // tail / past the end: clamp (never consumed)
+    dma_piece(Q4, i << 4, qs_lds + (unsigned)buf * (unsigned)kSlabBytes + (unsigned)piece * 1024u);
   };
 #pragma unroll
   for (int u = 0; u < kMyPieces; ++u) dma_one(0, 0, u);
@@ -286,6 +311,7 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
   auto now = [&]() -> unsigned { return (unsigned)__builtin_amdgcn_s_memtime(); };
 
   int buf = 0;
+  unsigned ovf_prev = 0;  // row-sets whose window in flight was requested by a revisit of the previous slab
   for (int64_t s0 = 0; s0 < n_cols; s0 += kSlabCols, buf ^= 1) {
     // piece u of the next slab, issued right before pass u: the 64 KiB do not hit the texture
     // path as one burst behind which every wave's window requests would queue
@@ -298,6 +324,8 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
     const int s_hi = ((int)s0 + kSlabCols) < ncols32 ? ((int)s0 + kSlabCols) : ncols32;
     const unsigned qbase = qs_lds + (unsigned)buf * (unsigned)kSlabBytes + (unsigned)sub_off;
     unsigned again = 0;
+    int rv_kind = 1;           // wait of a revisit: 1 at the mid point, 2 first round at the slab end, 0 drain
+    unsigned revisited = 0;    // row-sets revisited in this slab
 
     // Stage A of a pass: the window of (row-set k, every group) has arrived; the entries of this
     // slab are a prefix of it.  Count them per group, advance the cursors, request the next window.
@@ -320,8 +348,15 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
       if constexpr (MODE & 262144) __builtin_amdgcn_s_setprio(2);  // (timing: stage A above the gathers)
       unsigned tw0 = 0;
       if constexpr (MODE & 64) tw0 = now();
-      if constexpr (SLOW) wait_window<k, 0>(col, valbits);
-      else wait_window<k, kWaitMain>(col, valbits);
+      if constexpr (SLOW) {
+        // (a row-set that was revisited before in this slab waits for a request out of the counted order)
+        if (rv_kind == 1 && kMid >= 0 && !(revisited & (1u << k))) wait_window<k, (kMid >= 0 ? mid_wait(k) : 0)>(col, valbits);
+        else if (rv_kind == 2 && !(revisited & (1u << k))) wait_window<k, ovf_wait(k)>(col, valbits);
+        else wait_window<k, 0>(col, valbits);
+      } else {
+        if (ovf_prev & (1u << k)) wait_window<k, (strict_wait(k) < kWaitMain ? strict_wait(k) : kWaitMain)>(col, valbits);
+        else wait_window<k, kWaitMain>(col, valbits);
+      }
       if constexpr (MODE & 64) {
         const unsigned tw1 = now();
         t_wait += tw1 - tw0;
@@ -509,11 +544,27 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
         if constexpr (kSplit) b_finish(kc, w, low);
         else stage_b(kc, w);
         w = wn;
+        if constexpr (k == kMid && kEarlyMask != 0) {
+          // mid point: revisit the early row-sets now (one round; a second overflow waits for the slab end)
+          const unsigned pend = again & kEarlyMask;
+          if (pend) {
+            again &= ~kEarlyMask;
+            static_for<(kMid >= 2 ? kMid - 1 : 0)>([&](auto jc) {
+              constexpr int j = decltype(jc)::value;
+              if (pend & (1u << j)) {
+                const Win wo = stage_a(jc, std::true_type{});
+                stage_b(jc, wo);
+              }
+            });
+            revisited |= pend;
+          }
+        }
       });
       }
     }
 #pragma unroll
     for (int u = K; u < kMyPieces; ++u) next_piece(u);  // K < kMyPieces: the pieces left over
+    rv_kind = 2;
     if (again) {
       do {
         const unsigned pend = again;
@@ -528,11 +579,11 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
             if constexpr (MODE & 64) t_b += now() - t2;
           }
         });
+        revisited |= pend;
+        rv_kind = 0;
       } while (again);
-      // an overflow request of row-set k is younger than the main-pass requests the next slab's
-      // counted waits are set against: drain, so that the count only ever guards main-pass requests
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    ovf_prev = revisited;  // their requests are out of the counted order: strict waits in the next slab
     // The last DMA piece of the next slab went out before the requests of passes kMyPieces-1 ..
     // K-1: allowing that many outstanding VMEM operations proves the slab landed.
     unsigned tb0 = 0;
@@ -714,6 +765,8 @@ int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
                        void* stream) {
   MU_REQUIRE(B == 16 || B == 32 || B == 64, "B must be 16, 32 or 64");
   MU_REQUIRE(n_pos >= 0 && n_cols > 0 && n_cols < ((int64_t)1 << 31), "shape out of range");
+  // (the Q slabs are addressed with 32-bit byte offsets from d_Q)
+  MU_REQUIRE((n_cols + 512) * (int64_t)B * 4 < ((int64_t)1 << 32), "dense operand of 4 GiB or more");
   if (n_pos == 0) return MU_OK;
   MU_REQUIRE(d_sptr && d_ent && d_Q && d_Y, "null pointer");
   hipStream_t st = (hipStream_t)stream;
@@ -752,6 +805,7 @@ int mu_spmm_stream_f64(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
                        int accumulate, void* stream) {
   MU_REQUIRE(B == 16 || B == 32, "B must be 16 or 32");
   MU_REQUIRE(n_pos >= 0 && n_cols > 0 && n_cols < ((int64_t)1 << 31), "shape out of range");
+  MU_REQUIRE((n_cols + 512) * (int64_t)B * 8 < ((int64_t)1 << 32), "dense operand of 4 GiB or more");
   if (n_pos == 0) return MU_OK;
   MU_REQUIRE(d_sptr && d_ent && d_Q && d_Y, "null pointer");
   hipStream_t st = (hipStream_t)stream;
