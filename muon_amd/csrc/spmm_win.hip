@@ -368,7 +368,11 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
       const unsigned mm = mlo | mhi;
       Win w;
       w.any16 = (mm | (mm >> 16)) & 0xffffu;  // bit e: some group has entry e
-      w.a = (col & (kSlabCols - 1)) << kRowShift;  // always inside the slab buffer, valid or not
+      // (r03: the kernel runs at the chip's power limit - the same launch on an all-zero Q takes 16 % less
+      //  time, scripts/probes/spmm_power_probe.py -, and a third of the window slots a pass gathers are
+      //  padding: they all read row 0 of the slab instead of whatever row their stale column names, so
+      //  the padded gathers return the same bytes again and again)
+      w.a = valid ? ((col & (kSlabCols - 1)) << kRowShift) : 0;
       w.vv = valid ? __builtin_bit_cast(float, valbits) : 0.f;
       if constexpr (!(MODE & 8)) {
         // entries consumed by this lane's group: the bits of its 16 lanes in the ballot, counted on
