@@ -139,21 +139,40 @@ __global__ __launch_bounds__(kET) void k_mofa_w_colsums(int64_t D, int K, const 
 }
 
 // alpha_w / theta updates from the column sums and the ELBO terms of the W, alpha_w and theta nodes
+constexpr int kFinT = 1024, kFinChunks = 8;  // 128 (quantity, factor) values x 8 chunks of partial blocks
 template <typename T>
-__global__ __launch_bounds__(64) void k_mofa_w_finish(int64_t D, int K, int nb, int ard, int spikeslab,
-                                                      const double* __restrict__ partial, double a_alpha,
-                                                      double a0, double b0, double th_a0, double th_b0,
-                                                      T* __restrict__ alpha, T* __restrict__ lalpha,
-                                                      T* __restrict__ lth, T* __restrict__ l1mth,
-                                                      double* __restrict__ elbo) {
+__global__ __launch_bounds__(kFinT) void k_mofa_w_finish(int64_t D, int K, int nb, int ard, int spikeslab,
+                                                         const double* __restrict__ partial, double a_alpha,
+                                                         double a0, double b0, double th_a0, double th_b0,
+                                                         T* __restrict__ alpha, T* __restrict__ lalpha,
+                                                         T* __restrict__ lth, T* __restrict__ l1mth,
+                                                         double* __restrict__ elbo) {
   __shared__ double term[64];
+  __shared__ double red[kFinT];
+  __shared__ double cs[4][32];
+  {
+    // the partial blocks are summed in eight chunks side by side, the chunks in order (fixed order; r02
+    // walked all of them on one thread per factor: 31 us behind a 15 us pass)
+    constexpr int lanes = kFinT / kFinChunks;  // 128 >= 4 K
+    const int c = threadIdx.x / lanes, v = threadIdx.x % lanes;
+    const int b0_ = (int)((int64_t)nb * c / kFinChunks), b1_ = (int)((int64_t)nb * (c + 1) / kFinChunks);
+    double sacc = 0.0;
+    if (v < 4 * K)
+      for (int b = b0_; b < b1_; ++b) sacc += partial[(int64_t)b * 4 * K + v];  // v = q * K + k
+    red[threadIdx.x] = sacc;
+    __syncthreads();
+    if (c == 0 && v < 4 * K) {
+      double tot = 0.0;
+#pragma unroll
+      for (int q = 0; q < kFinChunks; ++q) tot += red[q * lanes + v];
+      cs[v / K][v % K] = tot;
+    }
+    __syncthreads();
+  }
   const int k = threadIdx.x;
   double e = 0.0;
   if (k < K) {
-    double c[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int b = 0; b < nb; ++b)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) c[q] += partial[((int64_t)b * 4 + q) * K + k];
+    const double c[4] = {cs[0][k], cs[1][k], cs[2][k], cs[3][k]};
     const double Dd = (double)D;
     double aw = 1.0, law = 0.0;
     if (ard) {
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(64) void k_mofa_w_finish(int64_t D, int K, int nb, 
       e += (lb - lb0) + (th_a0 - a) * lt + (th_b0 - b) * l1;
     }
   }
-  term[threadIdx.x] = e;
+  if (threadIdx.x < 64) term[threadIdx.x] = e;
   __syncthreads();
   if (threadIdx.x == 0) {
     double s = 0.0;
@@ -214,14 +233,23 @@ __global__ __launch_bounds__(kET) void k_mofa_z_colsums(int64_t n0, int64_t n1, 
   }
 }
 
-// out[q][k] = sum over the partial blocks, in order (the caller all-reduces it over the ranks)
-__global__ __launch_bounds__(64) void k_mofa_fold(int nb, int width, const double* __restrict__ partial,
-                                                  double* __restrict__ out) {
-  const int i = threadIdx.x;
-  if (i < width) {
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += partial[(int64_t)b * width + i];
-    out[i] = s;
+// out[q][k] = sum over the partial blocks in a fixed order: eight chunks of blocks side by side, then the
+// chunks (the caller all-reduces the result over the ranks); width <= 64
+__global__ __launch_bounds__(512) void k_mofa_fold(int nb, int width, const double* __restrict__ partial,
+                                                   double* __restrict__ out) {
+  __shared__ double red[512];
+  const int c = threadIdx.x / 64, i = threadIdx.x % 64;
+  const int b0 = (int)((int64_t)nb * c / 8), b1 = (int)((int64_t)nb * (c + 1) / 8);
+  double s = 0.0;
+  if (i < width)
+    for (int b = b0; b < b1; ++b) s += partial[(int64_t)b * width + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (c == 0 && i < width) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q * 64 + i];
+    out[i] = t;
   }
 }
 
@@ -266,7 +294,7 @@ inline int blocks_for(int64_t items, int per_block, int cap = kEBlocksMax) {
 }
 // the finish kernels add the partials up one after the other (fixed order): few, fat workgroups for
 // the column sums (512 partials made the one-workgroup finish 0.15 ms, ten times the pass itself)
-constexpr int kEColBlocks = 48;
+constexpr int kEColBlocks = 256;
 
 template <typename T>
 int run_tau(int64_t D, int K, int G, const void* yy, const void* Ngm, const void* EW, const void* EW2,
@@ -298,7 +326,7 @@ int run_w(int64_t D, int K, int ard, int spikeslab, const void* EWh2, const void
     hipLaunchKernelGGL((k_mofa_w_colsums<T, 32>), dim3(nb), dim3(kET), 0, st, D, K, (const T*)EWh2,
                        (const T*)gamma, (const T*)sig2, work);
   MU_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_mofa_w_finish<T>, dim3(1), dim3(64), 0, st, D, K, nb, ard, spikeslab, work, a_alpha,
+  hipLaunchKernelGGL(k_mofa_w_finish<T>, dim3(1), dim3(kFinT), 0, st, D, K, nb, ard, spikeslab, work, a_alpha,
                      a0, b0, th_a0, th_b0, (T*)alpha, (T*)lalpha, (T*)lth, (T*)l1mth, elbo);
   MU_CHECK_LAUNCH();
   return MU_OK;
@@ -316,7 +344,7 @@ int run_z_sums(int64_t n0, int64_t n1, int K, const void* EZ2, const void* sig2,
     hipLaunchKernelGGL((k_mofa_z_colsums<T, 32>), dim3(nb), dim3(kET), 0, st, n0, n1, K, (const T*)EZ2,
                        (const T*)sig2, work);
   MU_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_mofa_fold, dim3(1), dim3(64), 0, st, nb, 2 * K, work, out);
+  hipLaunchKernelGGL(k_mofa_fold, dim3(1), dim3(512), 0, st, nb, 2 * K, work, out);
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
