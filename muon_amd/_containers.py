@@ -137,6 +137,7 @@ class AnnData:
             uns=_copy.deepcopy(self.uns),
             shape=self._shape,
         )
+        new.obsp = {k: v.copy() for k, v in self.obsp.items()}
         return new
 
     @staticmethod
@@ -261,6 +262,7 @@ class MuData:
         new.obsm = {k: _copy.copy(v) for k, v in self.obsm.items()}
         new.varm = {k: _copy.copy(v) for k, v in self.varm.items()}
         new.uns = _copy.deepcopy(self.uns)
+        new.obsp = {k: v.copy() for k, v in self.obsp.items()}
         return new
 
     def __repr__(self):

@@ -1,0 +1,454 @@
+"""muon.pp.neighbors (weighted nearest neighbours), muon.pp.l2norm - SURVEY 8f.4.
+
+Host side mirrors /root/reference/muon/_core/preproc.py:182-260 (``l2norm``) and :264-640
+(``neighbors``: same signature, same slots - ``mdata.obsp[distances / connectivities]``,
+``mdata.uns[key]``, per-modality weights in ``mdata.obs["<mod>:mod_weight"]`` or the modalities' own
+``.obs``).  The reference searches neighbours with UMAP's NN-descent (approximate, seeded; numba metric
+kernels ``_jaccard_euclidean_metric`` :53-77, ``_sparse_csr_fast_knn_`` :112-134); here every search is
+EXHAUSTIVE on the device - distance tiles as GEMMs against the whole representation, top-k per tile -
+so ``random_state`` / ``low_memory`` are accepted and have nothing to influence; the result is the exact
+graph NN-descent approximates (oracle/wnn_oracle.py is the same computation in numpy loops).
+
+Device work: the within- and cross-modality neighbourhood means ``r_i = mean_{j in N(i)} x_j`` are
+products of the kNN graph with the n x p representation and run through the row-stream SpMM of the LSI
+(csrc/spmm_win.hip); distance tiles, selections, the shared-neighbour (Jaccard) counts and the fuzzy
+simplicial set are PyTorch-ROCm tensor operations on HBM-resident arrays (plumbing: no hand-written
+kernel is claimed for them).
+
+``knn`` writes what scanpy's ``sc.pp.neighbors`` would (scanpy is outside muon and absent here): the
+per-modality input the reference requires (:366-373).
+"""
+from __future__ import annotations
+
+import math
+from itertools import repeat
+from typing import Dict, Iterable, Optional, Union
+
+import numpy as np
+import torch
+from scipy.sparse import csr_matrix, issparse
+
+from .._containers import is_anndata, is_mudata
+
+_METRICS = ("euclidean", "sqeuclidean", "cosine", "cityblock", "manhattan", "chebyshev")
+
+
+def _backend(backend):
+    if backend is None:
+        from .._backend import get_backend
+
+        backend = get_backend()
+    return backend
+
+
+def _choose_representation(adata, use_rep=None, n_pcs=None):
+    """scanpy.tools._utils._choose_representation, the part the path needs (:372)."""
+    if use_rep is None or use_rep == -1:
+        if adata.X.shape[1] > 50 and "X_pca" in adata.obsm:
+            X = adata.obsm["X_pca"]
+            return X[:, :n_pcs] if n_pcs not in (None, -1, 0) else X
+        return adata.X
+    if use_rep == "X":
+        return adata.X
+    if use_rep in adata.obsm:
+        X = adata.obsm[use_rep]
+        if use_rep == "X_pca" and n_pcs not in (None, -1, 0):
+            X = X[:, :n_pcs]
+        return X
+    raise ValueError(f"Did not find {use_rep} in `.obsm.keys()`.")
+
+
+# -----------------------------------------------------------------------------------------------------
+# l2norm (reference :182-260)
+# -----------------------------------------------------------------------------------------------------
+def _l2norm(adata, rep=None, n_pcs=0):
+    X = _choose_representation(adata, rep, n_pcs)
+    if issparse(X):
+        m = X.tocsr() if X.format not in ("csr",) else X
+        nrm = np.sqrt(np.asarray(m.multiply(m).sum(axis=1)).reshape(-1))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            scale = np.repeat(1.0 / nrm, np.diff(m.indptr))
+        d = m.data * scale
+        d[~np.isfinite(d)] = 0
+        m.data[:] = d
+    else:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            norm = X / np.linalg.norm(X, ord=2, axis=1, keepdims=True)
+        norm[~np.isfinite(norm)] = 0
+        X[:] = norm
+
+
+def l2norm(mdata, mod=None, rep=None, n_pcs=0, copy: bool = False):
+    """Normalize observations to unit L2 norm (reference :205-260, same arguments)."""
+    if is_anndata(mdata):
+        for name, v in (("rep", rep), ("n_pcs", n_pcs)):
+            if v is not None and not isinstance(v, (str, int)):
+                v = list(v)
+                if len(v) != 1:
+                    raise RuntimeError(f"If '{name}' is an Iterable, it must have length 1")
+                if name == "rep":
+                    rep = v[0]
+                else:
+                    n_pcs = v[0]
+        if copy:
+            mdata = mdata.copy()
+        _l2norm(mdata, rep, n_pcs)
+    else:
+        if mod is None:
+            mod = mdata.mod.keys()
+        elif isinstance(mod, str):
+            mod = [mod]
+        if rep is None or isinstance(rep, str):
+            rep = repeat(rep)
+        if n_pcs is None or isinstance(n_pcs, int):
+            n_pcs = repeat(n_pcs)
+        if copy:
+            mdata = mdata.copy()
+        for m, r, n in zip(mod, rep, n_pcs):
+            _l2norm(mdata.mod[m], r, n)
+    return mdata if copy else None
+
+
+# -----------------------------------------------------------------------------------------------------
+# exhaustive k nearest neighbours on the device
+# -----------------------------------------------------------------------------------------------------
+def _pair_dist(A: torch.Tensor, B: torch.Tensor, metric: str) -> torch.Tensor:
+    """Row-wise distances d(A_i, B_i) (same shapes [..., p]), computed directly (no expansion)."""
+    if metric in ("euclidean", "sqeuclidean"):
+        d = ((A - B) ** 2).sum(dim=-1)
+        return d if metric == "sqeuclidean" else torch.sqrt(d)
+    if metric in ("cityblock", "manhattan"):
+        return (A - B).abs().sum(dim=-1)
+    if metric == "chebyshev":
+        return (A - B).abs().amax(dim=-1)
+    if metric == "cosine":
+        num = (A * B).sum(dim=-1)
+        den = torch.sqrt((A * A).sum(dim=-1) * (B * B).sum(dim=-1))
+        return 1.0 - num / den
+    raise NotImplementedError(f"metric '{metric}' (implemented: {_METRICS})")
+
+
+def device_knn(X: torch.Tensor, k: int, metric: str = "euclidean", chunk_elems: int = 1 << 28):
+    """The k nearest OTHER rows of every row of X [n, p] (f64 on the device): (indices [n, k] int64,
+    distances [n, k]) ascending, ties by index.  Tiles of queries against all rows: squared distances as
+    one GEMM (cosine: normalised rows), k + 8 candidates per query, exact distances of the candidates,
+    final selection - the cancellation of the GEMM form never decides the order."""
+    if metric not in _METRICS:
+        raise NotImplementedError(f"metric '{metric}' (implemented: {_METRICS})")
+    n, p = X.shape
+    k = min(int(k), n - 1)
+    kc = min(k + 8, n - 1)
+    rows = max(1, min(n, chunk_elems // max(n, 1)))
+    idx = torch.empty((n, k), dtype=torch.int64, device=X.device)
+    dst = torch.empty((n, k), dtype=X.dtype, device=X.device)
+    gemm = metric in ("euclidean", "sqeuclidean", "cosine")
+    Xn = X / torch.sqrt((X * X).sum(dim=1, keepdim=True)) if metric == "cosine" else X
+    sq = (Xn * Xn).sum(dim=1)
+    ar = torch.arange(n, device=X.device)
+    for lo in range(0, n, rows):
+        hi = min(n, lo + rows)
+        if gemm:
+            D = sq[lo:hi, None] + sq[None, :] - 2.0 * (Xn[lo:hi] @ Xn.T)
+        else:
+            D = torch.cdist(X[lo:hi], X, p=1.0 if metric in ("cityblock", "manhattan") else float("inf"))
+        D[ar[lo:hi] - lo, ar[lo:hi]] = float("inf")  # not the row itself
+        cand = torch.topk(D, kc, dim=1, largest=False).indices
+        del D
+        exact = _pair_dist(X[lo:hi, None, :].expand(hi - lo, kc, p), X[cand], metric)
+        # ascending by (distance, index): stable sort of the index-sorted candidates
+        o = torch.argsort(cand, dim=1)
+        cand, exact = torch.gather(cand, 1, o), torch.gather(exact, 1, o)
+        o = torch.argsort(exact, dim=1, stable=True)[:, :k]
+        idx[lo:hi], dst[lo:hi] = torch.gather(cand, 1, o), torch.gather(exact, 1, o)
+    return idx, dst
+
+
+# -----------------------------------------------------------------------------------------------------
+# UMAP connectivities (scanpy's `umap` connectivity: fuzzy_simplicial_set with set_op_mix_ratio = 1,
+# local_connectivity = 1; umap/umap_.py smooth_knn_dist + compute_membership_strengths)
+# -----------------------------------------------------------------------------------------------------
+def fuzzy_simplicial_set(knn_idx: torch.Tensor, knn_dist: torch.Tensor, n_obs: int, n_neighbors: int):
+    d = knn_dist.to(torch.float32).to(torch.float64)  # umap works on float32 distances
+    n, k = d.shape
+    target = math.log2(n_neighbors)
+    pos = torch.where(d > 0, d, torch.full_like(d, float("inf")))
+    has = torch.isfinite(pos).any(dim=1)
+    # rho: the first positive distance in storage order (local_connectivity = 1)
+    first = torch.argmax((d > 0).to(torch.int8), dim=1)
+    rho = torch.where(has, torch.gather(d, 1, first[:, None]).squeeze(1), torch.zeros(n, dtype=d.dtype, device=d.device))
+    lo = torch.zeros(n, dtype=d.dtype, device=d.device)
+    hi = torch.full((n,), float("inf"), dtype=d.dtype, device=d.device)
+    mid = torch.ones(n, dtype=d.dtype, device=d.device)
+    done = torch.zeros(n, dtype=torch.bool, device=d.device)
+    x = d[:, 1:] - rho[:, None]  # (the first stored neighbour is skipped, as in umap)
+    for _ in range(64):
+        ps = torch.where(x > 0, torch.exp(-x / mid[:, None]), torch.ones_like(x)).sum(dim=1)
+        done = done | ((ps - target).abs() < 1e-5)
+        up = ps > target
+        new_hi = torch.where(up & ~done, mid, hi)
+        new_lo = torch.where(~up & ~done, mid, lo)
+        new_mid = torch.where(up, (lo + mid) / 2.0, torch.where(torch.isinf(hi), mid * 2.0, (mid + hi) / 2.0))
+        mid = torch.where(done, mid, new_mid)
+        lo, hi = new_lo, new_hi
+        if bool(done.all()):
+            break
+    sigma = mid
+    mean_i = d.mean(dim=1)
+    mean_all = d.mean()
+    sigma = torch.where(rho > 0, torch.maximum(sigma, 1e-3 * mean_i), torch.maximum(sigma, 1e-3 * mean_all))
+    rows = torch.arange(n, device=d.device)[:, None].expand(n, k)
+    val = torch.where(knn_idx == rows, torch.zeros_like(d),
+                      torch.where((d - rho[:, None] <= 0) | (sigma[:, None] == 0), torch.ones_like(d),
+                                  torch.exp(-(d - rho[:, None]) / sigma[:, None])))
+    r = rows.reshape(-1).cpu().numpy()
+    c = knn_idx.reshape(-1).cpu().numpy()
+    v = val.reshape(-1).cpu().numpy()
+    res = csr_matrix((v, (r, c)), shape=(n_obs, n_obs))
+    res.eliminate_zeros()
+    t = res.T.tocsr()
+    out = (res + t - res.multiply(t)).tocsr()
+    out.eliminate_zeros()
+    return out
+
+
+def knn(adata, n_neighbors: int = 15, use_rep: Optional[str] = None, n_pcs: Optional[int] = None,
+        metric: str = "euclidean", key_added: Optional[str] = None, backend=None):
+    """Exact k-nearest-neighbour graph of one modality in scanpy's slots (``.obsp["distances"]`` with
+    n_neighbors - 1 entries per row, ``.obsp["connectivities"]``, ``.uns["neighbors"]``): the input
+    ``neighbors`` expects per modality (reference :366-373 "Run `sc.pp.neighbors` on all modalities first")."""
+    be = _backend(backend)
+    X = _choose_representation(adata, use_rep, n_pcs)
+    X = X.toarray() if issparse(X) else np.asarray(X)
+    Xd = be.to_device(np.ascontiguousarray(X, dtype=np.float64))
+    n = Xd.shape[0]
+    idx, dst = device_knn(Xd, n_neighbors - 1, metric)
+    self_i = torch.arange(n, device=idx.device)[:, None]
+    idx_s = torch.cat([self_i, idx], dim=1)
+    dst_s = torch.cat([torch.zeros((n, 1), dtype=dst.dtype, device=dst.device), dst], dim=1)
+    conn = fuzzy_simplicial_set(idx_s, dst_s, n, n_neighbors)
+    k1 = idx.shape[1]
+    distances = csr_matrix((be.to_host(dst).reshape(-1), be.to_host(idx).reshape(-1),
+                            np.arange(0, n * k1 + 1, k1)), shape=(n, n))
+    if key_added is None:
+        key_added, ck, dk = "neighbors", "connectivities", "distances"
+    else:
+        ck, dk = f"{key_added}_connectivities", f"{key_added}_distances"
+    adata.obsp[dk] = distances
+    adata.obsp[ck] = conn
+    params = {"n_neighbors": n_neighbors, "method": "umap", "metric": metric, "random_state": 0}
+    if use_rep is not None:
+        params["use_rep"] = use_rep
+    if n_pcs is not None:
+        params["n_pcs"] = n_pcs
+    adata.uns[key_added] = {"connectivities_key": ck, "distances_key": dk, "params": params}
+    return None
+
+
+# -----------------------------------------------------------------------------------------------------
+# weighted nearest neighbours (reference :264-640)
+# -----------------------------------------------------------------------------------------------------
+def _graph_mean(be, G: csr_matrix, X32: torch.Tensor) -> torch.Tensor:
+    """r_i = mean of the rows of X over the stored entries of row i of G (reference :493-497, one
+    ``np.mean(X[nonzero(G[cell])])`` per cell): a product of the row-normalised pattern of G with X -
+    the row-stream SpMM (csrc/spmm_win.hip), X padded to the block widths it serves."""
+    n, p = X32.shape
+    G = G.tocsr()
+    cnt = np.diff(G.indptr)
+    with np.errstate(divide="ignore"):
+        vals = np.repeat(1.0 / cnt, cnt).astype(np.float32)
+    out = torch.zeros((n, p), dtype=torch.float32, device=X32.device)
+    can = hasattr(be, "can_stream")
+    from .io import canonicalize
+
+    # (kNN rows are stored by ascending distance: column order is restored on the device)
+    Gd = canonicalize(be, be.upload_csr(G.indptr, G.indices, vals, G.shape, values_dtype=np.float32))
+    S = be.stream(Gd) if can and be.can_stream(Gd, 64) else Gd
+    for c0 in range(0, p, 64):
+        w = min(64, p - c0)
+        B = 16 if w <= 16 else (32 if w <= 32 else 64)
+        Q = torch.zeros((n, B), dtype=torch.float32, device=X32.device)
+        Q[:, :w] = X32[:, c0:c0 + w]
+        out[:, c0:c0 + w] = be.spmm(S, Q)[:, :w]
+    return out
+
+
+def _bandwidths(be, X: torch.Tensor, G: csr_matrix, n_bandwidth_neighbors: int) -> torch.Tensor:
+    """csigma_i (reference :400-472): the mean Euclidean distance from cell i to the
+    n_bandwidth_neighbors cells whose kNN sets overlap its own least (but do), ties towards the larger
+    distance - the reference's `_jaccard_euclidean_metric` searched exhaustively.  Candidates are the
+    cells that share a neighbour (A A^T pattern of the binary kNN graph A), the overlap counts are its
+    values."""
+    n = X.shape[0]
+    G = G.tocsr()
+    dev = X.device
+    rows = torch.as_tensor(np.repeat(np.arange(n), np.diff(G.indptr)), device=dev)
+    cols = torch.as_tensor(G.indices.astype(np.int64), device=dev)
+    deg = torch.as_tensor(np.diff(G.indptr).astype(np.float64), device=dev)
+    A = torch.sparse_coo_tensor(torch.stack([rows, cols]), torch.ones(rows.numel(), dtype=torch.float64, device=dev),
+                                (n, n)).coalesce()
+    I = torch.sparse.mm(A, A.transpose(0, 1)).coalesce()  # |N(i) & N(j)| for every pair that shares a neighbour
+    i, j = I.indices()
+    inter = I.values()
+    keep = i != j
+    i, j, inter = i[keep], j[keep], inter[keep]
+    jac_dist = 1.0 - inter / (deg[i] + deg[j] - inter)
+    bbox = torch.linalg.norm(X.amax(dim=0) - X.amin(dim=0))
+    e = torch.empty(i.numel(), dtype=X.dtype, device=dev)
+    step = 1 << 22
+    for lo in range(0, i.numel(), step):
+        e[lo:lo + step] = _pair_dist(X[i[lo:lo + step]], X[j[lo:lo + step]], "euclidean")
+    key = (n - jac_dist * n) + (bbox - e) / bbox
+    ok = jac_dist < 1.0
+    i, j, e, key = i[ok], j[ok], e[ok], key[ok]
+    # per row the n_bandwidth_neighbors smallest keys (ties by column): sort by (row, key, column)
+    o = torch.argsort(j, stable=True)
+    i, e, key = i[o], e[o], key[o]
+    o = torch.argsort(key, stable=True)
+    i, e = i[o], e[o]
+    o = torch.argsort(i, stable=True)
+    i, e = i[o], e[o]
+    start = torch.searchsorted(i, torch.arange(n, device=dev))
+    rank = torch.arange(i.numel(), device=dev) - start[i]
+    take = rank < n_bandwidth_neighbors
+    s = torch.zeros(n, dtype=X.dtype, device=dev).index_add_(0, i[take], e[take])
+    c = torch.zeros(n, dtype=X.dtype, device=dev).index_add_(0, i[take], torch.ones_like(e[take]))
+    return s / c
+
+
+def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: int = 20,
+              n_multineighbors: int = 200, neighbor_keys: Optional[Dict[str, Optional[str]]] = None,
+              metric: str = "euclidean", low_memory: Optional[bool] = None, key_added: Optional[str] = None,
+              weight_key: Optional[str] = "mod_weight", add_weights_to_modalities: bool = False,
+              eps: float = 1e-4, copy: bool = False, random_state=42, *, backend=None):
+    """
+    Multimodal nearest neighbor search (weighted nearest neighbours of Hao et al. / Swanson et al.).
+
+    Same arguments and slots as the reference (:264-340).  ``low_memory`` and ``random_state`` belong to
+    NN-descent and are recorded only: every search here is exhaustive.  All modalities must cover the same
+    observations (``mdata.intersect_obs()`` first).
+    """
+    if not is_mudata(mdata):
+        raise TypeError("Expected a MuData object")
+    be = _backend(backend)
+    mdata = mdata.copy() if copy else mdata
+    if neighbor_keys is None:
+        modalities = list(mdata.mod.keys())
+        neighbor_keys = {}
+    else:
+        modalities = list(neighbor_keys.keys())
+    if len(modalities) < 2:
+        raise ValueError("weighted nearest neighbours need at least two modalities")
+    observations = mdata.obs.index
+    params, reps, mod_reps, mod_n_pcs, mod_k = {}, {}, {}, {}, []
+    for mod in modalities:
+        nkey = neighbor_keys.get(mod) or "neighbors"
+        try:
+            nparams = mdata.mod[mod].uns[nkey]
+        except KeyError:
+            raise ValueError(
+                f'Did not find .uns["{nkey}"] for modality "{mod}". Run `sc.pp.neighbors` on all modalities first.'
+            )
+        use_rep = nparams["params"].get("use_rep", None)
+        n_pcs = nparams["params"].get("n_pcs", None)
+        mod_k.append(nparams["params"].get("n_neighbors", 0))
+        params[mod] = nparams
+        X = _choose_representation(mdata.mod[mod], use_rep, n_pcs)
+        reps[mod] = X.toarray() if issparse(X) else np.asarray(X)
+        mod_reps[mod] = use_rep if use_rep is not None else -1
+        mod_n_pcs[mod] = n_pcs if n_pcs is not None else -1
+        if not mdata.mod[mod].obs.index.equals(observations):
+            raise NotImplementedError(
+                f"modality '{mod}' does not cover the observations of the MuData object in the same order: "
+                "run `mdata.intersect_obs()` first (partial overlap is not implemented on the device path)")
+    if n_neighbors is None:
+        ks = np.asarray([k for k in mod_k if k > 0])
+        n_neighbors = int(round(np.mean(ks), 0))
+    n = len(observations)
+    M = len(modalities)
+    Xd = {m: be.to_device(np.ascontiguousarray(reps[m], dtype=np.float64)) for m in modalities}
+    X32 = {m: Xd[m].to(torch.float32).contiguous() for m in modalities}
+    graphs = {}
+    for m in modalities:
+        g = mdata.mod[m].obsp[params[m]["distances_key"]].tocsr()
+        cnt = np.diff(g.indptr)
+        if (cnt == 0).any():
+            i = int(np.nonzero(cnt == 0)[0][0])
+            raise ValueError(
+                f"Cell {i} in modality {m} does not have any neighbors. "
+                "This could be due to subsetting after nearest neighbors calculation. "
+                "Make sure to subset before calculating nearest neighbors."
+            )
+        graphs[m] = g
+    dev = Xd[modalities[0]].device
+    ratios = torch.full((n, M), -float("inf"), dtype=torch.float64, device=dev)
+    sigmas = {}
+    for i1, m1 in enumerate(modalities):
+        G1 = graphs[m1]
+        nnd = torch.as_tensor(np.minimum.reduceat(G1.data, G1.indptr[:-1]).astype(np.float64), device=dev)  # :389-398
+        csig = _bandwidths(be, Xd[m1], G1, n_bandwidth_neighbors)
+        thetas, cur = [], None
+        for i2, m2 in enumerate(modalities):  # :484-506
+            r = _graph_mean(be, graphs[m2], X32[m1]).to(torch.float64)
+            th = torch.exp(-torch.clamp(torch.linalg.norm(Xd[m1] - r, dim=1) - nnd, min=0) / (csig - nnd))
+            if i1 == i2:
+                cur = th
+            else:
+                thetas.append(th)
+        ratios[:, i1] = cur / (torch.stack(thetas, dim=1).amax(dim=1) + eps)  # :507
+        sigmas[m1] = csig
+    weights = torch.softmax(ratios, dim=1)  # :510
+    # candidates: the union of every modality's n_multineighbors nearest neighbours (:517-575)
+    keys = []
+    for m in modalities:
+        idx, _ = device_knn(Xd[m], n_multineighbors, params[m].get("metric", "euclidean"))  # (:520: the top-level key)
+        keys.append((torch.arange(n, device=dev)[:, None] * n + idx).reshape(-1))
+    key = torch.unique(torch.cat(keys))  # sorted: row-major
+    ri = torch.div(key, n, rounding_mode="floor")
+    ci = key - ri * n
+    aff = torch.zeros(key.numel(), dtype=torch.float64, device=dev)
+    step = 1 << 22
+    for i, m in enumerate(modalities):  # :579-609
+        X = Xd[m]
+        for lo in range(0, key.numel(), step):
+            a, b = ri[lo:lo + step], ci[lo:lo + step]
+            aff[lo:lo + step] += torch.exp(-_pair_dist(X[a], X[b], metric) / sigmas[m][a]) * weights[a, i]
+    dist = torch.sqrt(torch.clamp(0.5 * (1.0 - aff), min=0.0))  # :610
+    # the n_neighbors + 1 smallest per row (:612 `_sparse_csr_fast_knn`): sort by (row, distance, column)
+    o = torch.argsort(dist, stable=True)
+    ri_s, ci_s, d_s = ri[o], ci[o], dist[o]
+    o = torch.argsort(ri_s, stable=True)
+    ri_s, ci_s, d_s = ri_s[o], ci_s[o], d_s[o]
+    start = torch.searchsorted(ri_s, torch.arange(n, device=dev))
+    rank = torch.arange(ri_s.numel(), device=dev) - start[ri_s]
+    k1 = n_neighbors + 1
+    take = rank < k1
+    cnt = torch.bincount(ri_s[take], minlength=n)
+    if int(cnt.min()) < k1:
+        raise ValueError(f"fewer than n_neighbors + 1 = {k1} candidate neighbours for some cells: raise n_multineighbors")
+    knn_idx = ci_s[take].reshape(n, k1)
+    knn_d = d_s[take].reshape(n, k1)
+    distances = csr_matrix((be.to_host(knn_d).reshape(-1), be.to_host(knn_idx).reshape(-1),
+                            np.arange(0, n * k1 + 1, k1)), shape=(n, n))
+    connectivities = fuzzy_simplicial_set(knn_idx, knn_d, n, k1)  # :615-622
+
+    w_host = be.to_host(weights)
+    for i, m in enumerate(modalities):  # :583-588
+        if weight_key:
+            if add_weights_to_modalities:
+                mdata.mod[m].obs[weight_key] = w_host[:, i]
+            else:
+                mdata.obs[":".join([m, weight_key])] = w_host[:, i]
+    if key_added is None:
+        key_added, conns_key, dists_key = "neighbors", "connectivities", "distances"
+    else:
+        conns_key, dists_key = f"{key_added}_connectivities", f"{key_added}_distances"
+    mdata.obsp[dists_key] = distances
+    mdata.obsp[conns_key] = connectivities
+    mdata.uns[key_added] = {
+        "connectivities_key": conns_key, "distances_key": dists_key,
+        "params": {"n_neighbors": n_neighbors, "n_multineighbors": n_multineighbors, "metric": metric, "eps": eps,
+                   "random_state": random_state, "use_rep": mod_reps, "n_pcs": mod_n_pcs, "method": "umap"},
+    }
+    if hasattr(mdata, "update_obs"):
+        mdata.update_obs()
+    return mdata if copy else None

@@ -1,0 +1,68 @@
+"""SURVEY 8f.4 on the device: mu.pp.neighbors / knn through HipBackend (neighbourhood means on the
+row-stream SpMM kernel, searches and the fuzzy simplicial set as device tensor operations) against
+oracle/wnn_oracle.py, and downstream of the LSI: X_lsi -> knn -> weighted nearest neighbours."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from muon_amd import AnnData, MuData
+from muon_amd import atac as ac
+from muon_amd._core import preproc as pp
+from oracle import wnn_oracle
+from tests.synth import planted_topics_csr
+from tests.test_wnn import two_modalities
+
+pytestmark = pytest.mark.gpu
+
+
+def test_knn_and_wnn_match_the_oracle_on_the_gpu(hip):
+    lab, x1, x2 = two_modalities(260, 4)
+    md = MuData({"rna": AnnData(x1.copy()), "atac": AnnData(x2.copy())})
+    for name, m in md.mod.items():
+        pp.knn(m, n_neighbors=15, use_rep="X", backend=hip)
+        D, C, _ = wnn_oracle.knn_graph(m.X, 15)
+        assert (abs(m.obsp["distances"] - D) > 1e-9).nnz == 0 and (abs(m.obsp["connectivities"] - C) > 1e-6).nnz == 0
+    pp.neighbors(md, n_multineighbors=50, backend=hip)
+    ref = wnn_oracle.neighbors({"rna": x1, "atac": x2}, {k: v.obsp["distances"] for k, v in md.mod.items()},
+                               n_multineighbors=50)
+    D, C, W, _sig, k = ref
+    got = md.obsp["distances"]
+    # (the neighbourhood means run in f32 on the SpMM kernel: weights to 1e-4, the graph itself identical
+    #  up to exact ties)
+    np.testing.assert_allclose(md.obs["rna:mod_weight"].values, W[:, 0], rtol=2e-4, atol=2e-5)
+    same = np.mean(got.indices == D.indices)
+    assert same > 0.995, same
+    m = got.indices == D.indices
+    np.testing.assert_allclose(got.data[m], D.data[m], rtol=1e-4, atol=1e-6)
+    assert abs(md.obsp["connectivities"] - C).max() < 5e-3
+    w1 = md.obs["rna:mod_weight"].values
+    assert w1[lab <= 1].mean() > w1[lab >= 2].mean()
+
+
+def test_lsi_embedding_feeds_weighted_neighbours(hip):
+    """The consumer of X_lsi: tfidf -> lsi on a planted-topic ATAC matrix, a second modality with the same
+    clusters, knn per modality on the device, then mu.pp.neighbors: neighbours share the planted topic."""
+    n = 1200
+    X = planted_topics_csr(n, 1500, n_topics=6, density=0.06, seed=3, dtype=np.float32)
+    atac = AnnData(X)
+    ac.pp.tfidf(atac, backend=hip)
+    ac.tl.lsi(atac, n_comps=10, backend=hip)
+    emb = atac.obsm["X_lsi"][:, 1:]  # (first component = depth)
+    from sklearn.cluster import KMeans
+
+    lab = KMeans(6, n_init=4, random_state=0).fit_predict(emb)
+    rng = np.random.default_rng(0)
+    rna = AnnData(rng.standard_normal((6, 12))[lab] * 2 + rng.standard_normal((n, 12)))
+    atac.obsm["X_lsi"] = emb.copy()
+    md = MuData({"rna": rna, "atac": atac})
+    pp.knn(md.mod["rna"], n_neighbors=20, use_rep="X", backend=hip)
+    pp.knn(md.mod["atac"], n_neighbors=20, use_rep="X_lsi", backend=hip)
+    pp.l2norm(md, rep=["X", "X_lsi"])
+    pp.neighbors(md, n_multineighbors=100, backend=hip)
+    g = md.obsp["distances"]
+    assert g.shape == (n, n) and np.all(np.diff(g.indptr) == 21)
+    agree = np.mean(lab[g.indices] == np.repeat(lab, 21))
+    assert agree > 0.9, agree
+    assert md.uns["neighbors"]["params"]["use_rep"] == {"rna": "X", "atac": "X_lsi"}
+    c = md.obsp["connectivities"]
+    assert c.shape == (n, n) and abs(c - c.T).max() < 1e-12 and c.max() <= 1.0 + 1e-12

@@ -1,0 +1,101 @@
+"""muon.pp.neighbors (weighted nearest neighbours) and muon.pp.l2norm - host logic and the
+tensor formulation on the CPU test operator set against oracle/wnn_oracle.py (exhaustive search, numpy
+loops; the reference itself needs numba / umap / pynndescent / scanpy and has no test for this function)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import muon_amd as mu
+from muon_amd import AnnData, MuData
+from muon_amd._core import preproc as pp
+from oracle import wnn_oracle
+from tests.cpu_backend import CpuTestBackend
+
+BE = CpuTestBackend()
+
+
+def two_modalities(n=140, seed=0):
+    rng = np.random.default_rng(seed)
+    lab = rng.integers(0, 4, n)
+    c1 = rng.standard_normal((4, 8)) * 3
+    c2 = rng.standard_normal((4, 6)) * 3
+    c2[1] = c2[0]  # modality 2 cannot tell clusters 0 and 1 apart: modality 1 should win there
+    x1 = c1[lab] + rng.standard_normal((n, 8))
+    x2 = c2[lab] + rng.standard_normal((n, 6))
+    return lab, x1, x2
+
+
+def test_l2norm_dense_sparse_and_mudata():
+    _, x1, x2 = two_modalities()
+    a = AnnData(x1.copy())
+    pp.l2norm(a, rep="X")
+    np.testing.assert_allclose(np.linalg.norm(a.X, axis=1), 1.0, rtol=1e-12)
+    s = sp.random(50, 30, density=0.2, format="csr", random_state=1) + sp.eye(50, 30, format="csr")
+    b = AnnData(s.tocsr().astype(np.float64))
+    pp.l2norm(b, rep="X")
+    np.testing.assert_allclose(np.sqrt(np.asarray(b.X.multiply(b.X).sum(axis=1))).ravel(), 1.0, rtol=1e-12)
+    md = MuData({"a": AnnData(x1.copy()), "b": AnnData(x2.copy())})
+    out = pp.l2norm(md, rep="X", copy=True)
+    assert out is not md and np.allclose(np.linalg.norm(out.mod["b"].X, axis=1), 1.0)
+    assert not np.allclose(np.linalg.norm(md.mod["b"].X, axis=1), 1.0)
+    with pytest.raises(RuntimeError):
+        pp.l2norm(AnnData(x1.copy()), rep=["X", "X"])
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine", "cityblock"])
+def test_knn_matches_exhaustive_search(metric):
+    _, x1, _ = two_modalities()
+    a = AnnData(x1.copy())
+    pp.knn(a, n_neighbors=12, use_rep="X", metric=metric, backend=BE)
+    D, C, uns = wnn_oracle.knn_graph(x1, 12, metric)
+    got = a.obsp["distances"]
+    assert got.shape == D.shape and np.all(np.diff(got.indptr) == 11)
+    assert (abs(got - D) > 1e-10).nnz == 0
+    assert (abs(a.obsp["connectivities"] - C) > 1e-6).nnz == 0
+    assert a.uns["neighbors"]["params"]["n_neighbors"] == 12 and a.uns["neighbors"]["distances_key"] == "distances"
+
+
+def _run_both(n=140, seed=0, **kw):
+    lab, x1, x2 = two_modalities(n, seed)
+    md = MuData({"rna": AnnData(x1.copy()), "atac": AnnData(x2.copy())})
+    for m in md.mod.values():
+        pp.knn(m, n_neighbors=15, use_rep="X", backend=BE)
+    pp.neighbors(md, backend=BE, **kw)
+    graphs = {k: v.obsp["distances"] for k, v in md.mod.items()}
+    okw = {k: v for k, v in kw.items() if k in ("n_neighbors", "n_bandwidth_neighbors", "n_multineighbors", "metric", "eps")}
+    ref = wnn_oracle.neighbors({"rna": x1, "atac": x2}, graphs, **okw)
+    return lab, md, ref
+
+
+@pytest.mark.parametrize("kw", [dict(n_multineighbors=40), dict(n_multineighbors=30, n_neighbors=10, n_bandwidth_neighbors=12),
+                                dict(n_multineighbors=40, metric="cityblock")])
+def test_wnn_matches_oracle(kw):
+    lab, md, (D, C, W, sig, k) = _run_both(**kw)
+    got = md.obsp["distances"]
+    assert got.shape == D.shape and np.all(np.diff(got.indptr) == k + 1)
+    assert np.array_equal(got.indices, D.indices)
+    np.testing.assert_allclose(got.data, D.data, rtol=1e-6, atol=1e-9)
+    assert (abs(md.obsp["connectivities"] - C) > 1e-5).nnz == 0
+    np.testing.assert_allclose(md.obs["rna:mod_weight"].values, W[:, 0], rtol=1e-5)
+    np.testing.assert_allclose(md.obs["atac:mod_weight"].values + md.obs["rna:mod_weight"].values, 1.0, rtol=1e-12)
+    p = md.uns["neighbors"]["params"]
+    assert p["n_neighbors"] == k and p["method"] == "umap" and p["use_rep"] == {"rna": "X", "atac": "X"}
+    # where modality 2 cannot separate the clusters, modality 1 carries the weight
+    w1 = md.obs["rna:mod_weight"].values
+    assert w1[lab <= 1].mean() > w1[lab >= 2].mean()
+
+
+def test_wnn_slots_errors_and_copy():
+    _, x1, x2 = two_modalities(90, 1)
+    md = MuData({"a": AnnData(x1.copy()), "b": AnnData(x2.copy())})
+    with pytest.raises(ValueError, match="Run `sc.pp.neighbors`"):
+        pp.neighbors(md, backend=BE)
+    for m in md.mod.values():
+        pp.knn(m, n_neighbors=10, use_rep="X", backend=BE)
+    out = pp.neighbors(md, key_added="wnn", n_multineighbors=25, add_weights_to_modalities=True, copy=True, backend=BE)
+    assert "wnn" not in md.uns and "wnn_distances" in out.obsp and "wnn_connectivities" in out.obsp
+    assert out.uns["wnn"]["distances_key"] == "wnn_distances"
+    assert "mod_weight" in out.mod["a"].obs.columns and "a:mod_weight" not in out.obs.columns
+    with pytest.raises(TypeError):
+        pp.neighbors(AnnData(x1), backend=BE)
+    assert mu.pp.neighbors is pp.neighbors
