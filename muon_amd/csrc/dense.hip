@@ -210,6 +210,10 @@ static inline int gram_blocks(int64_t n_rows) {
   int64_t blocks = groups < 1 ? 1 : groups;
   const int per_cu = mu_tune_get("gram_wg") > 0 ? mu_tune_get("gram_wg") : 2;  // (probe: 1, 2, 4, 8 -> 81, 88, 104, 134 us per cross-Gram at 200k rows)
   const int64_t cap = (int64_t)mu_num_cus() * per_cu;
+  // (r03: capping small inputs at kGramFold blocks so that the reduction takes the partials directly -
+  //  two launches instead of three - made the 30 000-row Grams of a 10k x 30k call slower than the
+  //  launch it saved: wait 3.7 -> 4.6 ms per call; the direct path below stays for inputs that have
+  //  that few blocks anyway)
   return (int)(blocks > cap ? cap : blocks);
 }
 
@@ -321,85 +325,66 @@ __global__ __launch_bounds__(256) void k_randn(int64_t count, uint64_t seed, flo
 // sets *flag and is clamped, so that nothing non-finite is produced; the caller checks the flag
 // with its next host read and redoes the call on the host path.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_chol_rinv(int B, int w, const double* __restrict__ G,
-                                                  float* __restrict__ M, int* __restrict__ flag) {
+constexpr int kCholT = 256;
+// r03: the whole workgroup works on the factorisation (r02: one wave, lane i owned row i and walked its
+// dot products alone - 116 us per call, 8-12 calls per lsi(): 9 % of a 10k x 30k call).  Right-looking
+// Cholesky in LDS - per column: pivot, scale, rank-one update of the trailing block spread over the
+// threads - then L^-1 by the same column sweep on an identity.
+__global__ __launch_bounds__(kCholT) void k_chol_rinv(int B, int w, const double* __restrict__ G,
+                                                      float* __restrict__ M, int* __restrict__ flag) {
   __shared__ double L[64][65];
   __shared__ double X[64][65];
-  const int lane = threadIdx.x;
+  __shared__ double s_piv;
+  __shared__ int s_bad;
+  const int t = threadIdx.x;
+  if (t == 0) s_bad = 0;
+  for (int e = t; e < 64 * 64; e += kCholT) {
+    const int i = e >> 6, j = e & 63;
+    L[i][j] = (i < w && j < w && j <= i) ? G[(int64_t)i * B + j] : 0.0;
+    X[i][j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
   double dmax = 0.0;
-#pragma unroll 8
-  for (int i = 0; i < w; ++i) {
-    if (lane < w) L[i][lane] = G[(int64_t)i * B + lane];
-    const double d = G[(int64_t)i * B + i];
-    dmax = d > dmax ? d : dmax;
-  }
-  __syncthreads();
+  for (int i = 0; i < w; ++i) dmax = L[i][i] > dmax ? L[i][i] : dmax;
   const double tiny = dmax > 0.0 ? dmax * 1e-13 : 1.0;
-  bool bad = false;
-  // left-looking Cholesky, lane i owns row i of L
-  for (int k = 0; k < w; ++k) {
-    double s = 0.0;
-    if (lane >= k && lane < w) {
-      // (eight products per trip, their LDS reads issued together: one read-wait-FMA per trip made
-      //  this kernel 158 us, a chain of 4000 LDS round trips)
-      double s0 = L[lane][k], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int p = 0;
-      for (; p + 8 <= k; p += 8) {
-        double a[8], b[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          a[u] = L[lane][p + u];
-          b[u] = L[k][p + u];
-        }
-        s0 -= a[0] * b[0]; s1 -= a[1] * b[1]; s2 -= a[2] * b[2]; s3 -= a[3] * b[3];
-        s0 -= a[4] * b[4]; s1 -= a[5] * b[5]; s2 -= a[6] * b[6]; s3 -= a[7] * b[7];
-      }
-      for (; p < k; ++p) s0 -= L[lane][p] * L[k][p];
-      s = (s0 + s1) + (s2 + s3);
-    }
-    double piv = __shfl(s, k, 64);
-    if (!(piv > tiny)) {  // also catches NaN
-      bad = true;
-      piv = tiny;
-    }
-    const double r = sqrt(piv);
-    __syncthreads();
-    if (lane == k) L[k][k] = r;
-    else if (lane > k && lane < w) L[lane][k] = s / r;
-    __syncthreads();
-  }
-  // X = L^-1 (lower): lane j owns column j, forward substitution
-  if (lane < w) {
-    for (int i = 0; i < w; ++i) {
-      double x = 0.0;
-      if (i >= lane) {
-        double x0 = (i == lane) ? 1.0 : 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
-        int p = lane;
-        for (; p + 8 <= i; p += 8) {
-          double a[8], b[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            a[u] = L[i][p + u];
-            b[u] = X[p + u][lane];
-          }
-          x0 -= a[0] * b[0]; x1 -= a[1] * b[1]; x2 -= a[2] * b[2]; x3 -= a[3] * b[3];
-          x0 -= a[4] * b[4]; x1 -= a[5] * b[5]; x2 -= a[6] * b[6]; x3 -= a[7] * b[7];
-        }
-        for (; p < i; ++p) x0 -= L[i][p] * X[p][lane];
-        x = ((x0 + x1) + (x2 + x3)) / L[i][i];
-      }
-      X[i][lane] = x;
-    }
-  }
   __syncthreads();
-  // M = R^-1 = (L^-1)^T: M[r][c] = X[c][r] for r <= c < w
-  for (int r = 0; r < B; ++r) {
-    if (lane < B) {
-      const bool in = (r < w) && (lane < w) && (r <= lane);
-      M[(int64_t)r * B + lane] = in ? (float)X[lane][r] : 0.f;
+  for (int k = 0; k < w; ++k) {
+    if (t == 0) {
+      double piv = L[k][k];
+      if (!(piv > tiny)) {  // also catches NaN: a block with dependent columns
+        s_bad = 1;
+        piv = tiny;
+      }
+      s_piv = sqrt(piv);
     }
+    __syncthreads();
+    const double r = s_piv;
+    // column k of L, and row k of X = L^-1 (every entry of X[k][0..k] is final once divided by the pivot)
+    if (t < 64) {
+      if (t == k) L[k][k] = r;
+      else if (t > k && t < w) L[t][k] = L[t][k] / r;
+    } else if (t < 128) {
+      const int j = t - 64;
+      if (j <= k) X[k][j] = X[k][j] / r;
+    }
+    __syncthreads();
+    // trailing updates: L[i][j] -= L[i][k] L[j][k] (k < j <= i < w);  X[i][j] -= L[i][k] X[k][j] (i > k, j <= k)
+    const int m = w - k - 1;  // rows below the pivot
+    for (int e = t; e < m * 64; e += kCholT) {
+      const int i = k + 1 + (e >> 6), j = e & 63;
+      const double lik = L[i][k];
+      if (j > k && j <= i) L[i][j] -= lik * L[j][k];
+      if (j <= k) X[i][j] -= lik * X[k][j];
+    }
+    __syncthreads();
   }
-  if (bad && lane == 0) *flag = 1;
+  if (t == 0 && s_bad) *flag = 1;
+  // M = R^-1 = (L^-1)^T: M[r][c] = X[c][r] for r <= c < w
+  for (int e = t; e < B * B; e += kCholT) {
+    const int r = e / B, c = e % B;
+    const bool in = (r < w) && (c < w) && (r <= c);
+    M[e] = in ? (float)X[c][r] : 0.f;
+  }
 }
 
 extern "C" {
@@ -423,10 +408,14 @@ int mu_gram_cross_f32(int64_t n_rows, int B, const float* d_A, const float* d_Bm
   hipLaunchKernelGGL(k_gram_cross_partial<BB>, dim3(blocks), dim3(kGramThreads), 0, st, n_rows, d_A,  \
                      d_Bm, partial);                                                                  \
   MU_CHECK_LAUNCH();                                                                                  \
-  hipLaunchKernelGGL(k_gram_fold<BB>, dim3(rblocks, kGramFold), dim3(256), 0, st, blocks, partial,    \
-                     folded);                                                                         \
-  MU_CHECK_LAUNCH();                                                                                  \
-  hipLaunchKernelGGL(k_gram_cross_reduce<BB>, dim3(rblocks), dim3(256), 0, st, kGramFold, folded, d_C);
+  if (blocks <= kGramFold) {                                                                          \
+    hipLaunchKernelGGL(k_gram_cross_reduce<BB>, dim3(rblocks), dim3(256), 0, st, blocks, partial, d_C); \
+  } else {                                                                                            \
+    hipLaunchKernelGGL(k_gram_fold<BB>, dim3(rblocks, kGramFold), dim3(256), 0, st, blocks, partial,  \
+                       folded);                                                                       \
+    MU_CHECK_LAUNCH();                                                                                \
+    hipLaunchKernelGGL(k_gram_cross_reduce<BB>, dim3(rblocks), dim3(256), 0, st, kGramFold, folded, d_C); \
+  }
   switch (B) {
     case 64: MU_CROSS(64) break;
     case 32: MU_CROSS(32) break;
@@ -452,6 +441,10 @@ int mu_gram_f32(int64_t n_rows, int B, const float* d_A, double* d_G, double* d_
     case 64:
       hipLaunchKernelGGL(k_gram_partial<64>, dim3(blocks), dim3(kGramThreads), 0, st, n_rows, d_A, partial);
       MU_CHECK_LAUNCH();
+      if (blocks <= kGramFold) {
+        hipLaunchKernelGGL(k_gram_reduce<64>, dim3(rblocks), dim3(256), 0, st, blocks, partial, d_G, d_colsum);
+        break;
+      }
       hipLaunchKernelGGL(k_gram_fold<64>, dim3(rblocks, kGramFold), dim3(256), 0, st, blocks, partial, folded);
       MU_CHECK_LAUNCH();
       hipLaunchKernelGGL(k_gram_reduce<64>, dim3(rblocks), dim3(256), 0, st, kGramFold, folded, d_G, d_colsum);
@@ -459,6 +452,10 @@ int mu_gram_f32(int64_t n_rows, int B, const float* d_A, double* d_G, double* d_
     case 32:
       hipLaunchKernelGGL(k_gram_partial<32>, dim3(blocks), dim3(kGramThreads), 0, st, n_rows, d_A, partial);
       MU_CHECK_LAUNCH();
+      if (blocks <= kGramFold) {
+        hipLaunchKernelGGL(k_gram_reduce<32>, dim3(rblocks), dim3(256), 0, st, blocks, partial, d_G, d_colsum);
+        break;
+      }
       hipLaunchKernelGGL(k_gram_fold<32>, dim3(rblocks, kGramFold), dim3(256), 0, st, blocks, partial, folded);
       MU_CHECK_LAUNCH();
       hipLaunchKernelGGL(k_gram_reduce<32>, dim3(rblocks), dim3(256), 0, st, kGramFold, folded, d_G, d_colsum);
@@ -466,6 +463,10 @@ int mu_gram_f32(int64_t n_rows, int B, const float* d_A, double* d_G, double* d_
     default:
       hipLaunchKernelGGL(k_gram_partial<16>, dim3(blocks), dim3(kGramThreads), 0, st, n_rows, d_A, partial);
       MU_CHECK_LAUNCH();
+      if (blocks <= kGramFold) {
+        hipLaunchKernelGGL(k_gram_reduce<16>, dim3(rblocks), dim3(256), 0, st, blocks, partial, d_G, d_colsum);
+        break;
+      }
       hipLaunchKernelGGL(k_gram_fold<16>, dim3(rblocks, kGramFold), dim3(256), 0, st, blocks, partial, folded);
       MU_CHECK_LAUNCH();
       hipLaunchKernelGGL(k_gram_reduce<16>, dim3(rblocks), dim3(256), 0, st, kGramFold, folded, d_G, d_colsum);
@@ -541,7 +542,7 @@ int mu_randn_f32(int64_t count, uint64_t seed, float* d_out, void* stream) {
 int mu_chol_rinv_f64(int B, int w, const double* d_G, float* d_M, int* d_flag, void* stream) {
   MU_REQUIRE(B >= 1 && B <= 64 && w >= 0 && w <= B, "B must be 1..64 and 0 <= w <= B");
   MU_REQUIRE(d_G && d_M && d_flag, "null pointer");
-  hipLaunchKernelGGL(k_chol_rinv, dim3(1), dim3(64), 0, (hipStream_t)stream, B, w, d_G, d_M, d_flag);
+  hipLaunchKernelGGL(k_chol_rinv, dim3(1), dim3(kCholT), 0, (hipStream_t)stream, B, w, d_G, d_M, d_flag);
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
