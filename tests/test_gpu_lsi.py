@@ -8,6 +8,7 @@ import scipy.sparse as sp
 
 from muon_amd import AnnData
 from muon_amd import atac as ac
+from muon_amd._atac.tools import lsi_device
 from oracle import lsi_oracle
 from tests.synth import planted_topics_csr
 
@@ -197,3 +198,33 @@ def test_bench_starts_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["lsi"]["converged"]
     assert out["roofline"]["frac"] > 0 and out["roofline"]["lds_frac"] > 0
+
+
+def test_rank_deficient_input_takes_the_device_flag_and_the_host_redo(hip):
+    """min(n, d) >= 8192 selects the device-side Cholesky of CholeskyQR; a matrix of rank 20 asked for 30
+    components exhausts the Krylov space, the device flags the pivot that is not safely positive, the call
+    is redone on the host path (which truncates the dependent directions), and the 20 singular values
+    that exist come out right (this path had no test)."""
+    rng = np.random.default_rng(0)
+    n = d = 9000
+    base = sp.random(20, d, density=0.02, random_state=rng, format="csr", dtype=np.float32)
+    idx = rng.integers(0, 20, n)
+    X = (sp.diags((1 + rng.random(n)).astype(np.float32)) @ base[idx]).tocsr()
+    X.sort_indices()
+    Xd = hip.upload_csr(X.indptr, X.indices, X.data.astype(np.float32), X.shape)
+    calls = []
+    orig = hip.chol_rinv
+    hip.chol_rinv = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        U, stdev, V, info = lsi_device(hip, Xd, n_comps=30, n_obs=n, return_info=True)
+    finally:
+        del hip.chol_rinv
+    assert calls, "the device Cholesky path was not taken first"
+    s = stdev * np.sqrt(n - 1)
+    ref = np.linalg.svd((base.toarray().astype(np.float64).T * 1.0), compute_uv=False)  # (only for the count)
+    assert np.sum(ref > 1e-6) == 20
+    from scipy.sparse.linalg import svds
+
+    want = np.sort(svds(X.astype(np.float64), k=20, return_singular_vectors=False))[::-1]
+    np.testing.assert_allclose(s[:20], want, rtol=1e-5)
+    assert np.all(s[20:] < 1e-3 * s[0]) and np.all(np.isfinite(hip.to_host(U))) and np.all(np.isfinite(hip.to_host(V)))

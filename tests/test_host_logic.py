@@ -318,3 +318,21 @@ def test_lsi_reports_unconverged_instead_of_being_silently_wrong(case):
     if info["converged"]:
         assert angle < 1e-4
     np.testing.assert_allclose(sd, ref["stdev"], rtol=1e-5)  # singular values converge with the angle squared
+
+
+def test_lsi_more_components_than_rank_stops_with_exact_values():
+    """n_comps beyond the rank of the matrix: the Krylov space runs out after one expansion, the run ends
+    there (not at max_iter), the singular values that exist are exact and the rest ~0."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(0)
+    base = sp.random(20, 200, density=0.2, random_state=rng, format="csr", dtype=np.float32)
+    X = (sp.diags((1 + rng.random(300)).astype(np.float32)) @ base[rng.integers(0, 20, 300)]).tocsr()
+    X.sort_indices()
+    be = CpuTestBackend()
+    Xd = be.upload_csr(X.indptr, X.indices, X.data.astype(np.float32), X.shape)
+    U, stdev, V, info = lsi_device(be, Xd, n_comps=30, n_obs=300, return_info=True)
+    s = stdev * np.sqrt(299)
+    want = np.linalg.svd(X.toarray().astype(np.float64), compute_uv=False)
+    np.testing.assert_allclose(s[:20], want[:20], rtol=1e-5)
+    assert np.all(s[20:] < 1e-4 * s[0]) and info["iterations"] <= 3 and info["spmm"] <= 7
