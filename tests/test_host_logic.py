@@ -325,6 +325,8 @@ def test_lsi_more_components_than_rank_stops_with_exact_values():
     there (not at max_iter), the singular values that exist are exact and the rest ~0."""
     import scipy.sparse as sp
 
+    from muon_amd._atac.tools import lsi_device
+
     rng = np.random.default_rng(0)
     base = sp.random(20, 200, density=0.2, random_state=rng, format="csr", dtype=np.float32)
     X = (sp.diags((1 + rng.random(300)).astype(np.float32)) @ base[rng.integers(0, 20, 300)]).tocsr()
