@@ -22,7 +22,8 @@ the largest relative difference of the singular values go into the JSON line (`p
 
 secondary: the default run (c3, one GPU) also carries the two other single-GPU configurations of
 BASELINE.json as complete sub-records (ms, roofline, cpu_baseline, parity): `c2` (configs[0]/[1]) and
-`c4` (configs[3], mu.tl.mofa).  --no-secondary skips them.
+`c4` (configs[3], mu.tl.mofa, f32) + `c4_f64` (the same in the reference's default precision).
+--no-secondary skips them.
 
 Workloads (--workload):
   c3 (default)       BASELINE.json configs[2], the shape the metric is quoted on: 1 000 000 cells x
@@ -294,7 +295,7 @@ def run_lsi(args, workload, rank, world, local_rank, comm, steps, warmup, cpu_sa
     return out
 
 
-def run_c4(args, steps, warmup):
+def run_c4(args, steps, warmup, f64=False):
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("bench_mofa", os.path.join(ROOT, "scripts", "bench_mofa.py"))
@@ -303,8 +304,10 @@ def run_c4(args, steps, warmup):
     argv = ["--gpus", str(args.gpus), "--iters", str(steps), "--warmup", str(max(warmup, 3))]
     if args.cells and args.workload == "c4":
         argv += ["--cells", str(args.cells)]
-    if args.no_cpu_baseline:
+    if args.no_cpu_baseline or f64:
         argv += ["--no-cpu-baseline"]
+    if f64:
+        argv += ["--f64"]
     return mod.run(argv, init_dist=False)
 
 
@@ -388,6 +391,10 @@ def main():
                 sec["c4"] = run_c4(args, 100, 3)
             except Exception as e:  # noqa: BLE001
                 sec["c4"] = {"error": repr(e)}
+            try:  # the reference's default precision (use_float32=False, tools.py:308)
+                sec["c4_f64"] = run_c4(args, 100, 3, f64=True)
+            except Exception as e:  # noqa: BLE001
+                sec["c4_f64"] = {"error": repr(e)}
             out["secondary"] = sec
     if rank == 0 and out is not None:
         print(json.dumps(out))
