@@ -41,7 +41,14 @@ template <> struct Mma<float> {
 // line-lookup rate (measured 5.0 ms for 8 GB in f32, 1.6 TB/s), so a wave stages a 16-row x
 // 128-byte tile through LDS instead: two coalesced global_load_dwordx4 per tile (8 rows x one full
 // line each), ds_write_b128, then the transposed operand reads (row stride 144 B: conflict free).
-// Tiles are double buffered per wave; Tm (D x 16, a few MB) comes from L2 once per 16 rows.
+// r03: a workgroup owns kSub = 4 such tiles (64 rows) and its four waves split the columns in quarters
+// (partial products, added up through LDS in a fixed order): per wave the eight loads of the NEXT step
+// over d are in flight while the 4 x CW/4 MFMAs of this one run (r02 had one tile per wave in flight
+// and wrote it to LDS right behind its loads: no overlap inside a wave, 3.6 TB/s in f64), the CW/4
+// operands of Tm (D x 16, a few MB: L2) are loaded once per 64 rows instead of once per 16, one step
+// ahead, and 100 000 rows still give every CU six workgroups.  A wave's LDS writes and reads execute
+// in order: one staging buffer per wave, no barrier inside the sweep.
+constexpr int kSub = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void k_skinny_nn(int64_t n_rows, int64_t D, int64_t ldY,
                                                    const T* __restrict__ Y, const T* __restrict__ Tm,
@@ -50,50 +57,91 @@ __global__ __launch_bounds__(256) void k_skinny_nn(int64_t n_rows, int64_t D, in
   constexpr int CW = 128 / (int)sizeof(T);   // columns per tile: 32 (f32) / 16 (f64)
   constexpr int PE = 16 / (int)sizeof(T);    // elements per 16-byte piece: 4 / 2
   constexpr int RS = 144;                    // LDS row stride in bytes
-  __shared__ __attribute__((aligned(16))) char tiles[4][2][16 * RS];
+  constexpr int NU = CW / 4;                 // MFMA steps per tile: 8 / 4
+  constexpr int kStage = 4 * kSub * 16 * RS;                      // staging: 36 KiB
+  constexpr int kRed = 4 * kSub * 16 * 16 * (int)sizeof(T);       // the waves' partial products
+  __shared__ __attribute__((aligned(16))) char smem[kStage > kRed ? kStage : kRed];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane >> 4, lc = lane & 15;
   const int prow = lane >> 3, piece = lane & 7;  // loader view: 8 rows x 8 pieces per instruction
   const bool vec_ok = ((ldY * (int64_t)sizeof(T)) % 16 == 0) && ((reinterpret_cast<uintptr_t>(Y) % 16) == 0);
-  const int64_t n_tiles = (n_rows + 15) / 16;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t r0 = tile * 16;
-    acc_t acc = acc_t{0, 0, 0, 0};
-    auto load_tile = [&](int64_t d0, int buf) {
+  char* my_tiles = smem + wave * (kSub * 16 * RS);
+  const int64_t n_tiles = (n_rows + 16 * kSub - 1) / (16 * kSub);
+  // this wave's quarter of the columns, in whole tiles
+  const int64_t n_ct = (D + CW - 1) / CW;
+  const int64_t dlo = (n_ct * wave / 4) * CW, dhi_ = (n_ct * (wave + 1) / 4) * CW;
+  const int64_t dhi = dhi_ < D ? dhi_ : D;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t r0 = tile * (16 * kSub);
+    acc_t acc[kSub];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int64_t row = r0 + prow + 8 * h;
-        const int64_t d = d0 + piece * PE;
-        T v[PE];
-        if (row < n_rows && vec_ok && d + PE <= D) {
-          const float4 q = *reinterpret_cast<const float4*>(Y + row * ldY + d);
-          __builtin_memcpy(v, &q, 16);
-        } else {
+    for (int q = 0; q < kSub; ++q) acc[q] = acc_t{0, 0, 0, 0};
+    float4 yq[kSub][2];
+    T bq[NU];
+    auto gload = [&](int64_t d0) {  // this lane's two 16-byte pieces of every sub-tile at columns d0 ..
 #pragma unroll
-          for (int e = 0; e < PE; ++e) v[e] = (row < n_rows && d + e < D) ? Y[row * ldY + d + e] : (T)0;
+      for (int q = 0; q < kSub; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int64_t row = r0 + 16 * q + prow + 8 * h;
+          const int64_t d = d0 + piece * PE;
+          T v[PE];
+          if (row < n_rows && vec_ok && d + PE <= D) {
+            yq[q][h] = *reinterpret_cast<const float4*>(Y + row * ldY + d);
+          } else {
+#pragma unroll
+            for (int e = 0; e < PE; ++e) v[e] = (row < n_rows && d + e < D) ? Y[row * ldY + d + e] : (T)0;
+            __builtin_memcpy(&yq[q][h], v, 16);
+          }
         }
-        float4 q;
-        __builtin_memcpy(&q, v, 16);
-        *reinterpret_cast<float4*>(&tiles[wave][buf][(prow + 8 * h) * RS + piece * 16]) = q;
+    };
+    auto bload = [&](int64_t d0) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int64_t d = d0 + 4 * u + lr;
+        bq[u] = (d < D) ? Tm[d * 16 + lc] : (T)0;
       }
     };
-    load_tile(0, 0);
-    int buf = 0;
-    for (int64_t d0 = 0; d0 < D; d0 += CW, buf ^= 1) {
-      if (d0 + CW < D) load_tile(d0 + CW, buf ^ 1);  // the wave's LDS accesses execute in order
+    if (dlo < dhi) {
+      gload(dlo);
+      bload(dlo);
+    }
+    for (int64_t d0 = dlo; d0 < dhi; d0 += CW) {
 #pragma unroll
-      for (int u = 0; u < CW / 4; ++u) {
-        const int64_t d = d0 + 4 * u + lr;
-        const T b = (d < D) ? Tm[d * 16 + lc] : (T)0;
-        const T a = *reinterpret_cast<const T*>(&tiles[wave][buf][lc * RS + (4 * u + lr) * (int)sizeof(T)]);
-        acc = Mma<T>::fma(a, b, acc);
+      for (int q = 0; q < kSub; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          *reinterpret_cast<float4*>(&my_tiles[(q * 16 + prow + 8 * h) * RS + piece * 16]) = yq[q][h];
+      T b[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) b[u] = bq[u];
+      if (d0 + CW < dhi) {  // the next step's operands: in flight under this step's MFMAs
+        gload(d0 + CW);
+        bload(d0 + CW);
       }
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t orow = r0 + Mma<T>::row(lr, r);
-      if (orow < n_rows) out[orow * 16 + lc] = acc[r];
+      for (int q = 0; q < kSub; ++q)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const T a = *reinterpret_cast<const T*>(&my_tiles[(q * 16 + lc) * RS + (4 * u + lr) * (int)sizeof(T)]);
+          acc[q] = Mma<T>::fma(a, b[u], acc[q]);
+        }
     }
+    // the four quarters, added in wave order
+    __syncthreads();  // everyone is done with the staging buffers
+    T* red = reinterpret_cast<T*>(smem);
+#pragma unroll
+    for (int q = 0; q < kSub; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[((wave * kSub + q) * 16 + Mma<T>::row(lr, r)) * 16 + lc] = acc[q][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < kSub * 16 * 16; e += 256) {
+      const int64_t orow = r0 + e / 16;
+      if (orow < n_rows)
+        out[orow * 16 + (e & 15)] = ((red[e] + red[kSub * 256 + e]) + red[2 * kSub * 256 + e]) + red[3 * kSub * 256 + e];
+    }
+    __syncthreads();  // before the next step's staging writes
   }
 }
 
@@ -190,8 +238,7 @@ int mu_skinny_nn(int dtype, int64_t n_rows, int64_t D, int64_t ldY, const void* 
   MU_REQUIRE(n_rows >= 0 && D >= 0 && ldY >= D, "bad shape");
   if (n_rows == 0) return MU_OK;
   MU_REQUIRE(d_out && (D == 0 || (d_Y && d_T)), "null pointer");
-  const int64_t groups = (n_rows + 15) / 16;
-  int64_t blocks = (groups + 3) / 4;
+  int64_t blocks = (n_rows + 16 * kSub - 1) / (16 * kSub);  // 64-row steps, one per workgroup
   const int64_t cap = (int64_t)mu_num_cus() * 8;
   if (blocks > cap) blocks = cap;
   hipStream_t st = (hipStream_t)stream;
