@@ -26,7 +26,6 @@ from typing import Optional
 import numpy as np
 import torch
 import scipy.linalg
-from scipy.sparse import issparse
 
 from .._comm import default_comm
 from .._containers import is_anndata, is_mudata

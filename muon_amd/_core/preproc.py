@@ -22,7 +22,7 @@ from __future__ import annotations
 
 import math
 from itertools import repeat
-from typing import Dict, Iterable, Optional, Union
+from typing import Dict, Optional
 
 import numpy as np
 import torch

@@ -30,7 +30,7 @@ import pandas as pd
 import torch
 from scipy.sparse import csr_matrix, issparse
 
-from .._containers import AnnData, MuData, is_anndata, is_mudata
+from .._containers import MuData, is_anndata, is_mudata
 
 logger = logging.getLogger("muon_amd")
 
