@@ -191,6 +191,7 @@ def run_lsi(args, workload, rank, world, local_rank, comm, steps, warmup, cpu_sa
 
     for _ in range(warmup):
         step()
+    torch.cuda.reset_peak_memory_stats(local_rank)
     be.events.clear()
     be.enabled = True
     sync()
