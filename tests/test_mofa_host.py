@@ -259,3 +259,31 @@ def test_wrapper_elementwise_nan_in_a_dense_modality():
     md = MuData({"y1": AnnData(y1), "y2": AnnData(y2)})
     mu.tl.mofa(md, n_factors=8, n_iterations=30, quiet=True, backend=BE)
     assert np.all(np.isfinite(md.obsm["X_mofa"])) and md.obsm["X_mofa"].shape == (100, 8)
+
+
+def test_multi_group_with_shuffled_sample_names_like_the_reference_test():
+    """Reference tests/test_muon_tools.py:91-147 (TestMOFA2D.test_multi_group) without its two golden
+    values (they depend on mofapy2's private RNG stream): two groups, shuffled sample names,
+    `groups_label`: the group column survives, X_mofa rows follow mdata.obs order and equal the
+    oracle's factors for the same data."""
+    from oracle import mofa_oracle
+
+    n_g1, n_g2, d_m1, d_m2, k = 10, 20, 30, 40, 5
+    n = n_g1 + n_g2
+    np.random.seed(42)
+    z = np.concatenate([np.random.normal(size=(n_g1, k)), np.random.normal(size=(n_g2, k))], axis=0)
+    w1, w2 = np.random.normal(size=(d_m1, k)), np.random.normal(size=(d_m2, k))
+    y1 = z @ w1.T + np.random.normal(size=(n, d_m1))
+    y2 = z @ w2.T + np.random.normal(size=(n, d_m2))
+    names = [f"sample{i}_group{g}" for g, sz in {"A": n_g1, "B": n_g2}.items() for i in range(sz)]
+    np.random.shuffle(names)
+    groups = [s.split("_")[1] for s in names]
+    mdata = MuData({"view1": AnnData(y1, obs=pd.DataFrame(index=names)), "view2": AnnData(y2, obs=pd.DataFrame(index=names))})
+    mdata.obs = mdata.obs.join(pd.DataFrame({"sample": names, "group": groups}, index=names))
+    mu.tl.mofa(mdata, groups_label="group", n_factors=6, n_iterations=40, convergence_mode="slow", quiet=True, backend=BE)
+    assert all(mdata.obs.group.values == [s.split("_")[1] for s in mdata.obs["sample"]])
+    codes = pd.Index(pd.unique(np.asarray(groups))).get_indexer(groups)
+    ref = mofa_oracle.run([y1, y2], groups=codes, n_factors=6, n_iterations=40, convergence_mode="slow")
+    order = np.argsort(-ref["r2"].sum(axis=(0, 1)), kind="stable")
+    np.testing.assert_allclose(mdata.obsm["X_mofa"], ref["Z"][:, order], atol=1e-7)
+    assert set(mdata.uns["mofa"]["variance"]["view1"]) == set(pd.unique(np.asarray(groups)))
