@@ -30,7 +30,7 @@ int mu_num_cus() {
 // tuning / ablation knobs (tests and bench only)
 static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "spmm_waves", "spmm_pipe",
                                         "tpack_abl", "tpack_c", "gram_wg", "tpack_v2", "pack_wg",
-                                        "tpack_dbg", "tpack_rows", "tpack_narrow"};
+                                        "tpack_dbg", "tpack_rows", "tpack_narrow", "spmm_narrow_off"};
 constexpr int kTuneN = sizeof(kTuneKeys) / sizeof(kTuneKeys[0]);
 static int g_tune[kTuneN] = {};
 

@@ -731,6 +731,10 @@ int launch_f64(int B, hipStream_t st, int64_t n_pos, int64_t n_cols, const int64
 
 }  // namespace
 
+// csrc/spmm_narrow.hip: the B = 16 product on the same operand with 16 entries x 4 columns per wave step
+int mu_spmm_narrow_f32_launch(hipStream_t st, int64_t n_pos, int64_t n_cols, int K, const int64_t* sptr,
+                              const unsigned long long* ent, const int32_t* perm, const float* Q, float* Y);
+
 extern "C" {
 
 int mu_spmm_stream_k(int64_t n_rows) { return pick_k(n_rows); }
@@ -779,6 +783,9 @@ int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
   const int force_k = mu_tune_get("spmm_k");  // tests / tuning only (mu_tune_set); 0 in production
   if (force_k >= 1 && force_k <= kKMax) K = force_k;
   const int mode = mu_tune_get("spmm_mode");
+  // B = 16: the narrow-block kernel (tune spmm_narrow_off = 1: this file's NB = 1 instance, kept for A/B runs)
+  if (B == 16 && (mode == 0 || mode == 2 || mode == 3 || mode == 4) && mu_tune_get("spmm_narrow_off") == 0)
+    return mu_spmm_narrow_f32_launch(st, n_pos, n_cols, K, d_sptr, ent, d_perm, d_Q, d_Y);
 #define MU_ARGS B, st, n_pos, n_cols, d_sptr, ent, d_perm, d_Q, d_Y
   if (mode != 0) {
     // timing ablations that are still compiled (the others - 32, 4096, 8192, 16384, 65536, 131072,
