@@ -22,7 +22,8 @@ the largest relative difference of the singular values go into the JSON line (`p
 
 secondary: the default run (c3, one GPU) also carries the two other single-GPU configurations of
 BASELINE.json as complete sub-records (ms, roofline, cpu_baseline, parity): `c2` (configs[0]/[1]) and
-`c4` (configs[3], mu.tl.mofa, f32) + `c4_f64` (the same in the reference's default precision).
+`c4` (configs[3], mu.tl.mofa, f32) + `c4_f64` (the same in the reference's default precision), and
+`ingest` / `mofa_ng` / `wnn`: one measured record with parity per widened row of SURVEY 8f.
 --no-secondary skips them.
 
 Workloads (--workload):
@@ -39,6 +40,9 @@ Workloads (--workload):
                      metric = seconds per 100 ELBO iterations (lower is better), --steps = iterations
                      (default 100), cells sharded over the N GPUs; cpu_baseline = the numpy f64
                      restatement on a cell sample, extrapolated (scripts/bench_mofa.py)
+
+  ingest, mofa_ng,   the widened rows of SURVEY 8f on one GPU (scripts/bench_widened.py): 10x arrays -> device CSR
+  wnn                (PCIe included), MOFA+ with a poisson view and missing values, weighted nearest neighbours
 
 Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 either run it under
 torch.distributed.run (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env) or
@@ -66,6 +70,7 @@ WORKLOADS = {  # cells = TOTAL cells for strong scaling, cells PER GPU for weak 
     "c3shard": dict(cells=125_000, peaks=200_000, scaling="weak"),
     "c2": dict(cells=10_000, peaks=30_000, scaling="weak"),
     "c4": None,  # BASELINE.json configs[3]/[4]: mu.tl.mofa, 100 ELBO iterations (scripts/bench_mofa.py)
+    "ingest": None, "mofa_ng": None, "wnn": None,  # SURVEY 8f.2 - 8f.4 (scripts/bench_widened.py)
 }
 
 
@@ -312,6 +317,18 @@ def run_c4(args, steps, warmup, f64=False):
     return mod.run(argv, init_dist=False)
 
 
+def run_widened(name):
+    """Sub-records of the widened rows: scripts/bench_widened.py."""
+    import importlib.util
+
+    from muon_amd._backend import get_backend
+
+    spec = importlib.util.spec_from_file_location("bench_widened", os.path.join(ROOT, "scripts", "bench_widened.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.RUNNERS[name](get_backend())
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves."""
     import socket
@@ -376,6 +393,8 @@ def main():
 
     if args.workload == "c4":
         out = run_c4(args, args.steps or 100, args.warmup)
+    elif args.workload in ("ingest", "mofa_ng", "wnn"):
+        out = run_widened(args.workload) if rank == 0 else None
     else:
         out = run_lsi(args, args.workload, rank, world, local_rank, comm, args.steps or 3, args.warmup,
                       args.cpu_sample_cells)
@@ -396,6 +415,12 @@ def main():
                 sec["c4_f64"] = run_c4(args, 100, 3, f64=True)
             except Exception as e:  # noqa: BLE001
                 sec["c4_f64"] = {"error": repr(e)}
+            for name in ("ingest", "mofa_ng", "wnn"):  # the widened rows, seconds each
+                try:
+                    torch.cuda.empty_cache()
+                    sec[name] = run_widened(name)
+                except Exception as e:  # noqa: BLE001
+                    sec[name] = {"error": repr(e)}
             out["secondary"] = sec
     if rank == 0 and out is not None:
         print(json.dumps(out))

@@ -228,3 +228,21 @@ def test_rank_deficient_input_takes_the_device_flag_and_the_host_redo(hip):
     want = np.sort(svds(X.astype(np.float64), k=20, return_singular_vectors=False))[::-1]
     np.testing.assert_allclose(s[:20], want, rtol=1e-5)
     assert np.all(s[20:] < 1e-3 * s[0]) and np.all(np.isfinite(hip.to_host(U))) and np.all(np.isfinite(hip.to_host(V)))
+
+
+def test_widened_bench_records_run_small_and_hold_parity(hip):
+    """scripts/bench_widened.py (the `secondary` records of SURVEY 8f.2 - 8f.4 in the bench line) at toy
+    sizes: every record carries a value and its parity against the oracle / the scipy route."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_widened", os.path.join(root, "scripts", "bench_widened.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.run_ingest(hip, n_cells=3000, n_feat=5000, density=0.03)
+    assert r["parity"]["identical"] and r["value"] > 0 and r["config"]["kept_columns"] == 4000
+    r = mod.run_mofa_ng(hip, n=600, d_dense=50, d_sparse=300, iters=3, sample=200)
+    assert r["parity"]["elbo_max_rel"] < 1e-10 and r["parity"]["Z_max_abs"] < 1e-8 and r["elbo_monotone"]
+    r = mod.run_wnn(hip, n=3000, sample=300)
+    assert r["parity"]["graph_identical_fraction"] > 0.99 and r["parity"]["modality_weight_max_abs"] < 1e-4
