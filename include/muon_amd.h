@@ -294,6 +294,17 @@ int mu_mofa_rowstats(int dtype, int64_t r0, int64_t r1, int K, const void* d_E, 
                      void* d_out_t, int64_t ld_t, void* d_gram, void* d_s2, void* d_s1, double* d_work,
                      void* stream);
 
+/* ---- exhaustive nearest-neighbour search, the filter pass (replaces the n x n distance panels + radix top-k
+ * of the tensor formulation behind muon.pp.neighbors, /root/reference/muon/_core/preproc.py:366-373,453-461,
+ * 525-533, where the reference calls UMAP's approximate NN-descent).  For every query q < n_q and every
+ * candidate position c in [c_lo, c_hi) with |x_q - y_c|^2 = sqq[q] + sqc[c] - 2 x_q . y_c < thr[q] and
+ * c != self_pos[q]: append (c, that squared distance) to the query's buffer, rows of `cap` entries; cnt[q] =
+ * number of candidates that passed (may exceed cap: the caller then redoes the query).  Xq [n_q x p_pad],
+ * Xc [>= c_hi x p_pad] row-major f64, zero-padded to p_pad (a multiple of 4) columns. */
+int mu_knn_filter_f64(int64_t n_q, int64_t c_lo, int64_t c_hi, int p_pad, const double* d_Xq, const double* d_Xc,
+                      const double* d_sqq, const double* d_sqc, const double* d_thr, const int32_t* d_self_pos,
+                      int cap, int32_t* d_buf_pos, double* d_buf_d, int32_t* d_cnt, void* stream);
+
 /* ---- MOFA+ small nodes and the ELBO, fused (tools.py:585 ent.run(): mofapy2's Tau, AlphaW, ThetaW,
  * AlphaZ node updates and calculateELBO()).  Arithmetic in f64 for both storage types; every entry
  * ADDS its ELBO terms to the device scalar *d_elbo.  d_work: mu_mofa_elbo_work_doubles(K) doubles. */

@@ -623,6 +623,13 @@ class HipBackend:
                                             int(bool(scale_out)), _p(out_pad), ld, int(col0), _p(out_t), ld_t,
                                             _p(gram), _p(s2), _p(s1), _p(work), self._stream()))
 
+    def knn_filter(self, Xq, Xc, sqq, sqc, thr, self_pos, c_lo, c_hi, buf_pos, buf_d, cnt):
+        """Candidates of positions [c_lo, c_hi) that beat the queries' thresholds (include/muon_amd.h)."""
+        with self._dev_ctx():
+            check(self.lib.mu_knn_filter_f64(int(Xq.shape[0]), int(c_lo), int(c_hi), int(Xq.shape[1]), _p(Xq), _p(Xc),
+                                             _p(sqq), _p(sqc), _p(thr), _p(self_pos), int(buf_pos.shape[1]),
+                                             _p(buf_pos), _p(buf_d), _p(cnt), self._stream()))
+
     def mofa_elbo_work(self, K: int) -> torch.Tensor:
         return self.empty((int(self.lib.mu_mofa_elbo_work_doubles(int(K))),), torch.float64)
 

@@ -128,32 +128,109 @@ def _pair_dist(A: torch.Tensor, B: torch.Tensor, metric: str) -> torch.Tensor:
     raise NotImplementedError(f"metric '{metric}' (implemented: {_METRICS})")
 
 
-def device_knn(X: torch.Tensor, k: int, metric: str = "euclidean", chunk_elems: int = 1 << 28):
+def _candidates_filtered(be, Xn: torch.Tensor, sq: torch.Tensor, kc: int, chunk_elems: int, cap: Optional[int] = None) -> torch.Tensor:
+    """kc nearest candidates per row (GEMM-form squared distances) WITHOUT the n x n distance panels: the
+    rows are walked as candidates in a random order, in panels of doubling size.  The first panel is searched
+    densely and leaves every query its kc-th smallest distance so far as a threshold; for each later panel the
+    HIP filter kernel (csrc/knn.hip: distances on the f64 matrix cores, compared in registers) appends the
+    candidates that beat the threshold - about kc per query and panel, because a panel doubles what the query
+    has seen - and a top-k over [list ++ buffer] (4 kc wide instead of n) updates list and threshold.  A
+    buffer that overflowed (ties, duplicated rows) has its rows redone densely."""
+    n, p = Xn.shape
+    dev = Xn.device
+    p_pad = (p + 3) // 4 * 4
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    perm = torch.randperm(n, device=dev, generator=g)  # candidate position -> row
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n, device=dev)            # row -> candidate position
+    Xq = torch.zeros((n, p_pad), dtype=torch.float64, device=dev)
+    Xq[:, :p] = Xn
+    Xc = Xq[perm].contiguous()
+    sq = sq.contiguous()
+    sqc = sq[perm].contiguous()
+    self_pos = inv.to(torch.int32).contiguous()
+    ar = torch.arange(n, device=dev)
+
+    def dense(rows, c0, c1):
+        """squared distances of `rows` (tensor of row numbers, or None: all) to positions [c0, c1), self = inf"""
+        q = Xq if rows is None else Xq[rows]
+        D = (sq if rows is None else sq[rows])[:, None] + sqc[None, c0:c1] - 2.0 * (q @ Xc[c0:c1].T)
+        sp = inv if rows is None else inv[rows]
+        hit = (sp >= c0) & (sp < c1)
+        r = torch.nonzero(hit)[:, 0]
+        D[r, sp[r] - c0] = float("inf")
+        return D
+
+    p0 = min(n, max(2048, 4 * kc))
+    cur_d = torch.empty((n, kc), dtype=torch.float64, device=dev)
+    cur_p = torch.empty((n, kc), dtype=torch.int64, device=dev)
+    rows = max(1, min(n, chunk_elems // p0))
+    for lo in range(0, n, rows):
+        hi = min(n, lo + rows)
+        t = torch.topk(dense(ar[lo:hi], 0, p0), kc, dim=1, largest=False)
+        cur_d[lo:hi], cur_p[lo:hi] = t.values, t.indices
+    cap = int(cap) if cap else 3 * kc + 64
+    buf_pos = torch.empty((n, cap), dtype=torch.int32, device=dev)
+    buf_d = torch.empty((n, cap), dtype=torch.float64, device=dev)
+    cnt = torch.empty((n,), dtype=torch.int32, device=dev)
+    slot = torch.arange(cap, device=dev)[None, :]
+    c_lo = p0
+    while c_lo < n:
+        c_hi = min(n, 2 * c_lo)
+        thr = cur_d.amax(dim=1).contiguous()
+        be.knn_filter(Xq, Xc, sq, sqc, thr, self_pos, c_lo, c_hi, buf_pos, buf_d, cnt)
+        valid = slot < cnt[:, None]
+        d_all = torch.cat([cur_d, torch.where(valid, buf_d, torch.full_like(buf_d, float("inf")))], dim=1)
+        p_all = torch.cat([cur_p, buf_pos.long()], dim=1)
+        t = torch.topk(d_all, kc, dim=1, largest=False)
+        new_d, new_p = t.values, torch.gather(p_all, 1, t.indices)
+        over = torch.nonzero(cnt > cap)[:, 0]
+        if over.numel():  # (rare) more candidates than the buffer holds: those rows again, densely, over all seen
+            for lo in range(0, over.numel(), max(1, chunk_elems // c_hi)):
+                r = over[lo:lo + max(1, chunk_elems // c_hi)]
+                t = torch.topk(dense(r, 0, c_hi), kc, dim=1, largest=False)
+                new_d[r], new_p[r] = t.values, t.indices
+        cur_d, cur_p = new_d, new_p
+        c_lo = c_hi
+    return perm[cur_p]
+
+
+def device_knn(X: torch.Tensor, k: int, metric: str = "euclidean", chunk_elems: int = 1 << 28, backend=None):
     """The k nearest OTHER rows of every row of X [n, p] (f64 on the device): (indices [n, k] int64,
-    distances [n, k]) ascending, ties by index.  Tiles of queries against all rows: squared distances as
-    one GEMM (cosine: normalised rows), k + 8 candidates per query, exact distances of the candidates,
-    final selection - the cancellation of the GEMM form never decides the order."""
+    distances [n, k]) ascending, ties by index.  k + 8 candidates per query from squared distances in GEMM
+    form (cosine: normalised rows) - with a backend that has the filter kernel and enough rows through
+    ``_candidates_filtered``, else tiles of queries against all rows and a top-k per tile -, then the exact
+    distances of the candidates and the final selection: the cancellation of the GEMM form never decides
+    the order."""
     if metric not in _METRICS:
         raise NotImplementedError(f"metric '{metric}' (implemented: {_METRICS})")
     n, p = X.shape
     k = min(int(k), n - 1)
     kc = min(k + 8, n - 1)
-    rows = max(1, min(n, chunk_elems // max(n, 1)))
     idx = torch.empty((n, k), dtype=torch.int64, device=X.device)
     dst = torch.empty((n, k), dtype=X.dtype, device=X.device)
     gemm = metric in ("euclidean", "sqeuclidean", "cosine")
     Xn = X / torch.sqrt((X * X).sum(dim=1, keepdim=True)) if metric == "cosine" else X
     sq = (Xn * Xn).sum(dim=1)
     ar = torch.arange(n, device=X.device)
+    cand_all = None
+    if (gemm and backend is not None and hasattr(backend, "knn_filter") and X.dtype == torch.float64
+            and n >= 8192 and 4 * kc <= n // 2 and p <= 1024):
+        cand_all = _candidates_filtered(backend, Xn, sq, kc, chunk_elems)
+    rows = max(1, min(n, chunk_elems // max(n if cand_all is None else kc * p, 1)))
     for lo in range(0, n, rows):
         hi = min(n, lo + rows)
-        if gemm:
-            D = sq[lo:hi, None] + sq[None, :] - 2.0 * (Xn[lo:hi] @ Xn.T)
+        if cand_all is not None:
+            cand = cand_all[lo:hi]
         else:
-            D = torch.cdist(X[lo:hi], X, p=1.0 if metric in ("cityblock", "manhattan") else float("inf"))
-        D[ar[lo:hi] - lo, ar[lo:hi]] = float("inf")  # not the row itself
-        cand = torch.topk(D, kc, dim=1, largest=False).indices
-        del D
+            if gemm:
+                D = sq[lo:hi, None] + sq[None, :] - 2.0 * (Xn[lo:hi] @ Xn.T)
+            else:
+                D = torch.cdist(X[lo:hi], X, p=1.0 if metric in ("cityblock", "manhattan") else float("inf"))
+            D[ar[lo:hi] - lo, ar[lo:hi]] = float("inf")  # not the row itself
+            cand = torch.topk(D, kc, dim=1, largest=False).indices
+            del D
         exact = _pair_dist(X[lo:hi, None, :].expand(hi - lo, kc, p), X[cand], metric)
         # ascending by (distance, index): stable sort of the index-sorted candidates
         o = torch.argsort(cand, dim=1)
@@ -221,7 +298,7 @@ def knn(adata, n_neighbors: int = 15, use_rep: Optional[str] = None, n_pcs: Opti
     X = X.toarray() if issparse(X) else np.asarray(X)
     Xd = be.to_device(np.ascontiguousarray(X, dtype=np.float64))
     n = Xd.shape[0]
-    idx, dst = device_knn(Xd, n_neighbors - 1, metric)
+    idx, dst = device_knn(Xd, n_neighbors - 1, metric, backend=be)
     self_i = torch.arange(n, device=idx.device)[:, None]
     idx_s = torch.cat([self_i, idx], dim=1)
     dst_s = torch.cat([torch.zeros((n, 1), dtype=dst.dtype, device=dst.device), dst], dim=1)
@@ -400,7 +477,7 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
     # candidates: the union of every modality's n_multineighbors nearest neighbours (:517-575)
     keys = []
     for m in modalities:
-        idx, _ = device_knn(Xd[m], n_multineighbors, params[m].get("metric", "euclidean"))  # (:520: the top-level key)
+        idx, _ = device_knn(Xd[m], n_multineighbors, params[m].get("metric", "euclidean"), backend=be)  # (:520: the top-level key)
         keys.append((torch.arange(n, device=dev)[:, None] * n + idx).reshape(-1))
     key = torch.unique(torch.cat(keys))  # sorted: row-major
     ri = torch.div(key, n, rounding_mode="floor")

@@ -66,3 +66,53 @@ def test_lsi_embedding_feeds_weighted_neighbours(hip):
     assert md.uns["neighbors"]["params"]["use_rep"] == {"rna": "X", "atac": "X_lsi"}
     c = md.obsp["connectivities"]
     assert c.shape == (n, n) and abs(c - c.T).max() < 1e-12 and c.max() <= 1.0 + 1e-12
+
+
+@pytest.mark.parametrize("n,p,k,metric", [(9000, 7, 12, "euclidean"), (20000, 50, 200, "euclidean"),
+                                          (12000, 33, 30, "cosine"), (8300, 130, 15, "sqeuclidean")])
+def test_filter_kernel_search_equals_the_tiled_search(hip, n, p, k, metric):
+    """csrc/knn.hip behind device_knn: same neighbours and distances as the tiled tensor search (no backend)."""
+    import torch
+
+    rng = np.random.default_rng(n + k)
+    lab = rng.integers(0, 15, n)
+    X = rng.standard_normal((15, p))[lab] * 1.5 + rng.standard_normal((n, p))
+    Xd = hip.to_device(X)
+    i0, d0 = pp.device_knn(Xd, k, metric)
+    i1, d1 = pp.device_knn(Xd, k, metric, backend=hip)
+    assert torch.allclose(d0, d1, rtol=0, atol=1e-11)
+    assert float((i0 == i1).double().mean()) > 0.9999  # (exact ties aside)
+
+
+def test_filter_kernel_counts_and_buffers(hip):
+    """The kernel alone against a dense evaluation: every candidate of the panel below the threshold, nothing
+    else, the query itself left out, counts beyond the capacity reported."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    n, p, pp_ = 700, 10, 12
+    X = torch.zeros((n, pp_), dtype=torch.float64, device=hip.device)
+    X[:, :p] = hip.to_device(rng.standard_normal((n, p)))
+    sq = (X * X).sum(dim=1)
+    thr = hip.to_device(rng.uniform(3.0, 9.0, n))
+    self_pos = torch.arange(n, device=hip.device, dtype=torch.int32)
+    for c_lo, c_hi, cap in ((0, n, 64), (130, 517, 8)):
+        bp = torch.full((n, cap), -1, dtype=torch.int32, device=hip.device)
+        bd = torch.zeros((n, cap), dtype=torch.float64, device=hip.device)
+        cnt = torch.zeros((n,), dtype=torch.int32, device=hip.device)
+        hip.knn_filter(X, X, sq, sq, thr, self_pos, c_lo, c_hi, bp, bd, cnt)
+        D = sq[:, None] + sq[None, :] - 2.0 * (X @ X.T)
+        ok = D < thr[:, None]
+        ok.fill_diagonal_(False)
+        ok[:, :c_lo] = False
+        ok[:, c_hi:] = False
+        margin = (D - thr[:, None]).abs() < 1e-9  # rounding of the two evaluation orders
+        assert not bool((margin & ~torch.eye(n, dtype=torch.bool, device=hip.device)).any())
+        assert torch.equal(cnt.long(), ok.sum(dim=1))
+        for i in range(0, n, 37):
+            m = min(int(cnt[i]), cap)
+            got = bp[i, :m].long()
+            assert bool(ok[i, got].all()) and got.unique().numel() == m
+            assert torch.allclose(bd[i, :m], D[i, got], rtol=0, atol=1e-11)
+            if int(cnt[i]) <= cap:
+                assert set(got.tolist()) == set(torch.nonzero(ok[i])[:, 0].tolist())

@@ -99,3 +99,54 @@ def test_wnn_slots_errors_and_copy():
     with pytest.raises(TypeError):
         pp.neighbors(AnnData(x1), backend=BE)
     assert mu.pp.neighbors is pp.neighbors
+
+
+class _FilterEmulation(CpuTestBackend):
+    """CpuTestBackend + a torch emulation of the HIP filter kernel (csrc/knn.hip): exercises the panel walk,
+    the merges and the overflow redo of ``_candidates_filtered`` without a GPU."""
+
+    def knn_filter(self, Xq, Xc, sqq, sqc, thr, self_pos, c_lo, c_hi, buf_pos, buf_d, cnt):
+        import torch
+
+        cap = buf_pos.shape[1]
+        D = sqq[:, None] + sqc[None, c_lo:c_hi] - 2.0 * (Xq @ Xc[c_lo:c_hi].T)
+        ok = D < thr[:, None]
+        pos = torch.arange(c_lo, c_hi)[None, :].expand_as(D)
+        ok &= pos != self_pos[:, None].long()
+        cnt[:] = ok.sum(dim=1).to(cnt.dtype)
+        for i in torch.nonzero(cnt > 0)[:, 0].tolist():
+            j = torch.nonzero(ok[i])[:, 0][:cap]
+            buf_pos[i, : j.numel()] = (j + c_lo).to(buf_pos.dtype)
+            buf_d[i, : j.numel()] = D[i, j]
+
+
+@pytest.mark.parametrize("metric,k", [("euclidean", 12), ("cosine", 40)])
+def test_filtered_candidate_search_equals_the_tiled_search(metric, k):
+    import torch
+
+    rng = np.random.default_rng(5)
+    lab = rng.integers(0, 12, 9000)
+    X = rng.standard_normal((12, 7))[lab] * 2 + rng.standard_normal((9000, 7))
+    X[100:140] = X[100]  # duplicated rows: exact ties
+    Xd = torch.as_tensor(X)
+    i0, d0 = pp.device_knn(Xd, k, metric)
+    i1, d1 = pp.device_knn(Xd, k, metric, backend=_FilterEmulation())
+    np.testing.assert_allclose(d1.numpy(), d0.numpy(), rtol=0, atol=1e-12)
+    # the same neighbours, except WHICH of the 40 identical rows are listed where they tie
+    a, b = i0.numpy(), i1.numpy()
+    dup = lambda v: (v >= 100) & (v < 140)  # noqa: E731
+    assert np.all((a == b) | (dup(a) & dup(b)))
+
+
+def test_filtered_candidate_search_redoes_rows_whose_buffer_overflowed():
+    import torch
+
+    rng = np.random.default_rng(6)
+    X = torch.as_tensor(rng.standard_normal((8500, 5)))
+    sq = (X * X).sum(dim=1)
+    kc = 20
+    got = pp._candidates_filtered(_FilterEmulation(), X, sq, kc, 1 << 26, cap=3)  # ~kc candidates per panel >> 3
+    D = sq[:, None] + sq[None, :] - 2.0 * (X @ X.T)
+    D.fill_diagonal_(float("inf"))
+    want = torch.topk(D, kc, dim=1, largest=False).indices
+    assert torch.equal(torch.sort(got, dim=1).values, torch.sort(want, dim=1).values)
