@@ -144,6 +144,8 @@ def run(argv=None, init_dist=True):
     from muon_amd._core.mofa_engine import MofaEngine
 
     be = HipBackend(local_rank)
+    for kv in filter(None, os.environ.get("MUON_AMD_BENCH_TUNE", "").split(",")):  # A/B runs: key=value of mu_tune_set
+        be.tune(kv.split("=")[0], int(kv.split("=")[1]))
     T = torch.float64 if args.f64 else torch.float32
     row0 = rank * args.cells // world
     N = (rank + 1) * args.cells // world - row0
