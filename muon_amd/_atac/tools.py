@@ -20,6 +20,7 @@ Everything of size nnz, n x B or d x B stays in HBM; only B x B blocks cross PCI
 from __future__ import annotations
 
 import logging
+import os
 import time
 from typing import Optional
 
@@ -344,14 +345,31 @@ def _lsi_device(
     wasted = 0
     host = {"wait_ms": 0.0, "ritz_ms": 0.0}
 
+    # Measurement knob ("measure 16-bit Q on the GPU for the last expansion only"), not an API:
+    # MUON_AMD_LSI_Q16 = "<f16|bf16>:<p0>" rounds the dense operand of every product from product number p0 on
+    # (0-based: X Q_0 is 0, X^T Y_0 is 1, ...) to that type - the arithmetic stays f32, so this isolates what a
+    # 16-bit Q slab in LDS would do to the angle (scripts/probes/lsi_q16_probe.py).
+    q16 = os.environ.get("MUON_AMD_LSI_Q16")
+    q16_dtype, q16_from = None, 1 << 30
+    if q16:
+        q16_dtype = {"f16": torch.float16, "bf16": torch.bfloat16}[q16.split(":")[0]]
+        q16_from = int(q16.split(":")[1])
+    n_products = [0]
+
+    def product(A, Qd):
+        if n_products[0] >= q16_from:
+            Qd = Qd.to(q16_dtype).to(Qd.dtype)
+        n_products[0] += 1
+        return backend.spmm(A, Qd)
+
     def expand_product(j):
-        Zn = backend.spmm(Xt, Ys[j])
+        Zn = product(Xt, Ys[j])
         comm.all_reduce_sum(Zn)
         return Zn
 
     while True:
         j = len(Qs) - 1
-        Ys.append(backend.spmm(X, Qs[j]))
+        Ys.append(product(X, Qs[j]))
         grams = launch_block_grams(j)
         # The host's Ritz step (a few ms of LAPACK on (m w)^2 matrices) would leave the GPU idle.
         # Unless this step is expected to be the last one, X^T Y_j - needed by every step but the
