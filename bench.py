@@ -293,7 +293,7 @@ def run_lsi(args, workload, rank, world, local_rank, comm, steps, warmup, cpu_sa
             },
             "traffic_source": traffic_source,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (the CPU leg and the sample parity ride on the N = 1 line only)
             out["cpu_baseline"], out["parity"] = cpu_baseline(be._be, d, args.density, args.seed,
                                                               min(cpu_sample_cells, n_global), args.n_comps)
     del X, tf_vals, be
