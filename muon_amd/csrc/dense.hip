@@ -326,58 +326,132 @@ __global__ __launch_bounds__(256) void k_randn(int64_t count, uint64_t seed, flo
 // with its next host read and redoes the call on the host path.
 // ---------------------------------------------------------------------------------
 constexpr int kCholT = 256;
-// r03: the whole workgroup works on the factorisation (r02: one wave, lane i owned row i and walked its
-// dot products alone - 116 us per call, 8-12 calls per lsi(): 9 % of a 10k x 30k call).  Right-looking
-// Cholesky in LDS - per column: pivot, scale, rank-one update of the trailing block spread over the
-// threads - then L^-1 by the same column sweep on an identity.
+constexpr int kCholNb = 16;  // block size of the blocked factorisation
+// r03: blocked right-looking Cholesky of the (identity-padded) 64 x 64 matrix in LDS, 16-column panels:
+// per panel, wave 0 factors the diagonal block and inverts it (16 dependent steps, wave-synchronous: LDS
+// operations of a wave execute in order, no workgroup barrier), then all four waves form the panel below it
+// (L21 = A21 L11^-T as a product with the inverted block) and the trailing update - THREE workgroup barriers
+// per panel, twelve per call: 87 us per call in the kernel statistics (c2: 12 calls per lsi()).  The first r03
+// version swept column by column with three barriers per column (192 per call): 109 us, r02's one-wave version
+// 118 us.  What is left is the serial chain of wave 0 - 64 pivots, each a sqrt, a divide and three LDS round
+// trips.  L^-1: diagonal blocks from the factorisation, the blocks below
+// them block column by block column, one wave per block column, no barriers in between.
+__device__ __forceinline__ void chol_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(kCholT) void k_chol_rinv(int B, int w, const double* __restrict__ G,
                                                       float* __restrict__ M, int* __restrict__ flag) {
-  __shared__ double L[64][65];
-  __shared__ double X[64][65];
-  __shared__ double s_piv;
+  constexpr int NB = kCholNb;
+  __shared__ double A[64][65];          // lower triangle: the matrix, then L
+  __shared__ double X[64][65];          // L^-1 (lower)
+  __shared__ double P[64][NB + 1];      // the panel below the diagonal block
+  __shared__ double Tm[4][NB][NB + 1];  // per-wave scratch of the inverse's block products
   __shared__ int s_bad;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t == 0) s_bad = 0;
+  double dmax = 0.0;
+  for (int i = 0; i < w; ++i) {
+    const double g = G[(int64_t)i * B + i];
+    dmax = g > dmax ? g : dmax;
+  }
+  const double tiny = dmax > 0.0 ? dmax * 1e-13 : 1.0;
+  const double pad = dmax > 0.0 ? dmax : 1.0;  // rows past w: a diagonal that passes the pivot test
   for (int e = t; e < 64 * 64; e += kCholT) {
     const int i = e >> 6, j = e & 63;
-    L[i][j] = (i < w && j < w && j <= i) ? G[(int64_t)i * B + j] : 0.0;
-    X[i][j] = (i == j) ? 1.0 : 0.0;
+    A[i][j] = (i < w && j < w) ? (j <= i ? G[(int64_t)i * B + j] : 0.0) : (i == j ? pad : 0.0);
+    X[i][j] = 0.0;
   }
   __syncthreads();
-  double dmax = 0.0;
-  for (int i = 0; i < w; ++i) dmax = L[i][i] > dmax ? L[i][i] : dmax;
-  const double tiny = dmax > 0.0 ? dmax * 1e-13 : 1.0;
-  __syncthreads();
-  for (int k = 0; k < w; ++k) {
-    if (t == 0) {
-      double piv = L[k][k];
-      if (!(piv > tiny)) {  // also catches NaN: a block with dependent columns
-        s_bad = 1;
-        piv = tiny;
+
+  for (int k0 = 0; k0 < 64; k0 += NB) {
+    if (wave == 0) {
+      // diagonal block: unblocked Cholesky in place
+      for (int s = 0; s < NB; ++s) {
+        const int k = k0 + s;
+        double piv = A[k][k];
+        const bool bad = !(piv > tiny);  // also catches NaN: a block with dependent columns
+        if (bad) piv = tiny;
+        if (bad && lane == 0) s_bad = 1;
+        const double r = sqrt(piv);
+        chol_wave_sync();  // (every lane has read the pivot before lane s overwrites it)
+        if (lane < NB) {
+          const int i = k0 + lane;
+          if (lane == s) A[k][k] = r;
+          else if (lane > s) A[i][k] = A[i][k] / r;
+        }
+        chol_wave_sync();
+        for (int e = lane; e < NB * NB; e += 64) {
+          const int i = k0 + e / NB, j = k0 + e % NB;
+          if (j > k && j <= i) A[i][j] -= A[i][k] * A[j][k];
+        }
+        chol_wave_sync();
       }
-      s_piv = sqrt(piv);
+      // its inverse, column by column: lane c solves D x = e_c by forward substitution
+      if (lane < NB) {
+        double x[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          double v = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+            if (j < i) v -= A[k0 + i][k0 + j] * x[j];
+          x[i] = (i >= lane) ? v / A[k0 + i][k0 + i] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) X[k0 + i][k0 + lane] = x[i];
+      }
     }
     __syncthreads();
-    const double r = s_piv;
-    // column k of L, and row k of X = L^-1 (every entry of X[k][0..k] is final once divided by the pivot)
-    if (t < 64) {
-      if (t == k) L[k][k] = r;
-      else if (t > k && t < w) L[t][k] = L[t][k] / r;
-    } else if (t < 128) {
-      const int j = t - 64;
-      if (j <= k) X[k][j] = X[k][j] / r;
+    const int below = 64 - k0 - NB;  // rows under the diagonal block
+    // panel: L21[i][c] = sum_{j <= c} A21[i][j] invD[c][j]
+    for (int e = t; e < below * NB; e += kCholT) {
+      const int i = k0 + NB + e / NB, c = e % NB;
+      double v = 0.0;
+      for (int j = 0; j <= c; ++j) v += A[i][k0 + j] * X[k0 + c][k0 + j];
+      P[i][c] = v;
     }
     __syncthreads();
-    // trailing updates: L[i][j] -= L[i][k] L[j][k] (k < j <= i < w);  X[i][j] -= L[i][k] X[k][j] (i > k, j <= k)
-    const int m = w - k - 1;  // rows below the pivot
-    for (int e = t; e < m * 64; e += kCholT) {
-      const int i = k + 1 + (e >> 6), j = e & 63;
-      const double lik = L[i][k];
-      if (j > k && j <= i) L[i][j] -= lik * L[j][k];
-      if (j <= k) X[i][j] -= lik * X[k][j];
+    // trailing update A22 -= L21 L21^T (lower part), and L21 takes its place in A
+    for (int e = t; e < below * below; e += kCholT) {
+      const int i = k0 + NB + e / below, j = k0 + NB + e % below;
+      if (j <= i) {
+        double v = 0.0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) v += P[i][c] * P[j][c];
+        A[i][j] -= v;
+      }
+    }
+    for (int e = t; e < below * NB; e += kCholT) {
+      const int i = k0 + NB + e / NB, c = e % NB;
+      A[i][k0 + c] = P[i][c];
     }
     __syncthreads();
   }
+  // L^-1 below the diagonal blocks: wave kb owns block column kb;  X_ik = - X_ii (sum_{j = k}^{i-1} L_ij X_jk)
+  {
+    const int kb = wave;
+    for (int ib = kb + 1; ib < 64 / NB; ++ib) {
+      for (int e = lane; e < NB * NB; e += 64) {
+        const int r = e / NB, c = e % NB;
+        double v = 0.0;
+        for (int jb = kb; jb < ib; ++jb)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) v += A[ib * NB + r][jb * NB + j] * X[jb * NB + j][kb * NB + c];
+        Tm[wave][r][c] = v;
+      }
+      chol_wave_sync();
+      for (int e = lane; e < NB * NB; e += 64) {
+        const int r = e / NB, c = e % NB;
+        double v = 0.0;
+        for (int j = 0; j <= r; ++j) v += X[ib * NB + r][ib * NB + j] * Tm[wave][j][c];
+        X[ib * NB + r][kb * NB + c] = -v;
+      }
+      chol_wave_sync();
+    }
+  }
+  __syncthreads();
   if (t == 0 && s_bad) *flag = 1;
   // M = R^-1 = (L^-1)^T: M[r][c] = X[c][r] for r <= c < w
   for (int e = t; e < B * B; e += kCholT) {
