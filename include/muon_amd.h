@@ -305,6 +305,17 @@ int mu_knn_filter_f64(int64_t n_q, int64_t c_lo, int64_t c_hi, int p_pad, const 
                       const double* d_sqq, const double* d_sqc, const double* d_thr, const int32_t* d_self_pos,
                       int cap, int32_t* d_buf_pos, double* d_buf_d, int32_t* d_cnt, void* stream);
 
+/* ---- kernel bandwidths of muon.pp.neighbors (/root/reference/muon/_core/preproc.py:400-472): csigma[i] = mean
+ * Euclidean distance from cell i to the n_bw cells whose neighbour sets overlap its own least (but do), ties
+ * towards the larger distance, i.e. the n_bw smallest keys N (1 - jaccard distance) + (bbox - euclid) / bbox
+ * (:53-77), ties by cell number.  g_*: the kNN graph (CSR pattern, int64 row pointers, int32 columns), r_*: its
+ * transpose; X [n x p] f64 row-major, p <= 256.  NaN for a cell without candidates; *d_overflow = 1 when a
+ * cell's candidate list exceeds 8192 entries (repetitions included) - the caller then uses its tensor formulation;
+ * n_bw <= 64. */
+int mu_wnn_bandwidth_f64(int64_t n, int p, const double* d_X, const int64_t* d_g_indptr, const int32_t* d_g_indices,
+                         const int64_t* d_r_indptr, const int32_t* d_r_indices, int n_bw, double bbox,
+                         double* d_csigma, int32_t* d_overflow, void* stream);
+
 /* ---- MOFA+ small nodes and the ELBO, fused (tools.py:585 ent.run(): mofapy2's Tau, AlphaW, ThetaW,
  * AlphaZ node updates and calculateELBO()).  Arithmetic in f64 for both storage types; every entry
  * ADDS its ELBO terms to the device scalar *d_elbo.  d_work: mu_mofa_elbo_work_doubles(K) doubles. */

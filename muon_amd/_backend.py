@@ -623,6 +623,17 @@ class HipBackend:
                                             int(bool(scale_out)), _p(out_pad), ld, int(col0), _p(out_t), ld_t,
                                             _p(gram), _p(s2), _p(s1), _p(work), self._stream()))
 
+    def wnn_bandwidth(self, X, g_indptr, g_indices, r_indptr, r_indices, n_bw: int, bbox: float):
+        """csigma of muon.pp.neighbors, a wave per cell (include/muon_amd.h); returns (csigma, overflowed)."""
+        n, p = X.shape
+        out = self.empty((n,), torch.float64)
+        over = self.zeros((1,), torch.int32)
+        with self._dev_ctx():
+            check(self.lib.mu_wnn_bandwidth_f64(int(n), int(p), _p(X), _p(g_indptr), _p(g_indices), _p(r_indptr),
+                                                _p(r_indices), int(n_bw), float(bbox), _p(out), _p(over),
+                                                self._stream()))
+        return out, bool(int(over.item()))
+
     def knn_filter(self, Xq, Xc, sqq, sqc, thr, self_pos, c_lo, c_hi, buf_pos, buf_d, cnt):
         """Candidates of positions [c_lo, c_hi) that beat the queries' thresholds (include/muon_amd.h)."""
         with self._dev_ctx():

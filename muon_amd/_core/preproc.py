@@ -193,16 +193,19 @@ def _candidates_filtered(be, Xn: torch.Tensor, sq: torch.Tensor, kc: int, chunk_
                 new_d[r], new_p[r] = t.values, t.indices
         cur_d, cur_p = new_d, new_p
         c_lo = c_hi
-    return perm[cur_p]
+    return perm[cur_p], cur_d
 
 
-def device_knn(X: torch.Tensor, k: int, metric: str = "euclidean", chunk_elems: int = 1 << 28, backend=None):
+def device_knn(X: torch.Tensor, k: int, metric: str = "euclidean", chunk_elems: int = 1 << 28, backend=None,
+               indices_only: bool = False):
     """The k nearest OTHER rows of every row of X [n, p] (f64 on the device): (indices [n, k] int64,
     distances [n, k]) ascending, ties by index.  k + 8 candidates per query from squared distances in GEMM
     form (cosine: normalised rows) - with a backend that has the filter kernel and enough rows through
     ``_candidates_filtered``, else tiles of queries against all rows and a top-k per tile -, then the exact
     distances of the candidates and the final selection: the cancellation of the GEMM form never decides
-    the order."""
+    the order.  ``indices_only``: the caller wants the neighbour SET (the candidate union of ``neighbors``): with
+    the filter path the k smallest GEMM-form distances decide and the exact re-evaluation - a gather of
+    n x (k + 8) x p values - is skipped; the distances returned are then the GEMM-form ones."""
     if metric not in _METRICS:
         raise NotImplementedError(f"metric '{metric}' (implemented: {_METRICS})")
     n, p = X.shape
@@ -217,7 +220,12 @@ def device_knn(X: torch.Tensor, k: int, metric: str = "euclidean", chunk_elems: 
     cand_all = None
     if (gemm and backend is not None and hasattr(backend, "knn_filter") and X.dtype == torch.float64
             and n >= 8192 and 4 * kc <= n // 2 and p <= 1024):
-        cand_all = _candidates_filtered(backend, Xn, sq, kc, chunk_elems)
+        cand_all, cand_d = _candidates_filtered(backend, Xn, sq, kc, chunk_elems)
+        if indices_only:
+            t = torch.topk(cand_d, k, dim=1, largest=False, sorted=True)
+            d = t.values.clamp_min(0.0)
+            return torch.gather(cand_all, 1, t.indices), (d if metric == "sqeuclidean" else
+                                                            torch.sqrt(d) if metric == "euclidean" else d / 2.0)
     rows = max(1, min(n, chunk_elems // max(n if cand_all is None else kc * p, 1)))
     for lo in range(0, n, rows):
         hi = min(n, lo + rows)
@@ -358,6 +366,16 @@ def _bandwidths(be, X: torch.Tensor, G: csr_matrix, n_bandwidth_neighbors: int) 
     n = X.shape[0]
     G = G.tocsr()
     dev = X.device
+    if (hasattr(be, "wnn_bandwidth") and X.dtype == torch.float64 and X.shape[1] <= 256 and X.is_contiguous()
+            and n_bandwidth_neighbors <= 64):
+        # one wave per cell (csrc/wnn.hip): candidates from the reverse graph, sorted and counted in LDS
+        R = G.T.tocsr()
+        bbox = float(torch.linalg.norm(X.amax(dim=0) - X.amin(dim=0)))
+        cs, over = be.wnn_bandwidth(X, be.to_device(G.indptr, np.int64), be.to_device(G.indices, np.int32),
+                                    be.to_device(R.indptr, np.int64), be.to_device(R.indices, np.int32),
+                                    n_bandwidth_neighbors, bbox)
+        if not over:
+            return cs
     rows = torch.as_tensor(np.repeat(np.arange(n), np.diff(G.indptr)), device=dev)
     cols = torch.as_tensor(G.indices.astype(np.int64), device=dev)
     deg = torch.as_tensor(np.diff(G.indptr).astype(np.float64), device=dev)
@@ -477,7 +495,7 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
     # candidates: the union of every modality's n_multineighbors nearest neighbours (:517-575)
     keys = []
     for m in modalities:
-        idx, _ = device_knn(Xd[m], n_multineighbors, params[m].get("metric", "euclidean"), backend=be)  # (:520: the top-level key)
+        idx, _ = device_knn(Xd[m], n_multineighbors, params[m].get("metric", "euclidean"), backend=be, indices_only=True)  # (:520: the top-level key)
         keys.append((torch.arange(n, device=dev)[:, None] * n + idx).reshape(-1))
     key = torch.unique(torch.cat(keys))  # sorted: row-major
     ri = torch.div(key, n, rounding_mode="floor")

@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["runtime.hip", "tfidf.hip", "transpose.hip", "spmm.hip", "spmm_win.hip", "spmm_narrow.hip", "tpack.hip", "dense.hip", "skinny.hip", "synth.hip", "mofa.hip", "mofa_elbo.hip", "mofa_stats.hip", "knn.hip"]
+SOURCES = ["runtime.hip", "tfidf.hip", "transpose.hip", "spmm.hip", "spmm_win.hip", "spmm_narrow.hip", "tpack.hip", "dense.hip", "skinny.hip", "synth.hip", "mofa.hip", "mofa_elbo.hip", "mofa_stats.hip", "knn.hip", "wnn.hip"]
 HEADERS = ["common.hpp", "sweep.hpp", os.path.join(ROOT, "include", "muon_amd.h")]
 LIB = os.path.join(HERE, "libmuon_amd.so")
 ARCH = "gfx950"

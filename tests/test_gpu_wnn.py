@@ -116,3 +116,62 @@ def test_filter_kernel_counts_and_buffers(hip):
             assert torch.allclose(bd[i, :m], D[i, got], rtol=0, atol=1e-11)
             if int(cnt[i]) <= cap:
                 assert set(got.tolist()) == set(torch.nonzero(ok[i])[:, 0].tolist())
+
+
+def test_indices_only_search_returns_the_same_neighbour_sets(hip):
+    import torch
+
+    rng = np.random.default_rng(9)
+    lab = rng.integers(0, 10, 15000)
+    X = hip.to_device(rng.standard_normal((10, 20))[lab] * 1.5 + rng.standard_normal((15000, 20)))
+    i0, d0 = pp.device_knn(X, 150, "euclidean", backend=hip)
+    i1, d1 = pp.device_knn(X, 150, "euclidean", backend=hip, indices_only=True)
+    assert torch.equal(torch.sort(i0, dim=1).values, torch.sort(i1, dim=1).values)
+    assert torch.allclose(d0, d1, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("n,p,k", [(3000, 12, 15), (20000, 50, 20)])
+def test_bandwidth_kernel_equals_the_tensor_formulation(hip, n, p, k):
+    """csrc/wnn.hip (a wave per cell) against A A^T + pair distances + three sorts (the backend without the kernel)."""
+    import torch
+
+    rng = np.random.default_rng(n)
+    lab = rng.integers(0, 12, n)
+    X = rng.standard_normal((12, p))[lab] * 1.5 + rng.standard_normal((n, p))
+    a = AnnData(X.copy())
+    pp.knn(a, n_neighbors=k, use_rep="X", backend=hip)
+    G = a.obsp["distances"]
+    Xd = hip.to_device(X)
+
+    class _NoKernel:
+        def __getattr__(self, name):
+            if name == "wnn_bandwidth":
+                raise AttributeError(name)
+            return getattr(hip, name)
+
+    want = pp._bandwidths(_NoKernel(), Xd, G, 20)
+    got = pp._bandwidths(hip, Xd, G, 20)
+    assert torch.allclose(got, want, rtol=1e-12, atol=0, equal_nan=True)  # (sums in a different order)
+
+
+def test_bandwidth_kernel_reports_hub_cells(hip):
+    """A cell listed by more cells than the wave's buffer holds: the overflow flag sends the call to the tensor path."""
+    import torch
+
+    n = 9000  # (the wave's buffer holds 8192 entries)
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((n, 4))
+    X[0] = 0.0
+    idx = np.zeros((n, 3), dtype=np.int64)  # every cell lists cell 0 (a hub) and two others
+    idx[:, 1] = (np.arange(n) + 1) % n
+    idx[:, 2] = (np.arange(n) + 2) % n
+    idx[0, 0] = 3
+    G = sp.csr_matrix((np.ones(idx.size), idx.reshape(-1), np.arange(0, 3 * n + 1, 3)), shape=(n, n))
+    G.sort_indices()
+    Xd = hip.to_device(X)
+    cs, over = hip.wnn_bandwidth(Xd, hip.to_device(G.indptr, np.int64), hip.to_device(G.indices, np.int32),
+                                 hip.to_device(G.T.tocsr().indptr, np.int64), hip.to_device(G.T.tocsr().indices, np.int32),
+                                 20, 5.0)
+    assert over
+    out = pp._bandwidths(hip, Xd, G, 20)  # falls back, finite everywhere
+    assert bool(torch.isfinite(out).all())

@@ -145,7 +145,7 @@ def test_filtered_candidate_search_redoes_rows_whose_buffer_overflowed():
     X = torch.as_tensor(rng.standard_normal((8500, 5)))
     sq = (X * X).sum(dim=1)
     kc = 20
-    got = pp._candidates_filtered(_FilterEmulation(), X, sq, kc, 1 << 26, cap=3)  # ~kc candidates per panel >> 3
+    got, _ = pp._candidates_filtered(_FilterEmulation(), X, sq, kc, 1 << 26, cap=3)  # ~kc candidates per panel >> 3
     D = sq[:, None] + sq[None, :] - 2.0 * (X @ X.T)
     D.fill_diagonal_(float("inf"))
     want = torch.topk(D, kc, dim=1, largest=False).indices
