@@ -85,7 +85,10 @@ __device__ __forceinline__ float dpp_f(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
 }
 
-// ABL: timing ablations (wrong results on purpose): 1 only lanes 0-31 request their pair, 2 no gathers / FMAs
+// ABL: timing ablations (wrong results on purpose): 1 only lanes 0-31 request their pair, 2 no gathers / FMAs,
+// 3 every request fetches the NEXT 32 pairs of one sequential stream per wave (what a slab-major operand with a
+// count table would ask the memory system for), 4 cycle accounting (s_memtime per wave: window wait + count,
+// spread, gathers + FMAs, slab barrier; the sums replace the product)
 // STAGE: a window's (LDS offset, value) pairs reach their four lanes through a per-wave LDS staging row
 // (one ds_write_b64 + a broadcast ds_read_b64 per 16 entries; lane 4 e + c) instead of the lane swaps
 // (lane 16 c + e): 12 VALU instructions per visit less, 3.5 cheap LDS instructions more.
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
                                                       const int32_t* __restrict__ perm,
                                                       const float* __restrict__ Q, float* __restrict__ Y) {
   static_assert(RW >= 4 && RW <= 12, "a sweep covers 4 .. 12 rows per wave");
-  constexpr bool HALF = ABL == 1;
+  constexpr bool HALF = ABL == 1 || ABL == 3;
   typedef __attribute__((address_space(3))) const f4* lds_p;
   __shared__ f4 qs[2][kNSlabBytes / 16];  // Q row j of a slab at byte 64 j
   __shared__ unsigned long long stage[STAGE ? kNW : 1][64];
@@ -142,8 +145,16 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
   };
   const char* __restrict__ entb = reinterpret_cast<const char*>(entw);
   const unsigned lane8 = (unsigned)lane * 8u, last8 = wg_last * 8u;
+  unsigned seq = 0;  // (ABL 3)
+  unsigned long long t_win = 0, t_spread = 0, t_back = 0, t_bar = 0;  // (ABL 4)
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   auto request = [&](unsigned cur, int& col, float& val) {  // lane l: pair cur + l (clamped into the workgroup's stream)
     unsigned off = cur * 8u + lane8;
+    if constexpr (ABL == 3) {
+      off = ((unsigned)wave * (wg_n / kNW) + seq) * 8u + lane8;
+      seq += 32u;
+      if (seq + 64u > wg_n / kNW) seq = 0;
+    }
     off = off < last8 ? off : last8;
     unsigned long long e = 0x000000007fffffffull;
     if (!HALF || lane < 32)
@@ -207,6 +218,8 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
 #define MU_SPREAD_PARAMS unsigned &a0, unsigned &a1, unsigned &a2, unsigned &a3, float &v0, float &v1, float &v2, float &v3, int &n_out
       auto front = [&](auto rc, MU_SPREAD_PARAMS) {
         constexpr int r = decltype(rc)::value;
+        unsigned long long tc0 = 0;
+        if constexpr (ABL == 4) tc0 = __builtin_amdgcn_s_memtime();
         const int col = wcol[r];
         const float val = wval[r];
         // sorted rows: the entries of this slab are a prefix of the lanes still inside the row
@@ -215,6 +228,11 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
         const unsigned long long m = __builtin_amdgcn_ballot_w64(col < s_hi) & rowmask;
         const int n = __builtin_amdgcn_readfirstlane(__builtin_popcountll(m));
         n_out = n;
+        if constexpr (ABL == 4) {
+          const unsigned long long tc1 = __builtin_amdgcn_s_memtime();
+          t_win += tc1 - tc0;
+          tc0 = tc1;
+        }
         cur[r] += (unsigned)n;
         request(cur[r], wcol[r], wval[r]);
         if (n == 64) again |= 1u << r;  // the row goes on in this slab: its next window is the continuation
@@ -246,6 +264,10 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
           v2 = __builtin_bit_cast(float, V.x[2]);
           v3 = __builtin_bit_cast(float, V.x[3]);
         }
+        if constexpr (ABL == 4) {
+          asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+          t_spread += __builtin_amdgcn_s_memtime() - tc0;
+        }
       };
       // (the empty asm statements: the row's FMAs happen HERE - hipcc would sink them to the end of the
       //  slab and keep the gathered Q rows of every row of the sweep alive, 500+ registers - and the
@@ -257,6 +279,8 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
           acc[r][0] += v0 + v1 + __builtin_bit_cast(float, a0 ^ a1);
           return;
         }
+        unsigned long long tb0 = 0;
+        if constexpr (ABL == 4) tb0 = __builtin_amdgcn_s_memtime();
         const f4 q0 = *(lds_p)(a0 ^ qx);
         const f4 q1 = *(lds_p)(a1 ^ qx);
         if (n > 32) {  // uniform
@@ -272,6 +296,7 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
           acc[r] += v1 * q1;
           asm volatile("" : "+v"(acc[r]));
         }
+        if constexpr (ABL == 4) t_back += __builtin_amdgcn_s_memtime() - tb0;
       };
       {
         unsigned ea0, ea1, ea2, ea3, oa0, oa1, oa2, oa3;  // even / odd rows
@@ -305,8 +330,11 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
       }
 #undef MU_SPREAD_PARAMS
       // the DMA pieces are older than the window requests of rows 3 .. RW-1 (and of every revisit)
+      unsigned long long tq0 = 0;
+      if constexpr (ABL == 4) tq0 = __builtin_amdgcn_s_memtime();
       asm volatile("s_waitcnt vmcnt(%0)" ::"i"(RW - 3) : "memory");
       __syncthreads();  // next slab visible; everyone finished reading this one
+      if constexpr (ABL == 4) t_bar += __builtin_amdgcn_s_memtime() - tq0;
     }
 
     // slot partial sums -> row sums in a fixed order; lanes e == 0 store
@@ -331,6 +359,13 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
       }
       store_row(r0 + r, v);
     });
+  }
+  if constexpr (ABL == 4) {  // wave `w` of workgroup `b`: row 16 b + w of Y holds the sums
+    if (lane < 5 && blockIdx.x * 16 + wave < n_pos) {
+      const unsigned long long v = lane == 0 ? t_win : lane == 1 ? t_spread : lane == 2 ? t_back : lane == 3 ? t_bar
+                                                                 : __builtin_amdgcn_s_memtime() - t_begin;
+      Y[((int64_t)blockIdx.x * 16 + wave) * 16 + lane] = (float)v;
+    }
   }
 }
 
@@ -360,6 +395,18 @@ int mu_spmm_narrow_f32_launch(hipStream_t st, int64_t n_pos, int64_t n_cols, int
   if (mu_tune_get("spmm_mode") == 3 && narrow_rw(K) == 10) {  // A/B: window entries spread through an LDS staging row
     hipLaunchKernelGGL((k_spmm_narrow<10, 0, true>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos, n_cols, K, sptr,
                        ent, perm, Q, Y);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+  }
+  if (mu_tune_get("spmm_mode") == 6 && narrow_rw(K) == 10) {  // cycle accounting
+    hipLaunchKernelGGL((k_spmm_narrow<10, 4>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos, n_cols, K, sptr, ent, perm,
+                       Q, Y);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+  }
+  if (mu_tune_get("spmm_mode") == 5 && narrow_rw(K) == 10) {  // ablation: sequential 32-pair requests per wave
+    hipLaunchKernelGGL((k_spmm_narrow<10, 3>), dim3((unsigned)wgs), dim3(1024), 0, st, n_pos, n_cols, K, sptr, ent, perm,
+                       Q, Y);
     MU_CHECK_LAUNCH();
     return MU_OK;
   }

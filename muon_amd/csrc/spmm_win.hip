@@ -784,7 +784,7 @@ int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
   if (force_k >= 1 && force_k <= kKMax) K = force_k;
   const int mode = mu_tune_get("spmm_mode");
   // B = 16: the narrow-block kernel (tune spmm_narrow_off = 1: this file's NB = 1 instance, kept for A/B runs)
-  if (B == 16 && (mode == 0 || mode == 2 || mode == 3 || mode == 4) && mu_tune_get("spmm_narrow_off") == 0)
+  if (B == 16 && (mode == 0 || (mode >= 2 && mode <= 6)) && mu_tune_get("spmm_narrow_off") == 0)
     return mu_spmm_narrow_f32_launch(st, n_pos, n_cols, K, d_sptr, ent, d_perm, d_Q, d_Y);
 #define MU_ARGS B, st, n_pos, n_cols, d_sptr, ent, d_perm, d_Q, d_Y
   if (mode != 0) {

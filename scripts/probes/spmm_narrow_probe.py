@@ -54,7 +54,19 @@ def main():
         t_swap = timed(lambda: be.spmm(S, Q))
         be.tune("spmm_mode", 4)  # ablation: no gathers / FMAs
         t_nog = timed(lambda: be.spmm(S, Q))
+        be.tune("spmm_mode", 6)  # cycle accounting: per wave sums of s_memtime differences replace the product
+        acct = be.spmm(S, Q)
         be.tune("spmm_mode", 0)
+        nw = 16 * ((S.n_pos + 64 * S.k - 1) // (64 * S.k))
+        a = acct[:nw, :5].double()
+        tot = a[:, 4].mean().item()
+        print(f"{name:6s}: accounting (share of a wave's time): window wait + count {a[:, 0].mean().item() / tot:.2f}, "
+              f"mask + spread + request {a[:, 1].mean().item() / tot:.2f}, gathers + FMAs {a[:, 2].mean().item() / tot:.2f}, "
+              f"slab barrier {a[:, 3].mean().item() / tot:.2f}; ticks per wave {tot:.0f}", flush=True)
+        be.tune("spmm_mode", 5)  # ablation: every request = the next 32 pairs of one sequential stream per wave
+        t_seq = timed(lambda: be.spmm(S, Q))
+        be.tune("spmm_mode", 0)
+        print(f"{name:6s}: sequential 32-pair requests per wave (ablation) {t_seq:.3f} ms", flush=True)
         print(f"{name:6s}: narrow kernel with 32-entry requests (ablation) {t_half:.3f} ms, through an LDS staging row {t_swap:.3f} ms, "
               f"without gathers / FMAs (ablation) {t_nog:.3f} ms", flush=True)
         scale = ref.abs().max().item()
