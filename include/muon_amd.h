@@ -316,6 +316,16 @@ int mu_wnn_bandwidth_f64(int64_t n, int p, const double* d_X, const int64_t* d_g
                          const int64_t* d_r_indptr, const int32_t* d_r_indices, int n_bw, double bbox,
                          double* d_csigma, int32_t* d_overflow, void* stream);
 
+/* ---- MOFA+ with element-wise precisions (non-gaussian likelihoods, NaN entries): one Gauss-Seidel sweep over
+ * the K factors of every row r with the row's own statistics T[r] (K x K) and b[r] (K), tools.py:585 -> mofapy2's
+ * W / Z node updates:  t = b_k - sum_{j != k} E_j T_kj,  prec = T_kk + prior_k,  sigma2 = 1 / prec,  mu = t sigma2,
+ * gamma = sigmoid(lth_k - l1mth_k + (ln prior_k - ln prec + t^2 sigma2) / 2) (1 without spike-and-slab),
+ * E_k = gamma mu,  E2_k = gamma (mu^2 + sigma2),  Eh2_k = E2_k + (1 - gamma) / prior_k.  d_gamma / d_Eh2 nullable
+ * (sample rows).  f64 arithmetic, storage type `dtype`. */
+int mu_mofa_gs_update(int dtype, int64_t n, int K, const void* d_T, const void* d_b, const double* d_prior,
+                      const double* d_lth, const double* d_l1mth, int spikeslab, void* d_E, void* d_E2,
+                      void* d_gamma, void* d_Eh2, void* d_sig2, void* stream);
+
 /* ---- MOFA+ small nodes and the ELBO, fused (tools.py:585 ent.run(): mofapy2's Tau, AlphaW, ThetaW,
  * AlphaZ node updates and calculateELBO()).  Arithmetic in f64 for both storage types; every entry
  * ADDS its ELBO terms to the device scalar *d_elbo.  d_work: mu_mofa_elbo_work_doubles(K) doubles. */

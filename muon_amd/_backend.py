@@ -641,6 +641,16 @@ class HipBackend:
                                              _p(sqq), _p(sqc), _p(thr), _p(self_pos), int(buf_pos.shape[1]),
                                              _p(buf_pos), _p(buf_d), _p(cnt), self._stream()))
 
+    def mofa_gs_update(self, Tm, b, prior, lth, l1mth, spikeslab, E, E2, gamma, Eh2, sig2):
+        """Gauss-Seidel sweep over the factors of every row with row-wise K x K statistics (include/muon_amd.h);
+        prior / lth / l1mth: f64 [K]."""
+        n, K = E.shape
+        assert Tm.is_contiguous() and b.is_contiguous() and E.is_contiguous() and E2.is_contiguous() and sig2.is_contiguous()
+        with self._dev_ctx():
+            check(self.lib.mu_mofa_gs_update(_dt(E), int(n), int(K), _p(Tm), _p(b), _p(prior), _p(lth), _p(l1mth),
+                                             int(bool(spikeslab)), _p(E), _p(E2), _p(gamma), _p(Eh2), _p(sig2),
+                                             self._stream()))
+
     def mofa_elbo_work(self, K: int) -> torch.Tensor:
         return self.empty((int(self.lib.mu_mofa_elbo_work_doubles(int(K))),), torch.float64)
 

@@ -288,7 +288,14 @@ class GeneralMofaEngine:
                 b += R.T @ Zc
         Tm, b = self._allreduce(Tm, b)
         Tm = Tm.reshape(V.D, K, K)
-        aw = (Wm.alpha if self.opts["ard_weights"] else torch.ones_like(Wm.alpha)).to(self.T)
+        aw64 = (Wm.alpha if self.opts["ard_weights"] else torch.ones_like(Wm.alpha)).to(torch.float64).contiguous()
+        if hasattr(self.be, "mofa_gs_update"):
+            # one Gauss-Seidel sweep over the factors per feature, a thread per feature (csrc/mofa_stats.hip)
+            self.be.mofa_gs_update(Tm.contiguous(), b.contiguous(), aw64, Wm.lth.to(torch.float64).contiguous(),
+                                   Wm.l1mth.to(torch.float64).contiguous(), self.opts["spikeslab_weights"], Wm.EW,
+                                   Wm.EW2, Wm.gamma, Wm.EWh2, Wm.sig2)
+            return
+        aw = aw64.to(self.T)
         lth, l1mth = Wm.lth.to(self.T), Wm.l1mth.to(self.T)
         EW = Wm.EW
         for k in range(K):
@@ -324,6 +331,11 @@ class GeneralMofaEngine:
                         S[l2 - lo:h2 - lo] += Om @ WW[m]
                         a[l2 - lo:h2 - lo] += R @ self.W[m].EW
                 S = S.reshape(hi - lo, K, K)
+                if hasattr(self.be, "mofa_gs_update"):
+                    # (row slices of contiguous [N, K] tensors are contiguous: updated in place)
+                    self.be.mofa_gs_update(S.contiguous(), a.contiguous(), az[g].to(torch.float64).contiguous(), None,
+                                           None, False, Zc, Z2c, None, None, self.sig2z[lo:hi])
+                    continue
                 for k in range(K):
                     num = a[:, k] - (Zc * S[:, k, :]).sum(dim=1) + Zc[:, k] * S[:, k, k]
                     prec = az[g, k] + S[:, k, k]

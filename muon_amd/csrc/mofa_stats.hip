@@ -154,3 +154,82 @@ int mu_mofa_rowstats(int dtype, int64_t r0, int64_t r1, int K, const void* d_E, 
 }
 
 }  // extern "C"
+
+// ---- Gauss-Seidel sweep over the K factors of every row with ROW-WISE K x K statistics (r03) --------------
+// The nodes of the element-wise-precision model (non-gaussian likelihoods, NaN entries: muon_amd/_core/
+// mofa_general.py; mofapy2's W / Z nodes reached from /root/reference/muon/_core/tools.py:585) update factor k of
+// row r from  t = b[r][k] - sum_j E[r][j] T[r][k][j] + E[r][k] T[r][k][k],  prec = T[r][k][k] + a_k  with the
+// row's OWN K x K matrix T[r] (sum_n Omega_nd <z z^T> for a weight row, sum_d Omega_nd <w w^T> for a sample),
+// one factor after the other with the fresh values of the earlier ones.  As tensor operations that was K x ~15
+// launches over n x K slices per view; here a thread takes a row.  Arithmetic in f64 for both storage types.
+namespace {
+
+template <typename T, int KP>
+__global__ __launch_bounds__(256) void k_gs_update(int64_t n, int K, const T* __restrict__ Tm, const T* __restrict__ b,
+                                                   const double* __restrict__ prior, const double* __restrict__ lth,
+                                                   const double* __restrict__ l1mth, int spikeslab, T* __restrict__ E,
+                                                   T* __restrict__ E2, T* __restrict__ gamma, T* __restrict__ Eh2,
+                                                   T* __restrict__ sig2) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  double e[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) e[k] = k < K ? (double)E[r * K + k] : 0.0;
+  const T* Tr = Tm + r * (int64_t)K * K;
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    if (k < K) {
+    double t = (double)b[r * K + k];
+    double tkk = 0.0;
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+      if (j < K) {
+        const double v = (double)Tr[k * K + j];
+        if (j == k) tkk = v;
+        else t -= e[j] * v;
+      }
+    }
+    const double a = prior[k];
+    const double prec = tkk + a;
+    const double s2 = 1.0 / prec;
+    const double mu = t * s2;
+    double gam = 1.0;
+    if (spikeslab) {
+      const double lam = lth[k] - l1mth[k] + 0.5 * log(a) - 0.5 * log(prec) + 0.5 * t * t * s2;
+      gam = 1.0 / (1.0 + exp(-lam));
+    }
+    e[k] = gam * mu;
+    const double m2 = gam * (mu * mu + s2);
+    E[r * K + k] = (T)e[k];
+    E2[r * K + k] = (T)m2;
+    if (gamma) gamma[r * K + k] = (T)gam;
+    if (Eh2) Eh2[r * K + k] = (T)(m2 + (1.0 - gam) / a);
+    sig2[r * K + k] = (T)s2;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mu_mofa_gs_update(int dtype, int64_t n, int K, const void* d_T, const void* d_b, const double* d_prior,
+                                 const double* d_lth, const double* d_l1mth, int spikeslab, void* d_E, void* d_E2,
+                                 void* d_gamma, void* d_Eh2, void* d_sig2, void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  MU_REQUIRE(K >= 1 && K <= 32 && n >= 0, "1 <= n_factors <= 32");
+  if (n == 0) return MU_OK;
+  MU_REQUIRE(d_T && d_b && d_prior && d_E && d_E2 && d_sig2, "null pointer");
+  MU_REQUIRE(!spikeslab || (d_lth && d_l1mth), "spike-and-slab needs the theta expectations");
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+#define MU_GS(T_, KP_)                                                                                          \
+  hipLaunchKernelGGL((k_gs_update<T_, KP_>), dim3(blocks), dim3(256), 0, st, n, K, (const T_*)d_T, (const T_*)d_b,  \
+                     d_prior, d_lth, d_l1mth, spikeslab, (T_*)d_E, (T_*)d_E2, (T_*)d_gamma, (T_*)d_Eh2, (T_*)d_sig2)
+  if (dtype == MU_DTYPE_F32) {
+    if (K <= 16) MU_GS(float, 16); else MU_GS(float, 32);
+  } else {
+    if (K <= 16) MU_GS(double, 16); else MU_GS(double, 32);
+  }
+#undef MU_GS
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}

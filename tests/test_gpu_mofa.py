@@ -267,3 +267,36 @@ def test_rowstats_kernel_matches_tensor_formulas(hip, dtype, K, R):
         assert float((gram.double() - (ww[:, None] * e).T @ e).abs().max()) <= tol * scale_g
         assert float((s2.double() - (ww[:, None] * e2).sum(0)).abs().max()) <= tol * scale_g
         assert float((s1.double() - ((aa * ww)[:, None] * e).sum(0)).abs().max()) <= tol * scale_g
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("K,spike", [(5, True), (10, False), (20, True)])
+def test_gauss_seidel_row_kernel_matches_the_tensor_loop(hip, dt, K, spike):
+    """mu_mofa_gs_update (a thread per row, row-wise K x K statistics) against the per-factor tensor loop it replaced."""
+    g = torch.Generator(device="cpu").manual_seed(K)
+    n = 3001
+    A = torch.randn((n, K, K), generator=g, dtype=torch.float64)
+    Tm = (A @ A.transpose(1, 2) + 0.5 * torch.eye(K, dtype=torch.float64)).to(dt).to(hip.device).contiguous()
+    b = torch.randn((n, K), generator=g, dtype=torch.float64).to(dt).to(hip.device).contiguous()
+    E0 = torch.randn((n, K), generator=g, dtype=torch.float64).to(dt).to(hip.device)
+    prior = (torch.rand((K,), generator=g, dtype=torch.float64) + 0.5).to(hip.device)
+    lth = -torch.rand((K,), generator=g, dtype=torch.float64).to(hip.device)
+    l1m = -torch.rand((K,), generator=g, dtype=torch.float64).to(hip.device)
+    E, E2, gam, Eh2, s2 = (E0.clone(), torch.zeros_like(E0), torch.zeros_like(E0), torch.zeros_like(E0), torch.zeros_like(E0))
+    hip.mofa_gs_update(Tm, b, prior, lth, l1m, spike, E, E2, gam, Eh2, s2)
+    R, T64, b64 = E0.double().clone(), Tm.double(), b.double()
+    for k in range(K):
+        t = b64[:, k] - (R * T64[:, k, :]).sum(dim=1) + R[:, k] * T64[:, k, k]
+        prec = T64[:, k, k] + prior[k]
+        mu = t / prec
+        gm = torch.ones_like(mu)
+        if spike:
+            gm = torch.sigmoid(lth[k] - l1m[k] + 0.5 * torch.log(prior[k]) - 0.5 * torch.log(prec) + 0.5 * t * t / prec)
+        R[:, k] = gm * mu
+        tol = 1e-12 if dt == torch.float64 else 2e-5
+        assert torch.allclose(E[:, k].double(), R[:, k], rtol=tol, atol=tol)
+        assert torch.allclose(E2[:, k].double(), gm * (mu * mu + 1 / prec), rtol=tol, atol=tol)
+        assert torch.allclose(gam[:, k].double(), gm, rtol=tol, atol=tol)
+        assert torch.allclose(Eh2[:, k].double(), gm * (mu * mu + 1 / prec) + (1 - gm) / prior[k], rtol=tol, atol=tol)
+        assert torch.allclose(s2[:, k].double(), 1 / prec, rtol=tol, atol=tol)
+        R[:, k] = E[:, k].double()  # (continue from the kernel's rounded value, as the kernel does not)
