@@ -90,3 +90,51 @@ def test_lsi_eigen_residuals_full_size(hip, shard):
     assert res[:40].max().item() < 2e-4, res[:40].max().item()
     Ud = U.double()
     assert Ud.mean(dim=0).abs().max().item() < 1e-3 and (Ud.std(dim=0, unbiased=False) - 1).abs().max().item() < 1e-3
+
+
+def test_c4_sparse_view_products_with_the_narrow_block_kernel(hip):
+    """BASELINE configs[3]'s sparse view (100 000 x 100 000 at 3 %) through csrc/spmm_narrow.hip, B = 16:
+    the adjoint identity <X q, y> == <q, X^T y> across the two operands, the B = 64 kernel's NB = 1 instance
+    as a second implementation, bit-reproducibility."""
+    import torch
+
+    from muon_amd._atac.preproc import tfidf_device
+
+    n = d = 100_000
+    X = tfidf_device(hip, hip.synth_counts(0, n, d, 50, 0.03, 0), n, 3, 1e4)
+    P, Pt = hip.stream(X), hip.transpose_stream(X)
+    q, y = hip.randn(d, 16, 5), hip.randn(n, 16, 6)
+    Xq, Xty = hip.spmm(P, q), hip.spmm(Pt, y)
+    lhs = (Xq.double() * y.double()).sum(dim=0)
+    rhs = (q.double() * Xty.double()).sum(dim=0)
+    assert torch.allclose(lhs, rhs, rtol=1e-5, atol=1e-5 * float(lhs.abs().max()))
+    assert torch.equal(Xq, hip.spmm(P, q))
+    try:
+        hip.tune("spmm_narrow_off", 1)
+        ref = hip.spmm(P, q)
+    finally:
+        hip.tune("spmm_narrow_off", 0)
+    scale = float(ref.abs().max())
+    assert float((Xq - ref).abs().max()) < 2e-5 * scale  # (two summation orders in f32)
+
+
+def test_exhaustive_search_at_100k_cells(hip):
+    """The filter-kernel search at the size of the WNN bench record: every sampled query's neighbours equal a
+    dense evaluation of its row, distances ascending, nobody is its own neighbour."""
+    import torch
+
+    from muon_amd._core import preproc as pp
+
+    n, p, k = 100_000, 50, 20
+    rng = np.random.default_rng(2)
+    lab = rng.integers(0, 30, n)
+    X = hip.to_device(rng.standard_normal((30, p))[lab] * 2 + rng.standard_normal((n, p)))
+    idx, dst = pp.device_knn(X, k, "euclidean", backend=hip)
+    assert idx.shape == (n, k) and bool((idx != torch.arange(n, device=idx.device)[:, None]).all())
+    assert bool((dst[:, 1:] >= dst[:, :-1]).all())
+    rows = torch.as_tensor(rng.choice(n, 256, replace=False), device=X.device)
+    D = torch.cdist(X[rows], X)
+    D[torch.arange(rows.numel(), device=X.device), rows] = float("inf")
+    want = torch.topk(D, k, dim=1, largest=False)
+    assert torch.allclose(dst[rows], want.values, rtol=1e-10, atol=1e-10)
+    assert torch.equal(torch.sort(idx[rows], dim=1).values, torch.sort(want.indices, dim=1).values)
