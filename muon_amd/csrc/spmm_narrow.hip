@@ -298,6 +298,33 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
         }
         if constexpr (ABL == 4) t_back += __builtin_amdgcn_s_memtime() - tb0;
       };
+      // Three stages per row, in this order inside a turn: the gathers of row r go out, the front of row r + 1
+      // runs under their latency (it has no LDS operation: the spread is lane swaps), then the FMAs of row r.
+      // (cycle accounting of the two-stage order: gathers + FMAs 39 % of a wave's time, most of it the wait)
+      auto gather = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, int n, f4& q0, f4& q1, f4& q2, f4& q3) {
+        q0 = *(lds_p)(a0 ^ qx);
+        q1 = *(lds_p)(a1 ^ qx);
+        if (n > 32) {  // uniform
+          q2 = *(lds_p)(a2 ^ qx);
+          q3 = *(lds_p)(a3 ^ qx);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (the reads stay in front of the next row's front stage)
+      };
+      auto fmas = [&](auto rc, const f4& q0, const f4& q1, const f4& q2, const f4& q3, float v0, float v1, float v2,
+                      float v3, int n) {
+        constexpr int r = decltype(rc)::value;
+        if (n > 32) {  // uniform
+          acc[r] += v0 * q0;
+          acc[r] += v1 * q1;
+          acc[r] += v2 * q2;
+          acc[r] += v3 * q3;
+          asm volatile("" : "+v"(acc[r]));
+        } else {
+          acc[r] += v0 * q0;
+          acc[r] += v1 * q1;
+          asm volatile("" : "+v"(acc[r]));
+        }
+      };
       {
         unsigned ea0, ea1, ea2, ea3, oa0, oa1, oa2, oa3;  // even / odd rows
         float ev0, ev1, ev2, ev3, ov0, ov1, ov2, ov3;
@@ -306,13 +333,24 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
         front(std::integral_constant<int, 0>{}, ea0, ea1, ea2, ea3, ev0, ev1, ev2, ev3, en);
         n_static_for<RW>([&](auto rc) {
           constexpr int r = decltype(rc)::value;
+          constexpr bool kPipe3 = (ABL == 0) && !STAGE;
+          f4 q0, q1, q2, q3;
+          if constexpr (kPipe3) {
+            if constexpr (r & 1) gather(oa0, oa1, oa2, oa3, on, q0, q1, q2, q3);
+            else gather(ea0, ea1, ea2, ea3, en, q0, q1, q2, q3);
+          }
           if constexpr (r + 1 < RW) {
             if constexpr (r + 1 < 4) dma_one(s0 + kNSlab, buf ^ 1, r + 1);
             if constexpr ((r + 1) & 1) front(std::integral_constant<int, r + 1>{}, oa0, oa1, oa2, oa3, ov0, ov1, ov2, ov3, on);
             else front(std::integral_constant<int, r + 1>{}, ea0, ea1, ea2, ea3, ev0, ev1, ev2, ev3, en);
           }
-          if constexpr (r & 1) back(rc, oa0, oa1, oa2, oa3, ov0, ov1, ov2, ov3, on);
-          else back(rc, ea0, ea1, ea2, ea3, ev0, ev1, ev2, ev3, en);
+          if constexpr (kPipe3) {
+            if constexpr (r & 1) fmas(rc, q0, q1, q2, q3, ov0, ov1, ov2, ov3, on);
+            else fmas(rc, q0, q1, q2, q3, ev0, ev1, ev2, ev3, en);
+          } else {
+            if constexpr (r & 1) back(rc, oa0, oa1, oa2, oa3, ov0, ov1, ov2, ov3, on);
+            else back(rc, ea0, ea1, ea2, ea3, ev0, ev1, ev2, ev3, en);
+          }
         });
       }
       while (again) {  // rows with 64 and more entries in one slab (uniform, rare)
