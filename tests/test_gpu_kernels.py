@@ -552,5 +552,3 @@ def test_project_out_block_equals_apply_and_subtract(hip, B):
     want = Z - hip.apply(Q, C.to(torch.float32).contiguous())
     got = hip.project_out_block(Q, C, Z.clone())
     assert torch.equal(got, want)
-
-
