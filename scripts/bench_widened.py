@@ -42,14 +42,15 @@ def run_ingest(be, n_cells=60000, n_feat=200000, density=0.03, seed=0):
     del X
     nnz = int(host["indptr"][-1])
     best = None
-    for _ in range(2):  # the first call pins the staging buffers and starts the copy threads
+    for _ in range(4):  # the first call pins the staging buffers and starts the copy threads; then the best of three
         D = None
         _sync()
         t0 = time.perf_counter()
         D, keep, _ = mio.device_csr_from_10x(host, None, be, True, ft)
         _sync()
         t1 = time.perf_counter()
-        best = (t0, t1)
+        if _ > 0 and (best is None or t1 - t0 < best[1] - best[0]):
+            best = (t0, t1)
     t0, t1 = best
     T = tfidf_device(be, D, n_cells, 3, 1e4)
     _sync()
