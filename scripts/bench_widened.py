@@ -42,19 +42,20 @@ def run_ingest(be, n_cells=60000, n_feat=200000, density=0.03, seed=0):
     del X
     nnz = int(host["indptr"][-1])
     best = None
-    for _ in range(4):  # the first call pins the staging buffers and starts the copy threads; then the best of three
+    for it in range(4):  # the first call pins the staging buffers and starts the copy threads; then the best of three
         D = None
         _sync()
         t0 = time.perf_counter()
         D, keep, _ = mio.device_csr_from_10x(host, None, be, True, ft)
         _sync()
         t1 = time.perf_counter()
-        if _ > 0 and (best is None or t1 - t0 < best[1] - best[0]):
+        if it > 0 and (best is None or t1 - t0 < best[1] - best[0]):
             best = (t0, t1)
     t0, t1 = best
+    ta = time.perf_counter()
     T = tfidf_device(be, D, n_cells, 3, 1e4)
     _sync()
-    t2 = time.perf_counter()
+    tfidf_ms = 1e3 * (time.perf_counter() - ta)
     # the reference's route on the host (scanpy's reader ends in the same two scipy calls), timed on a sample
     ns = min(n_cells, 6000)
     hi = int(host["indptr"][ns])
@@ -67,7 +68,7 @@ def run_ingest(be, n_cells=60000, n_feat=200000, density=0.03, seed=0):
     in_bytes = host["data"].nbytes + host["indices"].nbytes + host["indptr"].nbytes
     return {"metric": "stored entries/sec, host 10x arrays -> device CSR of the peak columns (PCIe upload included)",
             "value": nnz / (t1 - t0), "unit": "entries/s", "higher_is_better": True, "n_gpus": 1, "data": "synthetic",
-            "dtype": "int32 counts -> f32, int64 -> int32 indices", "ms": 1e3 * (t1 - t0), "tfidf_after_ms": 1e3 * (t2 - t1),
+            "dtype": "int32 counts -> f32, int64 -> int32 indices", "ms": 1e3 * (t1 - t0), "tfidf_after_ms": tfidf_ms,
             "host_bytes_per_s": in_bytes / (t1 - t0),
             "config": {"workload": f"ingest: {n_cells} cells x {n_feat} features, {nnz} stored entries, 4/5 of the columns are peaks",
                        "kept_columns": int(len(keep)), "device_entries": int(D.nnz)},
