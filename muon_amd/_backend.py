@@ -409,6 +409,12 @@ class HipBackend:
         n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         if n_wg > n_cus and not self.__dict__.get("_no_round_fill"):
             n_wg = -(-n_wg // n_cus) * n_cus
+        elif (5 * n_wg >= 4 * n_cus and not self.__dict__.get("_no_round_fill")
+              and os.environ.get("MUON_AMD_SPREAD_WGS", "1") != "0"):
+            # a little less than one round: every CU takes a workgroup (100 000 rows at K = 7: 224 -> 256
+            # workgroups of 391 rows; empty row slots are cheap).  A/B on one box: MOFA c4 -1 %, c3shard -0.3 %;
+            # at 157 of 256 workgroups (10k x 30k) it cost 1 %: hence the 4 / 5 threshold.
+            n_wg = n_cus
         n_pos = n_wg * per_wg
         order = torch.argsort(lens, descending=True, stable=True)
         i = torch.arange(n, device=lens.device)

@@ -236,6 +236,11 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
         cur[r] += (unsigned)n;
         request(cur[r], wcol[r], wval[r]);
         if (n == 64) again |= 1u << r;  // the row goes on in this slab: its next window is the continuation
+        if (n == 0) {  // uniform: nothing of this row in the slab (an empty slot of the layout, a short row)
+          a0 = a1 = a2 = a3 = 0u;
+          v0 = v1 = v2 = v3 = 0.f;
+          return;
+        }
         // 64 j + 16 ((j >> 2) & 3) with j = col - s0 (s0 is a multiple of 1024: the swizzle bits are col's own)
         unsigned a = ((unsigned)col << 6) + neg;
         a |= ((unsigned)col & 12u) << 2;
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
       // runs under their latency (it has no LDS operation: the spread is lane swaps), then the FMAs of row r.
       // (cycle accounting of the two-stage order: gathers + FMAs 39 % of a wave's time, most of it the wait)
       auto gather = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3, int n, f4& q0, f4& q1, f4& q2, f4& q3) {
+        if (n == 0) return;  // uniform
         q0 = *(lds_p)(a0 ^ qx);
         q1 = *(lds_p)(a1 ^ qx);
         if (n > 32) {  // uniform
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
           acc[r] += v2 * q2;
           acc[r] += v3 * q3;
           asm volatile("" : "+v"(acc[r]));
-        } else {
+        } else if (n > 0) {
           acc[r] += v0 * q0;
           acc[r] += v1 * q1;
           asm volatile("" : "+v"(acc[r]));
