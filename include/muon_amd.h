@@ -326,6 +326,14 @@ int mu_mofa_gs_update(int dtype, int64_t n, int K, const void* d_T, const void* 
                       const double* d_lth, const double* d_l1mth, int spikeslab, void* d_E, void* d_E2,
                       void* d_gamma, void* d_Eh2, void* d_sig2, void* stream);
 
+/* ---- UMAP connectivities of a fixed-degree neighbour table (scanpy's `umap` method behind sc.pp.neighbors /
+ * mu.pp.neighbors, preproc.py:615-622): per row rho (first positive distance), sigma by 64 bisection steps towards
+ * sum_{j >= 1} exp(-max(d_j - rho, 0) / sigma) = target (= log2 n_neighbors), floors, then val[r][j] = 0 for the row
+ * itself, 1 where d <= rho, exp(-(d - rho) / sigma) elsewhere.  dist [n x k] f64 (rounded to f32 inside, as umap),
+ * idx [n x k] int64, mean_all = the table's mean distance. */
+int mu_umap_strengths_f64(int64_t n, int k, const double* d_dist, const int64_t* d_idx, double target, double mean_all,
+                          double* d_val, void* stream);
+
 /* ---- MOFA+ small nodes and the ELBO, fused (tools.py:585 ent.run(): mofapy2's Tau, AlphaW, ThetaW,
  * AlphaZ node updates and calculateELBO()).  Arithmetic in f64 for both storage types; every entry
  * ADDS its ELBO terms to the device scalar *d_elbo.  d_work: mu_mofa_elbo_work_doubles(K) doubles. */

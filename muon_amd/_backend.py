@@ -629,6 +629,16 @@ class HipBackend:
                                             int(bool(scale_out)), _p(out_pad), ld, int(col0), _p(out_t), ld_t,
                                             _p(gram), _p(s2), _p(s1), _p(work), self._stream()))
 
+    def umap_strengths(self, dist, idx, target: float, mean_all: float):
+        """Membership strengths of a neighbour table [n, k] (include/muon_amd.h): a thread per row."""
+        n, k = dist.shape
+        assert dist.dtype == torch.float64 and idx.dtype == torch.int64 and dist.is_contiguous() and idx.is_contiguous()
+        out = self.empty((n, k), torch.float64)
+        with self._dev_ctx():
+            check(self.lib.mu_umap_strengths_f64(int(n), int(k), _p(dist), _p(idx), float(target), float(mean_all),
+                                                 _p(out), self._stream()))
+        return out
+
     def wnn_bandwidth(self, X, g_indptr, g_indices, r_indptr, r_indices, n_bw: int, bbox: float):
         """csigma of muon.pp.neighbors, a wave per cell (include/muon_amd.h); returns (csigma, overflowed)."""
         n, p = X.shape

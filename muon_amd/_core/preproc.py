@@ -252,10 +252,14 @@ def device_knn(X: torch.Tensor, k: int, metric: str = "euclidean", chunk_elems: 
 # UMAP connectivities (scanpy's `umap` connectivity: fuzzy_simplicial_set with set_op_mix_ratio = 1,
 # local_connectivity = 1; umap/umap_.py smooth_knn_dist + compute_membership_strengths)
 # -----------------------------------------------------------------------------------------------------
-def fuzzy_simplicial_set(knn_idx: torch.Tensor, knn_dist: torch.Tensor, n_obs: int, n_neighbors: int):
+def fuzzy_simplicial_set(knn_idx: torch.Tensor, knn_dist: torch.Tensor, n_obs: int, n_neighbors: int, backend=None):
     d = knn_dist.to(torch.float32).to(torch.float64)  # umap works on float32 distances
     n, k = d.shape
     target = math.log2(n_neighbors)
+    if backend is not None and hasattr(backend, "umap_strengths") and n > 0:
+        # rho, the 64 bisection steps for sigma and the strengths: a thread per row (csrc/wnn.hip)
+        val = backend.umap_strengths(d.contiguous(), knn_idx.to(torch.int64).contiguous(), target, float(d.mean()))
+        return _symmetrise(knn_idx, val, n_obs)
     pos = torch.where(d > 0, d, torch.full_like(d, float("inf")))
     has = torch.isfinite(pos).any(dim=1)
     # rho: the first positive distance in storage order (local_connectivity = 1)
@@ -285,7 +289,13 @@ def fuzzy_simplicial_set(knn_idx: torch.Tensor, knn_dist: torch.Tensor, n_obs: i
     val = torch.where(knn_idx == rows, torch.zeros_like(d),
                       torch.where((d - rho[:, None] <= 0) | (sigma[:, None] == 0), torch.ones_like(d),
                                   torch.exp(-(d - rho[:, None]) / sigma[:, None])))
-    r = rows.reshape(-1).cpu().numpy()
+    return _symmetrise(knn_idx, val, n_obs)
+
+
+def _symmetrise(knn_idx: torch.Tensor, val: torch.Tensor, n_obs: int):
+    """P + P^T - P o P^T of the membership strengths (set_op_mix_ratio = 1), as a CSR for .obsp."""
+    n, k = val.shape
+    r = np.repeat(np.arange(n), k)
     c = knn_idx.reshape(-1).cpu().numpy()
     v = val.reshape(-1).cpu().numpy()
     res = csr_matrix((v, (r, c)), shape=(n_obs, n_obs))
@@ -310,7 +320,7 @@ def knn(adata, n_neighbors: int = 15, use_rep: Optional[str] = None, n_pcs: Opti
     self_i = torch.arange(n, device=idx.device)[:, None]
     idx_s = torch.cat([self_i, idx], dim=1)
     dst_s = torch.cat([torch.zeros((n, 1), dtype=dst.dtype, device=dst.device), dst], dim=1)
-    conn = fuzzy_simplicial_set(idx_s, dst_s, n, n_neighbors)
+    conn = fuzzy_simplicial_set(idx_s, dst_s, n, n_neighbors, backend=be)
     k1 = idx.shape[1]
     distances = csr_matrix((be.to_host(dst).reshape(-1), be.to_host(idx).reshape(-1),
                             np.arange(0, n * k1 + 1, k1)), shape=(n, n))
@@ -524,7 +534,7 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
     knn_d = d_s[take].reshape(n, k1)
     distances = csr_matrix((be.to_host(knn_d).reshape(-1), be.to_host(knn_idx).reshape(-1),
                             np.arange(0, n * k1 + 1, k1)), shape=(n, n))
-    connectivities = fuzzy_simplicial_set(knn_idx, knn_d, n, k1)  # :615-622
+    connectivities = fuzzy_simplicial_set(knn_idx, knn_d, n, k1, backend=be)  # :615-622
 
     w_host = be.to_host(weights)
     for i, m in enumerate(modalities):  # :583-588

@@ -184,3 +184,71 @@ int mu_wnn_bandwidth_f64(int64_t n, int p, const double* d_X, const int64_t* d_g
 }
 
 }  // extern "C"
+
+// ---- UMAP's smooth_knn_dist + membership strengths for a fixed-degree neighbour table, a thread per row ------------
+// scanpy's `umap` connectivities behind sc.pp.neighbors / mu.pp.neighbors (/root/reference/muon/_core/preproc.py:
+// 615-622 -> _compute_connectivities_umap; umap/umap_.py smooth_knn_dist, compute_membership_strengths with
+// local_connectivity = 1, bandwidth = 1): rho = the first positive distance of the row, sigma by 64 bisection
+// steps so that sum_{j >= 1} exp(-max(d_j - rho, 0) / sigma) = log2(n_neighbors), floors at 1e-3 of the row's /
+// the table's mean distance, then the membership strength of every entry.  As tensor operations the bisection
+// was 64 x ~10 launches over [n, k] tensors with a host check per step.  Arithmetic in f64 on f32-rounded
+// distances, as umap (float32 distances) and the tensor version did.
+namespace {
+
+__global__ __launch_bounds__(256) void k_umap_strengths(int64_t n, int k, const double* __restrict__ dist,
+                                                        const int64_t* __restrict__ idx, double target,
+                                                        double mean_all, double* __restrict__ val) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const double* d = dist + r * k;
+  double rho = 0.0, sum = 0.0;
+  bool has = false;
+  for (int j = 0; j < k; ++j) {
+    const double x = (double)(float)d[j];
+    sum += x;
+    if (!has && x > 0.0) {
+      rho = x;
+      has = true;
+    }
+  }
+  double lo = 0.0, hi = __builtin_inf(), mid = 1.0;
+  for (int it = 0; it < 64; ++it) {
+    double ps = 0.0;
+    for (int j = 1; j < k; ++j) {
+      const double x = (double)(float)d[j] - rho;
+      ps += x > 0.0 ? exp(-x / mid) : 1.0;
+    }
+    if (fabs(ps - target) < 1e-5) break;
+    if (ps > target) {
+      hi = mid;
+      mid = (lo + mid) * 0.5;  // (lo is the old one: it did not move)
+    } else {
+      lo = mid;
+      mid = (hi == __builtin_inf()) ? mid * 2.0 : (mid + hi) * 0.5;
+    }
+  }
+  double sigma = mid;
+  const double floor_ = 1e-3 * (rho > 0.0 ? sum / (double)k : mean_all);
+  sigma = sigma > floor_ ? sigma : floor_;
+  for (int j = 0; j < k; ++j) {
+    const double x = (double)(float)d[j];
+    double v;
+    if (idx[r * k + j] == r) v = 0.0;
+    else if (x - rho <= 0.0 || sigma == 0.0) v = 1.0;
+    else v = exp(-(x - rho) / sigma);
+    val[r * k + j] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int mu_umap_strengths_f64(int64_t n, int k, const double* d_dist, const int64_t* d_idx, double target,
+                                     double mean_all, double* d_val, void* stream) {
+  MU_REQUIRE(n >= 0 && k >= 1, "shape");
+  if (n == 0) return MU_OK;
+  MU_REQUIRE(d_dist && d_idx && d_val, "null pointer");
+  hipLaunchKernelGGL(k_umap_strengths, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, k,
+                     d_dist, d_idx, target, mean_all, d_val);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}

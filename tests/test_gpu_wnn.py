@@ -175,3 +175,21 @@ def test_bandwidth_kernel_reports_hub_cells(hip):
     assert over
     out = pp._bandwidths(hip, Xd, G, 20)  # falls back, finite everywhere
     assert bool(torch.isfinite(out).all())
+
+
+def test_umap_strengths_kernel_equals_the_tensor_bisection(hip):
+    """csrc/wnn.hip k_umap_strengths (a thread per row) against the 64-step tensor bisection it replaces, incl.
+    rows with duplicates (zero distances) and a row that lists itself."""
+    import torch
+
+    rng = np.random.default_rng(4)
+    n, k = 5000, 21
+    d = np.sort(rng.gamma(2.0, 1.0, (n, k)), axis=1)
+    d[:, 0] = 0.0
+    d[::50, 1:4] = 0.0  # duplicated points
+    idx = rng.integers(0, n, (n, k))
+    idx[:, 0] = np.arange(n)
+    dd, ii = hip.to_device(d), hip.to_device(idx, np.int64)
+    want = pp.fuzzy_simplicial_set(ii, dd, n, k)
+    got = pp.fuzzy_simplicial_set(ii, dd, n, k, backend=hip)
+    assert got.shape == want.shape and abs(got - want).max() < 1e-6
