@@ -289,7 +289,7 @@ class GeneralMofaEngine:
         Tm, b = self._allreduce(Tm, b)
         Tm = Tm.reshape(V.D, K, K)
         aw64 = (Wm.alpha if self.opts["ard_weights"] else torch.ones_like(Wm.alpha)).to(torch.float64).contiguous()
-        if hasattr(self.be, "mofa_gs_update"):
+        if hasattr(self.be, "mofa_gs_update") and K <= 32:
             # one Gauss-Seidel sweep over the factors per feature, a thread per feature (csrc/mofa_stats.hip)
             self.be.mofa_gs_update(Tm.contiguous(), b.contiguous(), aw64, Wm.lth.to(torch.float64).contiguous(),
                                    Wm.l1mth.to(torch.float64).contiguous(), self.opts["spikeslab_weights"], Wm.EW,
@@ -331,7 +331,7 @@ class GeneralMofaEngine:
                         S[l2 - lo:h2 - lo] += Om @ WW[m]
                         a[l2 - lo:h2 - lo] += R @ self.W[m].EW
                 S = S.reshape(hi - lo, K, K)
-                if hasattr(self.be, "mofa_gs_update"):
+                if hasattr(self.be, "mofa_gs_update") and K <= 32:
                     # (row slices of contiguous [N, K] tensors are contiguous: updated in place)
                     self.be.mofa_gs_update(S.contiguous(), a.contiguous(), az[g].to(torch.float64).contiguous(), None,
                                            None, False, Zc, Z2c, None, None, self.sig2z[lo:hi])
