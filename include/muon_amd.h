@@ -334,6 +334,12 @@ int mu_mofa_gs_update(int dtype, int64_t n, int K, const void* d_T, const void* 
 int mu_umap_strengths_f64(int64_t n, int k, const double* d_dist, const int64_t* d_idx, double target, double mean_all,
                           double* d_val, void* stream);
 
+/* Poisson pseudo-data of a dense chunk of predictions zeta [n_rows x D] (mofapy2's Poisson node, Seeger bound):
+ * rate = softplus(zeta) clamped away from 0;  mode 0: out = kappa_d zeta - sigmoid(zeta) (1 - y / rate);
+ * mode 1: out = y ln(rate) - rate.  Element-wise, f64 arithmetic, storage type `dtype`; d_out may alias d_zeta. */
+int mu_mofa_poisson_pseudo(int dtype, int64_t n_rows, int64_t D, int mode, const void* d_zeta, const void* d_Y,
+                           const void* d_kappa, void* d_out, void* stream);
+
 /* ---- MOFA+ small nodes and the ELBO, fused (tools.py:585 ent.run(): mofapy2's Tau, AlphaW, ThetaW,
  * AlphaZ node updates and calculateELBO()).  Arithmetic in f64 for both storage types; every entry
  * ADDS its ELBO terms to the device scalar *d_elbo.  d_work: mu_mofa_elbo_work_doubles(K) doubles. */

@@ -657,6 +657,15 @@ class HipBackend:
                                              _p(sqq), _p(sqc), _p(thr), _p(self_pos), int(buf_pos.shape[1]),
                                              _p(buf_pos), _p(buf_d), _p(cnt), self._stream()))
 
+    def mofa_poisson_pseudo(self, zeta, Y, kappa, mode: int):
+        """Poisson pseudo-data (mode 0) / likelihood terms (mode 1) of a dense chunk, in place of zeta."""
+        n, D = zeta.shape
+        assert zeta.is_contiguous() and Y.is_contiguous() and Y.shape == zeta.shape and Y.dtype == zeta.dtype
+        with self._dev_ctx():
+            check(self.lib.mu_mofa_poisson_pseudo(_dt(zeta), int(n), int(D), int(mode), _p(zeta), _p(Y), _p(kappa),
+                                                  _p(zeta), self._stream()))
+        return zeta
+
     def mofa_gs_update(self, Tm, b, prior, lth, l1mth, spikeslab, E, E2, gamma, Eh2, sig2):
         """Gauss-Seidel sweep over the factors of every row with row-wise K x K statistics (include/muon_amd.h);
         prior / lth / l1mth: f64 [K]."""

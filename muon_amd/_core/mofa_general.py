@@ -245,26 +245,33 @@ class GeneralMofaEngine:
         raise IndexError(row)
 
     def _omega_r(self, V, Wm, g, Y, M, Zc, Z2c):
-        """(Omega, R, zeta) of a chunk: the element-wise precision, precision x pseudo-data, prediction."""
+        """(Omega, R, zeta, omega_vec) of a chunk: the element-wise precision, precision x pseudo-data, prediction.
+        Where the precision does not depend on the sample (gaussian / poisson without missing entries) Omega is
+        None and ``omega_vec`` [D] says it all: the K x K statistics then factorise (sum_n Omega_nd <z z^T> =
+        omega_d sum_n <z z^T>) and nothing of size N x D x K^2 is multiplied."""
         zeta = Zc @ Wm.EW.T
         if V.lik == "gaussian":
-            Om = Wm.tau[g][None, :].expand_as(zeta)
-            if M is not None:
-                Om = Om * M
-            return Om, Om * Y, zeta
+            if M is None:
+                tau = Wm.tau[g]
+                return None, tau[None, :] * Y, zeta, tau
+            Om = Wm.tau[g][None, :] * M
+            return Om, Om * Y, zeta, None
         if V.lik == "poisson":
-            rate = torch.nn.functional.softplus(zeta).clamp(min=1e-300 if self.T == torch.float64 else 1e-30)
-            Om = V.kappa[None, :].expand_as(zeta)
-            R = V.kappa[None, :] * zeta - torch.sigmoid(zeta) * (1.0 - Y / rate)
+            if hasattr(self.be, "mofa_poisson_pseudo") and Y.is_contiguous():
+                R = self.be.mofa_poisson_pseudo(zeta, Y, V.kappa.contiguous(), 0)  # one pass, in place of zeta
+                zeta = None  # (no caller needs the prediction of a poisson chunk)
+            else:
+                rate = torch.nn.functional.softplus(zeta).clamp(min=1e-300 if self.T == torch.float64 else 1e-30)
+                R = V.kappa[None, :] * zeta - torch.sigmoid(zeta) * (1.0 - Y / rate)
             if M is not None:
-                Om, R = Om * M, R * M
-            return Om, R, zeta
+                return V.kappa[None, :] * M, R * M, zeta, None
+            return None, R, zeta, V.kappa
         xi2 = zeta ** 2 + Z2c @ Wm.EW2.T - (Zc ** 2) @ (Wm.EW ** 2).T
         Om = 2.0 * _lambda_jj(torch.sqrt(xi2.clamp(min=0.0)))
         R = Y - 0.5
         if M is not None:
             Om, R = Om * M, R * M
-        return Om, R, zeta
+        return Om, R, zeta, None
 
     @staticmethod
     def _outer_moments(E, E2):
@@ -283,8 +290,12 @@ class GeneralMofaEngine:
         for g, (a0, b0) in enumerate(self.gslice):
             for lo, hi, Y, M in self._chunks(V, a0, b0):
                 Zc, Z2c = self.EZ[lo:hi], self.EZ2[lo:hi]
-                Om, R, _ = self._omega_r(V, Wm, g, Y, M, Zc, Z2c)
-                Tm += Om.T @ self._outer_moments(Zc, Z2c)
+                Om, R, _, om_vec = self._omega_r(V, Wm, g, Y, M, Zc, Z2c)
+                P = self._outer_moments(Zc, Z2c)
+                if Om is None:
+                    Tm += om_vec[:, None] * P.sum(dim=0)[None, :]
+                else:
+                    Tm += Om.T @ P
                 b += R.T @ Zc
         Tm, b = self._allreduce(Tm, b)
         Tm = Tm.reshape(V.D, K, K)
@@ -327,8 +338,11 @@ class GeneralMofaEngine:
                 a = torch.zeros((hi - lo, K), dtype=self.T, device=self.dev)
                 for m, V in enumerate(self.views):
                     for l2, h2, Y, M in self._chunks_range(V, lo, hi):
-                        Om, R, _ = self._omega_r(V, self.W[m], g, Y, M, self.EZ[l2:h2], self.EZ2[l2:h2])
-                        S[l2 - lo:h2 - lo] += Om @ WW[m]
+                        Om, R, _, om_vec = self._omega_r(V, self.W[m], g, Y, M, self.EZ[l2:h2], self.EZ2[l2:h2])
+                        if Om is None:
+                            S[l2 - lo:h2 - lo] += (om_vec @ WW[m])[None, :]
+                        else:
+                            S[l2 - lo:h2 - lo] += Om @ WW[m]
                         a[l2 - lo:h2 - lo] += R @ self.W[m].EW
                 S = S.reshape(hi - lo, K, K)
                 if hasattr(self.be, "mofa_gs_update") and K <= 32:
@@ -369,9 +383,12 @@ class GeneralMofaEngine:
                             Ngd[g] += float(hi - lo)
                         S[g] += res.sum(dim=0).to(f64)
                     elif V.lik == "poisson":
-                        rate = torch.nn.functional.softplus(zeta).clamp(min=1e-300 if self.T == f64 else 1e-30)
-                        t = Y * torch.log(rate) - rate
-                        part += ((t * M) if M is not None else t).sum().to(f64)
+                        if hasattr(self.be, "mofa_poisson_pseudo") and Y.is_contiguous():
+                            t = self.be.mofa_poisson_pseudo(zeta, Y, None, 1)
+                        else:
+                            rate = torch.nn.functional.softplus(zeta).clamp(min=1e-300 if self.T == f64 else 1e-30)
+                            t = Y * torch.log(rate) - rate
+                        part += ((t * M) if M is not None else t).sum(dtype=f64)
                     else:
                         t = Y * zeta - torch.nn.functional.softplus(zeta)
                         part += ((t * M) if M is not None else t).sum().to(f64)
@@ -465,7 +482,9 @@ class GeneralMofaEngine:
             for g, (a0, b0) in enumerate(self.gslice):
                 for lo, hi, Y, M in self._chunks(V, a0, b0):
                     Zc = self.EZ[lo:hi]
-                    Om, R, _ = self._omega_r(V, Wm, g, Y, M, Zc, self.EZ2[lo:hi])
+                    Om, R, _, om_vec = self._omega_r(V, Wm, g, Y, M, Zc, self.EZ2[lo:hi])
+                    if Om is None:
+                        Om = om_vec[None, :].expand_as(R)
                     Yh = torch.where(Om > 0, R / torch.where(Om > 0, Om, torch.ones_like(Om)), torch.zeros_like(R))
                     obs = (Om > 0).to(self.T) if M is None else M
                     ss[m, g] += (obs * Yh * Yh).sum().double()
