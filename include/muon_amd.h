@@ -336,7 +336,7 @@ int mu_umap_strengths_f64(int64_t n, int k, const double* d_dist, const int64_t*
 
 /* Poisson pseudo-data of a dense chunk of predictions zeta [n_rows x D] (mofapy2's Poisson node, Seeger bound):
  * rate = softplus(zeta) clamped away from 0;  mode 0: out = kappa_d zeta - sigmoid(zeta) (1 - y / rate);
- * mode 1: out = y ln(rate) - rate.  Element-wise, f64 arithmetic, storage type `dtype`; d_out may alias d_zeta. */
+ * mode 1: out = y ln(rate) - rate.  Element-wise, arithmetic in the storage type `dtype`; d_out may alias d_zeta. */
 int mu_mofa_poisson_pseudo(int dtype, int64_t n_rows, int64_t D, int mode, const void* d_zeta, const void* d_Y,
                            const void* d_kappa, void* d_out, void* stream);
 
