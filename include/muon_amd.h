@@ -334,6 +334,12 @@ int mu_mofa_gs_update(int dtype, int64_t n, int K, const void* d_T, const void* 
 int mu_umap_strengths_f64(int64_t n, int k, const double* d_dist, const int64_t* d_idx, double target, double mean_all,
                           double* d_val, void* stream);
 
+/* Rows [r0, r1) of a CSR (int64 row pointers, int32 columns, values of `dtype`) as a dense row-major chunk
+ * d_out [(r1 - r0) x D]: zero fill and scatter in one pass (the chunk walks of the element-wise-precision MOFA
+ * engine: zeros are data for a count likelihood, tools.py:117-141 densifies whole modalities on the host). */
+int mu_csr_densify_rows(int dtype, int64_t r0, int64_t r1, int64_t D, const int64_t* d_indptr,
+                        const int32_t* d_indices, const void* d_values, void* d_out, void* stream);
+
 /* Poisson pseudo-data of a dense chunk of predictions zeta [n_rows x D] (mofapy2's Poisson node, Seeger bound):
  * rate = softplus(zeta) clamped away from 0;  mode 0: out = kappa_d zeta - sigmoid(zeta) (1 - y / rate);
  * mode 1: out = y ln(rate) - rate.  Element-wise, arithmetic in the storage type `dtype`; d_out may alias d_zeta. */

@@ -657,6 +657,14 @@ class HipBackend:
                                              _p(sqq), _p(sqc), _p(thr), _p(self_pos), int(buf_pos.shape[1]),
                                              _p(buf_pos), _p(buf_d), _p(cnt), self._stream()))
 
+    def densify_rows(self, X: DeviceCSR, lo: int, hi: int) -> torch.Tensor:
+        """Rows [lo, hi) of a device CSR as a dense chunk (include/muon_amd.h)."""
+        out = self.empty((hi - lo, X.shape[1]), X.values.dtype)
+        with self._dev_ctx():
+            check(self.lib.mu_csr_densify_rows(_dt(X.values), int(lo), int(hi), int(X.shape[1]), _p(X.indptr),
+                                               _p(X.indices), _p(X.values), _p(out), self._stream()))
+        return out
+
     def mofa_poisson_pseudo(self, zeta, Y, kappa, mode: int):
         """Poisson pseudo-data (mode 0) / likelihood terms (mode 1) of a dense chunk, in place of zeta."""
         n, D = zeta.shape

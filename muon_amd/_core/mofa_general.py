@@ -223,8 +223,12 @@ class GeneralMofaEngine:
                 M = V.mask[lo:hi] if V.mask is not None else None
             else:
                 X = V.X
-                p0, p1 = int(X.indptr[lo].item()), int(X.indptr[hi].item())
-                Y = torch.zeros((hi - lo, V.D), dtype=self.T, device=V.dev)
+                if hasattr(self.be, "densify_rows") and X.values.dtype == self.T:
+                    Y = self.be.densify_rows(X, lo, hi)
+                    p0 = p1 = 0
+                else:
+                    p0, p1 = int(X.indptr[lo].item()), int(X.indptr[hi].item())
+                    Y = torch.zeros((hi - lo, V.D), dtype=self.T, device=V.dev)
                 if p1 > p0:
                     rows = torch.repeat_interleave(torch.arange(hi - lo, device=V.dev),
                                                    (X.indptr[lo + 1:hi + 1] - X.indptr[lo:hi]))

@@ -292,3 +292,37 @@ extern "C" int mu_mofa_poisson_pseudo(int dtype, int64_t n_rows, int64_t D, int 
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
+
+// ---- rows [r0, r1) of a CSR as a dense chunk (zeros are data for a count likelihood): one pass, a workgroup per row ----
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_densify_rows(int64_t r0, int64_t D, const int64_t* __restrict__ indptr,
+                                                      const int32_t* __restrict__ indices, const T* __restrict__ values,
+                                                      T* __restrict__ out) {
+  const int64_t row = r0 + blockIdx.x;
+  T* o = out + (int64_t)blockIdx.x * D;
+  for (int64_t j = threadIdx.x; j < D; j += blockDim.x) o[j] = (T)0;
+  __syncthreads();
+  const int64_t a = indptr[row], b = indptr[row + 1];
+  for (int64_t p = a + threadIdx.x; p < b; p += blockDim.x) o[indices[p]] = values[p];
+}
+
+}  // namespace
+
+extern "C" int mu_csr_densify_rows(int dtype, int64_t r0, int64_t r1, int64_t D, const int64_t* d_indptr,
+                                   const int32_t* d_indices, const void* d_values, void* d_out, void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  MU_REQUIRE(r0 >= 0 && r1 >= r0 && D >= 1 && r1 - r0 < ((int64_t)1 << 31), "row range");
+  if (r1 == r0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_out, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MU_DTYPE_F32)
+    hipLaunchKernelGGL(k_densify_rows<float>, dim3((unsigned)(r1 - r0)), dim3(256), 0, st, r0, D, d_indptr, d_indices,
+                       (const float*)d_values, (float*)d_out);
+  else
+    hipLaunchKernelGGL(k_densify_rows<double>, dim3((unsigned)(r1 - r0)), dim3(256), 0, st, r0, D, d_indptr, d_indices,
+                       (const double*)d_values, (double*)d_out);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
