@@ -340,6 +340,11 @@ int mu_umap_strengths_f64(int64_t n, int k, const double* d_dist, const int64_t*
 int mu_csr_densify_rows(int dtype, int64_t r0, int64_t r1, int64_t D, const int64_t* d_indptr,
                         const int32_t* d_indices, const void* d_values, void* d_out, void* stream);
 
+/* Bernoulli pseudo-data precision of a dense chunk (mofapy2's Bernoulli node, Jaakkola bound): out = 2 lambda(xi) =
+ * tanh(xi / 2) / (2 xi) with xi^2 = max(zeta^2 + a - b, 0), xi >= 1e-8; n elements, arithmetic in the storage type. */
+int mu_mofa_jaakkola(int dtype, int64_t n, const void* d_zeta, const void* d_a, const void* d_b, void* d_out,
+                     void* stream);
+
 /* Poisson pseudo-data of a dense chunk of predictions zeta [n_rows x D] (mofapy2's Poisson node, Seeger bound):
  * rate = softplus(zeta) clamped away from 0;  mode 0: out = kappa_d zeta - sigmoid(zeta) (1 - y / rate);
  * mode 1: out = y ln(rate) - rate.  Element-wise, arithmetic in the storage type `dtype`; d_out may alias d_zeta. */

@@ -665,6 +665,13 @@ class HipBackend:
                                                _p(X.indices), _p(X.values), _p(out), self._stream()))
         return out
 
+    def mofa_jaakkola(self, zeta, a, b):
+        """Bernoulli pseudo-data precision 2 lambda(xi), xi^2 = zeta^2 + a - b, written over ``a``."""
+        assert zeta.is_contiguous() and a.is_contiguous() and b.is_contiguous() and a.shape == zeta.shape == b.shape
+        with self._dev_ctx():
+            check(self.lib.mu_mofa_jaakkola(_dt(zeta), int(zeta.numel()), _p(zeta), _p(a), _p(b), _p(a), self._stream()))
+        return a
+
     def mofa_poisson_pseudo(self, zeta, Y, kappa, mode: int):
         """Poisson pseudo-data (mode 0) / likelihood terms (mode 1) of a dense chunk, in place of zeta."""
         n, D = zeta.shape

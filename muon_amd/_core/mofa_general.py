@@ -270,8 +270,11 @@ class GeneralMofaEngine:
             if M is not None:
                 return V.kappa[None, :] * M, R * M, zeta, None
             return None, R, zeta, V.kappa
-        xi2 = zeta ** 2 + Z2c @ Wm.EW2.T - (Zc ** 2) @ (Wm.EW ** 2).T
-        Om = 2.0 * _lambda_jj(torch.sqrt(xi2.clamp(min=0.0)))
+        if hasattr(self.be, "mofa_jaakkola"):
+            Om = self.be.mofa_jaakkola(zeta, Z2c @ Wm.EW2.T, (Zc ** 2) @ (Wm.EW ** 2).T)  # one pass
+        else:
+            xi2 = zeta ** 2 + Z2c @ Wm.EW2.T - (Zc ** 2) @ (Wm.EW ** 2).T
+            Om = 2.0 * _lambda_jj(torch.sqrt(xi2.clamp(min=0.0)))
         R = Y - 0.5
         if M is not None:
             Om, R = Om * M, R * M

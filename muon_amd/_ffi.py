@@ -89,6 +89,7 @@ SIGNATURES = {
     "mu_wnn_bandwidth_f64": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _vp, _vp, _vp]),
     "mu_knn_filter_f64": (C.c_int, [_i64, _i64, _i64, _i32] + [_vp] * 6 + [_i32] + [_vp] * 4),
     "mu_csr_densify_rows": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "mu_mofa_jaakkola": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_poisson_pseudo": (C.c_int, [_i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_gs_update": (C.c_int, [_i32, _i64, _i32] + [_vp] * 5 + [_i32] + [_vp] * 6),
     "mu_mofa_elbo_work_doubles": (_sz, [_i32]),

@@ -326,3 +326,49 @@ extern "C" int mu_csr_densify_rows(int dtype, int64_t r0, int64_t r1, int64_t D,
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
+
+// ---- bernoulli pseudo-data precision of a dense chunk (Jaakkola bound), element-wise (r03) -----------------------------
+//   xi^2 = zeta^2 + a - b  (a = <Z^2> <W^2>^T, b = <Z>^2 (<W>^2)^T: the variance of the prediction),
+//   Omega = 2 lambda(xi) = tanh(xi / 2) / (2 xi),  xi clamped to >= 1e-8     (mofapy2's Bernoulli node, tools.py:585)
+// As tensor operations: twelve passes over the N x D chunk.  Arithmetic in the storage type.  out may alias zeta.
+namespace {
+
+__device__ __forceinline__ float jj_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ double jj_tanh(double x) { return tanh(x); }
+__device__ __forceinline__ float jj_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double jj_sqrt(double x) { return sqrt(x); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_jaakkola(int64_t n, const T* __restrict__ zeta, const T* __restrict__ a,
+                                                  const T* __restrict__ b, T* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const T z = zeta[i];
+    T xi2 = z * z + a[i] - b[i];
+    xi2 = xi2 > (T)0 ? xi2 : (T)0;
+    T x = jj_sqrt(xi2);
+    x = x > (T)1e-8 ? x : (T)1e-8;
+    out[i] = (T)2 * (jj_tanh((T)0.5 * x) / ((T)4 * x));
+  }
+}
+
+}  // namespace
+
+extern "C" int mu_mofa_jaakkola(int dtype, int64_t n, const void* d_zeta, const void* d_a, const void* d_b, void* d_out,
+                                void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  MU_REQUIRE(n >= 0, "size");
+  if (n == 0) return MU_OK;
+  MU_REQUIRE(d_zeta && d_a && d_b && d_out, "null pointer");
+  int64_t blocks = (n + 255) / 256;
+  const int64_t cap = (int64_t)mu_num_cus() * 32;
+  if (blocks > cap) blocks = cap;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MU_DTYPE_F32)
+    hipLaunchKernelGGL(k_jaakkola<float>, dim3((unsigned)blocks), dim3(256), 0, st, n, (const float*)d_zeta,
+                       (const float*)d_a, (const float*)d_b, (float*)d_out);
+  else
+    hipLaunchKernelGGL(k_jaakkola<double>, dim3((unsigned)blocks), dim3(256), 0, st, n, (const double*)d_zeta,
+                       (const double*)d_a, (const double*)d_b, (double*)d_out);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}

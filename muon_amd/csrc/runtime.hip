@@ -36,7 +36,7 @@ static int g_tune[kTuneN] = {};
 
 extern "C" {
 
-int mu_version(void) { return 306; }  // r03: mu_mofa_rowstats, mu_mofa_gs_update, mu_mofa_poisson_pseudo, mu_csr_densify_rows, mu_knn_filter_f64, mu_wnn_bandwidth_f64, mu_umap_strengths_f64 added, mu_mofa_update_z takes d_corr, mu_spmm_ws_* removed
+int mu_version(void) { return 307; }  // r03: mu_mofa_rowstats, mu_mofa_gs_update, mu_mofa_poisson_pseudo, mu_mofa_jaakkola, mu_csr_densify_rows, mu_knn_filter_f64, mu_wnn_bandwidth_f64, mu_umap_strengths_f64 added, mu_mofa_update_z takes d_corr, mu_spmm_ws_* removed
 
 int mu_tune_set(const char* key, int value) {
   MU_REQUIRE(key, "null key");
