@@ -101,7 +101,7 @@ __global__ __launch_bounds__(1024) void k_spmm_narrow(int64_t n_pos, int64_t n_c
   static_assert(RW >= 4 && RW <= 12, "a sweep covers 4 .. 12 rows per wave");
   constexpr bool HALF = ABL == 1 || ABL == 3;
   typedef __attribute__((address_space(3))) const f4* lds_p;
-  __shared__ f4 qs[2][kNSlabBytes / 16];  // Q row j of a slab at byte 64 j
+  __shared__ __attribute__((aligned(65536))) f4 qs[2][kNSlabBytes / 16];  // Q row j of a slab at byte 64 j (64 KiB aligned: the XOR addressing)
   __shared__ unsigned long long stage[STAGE ? kNW : 1][64];
   const int lane = threadIdx.x & 63;
   const int wave = uniform32(threadIdx.x >> 6);
