@@ -202,11 +202,50 @@ int mu_spmm_stream_f64(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
                        int accumulate, void* stream);
 
 
+/* ---- matrix-core SpMM of the LSI iteration (r04; csrc/spmm_mfma.hip) --------------------------------------
+ * Replaces, like mu_spmm_stream_f32, the csr_matvec / csr_matvecs calls of ARPACK's reverse-communication loop
+ * behind scipy.sparse.linalg.svds (/root/reference/muon/_atac/tools.py:53, scipy _svds.py:441-466,516), for
+ * 64-column blocks: rows of the dense operand are gathered from LDS with ds_read_b64_tr_b16 and summed per
+ * matrix row by v_mfma_f32_16x16x32_f16 (A = the stored values placed in the row they belong to).
+ *
+ * Operand ("cells"): rows in tiles of 8, 4 tiles = a band of 32 rows, operand rows in slabs of slab_rows.  The
+ * entries of (tile, slab) form a cell = steps of 32 k-slots; a step is step_bytes = 224 bytes:
+ *   hi[32] f16 | lo[32] f16   value / value_scale = hi + lo
+ *   off[32] u16               in gather order: index 8 kb + 2 j + t holds slot 8 kb + 4 t + j; bits 0-13 = row of
+ *                             the dense operand inside the slab * (stride / 8), bits 14-15 of off[0] = tile of the band
+ *   mask[4][8] u8             bit i of mask[kb][r]: slot 8 kb + i belongs to tile row r (no bit: padding slot)
+ * A band's steps are contiguous from step d_band_base[band], ordered (slab, tile, step); d_hdr[band][slab] is the
+ * number of steps of the band in that slab.  d_band_base[band + 1] - d_band_base[band] >= the steps of the band
+ * (mu_cells_cut reports a violated bound through *d_err); d_cells needs `ring` steps of slack behind the last band. */
+int mu_cells_geometry(int nset, int* slab_rows, int* stride, int* step_bytes, int* band_rows, int* ring);
+/* Cut a canonical (sorted) f32 CSR into cells.  *d_value_inv_scale: 1 / value_scale, a power of two (device). */
+int mu_cells_cut(int nset, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
+                 const float* d_values, const float* d_value_inv_scale, const int64_t* d_band_base, void* d_cells,
+                 int32_t* d_hdr, int* d_err, void* stream);
+/* f32 block [rows, 64] -> padded f16 operand [rows_padded, stride bytes] (nset 1: 64 f16; 2: hi 64 | lo 64) with one
+ * power-of-two scale per column (d_scale, its inverse d_inv; the largest entry of a column lands in [2^13, 2^14)).
+ * rewrite != 0: d_Q is replaced by the rounded block (float(hi) * scale) - the caller keeps THAT as its basis. */
+size_t mu_dense_f16_worksize(int64_t rows);
+int mu_dense_to_f16(int nset, int64_t rows, int64_t rows_padded, float* d_Q, int rewrite, void* d_out,
+                    float* d_scale, float* d_inv, void* d_work, size_t work_bytes, void* stream);
+/* Y[n_rows, 64] = (cells) x (f16 operand), f32 accumulation, Y[:, c] multiplied by d_outscale[c]
+ * (= column scale x value scale).  nset 1 / 2: the operand of mu_dense_to_f16(nset). */
+int mu_spmm_cells_f32(int nset, int64_t n_rows, int64_t n_operand_rows, const int32_t* d_hdr,
+                      const int64_t* d_band_base, const void* d_cells, const void* d_B16,
+                      const float* d_outscale, float* d_Y, void* stream);
+/* hardware semantics the kernel rests on (tests/test_gpu_mfma.py): one wave reads d_image (LDS copy, <= 64 KiB)
+ * with ds_read_b64_tr_b16 at the per-lane byte addresses d_addr[64] -> d_out[64][2] dwords; one
+ * v_mfma_f32_16x16x32_f16 on per-lane fragments d_a[64][4], d_b[64][4] dwords -> d_d[64][4] floats. */
+int mu_probe_tr16(const void* d_image, int n_dwords, const void* d_addr, void* d_out, void* stream);
+int mu_probe_mfma16(const void* d_a, const void* d_b, float* d_d, void* stream);
+
 /* Tuning / ablation knobs (tests and bench only; all default to 0 = what ships):
  *   "spmm_k"     row-sets per wave of the packed SpMM (0 = automatic)
  *   "spmm_waves" waves per workgroup of the packed SpMM: 16 (default), 12, 8
  *   "spmm_pipe"  software pipelining level of the packed SpMM
- *   "spmm_mode"  timing ablations of the packed SpMM (bit mask; results are then WRONG) */
+ *   "spmm_mode"  timing ablations of the packed SpMM (bit mask; results are then WRONG)
+ *   "mfma_mode"  timing ablations of the matrix-core SpMM (1 no MFMA, 2 no gathers, 4 no masks; WRONG results)
+ *   "mfma_trmap" lane -> (row, piece) assignment of the transpose read (0 = lane 4 j + c, what ships) */
 int mu_tune_set(const char* key, int value);
 int mu_tune_get(const char* key);
 

@@ -221,7 +221,18 @@ def _lsi_device(
     # straight from the CSR of X, no CSR of X^T in between.  (`pack=False`: plain CSR kernels.)
     if pack is None:
         pack = Xt is None and hasattr(backend, "can_stream") and backend.can_stream(X, B)
-    if pack and getattr(X, "stream", None) is not None:
+    # r04 experiment, OFF unless MUON_AMD_LSI_MFMA=1: X Q_j on the matrix cores (csrc/spmm_mfma.hip).
+    # The operand is cut into cells and the product rounds Q_j IN PLACE to f16 (a power-of-two scale per column)
+    # before it is used anywhere else, so Y_j = X Q_j is exact for the block that is kept as the basis.  Measured:
+    # 3.3 against 4.0 ms per product at 125 000 x 200 000 and - rounding the basis blocks perturbs the Krylov
+    # space - 7e-5 .. 1e-4 rad where the f32 products reach 1e-6 (scripts/probes/f16_operand_precision.py, mode
+    # "basis"): not the default.  X^T Y_j keeps the f32 row-stream kernel either way.
+    mfma = (pack and hasattr(backend, "can_cells") and os.environ.get("MUON_AMD_LSI_MFMA", "0") == "1"
+            and backend.can_cells(X, B))
+    if mfma:
+        Xt = backend.transpose_stream(X)
+        X = backend.cells(X)
+    elif pack and getattr(X, "stream", None) is not None:
         Xs = X.stream  # written by the TF-IDF scale pass of the same call sequence
         Xt = backend.transpose_stream(X)
         X = Xs

@@ -76,6 +76,28 @@ class SplitStream:
         return self.hi.shape
 
 
+@dataclass
+class DeviceCells:
+    """A sparse operand cut into cells for the matrix-core SpMM (csrc/spmm_mfma.hip, include/muon_amd.h):
+    rows in tiles of 8 / bands of 32, columns in slabs of ``slab_rows`` operand rows; ``hdr[band, slab]`` =
+    steps (32 k-slots, 224 bytes) of the band in that slab, ``band_base[band]`` = first step of the band's
+    stream inside ``cells``; the stored values were divided by ``vscale`` (a power of two) and split into
+    two f16.  ``nset`` = 1: the dense operand is a basis block that the product ROUNDS IN PLACE to f16
+    (one power-of-two scale per column) - X Q~ is then exact; 2: the dense operand is read as hi + lo.
+    SpMM-only."""
+
+    hdr: torch.Tensor
+    band_base: torch.Tensor
+    cells: torch.Tensor
+    shape: Tuple[int, int]
+    nnz: int
+    nset: int
+    vscale: torch.Tensor
+    slab_rows: int
+    stride: int
+    cache: dict = None
+
+
 _NULL_CTX = contextlib.nullcontext()
 
 
@@ -428,6 +450,93 @@ class HipBackend:
         inv[order] = pos.to(torch.int32)
         return perm, inv, K
 
+    # -- matrix-core SpMM operand (csrc/spmm_mfma.hip) ------------------------------------------
+    def cells_geometry(self, nset: int):
+        import ctypes as C
+
+        v = [C.c_int(0) for _ in range(5)]
+        check(self.lib.mu_cells_geometry(nset, *[C.byref(x) for x in v]))
+        return dict(slab_rows=v[0].value, stride=v[1].value, step_bytes=v[2].value, band_rows=v[3].value,
+                    ring=v[4].value)
+
+    def can_cells(self, X: DeviceCSR, B: int, nset: int = 1) -> bool:
+        """The matrix-core SpMM exists for f32 values and 64-column blocks; its cell stream is sized by a
+        bound (stored entries / 32 + 4 steps per band and slab) that must stay near the entries themselves."""
+        if not (X.values.dtype == torch.float32 and B == 64 and X.shape[0] > 0 and X.shape[1] > 0 and X.nnz > 0):
+            return False
+        g = self.cells_geometry(nset)
+        n_bands = -(-X.shape[0] // g["band_rows"])
+        n_slabs = -(-X.shape[1] // g["slab_rows"])
+        if n_slabs * g["slab_rows"] * g["stride"] >= (1 << 32):
+            return False
+        return 5 * n_slabs * n_bands <= 2 * (X.nnz // 32) + 4096
+
+    def cells(self, X: DeviceCSR, nset: int = 1) -> DeviceCells:
+        """Cut a canonical f32 CSR into cells (one pass over the matrix, once per lsi call)."""
+        n, d = X.shape
+        assert X.values.dtype == torch.float32
+        g = self.cells_geometry(nset)
+        br, sr, sb = g["band_rows"], g["slab_rows"], g["step_bytes"]
+        n_bands, n_slabs = -(-n // br), -(-d // sr)
+        # steps of a band: sum over its cells of ceil(entries / 32) <= entries / 32 + cells
+        edge = X.indptr[::br]
+        if edge.numel() < n_bands + 1:
+            edge = torch.cat([edge, X.indptr[-1:]])
+        ub = (edge[1:] - edge[:-1]) // 32 + 5 * n_slabs  # (+ an all-zero step where a band's count in a slab is odd)
+        band_base = torch.zeros((n_bands + 1,), dtype=torch.int64, device=self.device)
+        torch.cumsum(ub, 0, out=band_base[1:])
+        total = int(band_base[-1].item()) + g["ring"] + 1  # (the step ring reads ahead of the last step)
+        cells = self.empty((total * sb,), torch.uint8)
+        hdr = self.empty((n_bands, n_slabs), torch.int32)
+        err = self.zeros((1,), torch.int32)
+        # stored values are divided by a power of two that puts the largest one into [2^13, 2^14)
+        vmax = X.values.abs().max()
+        e = torch.where(vmax > 0, torch.floor(torch.log2(vmax)) - 13.0, torch.zeros_like(vmax))
+        vscale = torch.exp2(e).to(torch.float32).reshape(1)
+        vinv = torch.exp2(-e).to(torch.float32).reshape(1)
+        with self._dev_ctx():
+            check(self.lib.mu_cells_cut(nset, n, d, _p(X.indptr), _p(X.indices), _p(X.values), _p(vinv),
+                                        _p(band_base), _p(cells), _p(hdr), _p(err), self._stream()))
+        out = DeviceCells(hdr, band_base, cells, (n, d), X.nnz, nset, vscale, sr, g["stride"], {})
+        out.cache["err"] = err
+        return out
+
+    def _cells_check(self, Xc: DeviceCells) -> None:
+        err = Xc.cache.pop("err", None)
+        if err is not None and int(err.item()) != 0:
+            raise _ffi.MuonAmdError("mu_cells_cut: a band needed more steps than the caller's bound")
+
+    def dense16(self, Xc: DeviceCells, Q: torch.Tensor, rewrite: bool):
+        """f32 block [d, 64] -> the padded f16 operand of the matrix-core SpMM (+ per-column scales);
+        ``rewrite``: Q is replaced by its rounded self (the block IS what the f16 operand holds)."""
+        d = Xc.shape[1]
+        rows_padded = -(-d // Xc.slab_rows) * Xc.slab_rows
+        c = Xc.cache
+        if "b16" not in c:
+            c["b16"] = self.zeros((rows_padded * Xc.stride,), torch.uint8)  # (the pad bytes stay zero)
+            c["scale"] = self.empty((64,), torch.float32)
+            c["inv"] = self.empty((64,), torch.float32)
+            c["work"] = self.empty((int(self.lib.mu_dense_f16_worksize(d)),), torch.uint8)
+        with self._dev_ctx():
+            check(self.lib.mu_dense_to_f16(Xc.nset, d, rows_padded, _p(Q), int(bool(rewrite)), _p(c["b16"]),
+                                           _p(c["scale"]), _p(c["inv"]), _p(c["work"]), c["work"].numel(),
+                                           self._stream()))
+        return c["b16"], c["scale"]
+
+    def spmm_cells(self, Xc: DeviceCells, Q: torch.Tensor, out=None) -> torch.Tensor:
+        n, d = Xc.shape
+        if Q.shape != (d, 64) or Q.dtype != torch.float32 or not Q.is_contiguous():
+            raise TypeError("the matrix-core SpMM needs a contiguous f32 block of 64 columns")
+        self._cells_check(Xc)
+        b16, scale = self.dense16(Xc, Q, rewrite=(Xc.nset == 1))
+        outscale = scale * Xc.vscale
+        if out is None:
+            out = self.empty((n, 64), torch.float32)
+        with self._dev_ctx():
+            check(self.lib.mu_spmm_cells_f32(Xc.nset, n, d, _p(Xc.hdr), _p(Xc.band_base), _p(Xc.cells), _p(b16),
+                                             _p(outscale), _p(out), self._stream()))
+        return out
+
     def stream_both(self, X: DeviceCSR):
         """(row stream of X, row stream of X^T).  The two builders are independent; the streaming
         copy of X (HBM bound) runs on a second stream under the transposition, whose fill is
@@ -491,6 +600,9 @@ class HipBackend:
             if X.lo is not None:
                 self.spmm(X.lo, Q, out=out, accumulate=True)
             return out
+        if isinstance(X, DeviceCells):
+            assert not accumulate
+            return self.spmm_cells(X, Q, out=out)
         if isinstance(X, DeviceStream):
             wide = Q.dtype == torch.float64
             if B not in ((16, 32) if wide else (16, 32, 64)):

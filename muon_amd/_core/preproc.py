@@ -61,16 +61,32 @@ def _choose_representation(adata, use_rep=None, n_pcs=None):
 # -----------------------------------------------------------------------------------------------------
 # l2norm (reference :182-260)
 # -----------------------------------------------------------------------------------------------------
+# widest representation the filter kernel's LDS tiles hold (csrc/knn.hip: two 64-row operand tiles of p_pad + 1
+# doubles in 160 KiB); wider ones take the tiled search (the gate said 1024 and the kernel raised)
+_KNN_FILTER_MAX_P = 156
+
+
 def _l2norm(adata, rep=None, n_pcs=0):
     X = _choose_representation(adata, rep, n_pcs)
     if issparse(X):
-        m = X.tocsr() if X.format not in ("csr",) else X
-        nrm = np.sqrt(np.asarray(m.multiply(m).sum(axis=1)).reshape(-1))
+        # in place on X's own arrays, whatever the format (reference :194-195 writes `X.data[:]` for csr, csc and
+        # coo; r03 normalised a csr COPY of csc / coo input and left X untouched - ADVICE r03).  Like there, the
+        # scaled values are cast to X's dtype on assignment.
+        fmt = X.format
+        if fmt == "csr":
+            rows = np.repeat(np.arange(X.shape[0]), np.diff(X.indptr))
+        elif fmt == "csc":
+            rows = np.asarray(X.indices)
+        elif fmt == "coo":
+            rows = np.asarray(X.row)
+        else:
+            raise TypeError(f"l2norm: sparse format '{fmt}' is not supported (csr, csc, coo)")
+        data = np.asarray(X.data, dtype=np.float64)
+        nrm = np.sqrt(np.bincount(rows, weights=data * data, minlength=X.shape[0]))
         with np.errstate(divide="ignore", invalid="ignore"):
-            scale = np.repeat(1.0 / nrm, np.diff(m.indptr))
-        d = m.data * scale
+            d = data / nrm[rows]
         d[~np.isfinite(d)] = 0
-        m.data[:] = d
+        X.data[:] = d
     else:
         with np.errstate(divide="ignore", invalid="ignore"):
             norm = X / np.linalg.norm(X, ord=2, axis=1, keepdims=True)
@@ -219,7 +235,7 @@ def device_knn(X: torch.Tensor, k: int, metric: str = "euclidean", chunk_elems: 
     ar = torch.arange(n, device=X.device)
     cand_all = None
     if (gemm and backend is not None and hasattr(backend, "knn_filter") and X.dtype == torch.float64
-            and n >= 8192 and 4 * kc <= n // 2 and p <= 1024):
+            and n >= 8192 and 4 * kc <= n // 2 and -(-p // 4) * 4 <= _KNN_FILTER_MAX_P):
         cand_all, cand_d = _candidates_filtered(backend, Xn, sq, kc, chunk_elems)
         if indices_only:
             t = torch.topk(cand_d, k, dim=1, largest=False, sorted=True)

@@ -67,6 +67,13 @@ SIGNATURES = {
     "mu_csr_tpack_fill_stream": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_stream_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "mu_spmm_stream_f64": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
+    "mu_cells_geometry": (C.c_int, [_i32] + [C.POINTER(C.c_int)] * 5),
+    "mu_cells_cut": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mu_dense_f16_worksize": (_sz, [_i64]),
+    "mu_dense_to_f16": (C.c_int, [_i32, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mu_spmm_cells_f32": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mu_probe_tr16": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
+    "mu_probe_mfma16": (C.c_int, [_vp, _vp, _vp, _vp]),
     "mu_tune_set": (C.c_int, [C.c_char_p, _i32]),
     "mu_tune_get": (C.c_int, [C.c_char_p]),
     "mu_spmm_f64": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),

@@ -30,13 +30,14 @@ int mu_num_cus() {
 // tuning / ablation knobs (tests and bench only)
 static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "spmm_waves", "spmm_pipe",
                                         "tpack_abl", "tpack_c", "gram_wg", "tpack_v2", "pack_wg",
-                                        "tpack_dbg", "tpack_rows", "tpack_narrow", "spmm_narrow_off"};
+                                        "tpack_dbg", "tpack_rows", "tpack_narrow", "spmm_narrow_off",
+                                        "mfma_mode"};
 constexpr int kTuneN = sizeof(kTuneKeys) / sizeof(kTuneKeys[0]);
 static int g_tune[kTuneN] = {};
 
 extern "C" {
 
-int mu_version(void) { return 307; }  // r03: mu_mofa_rowstats, mu_mofa_gs_update, mu_mofa_poisson_pseudo, mu_mofa_jaakkola, mu_csr_densify_rows, mu_knn_filter_f64, mu_wnn_bandwidth_f64, mu_umap_strengths_f64 added, mu_mofa_update_z takes d_corr, mu_spmm_ws_* removed
+int mu_version(void) { return 400; }  // r04: matrix-core SpMM (mu_cells_*, mu_dense_to_f16, mu_spmm_cells_f32, probes);  // r03: mu_mofa_rowstats, mu_mofa_gs_update, mu_mofa_poisson_pseudo, mu_mofa_jaakkola, mu_csr_densify_rows, mu_knn_filter_f64, mu_wnn_bandwidth_f64, mu_umap_strengths_f64 added, mu_mofa_update_z takes d_corr, mu_spmm_ws_* removed
 
 int mu_tune_set(const char* key, int value) {
   MU_REQUIRE(key, "null key");

@@ -34,6 +34,13 @@ def test_l2norm_dense_sparse_and_mudata():
     b = AnnData(s.tocsr().astype(np.float64))
     pp.l2norm(b, rep="X")
     np.testing.assert_allclose(np.sqrt(np.asarray(b.X.multiply(b.X).sum(axis=1))).ravel(), 1.0, rtol=1e-12)
+    # csc and coo are normalised in place too (reference preproc.py:194-195; r03 normalised a copy)
+    for fmt in ("csc", "coo"):
+        c = AnnData(s.asformat(fmt).astype(np.float64))
+        pp.l2norm(c, rep="X")
+        assert c.X.format == fmt
+        np.testing.assert_allclose(np.sqrt(np.asarray(c.X.multiply(c.X).sum(axis=1))).ravel(), 1.0, rtol=1e-12)
+        np.testing.assert_allclose(c.X.toarray(), b.X.toarray(), rtol=1e-12)
     md = MuData({"a": AnnData(x1.copy()), "b": AnnData(x2.copy())})
     out = pp.l2norm(md, rep="X", copy=True)
     assert out is not md and np.allclose(np.linalg.norm(out.mod["b"].X, axis=1), 1.0)
