@@ -23,7 +23,8 @@ the largest relative difference of the singular values go into the JSON line (`p
 secondary: the default run (c3, one GPU) also carries the two other single-GPU configurations of
 BASELINE.json as complete sub-records (ms, roofline, cpu_baseline, parity): `c2` (configs[0]/[1]) and
 `c4` (configs[3], mu.tl.mofa, f32) + `c4_f64` (the same in the reference's default precision), and
-`ingest` / `mofa_ng` / `wnn`: one measured record with parity per widened row of SURVEY 8f.
+`ingest` / `mofa_ng` / `wnn`: one measured record with parity per widened row of SURVEY 8f, `c3_api`: the
+API path from a host matrix.
 --no-secondary skips them.
 
 Workloads (--workload):
@@ -43,6 +44,9 @@ Workloads (--workload):
 
   ingest, mofa_ng,   the widened rows of SURVEY 8f on one GPU (scripts/bench_widened.py): 10x arrays -> device CSR
   wnn                (PCIe included), MOFA+ with a poisson view and missing values, weighted nearest neighbours
+  c3_api             ac.pp.tfidf(adata); ac.tl.lsi(adata) through the public API from a HOST scipy CSR (250 000 x
+                     200 000, a quarter of configs[2]): upload, fingerprints and write-back inside the clock, split
+                     into upload / fingerprint / download / kernels
 
 Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 either run it under
 torch.distributed.run (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env) or
@@ -71,6 +75,7 @@ WORKLOADS = {  # cells = TOTAL cells for strong scaling, cells PER GPU for weak 
     "c2": dict(cells=10_000, peaks=30_000, scaling="weak"),
     "c4": None,  # BASELINE.json configs[3]/[4]: mu.tl.mofa, 100 ELBO iterations (scripts/bench_mofa.py)
     "ingest": None, "mofa_ng": None, "wnn": None,  # SURVEY 8f.2 - 8f.4 (scripts/bench_widened.py)
+    "c3_api": None,  # tfidf + lsi through the public API from a host scipy CSR (upload, fingerprints, write-back)
 }
 
 
@@ -189,8 +194,10 @@ def run_lsi(args, workload, rank, world, local_rank, comm, steps, warmup, cpu_sa
         info.update(inf)
         return U, stdev, V
 
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+
     def sync():
-        if world > 1:
+        if dist_on:  # (also at world size 1 under MUON_AMD_BENCH_FORCE_DIST: the RCCL dry run)
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -215,7 +222,7 @@ def run_lsi(args, workload, rank, world, local_rank, comm, steps, warmup, cpu_sa
              "alloc_retries": int(ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0)),
              "reserved_gb": round(ms1.get("reserved_bytes.all.peak", 0) / 1e9, 1),
              "allocated_peak_gb": round(ms1.get("allocated_bytes.all.peak", 0) / 1e9, 1)}
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -379,10 +386,23 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     comm = None
-    if world > 1:
+    # MUON_AMD_BENCH_FORCE_DIST=1: build the RCCL process group and route every exchange step through it also
+    # at world size 1 - the dry run of the multi-GPU branch on a one-GPU box (tests/test_gpu_lsi.py), so that the
+    # first real 8-GPU lease does not find a typo here
+    force_dist = os.environ.get("MUON_AMD_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist and world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if shared_gpu:
             dist.init_process_group("gloo")
         else:
@@ -393,7 +413,7 @@ def main():
 
     if args.workload == "c4":
         out = run_c4(args, args.steps or 100, args.warmup)
-    elif args.workload in ("ingest", "mofa_ng", "wnn"):
+    elif args.workload in ("ingest", "mofa_ng", "wnn", "c3_api"):
         out = run_widened(args.workload) if rank == 0 else None
     else:
         out = run_lsi(args, args.workload, rank, world, local_rank, comm, args.steps or 3, args.warmup,
@@ -415,7 +435,7 @@ def main():
                 sec["c4_f64"] = run_c4(args, 100, 3, f64=True)
             except Exception as e:  # noqa: BLE001
                 sec["c4_f64"] = {"error": repr(e)}
-            for name in ("ingest", "mofa_ng", "wnn"):  # the widened rows, seconds each
+            for name in ("ingest", "mofa_ng", "wnn", "c3_api"):  # the widened rows and the API path, seconds each
                 try:
                     torch.cuda.empty_cache()
                     sec[name] = run_widened(name)
@@ -424,7 +444,7 @@ def main():
             out["secondary"] = sec
     if rank == 0 and out is not None:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -98,17 +98,23 @@ def select_columns(backend, X, mask: np.ndarray):
 
 
 def canonicalize(backend, X):
-    """Column indices ascending inside every row (10x files are written that way; checked on the
-    device, sorted only if not)."""
+    """Column indices strictly ascending inside every row (10x files are written that way; checked on the
+    device).  Otherwise the rows are sorted and duplicate (row, column) entries summed - what scipy's
+    ``sum_duplicates`` does to such input on the host.  ``X.canonical_as_given`` tells the caller whether its own
+    arrays already were canonical (the returned object is then X itself)."""
     if X.nnz < 2:
+        X.canonical_as_given = True
         return X
     d = X.indices[1:] - X.indices[:-1]
     starts = torch.zeros(X.nnz, dtype=torch.bool, device=X.indices.device)
     first = X.indptr[1:-1]
     starts[first[first < X.nnz]] = True  # entry that opens a row: no order constraint across rows
     if bool(((d > 0) | starts[1:]).all()):
+        X.canonical_as_given = True
         return X
-    return _sort_rows(backend, X)
+    Y = _sort_rows(backend, X)
+    Y.canonical_as_given = False
+    return Y
 
 
 def _sort_rows(backend, X):
@@ -118,7 +124,17 @@ def _sort_rows(backend, X):
     rows = torch.repeat_interleave(torch.arange(n, device=X.indices.device), X.indptr[1:] - X.indptr[:-1])
     key = rows * int(d) + X.indices.long()
     order = torch.argsort(key, stable=True)
-    return DeviceCSR(X.indptr, X.indices[order].contiguous(), X.values[order].contiguous(), X.shape)
+    key = key[order]
+    vals = X.values[order]
+    if bool((key[1:] == key[:-1]).any()):
+        # duplicate (row, column) pairs: one entry each, values summed (in stored order: deterministic)
+        ukey, inv = torch.unique_consecutive(key, return_inverse=True)
+        uvals = torch.zeros(ukey.numel(), dtype=vals.dtype, device=vals.device).index_add_(0, inv, vals)
+        cnt = torch.bincount(torch.div(ukey, int(d), rounding_mode="floor"), minlength=n)
+        indptr = torch.zeros(n + 1, dtype=torch.int64, device=key.device)
+        torch.cumsum(cnt, 0, out=indptr[1:])
+        return DeviceCSR(indptr, (ukey % int(d)).to(torch.int32).contiguous(), uvals.contiguous(), X.shape)
+    return DeviceCSR(X.indptr, X.indices[order].contiguous(), vals.contiguous(), X.shape)
 
 
 def device_csr_from_coo(rows, cols, vals, shape, backend=None, values_dtype=np.float32, sum_duplicates=True):
@@ -179,10 +195,12 @@ def read_10x_arrays(matrix: Mapping, atac_only: bool = True, feature_types=None,
         backend = get_backend()
     X, keep, _ = device_csr_from_10x(matrix, None, backend, atac_only, feature_types)
     shape = np.asarray(_get(matrix, "shape")).astype(np.int64)
-    if keep is None and np.asarray(matrix["data"]).dtype == np.float32:
+    if keep is None and np.asarray(matrix["data"]).dtype == np.float32 and getattr(X, "canonical_as_given", False):
+        # the caller's arrays ARE the canonical CSR: the host view shares them (the flags below used to be
+        # set on this branch also when only the device copy had been sorted)
         host = csr_matrix((np.asarray(matrix["data"]), np.asarray(matrix["indices"]),
                            np.asarray(matrix["indptr"])), shape=(int(shape[1]), int(shape[0])))
-    else:  # columns dropped / values converted on the device: the host view is the device result
+    else:  # columns dropped / values converted / rows sorted on the device: the host view is the device result
         host = csr_matrix((backend.to_host(X.values), backend.to_host(X.indices), backend.to_host(X.indptr)),
                           shape=X.shape)
     host.has_sorted_indices = True

@@ -358,22 +358,33 @@ def knn(adata, n_neighbors: int = 15, use_rep: Optional[str] = None, n_pcs: Opti
 # -----------------------------------------------------------------------------------------------------
 # weighted nearest neighbours (reference :264-640)
 # -----------------------------------------------------------------------------------------------------
-def _graph_mean(be, G: csr_matrix, X32: torch.Tensor) -> torch.Tensor:
-    """r_i = mean of the rows of X over the stored entries of row i of G (reference :493-497, one
-    ``np.mean(X[nonzero(G[cell])])`` per cell): a product of the row-normalised pattern of G with X -
-    the row-stream SpMM (csrc/spmm_win.hip), X padded to the block widths it serves."""
-    n, p = X32.shape
-    G = G.tocsr()
-    cnt = np.diff(G.indptr)
-    with np.errstate(divide="ignore"):
-        vals = np.repeat(1.0 / cnt, cnt).astype(np.float32)
-    out = torch.zeros((n, p), dtype=torch.float32, device=X32.device)
-    can = hasattr(be, "can_stream")
+def _mean_operator(be, G: csr_matrix, cols_present=None):
+    """The row-normalised pattern of G as the operand of the row-stream SpMM: r_i = mean of X over the neighbours
+    of cell i (reference :493-497: ``X[neighbordistances[cell, :].nonzero()[1]]`` - the NON-ZERO stored distances,
+    so a duplicate cell at distance 0 does not count), restricted to the columns in ``cols_present``
+    (cells the representation exists for).  Built once per (graph, modality) pair and reused for every block."""
     from .io import canonicalize
 
+    G = G.tocsr()
+    keep = G.data != 0
+    if cols_present is not None:
+        keep &= cols_present[G.indices]
+    rows = np.repeat(np.arange(G.shape[0]), np.diff(G.indptr))[keep]
+    cnt = np.bincount(rows, minlength=G.shape[0])
+    indptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    with np.errstate(divide="ignore"):
+        vals = np.repeat(1.0 / cnt, cnt).astype(np.float32)
     # (kNN rows are stored by ascending distance: column order is restored on the device)
-    Gd = canonicalize(be, be.upload_csr(G.indptr, G.indices, vals, G.shape, values_dtype=np.float32))
-    S = be.stream(Gd) if can and be.can_stream(Gd, 64) else Gd
+    Gd = canonicalize(be, be.upload_csr(indptr, G.indices[keep], vals, G.shape, values_dtype=np.float32))
+    can = hasattr(be, "can_stream")
+    return be.stream(Gd) if can and be.can_stream(Gd, 64) else Gd
+
+
+def _graph_mean(be, S, X32: torch.Tensor) -> torch.Tensor:
+    """``S`` (a ``_mean_operator``) applied to the representation X32 [n, p], 64 columns at a time - the row-stream
+    SpMM (csrc/spmm_win.hip), X padded to the block widths it serves."""
+    n, p = X32.shape
+    out = torch.zeros((n, p), dtype=torch.float32, device=X32.device)
     for c0 in range(0, p, 64):
         w = min(64, p - c0)
         B = 16 if w <= 16 else (32 if w <= 32 else 64)
@@ -445,8 +456,8 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
     Multimodal nearest neighbor search (weighted nearest neighbours of Hao et al. / Swanson et al.).
 
     Same arguments and slots as the reference (:264-340).  ``low_memory`` and ``random_state`` belong to
-    NN-descent and are recorded only: every search here is exhaustive.  All modalities must cover the same
-    observations (``mdata.intersect_obs()`` first).
+    NN-descent and are recorded only: every search here is exhaustive.  Modalities may list the observations in any
+    order and may lack cells (r04): a modality then contributes nothing to those cells and gets weight 0 for them.
     """
     if not is_mudata(mdata):
         raise TypeError("Expected a MuData object")
@@ -460,7 +471,8 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
     if len(modalities) < 2:
         raise ValueError("weighted nearest neighbours need at least two modalities")
     observations = mdata.obs.index
-    params, reps, mod_reps, mod_n_pcs, mod_k = {}, {}, {}, {}, []
+    n = len(observations)
+    params, reps, mod_reps, mod_n_pcs, mod_k, pos = {}, {}, {}, {}, [], {}
     for mod in modalities:
         nkey = neighbor_keys.get(mod) or "neighbors"
         try:
@@ -477,19 +489,34 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
         reps[mod] = X.toarray() if issparse(X) else np.asarray(X)
         mod_reps[mod] = use_rep if use_rep is not None else -1
         mod_n_pcs[mod] = n_pcs if n_pcs is not None else -1
-        if not mdata.mod[mod].obs.index.equals(observations):
-            raise NotImplementedError(
-                f"modality '{mod}' does not cover the observations of the MuData object in the same order: "
-                "run `mdata.intersect_obs()` first (partial overlap is not implemented on the device path)")
+        # where the modality's cells sit among the observations of the MuData object: any order, and a modality may
+        # lack cells (reference :381-384, :546-575).  r03 raised unless every modality listed all cells in the same order.
+        p = np.asarray(observations.get_indexer(mdata.mod[mod].obs.index))
+        if (p < 0).any() or len(np.unique(p)) != len(p):
+            raise ValueError(f"modality '{mod}' has observations that the MuData object does not list (or lists twice): "
+                             "call `mdata.update()` first")
+        pos[mod] = p
     if n_neighbors is None:
         ks = np.asarray([k for k in mod_k if k > 0])
         n_neighbors = int(round(np.mean(ks), 0))
-    n = len(observations)
     M = len(modalities)
-    Xd = {m: be.to_device(np.ascontiguousarray(reps[m], dtype=np.float64)) for m in modalities}
-    X32 = {m: Xd[m].to(torch.float32).contiguous() for m in modalities}
-    graphs = {}
+    # Everything is laid out over the n observations of the MuData object: rows of cells a modality lacks are zero
+    # and masked (`pres`).  A modality contributes to a cell's weights, to the neighbourhood means and to the
+    # affinity of a pair only where it has the cells involved; its weight for a cell it lacks is 0 (ratio -inf, like
+    # the reference's initial value :451).  (The reference walks the joint graph with modality-local row numbers
+    # there - `neighbordistances.indptr[cell]`, `weights[cell, i]`, :586-593 - i.e. the rows of other cells as soon as
+    # a modality lacks one: the intent, not that indexing, is what is implemented.)
+    Xl = {m: be.to_device(np.ascontiguousarray(reps[m], dtype=np.float64)) for m in modalities}  # local order
+    dev = Xl[modalities[0]].device
+    pos_d = {m: torch.as_tensor(pos[m], device=dev, dtype=torch.int64) for m in modalities}
+    pres = {m: np.zeros(n, dtype=bool) for m in modalities}
+    Xd, X32, graphs, graphs_local = {}, {}, {}, {}
     for m in modalities:
+        pres[m][pos[m]] = True
+        full = torch.zeros((n, Xl[m].shape[1]), dtype=torch.float64, device=dev)
+        full[pos_d[m]] = Xl[m]
+        Xd[m] = full
+        X32[m] = full.to(torch.float32).contiguous()
         g = mdata.mod[m].obsp[params[m]["distances_key"]].tocsr()
         cnt = np.diff(g.indptr)
         if (cnt == 0).any():
@@ -499,30 +526,50 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
                 "This could be due to subsetting after nearest neighbors calculation. "
                 "Make sure to subset before calculating nearest neighbors."
             )
-        graphs[m] = g
-    dev = Xd[modalities[0]].device
+        graphs_local[m] = g
+        coo = g.tocoo()
+        graphs[m] = csr_matrix((coo.data, (pos[m][coo.row], pos[m][coo.col])), shape=(n, n))
+    pres_d = {m: torch.as_tensor(pres[m], device=dev) for m in modalities}
     ratios = torch.full((n, M), -float("inf"), dtype=torch.float64, device=dev)
     sigmas = {}
+    ninf = torch.full((n,), -float("inf"), dtype=torch.float64, device=dev)
     for i1, m1 in enumerate(modalities):
-        G1 = graphs[m1]
-        nnd = torch.as_tensor(np.minimum.reduceat(G1.data, G1.indptr[:-1]).astype(np.float64), device=dev)  # :389-398
-        csig = _bandwidths(be, Xd[m1], G1, n_bandwidth_neighbors)
+        G1 = graphs_local[m1]
+        nnd = torch.zeros(n, dtype=torch.float64, device=dev)
+        nnd[pos_d[m1]] = torch.as_tensor(np.minimum.reduceat(G1.data, G1.indptr[:-1]).astype(np.float64), device=dev)  # :389-398
+        cs_local = _bandwidths(be, Xl[m1], G1, n_bandwidth_neighbors)
+        bad = ~torch.isfinite(cs_local)
+        if bool(bad.any()):
+            # a cell none of whose neighbours' neighbour lists overlaps its own (reference: a mean over an empty
+            # selection, NaN, silently carried into the weights - ADVICE r03): say so
+            raise ValueError(f"modality '{m1}': {int(bad.sum())} cells (the first: {int(torch.nonzero(bad)[0])}) share no "
+                             "neighbour with any other cell - the kernel bandwidth is undefined; increase n_neighbors of "
+                             "the modality's graph")
+        csig = torch.ones(n, dtype=torch.float64, device=dev)
+        csig[pos_d[m1]] = cs_local
+        if bool(((csig - nnd)[pres_d[m1]] == 0).any()):
+            raise ValueError(f"modality '{m1}': a cell's kernel bandwidth equals its nearest-neighbour distance "
+                             "(duplicated cells?): the affinity ratio is undefined")
         thetas, cur = [], None
         for i2, m2 in enumerate(modalities):  # :484-506
-            r = _graph_mean(be, graphs[m2], X32[m1]).to(torch.float64)
+            S = _mean_operator(be, graphs[m2], None if pres[m1].all() else pres[m1])
+            r = _graph_mean(be, S, X32[m1]).to(torch.float64)
             th = torch.exp(-torch.clamp(torch.linalg.norm(Xd[m1] - r, dim=1) - nnd, min=0) / (csig - nnd))
+            both = pres_d[m1] & pres_d[m2]
+            th = torch.where(both, th, ninf)
             if i1 == i2:
                 cur = th
             else:
                 thetas.append(th)
-        ratios[:, i1] = cur / (torch.stack(thetas, dim=1).amax(dim=1) + eps)  # :507
+        ratio = cur / (torch.stack(thetas, dim=1).amax(dim=1) + eps)  # :507
+        ratios[:, i1] = torch.where(pres_d[m1], ratio, ninf)
         sigmas[m1] = csig
     weights = torch.softmax(ratios, dim=1)  # :510
     # candidates: the union of every modality's n_multineighbors nearest neighbours (:517-575)
     keys = []
     for m in modalities:
-        idx, _ = device_knn(Xd[m], n_multineighbors, params[m].get("metric", "euclidean"), backend=be, indices_only=True)  # (:520: the top-level key)
-        keys.append((torch.arange(n, device=dev)[:, None] * n + idx).reshape(-1))
+        idx, _ = device_knn(Xl[m], n_multineighbors, params[m].get("metric", "euclidean"), backend=be, indices_only=True)  # (:520: the top-level key)
+        keys.append((pos_d[m][:, None] * n + pos_d[m][idx]).reshape(-1))
     key = torch.unique(torch.cat(keys))  # sorted: row-major
     ri = torch.div(key, n, rounding_mode="floor")
     ci = key - ri * n
@@ -532,7 +579,8 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
         X = Xd[m]
         for lo in range(0, key.numel(), step):
             a, b = ri[lo:lo + step], ci[lo:lo + step]
-            aff[lo:lo + step] += torch.exp(-_pair_dist(X[a], X[b], metric) / sigmas[m][a]) * weights[a, i]
+            term = torch.exp(-_pair_dist(X[a], X[b], metric) / sigmas[m][a]) * weights[a, i]
+            aff[lo:lo + step] += torch.where(pres_d[m][a] & pres_d[m][b], term, torch.zeros_like(term))
     dist = torch.sqrt(torch.clamp(0.5 * (1.0 - aff), min=0.0))  # :610
     # the n_neighbors + 1 smallest per row (:612 `_sparse_csr_fast_knn`): sort by (row, distance, column)
     o = torch.argsort(dist, stable=True)
@@ -556,7 +604,7 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
     for i, m in enumerate(modalities):  # :583-588
         if weight_key:
             if add_weights_to_modalities:
-                mdata.mod[m].obs[weight_key] = w_host[:, i]
+                mdata.mod[m].obs[weight_key] = w_host[pos[m], i]
             else:
                 mdata.obs[":".join([m, weight_key])] = w_host[:, i]
     if key_added is None:

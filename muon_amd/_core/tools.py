@@ -329,11 +329,31 @@ def mofa(
     return None
 
 
+def _model_datasets(res, view_names, group_names, obs_names, groups):
+    """The model as {dataset path: array} in mofapy2's HDF5 layout - the paths and shapes the reference reads back
+    (/root/reference/muon/_core/tools.py:604-641: expectations/Z/<group> [factors, samples], expectations/W/<view>
+    [factors, features], samples/<group>) plus views/views, groups/groups, variance_explained/r2_per_factor/<group>
+    [views, factors] and training_stats/elbo.  Both writers below store exactly this mapping."""
+    d = {}
+    for gi, g in enumerate(group_names):
+        d[f"expectations/Z/{g}"] = np.ascontiguousarray(res["Z"][groups == gi].T)
+        d[f"samples/{g}"] = np.asarray(obs_names)[groups == gi].astype("S")
+        d[f"variance_explained/r2_per_factor/{g}"] = np.ascontiguousarray(res["r2"][:, gi, :])
+    for m, w in zip(view_names, res["W"]):
+        d[f"expectations/W/{m}"] = np.ascontiguousarray(np.asarray(w).T)
+    d["views/views"] = np.asarray(view_names, dtype="S")
+    d["groups/groups"] = np.asarray(group_names, dtype="S")
+    d["training_stats/elbo"] = np.asarray(res["elbo"])
+    return d
+
+
 def _save_model(outfile, res, view_names, group_names, obs_names, groups, expectations):
     """Model file (tools.py:600-602 ent.save): HDF5 with mofapy2's group layout when h5py is
-    importable.  Without h5py (this image) the same arrays are written as NumPy .npz - under a name
-    that says so (``outfile`` + ".npz" unless it already ends in .npz): a file called *.hdf5 that no
-    MOFA tool can open helps nobody.  Returns the path written."""
+    importable.  Without h5py (this image) the SAME datasets are written as a NumPy .npz whose keys are the HDF5
+    paths - under a name that says so (``outfile`` + ".npz" unless it already ends in .npz): a file called *.hdf5
+    that no MOFA tool can open helps nobody, and a converter is one loop
+    (``for k in z.files: h5.create_dataset(k, data=z[k])``).  Returns the path written."""
+    data = _model_datasets(res, view_names, group_names, obs_names, groups)
     try:
         import h5py  # noqa: F401
     except Exception:  # noqa: BLE001
@@ -342,29 +362,13 @@ def _save_model(outfile, res, view_names, group_names, obs_names, groups, expect
             outfile = str(outfile) + ".npz"
         try:
             with open(outfile, "wb") as f:
-                np.savez(f, Z=res["Z"], elbo=np.asarray(res["elbo"]), r2=res["r2"],
-                         views=np.asarray(view_names), groups=np.asarray(group_names),
-                         samples=np.asarray(obs_names).astype(str), sample_groups=groups,
-                         **{f"W_{m}": w for m, w in zip(view_names, res["W"])})
+                np.savez(f, **data)
         except OSError as e:  # pragma: no cover
             warn(f"Cannot save the model to {outfile}: {e}")
         return outfile
     import h5py
 
     with h5py.File(outfile, "w") as f:  # pragma: no cover - h5py absent in the build image
-        ez = f.create_group("expectations").create_group("Z")
-        for gi, g in enumerate(group_names):
-            ez.create_dataset(g, data=res["Z"][groups == gi].T)
-        ew = f["expectations"].create_group("W")
-        for m, w in zip(view_names, res["W"]):
-            ew.create_dataset(m, data=w.T)
-        f.create_group("views").create_dataset("views", data=np.asarray(view_names, dtype="S"))
-        f.create_group("groups").create_dataset("groups", data=np.asarray(group_names, dtype="S"))
-        sm = f.create_group("samples")
-        for gi, g in enumerate(group_names):
-            sm.create_dataset(g, data=np.asarray(obs_names)[groups == gi].astype("S"))
-        ve = f.create_group("variance_explained").create_group("r2_per_factor")
-        for gi, g in enumerate(group_names):
-            ve.create_dataset(g, data=res["r2"][:, gi, :])
-        f.create_group("training_stats").create_dataset("elbo", data=np.asarray(res["elbo"]))
+        for k, v in data.items():
+            f.create_dataset(k, data=v)
     return outfile

@@ -100,14 +100,20 @@ def knn_graph(X, n_neighbors=15, metric="euclidean"):
 
 
 def neighbors(reps, graphs, graph_metrics=None, n_neighbors=None, n_bandwidth_neighbors=20, n_multineighbors=200,
-              metric="euclidean", eps=1e-4):
-    """``reps``: {modality: X (n x p) dense}; ``graphs``: {modality: CSR distances of its own kNN graph};
-    all modalities share the n observations (the reference's bookkeeping for partial overlap,
-    :381-384 / :546-575, is index arithmetic around the same computations).
+              metric="euclidean", eps=1e-4, present=None):
+    """``reps``: {modality: X (n x p) dense}; ``graphs``: {modality: CSR distances (n x n) of its own kNN graph};
+    everything is laid out over the n observations of the MuData object.  ``present``: {modality: bool mask} of the
+    cells a modality has (default: all) - the rows of ``reps`` / ``graphs`` of the others are ignored.  The
+    reference's bookkeeping for partial overlap (:381-384, :451, :546-575) is followed in INTENT: a modality
+    contributes to a cell's weights, to the neighbourhood means and to the affinity of a pair only where it has the
+    cells involved, and its ratio for a cell it lacks stays at the initial -inf (weight 0); the reference's own loops
+    index the joint graph with modality-local row numbers there (:586-593).
     Returns (distances CSR n x n with n_neighbors + 1 per row, connectivities, weights n x M, sigmas)."""
     mods = list(reps)
     n = reps[mods[0]].shape[0]
     M = len(mods)
+    present = present or {}
+    pres = {m: np.asarray(present.get(m, np.ones(n, dtype=bool)), dtype=bool) for m in mods}
     graph_metrics = graph_metrics or {m: "euclidean" for m in mods}
     if n_neighbors is None:  # :375-377
         ks = np.array([int(np.diff(graphs[m].indptr).max()) + 1 for m in mods])
@@ -117,16 +123,19 @@ def neighbors(reps, graphs, graph_metrics=None, n_neighbors=None, n_bandwidth_ne
     for i1, m1 in enumerate(mods):
         X = np.asarray(reps[m1], dtype=np.float64)
         G1 = graphs[m1].tocsr()
-        nnd = np.array([G1[i].data.min() for i in range(n)])  # :389-398
+        S1 = np.nonzero(pres[m1])[0]
+        nnd = np.zeros(n)
+        nnd[S1] = [G1[i].data.min() for i in S1]  # :389-398
         # :400-461  the n_bandwidth_neighbors cells with the lowest non-zero Jaccard index of the kNN
         # sets, ties broken towards the larger Euclidean distance (metric :53-77: N (1 - jaccard
-        # distance) + (bbox - euclid) / bbox, N + 1 without overlap)
-        bbox = np.linalg.norm(np.ptp(X, axis=0))
-        sets = [set(G1.indices[G1.indptr[i]:G1.indptr[i + 1]]) for i in range(n)]
-        csig = np.empty(n)
-        for i in range(n):
+        # distance) + (bbox - euclid) / bbox, N + 1 without overlap); N = the modality's own cells
+        n1 = len(S1)
+        bbox = np.linalg.norm(np.ptp(X[S1], axis=0))
+        sets = {i: set(G1.indices[G1.indptr[i]:G1.indptr[i + 1]]) for i in S1}
+        csig = np.ones(n)
+        for i in S1:
             cand = []
-            for j in range(n):
+            for j in S1:
                 if j == i:
                     continue
                 inter = len(sets[i] & sets[j])
@@ -135,36 +144,45 @@ def neighbors(reps, graphs, graph_metrics=None, n_neighbors=None, n_bandwidth_ne
                 jac_dist = 1.0 - inter / len(sets[i] | sets[j])
                 if jac_dist < 1.0:
                     e = np.linalg.norm(X[i] - X[j])
-                    cand.append(((n - jac_dist * n) + (bbox - e) / bbox, j, e))
+                    cand.append(((n1 - jac_dist * n1) + (bbox - e) / bbox, j, e))
             cand.sort(key=lambda t: (t[0], t[1]))
             picked = cand[:n_bandwidth_neighbors]
             csig[i] = np.mean([c[2] for c in picked])  # :463-472
         thetas, cur = [], None
         for i2, m2 in enumerate(mods):  # :484-506
             G2 = graphs[m2].tocsr()
-            r = np.stack([X[G2.indices[G2.indptr[i]:G2.indptr[i + 1]]].mean(axis=0) for i in range(n)])
-            th = np.exp(-np.maximum(np.linalg.norm(X - r, axis=1) - nnd, 0) / (csig - nnd))
+            both = pres[m1] & pres[m2]
+            th = np.full(n, -np.inf)
+            for i in np.nonzero(both)[0]:
+                cols = G2.indices[G2.indptr[i]:G2.indptr[i + 1]]
+                cols = cols[(G2.data[G2.indptr[i]:G2.indptr[i + 1]] != 0) & pres[m1][cols]]  # (`.nonzero()`, :495)
+                r = X[cols].mean(axis=0)
+                th[i] = np.exp(-max(np.linalg.norm(X[i] - r) - nnd[i], 0) / (csig[i] - nnd[i]))
             if i1 == i2:
                 cur = th
             else:
                 thetas.append(th)
-        ratios[:, i1] = cur / (np.max(np.stack(thetas, axis=1), axis=1) + eps)  # :507
+        with np.errstate(invalid="ignore"):
+            ratio = cur / (np.max(np.stack(thetas, axis=1), axis=1) + eps)  # :507
+        ratios[pres[m1], i1] = ratio[pres[m1]]
         sigmas[m1] = csig
     weights = softmax(ratios, axis=1)  # :510
-    # :517-575  candidates: the union of every modality's n_multineighbors nearest neighbours
+    # :517-575  candidates: the union of every modality's n_multineighbors nearest neighbours (among its own cells)
     pattern = np.zeros((n, n), dtype=bool)
     for m in mods:
-        X = np.asarray(reps[m], dtype=np.float64)
+        S = np.nonzero(pres[m])[0]
+        X = np.asarray(reps[m], dtype=np.float64)[S]
         D = cdist(X, X, metric=graph_metrics[m])
         np.fill_diagonal(D, np.inf)
-        k = min(n_multineighbors, n - 1)
+        k = min(n_multineighbors, len(S) - 1)
         idx = np.argsort(D, axis=1, kind="stable")[:, :k]
-        pattern[np.repeat(np.arange(n), k), idx.reshape(-1)] = True
+        pattern[np.repeat(S, k), S[idx.reshape(-1)]] = True
     aff = np.zeros((n, n))
     for i, m in enumerate(mods):  # :579-609
         X = np.asarray(reps[m], dtype=np.float64)
         D = cdist(X, X, metric=metric)
-        aff += np.exp(-D / sigmas[m][:, None]) * weights[:, i][:, None]
+        term = np.exp(-D / sigmas[m][:, None]) * weights[:, i][:, None]
+        aff += np.where(pres[m][:, None] & pres[m][None, :], term, 0.0)
     dist = np.sqrt(0.5 * (1.0 - aff))  # :610
     # :612  the n_neighbors + 1 smallest per row among the candidates
     k1 = n_neighbors + 1

@@ -133,7 +133,17 @@ def run_mofa_ng(be, n=20000, d_dense=2000, d_sparse=20000, iters=20, sample=400,
                        "Z_max_abs": float(np.max(np.abs(res["Z"] - ref["Z"]))),
                        "W_max_abs": float(max(np.max(np.abs(a - b)) for a, b in zip(res["W"], ref["W"])))},
             "cpu_baseline": {"value": cpu_per * 100, "unit": "s", "cores": 1, "kind": "port",
-                             "sample": f"oracle on {sample} cells (densified), {len(rr)} iterations, scaled by cells"}}
+                             "sample": f"oracle on {sample} cells (densified), {len(rr)} iterations, scaled by cells"},
+            # what a FUSED tile kernel per chunk pass would do (prediction zeta = Z W^T on the matrix
+            # cores, pseudo-data transform in registers, one reduction against a K-column block): three passes over
+            # the N x D predictions, 4 N D K flops each - against the f32 matrix-core peak.  The engine's chunk
+            # passes are tensor operations over densified chunks: the small fraction is the point of the record.
+            "roofline": (lambda fl: {"bound": "mfma", "achieved": fl / per / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                     "frac": fl / per / 157.3e12, "traffic": None,
+                                     "algorithmic_flops_per_iteration": fl,
+                                     "note": "12 N D K flops per iteration (3 chunk passes x (prediction + one reduction)), "
+                                             "f32-input MFMA peak of MI355X_MICROARCH.md"})(
+                12.0 * n * (d_dense + d_sparse) * 10)}
 
 
 def run_wnn(be, n=100000, sample=1500, seed=0):
@@ -187,10 +197,86 @@ def run_wnn(be, n=100000, sample=1500, seed=0):
                        "distance_max_rel_where_identical": float(np.max(np.abs(got.data[eq] - D.data[eq]) / np.maximum(D.data[eq], 1e-12))),
                        "connectivities_max_abs": float(abs(ms.obsp["connectivities"] - C).max())},
             "cpu_baseline": {"value": sample / (c1_ - c0), "unit": "cells/s", "cores": 1, "kind": "port",
-                             "sample": f"oracle on {sample} cells (quadratic in the cell count: not an extrapolation)"}}
+                             "sample": f"oracle on {sample} cells (quadratic in the cell count: not an extrapolation)"},
+            # the exhaustive searches are what the call computes: two per modality (its own kNN graph, the
+            # n_multineighbors candidates), 2 n^2 p flops each in GEMM form, f64 - against the f64 matrix-core peak.
+            # Top-k merges, the kernel bandwidths and the fuzzy simplicial set ride on top (profiles/r03_wnn_kernel_stats.md).
+            "roofline": (lambda fl: {"bound": "mfma", "achieved": fl / dt / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                                     "frac": fl / dt / 78.6e12, "traffic": None, "algorithmic_flops": fl,
+                                     "note": "sum over 4 searches of 2 n^2 p flops; MI355X f64 matrix peak 78.6 TFLOP/s"})(
+                2.0 * 2.0 * n * n * (50 + 30))}
 
 
-RUNNERS = {"ingest": run_ingest, "mofa_ng": run_mofa_ng, "wnn": run_wnn}
+def run_c3_api(be, n_cells=250_000, n_feat=200_000, density=0.03, seed=0):
+    """End to end through the PUBLIC API from a host scipy CSR (VERDICT r03 missing #6; SURVEY 7 hard part 7):
+    ``ac.pp.tfidf(adata); ac.tl.lsi(adata)`` (/root/reference/muon/_atac/preproc.py:16-129, tools.py:29-71) with the
+    upload, the fingerprints of the resident copies and the write-back inside the clock.  The matrix is a quarter
+    of configs[2] (what a host with 64 GB holds next to its copies), same generator, same density."""
+    import muon_amd
+    from muon_amd import AnnData
+    from muon_amd import atac as ac
+    from muon_amd._atac import preproc as P
+
+    X = be.synth_counts(0, n_cells, n_feat, 50, density, seed)
+    m = sp.csr_matrix((be.to_host(X.values).astype(np.float32), be.to_host(X.indices), be.to_host(X.indptr)),
+                      shape=X.shape)
+    m.has_sorted_indices = True
+    m.has_canonical_format = True
+    nnz = m.nnz
+    del X
+    torch.cuda.empty_cache()
+    spans = {"upload": 0.0, "download": 0.0, "fingerprint": 0.0}
+
+    def timed(obj, name, key):
+        f = getattr(obj, name)
+
+        def g(*a, **k):
+            t = time.perf_counter()
+            try:
+                return f(*a, **k)
+            finally:
+                _sync()
+                spans[key] += time.perf_counter() - t
+        setattr(obj, name, g)
+        return f
+
+    best = None
+    for it in range(2):  # the first call pins staging buffers and warms the allocator
+        for k in spans:
+            spans[k] = 0.0
+        ad = AnnData(m.copy())
+        saved = [(be, "upload_csr", timed(be, "upload_csr", "upload")), (be, "to_host", timed(be, "to_host", "download")),
+                 (P, "_fingerprint", timed(P, "_fingerprint", "fingerprint"))]
+        _sync()
+        t0 = time.perf_counter()
+        ac.pp.tfidf(ad, backend=be)
+        _sync()
+        t1 = time.perf_counter()
+        ac.tl.lsi(ad, backend=be)
+        _sync()
+        t2 = time.perf_counter()
+        for obj, name, f in saved:
+            setattr(obj, name, f)
+        best = (t1 - t0, t2 - t1, dict(spans))
+        del ad
+    t_tfidf, t_lsi, sp_ = best
+    total = t_tfidf + t_lsi
+    return {"metric": "cells/sec through the public API from a host scipy CSR: ac.pp.tfidf(adata); ac.tl.lsi(adata)",
+            "value": n_cells / total, "unit": "cells/s", "higher_is_better": True, "n_gpus": 1, "dtype": "f32",
+            "data": "synthetic", "ms": total * 1e3,
+            "split_ms": {"tfidf_call": t_tfidf * 1e3, "lsi_call": t_lsi * 1e3, "upload_pcie": sp_["upload"] * 1e3,
+                         "download_pcie": sp_["download"] * 1e3, "fingerprints_xxh3": sp_["fingerprint"] * 1e3,
+                         "kernels_and_host_logic": (total - sum(sp_.values())) * 1e3},
+            "config": {"workload": f"c3_api: {n_cells} cells x {n_feat} peaks ({nnz} stored entries, a quarter of configs[2]) as a host "
+                                   f"scipy CSR in an AnnData; tfidf writes adata.X back, lsi finds the device copy "
+                                   f"(fingerprint check) and writes obsm / varm / uns"},
+            "roofline": {"bound": "pcie", "achieved": (12.0 * nnz + 4.0 * nnz) / total / 1e9, "peak": 64.0, "unit": "GB/s",
+                         "frac": (16.0 * nnz) / total / 64e9, "traffic": None,
+                         "note": "12 B per entry up (indices, values; the row pointers are noise) + 4 B per entry down (TF-IDF values) over "
+                                 "PCIe 5 x16 against the WHOLE call sequence: what the API costs when nothing is resident"}}
+
+
+RUNNERS = {"ingest": run_ingest, "mofa_ng": run_mofa_ng, "wnn": run_wnn, "c3_api": run_c3_api}
 
 if __name__ == "__main__":
     import json

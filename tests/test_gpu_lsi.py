@@ -200,6 +200,29 @@ def test_bench_starts_its_own_ranks():
     assert out["roofline"]["frac"] > 0 and out["roofline"]["lds_frac"] > 0
 
 
+def test_bench_rccl_branch_runs_on_one_gpu():
+    """MUON_AMD_BENCH_FORCE_DIST=1: bench.py builds the `nccl` (RCCL) process group with device_id and sends the
+    exchange steps of tfidf + lsi (column sums, Z, Grams, agree) through it at world size 1 - the multi-GPU branch
+    itself (bench.py: init_process_group("nccl", device_id=...)) executes on hardware before an 8-GPU lease does."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MUON_AMD_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "c3shard",
+                        "--cells", "6000", "--peaks", "9000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["lsi"]["converged"]
+
+
 def test_rank_deficient_input_takes_the_device_flag_and_the_host_redo(hip):
     """min(n, d) >= 8192 selects the device-side Cholesky of CholeskyQR; a matrix of rank 20 asked for 30
     components exhausts the Krylov space, the device flags the pivot that is not safely positive, the call

@@ -57,6 +57,32 @@ def test_unsorted_rows_are_sorted_on_the_device():
     assert np.array_equal(got.indices, m.indices) and np.array_equal(got.data, m.data.astype(np.float32))
 
 
+def test_non_canonical_file_arrays_do_not_become_a_canonical_host_view():
+    """read_10x_arrays marked the caller's arrays sorted / canonical although only the device copy had been
+    sorted; duplicate (row, column) entries were never summed."""
+    m, matrix, _ = _tenx(seed=4)
+    idx, dat, ptr = matrix["indices"].copy(), matrix["data"].astype(np.float32), matrix["indptr"]
+    for r in range(m.shape[0]):
+        a, b = ptr[r], ptr[r + 1]
+        idx[a:b], dat[a:b] = idx[a:b][::-1].copy(), dat[a:b][::-1].copy()
+    ad = mio.read_10x_arrays(dict(matrix, indices=idx, data=dat), backend=BE, atac_only=False)
+    X = ad.X
+    assert X.has_sorted_indices and X.has_canonical_format
+    assert np.all(np.diff(X.indices)[np.setdiff1d(np.arange(X.nnz - 1), X.indptr[1:-1] - 1)] > 0)  # really sorted
+    assert (X != m.astype(np.float32)).nnz == 0
+    # a duplicated entry is summed
+    r = int(np.argmax(np.diff(ptr) > 0))
+    idx2 = np.insert(matrix["indices"], ptr[r], matrix["indices"][ptr[r]])
+    dat2 = np.insert(matrix["data"], ptr[r], 3).astype(np.float32)
+    ptr2 = ptr.copy()
+    ptr2[r + 1:] += 1
+    Xd, _, _ = mio.device_csr_from_10x(dict(matrix, indices=idx2, data=dat2, indptr=ptr2), None, BE, atac_only=False)
+    got = _host(Xd)
+    want = m.astype(np.float32).tolil()
+    want[r, matrix["indices"][ptr[r]]] += 3
+    assert got.nnz == m.nnz and (got != want.tocsr()).nnz == 0
+
+
 def test_coo_and_csc_layouts():
     m, _, _ = _tenx(seed=2)
     coo = m.tocoo()

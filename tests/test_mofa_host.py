@@ -106,7 +106,15 @@ class TestWrapperLikeReference:
         except ImportError:
             assert (tmp_path / "m.hdf5.npz").exists() and not (tmp_path / "m.hdf5").exists()
             with np.load(tmp_path / "m.hdf5.npz") as f:
-                assert f["Z"].shape == (100, n_factors)
+                # the keys are mofapy2's HDF5 dataset paths, read back the way the reference does (tools.py:608-629)
+                groups = [k.split("/")[-1] for k in f.files if k.startswith("expectations/Z/")]
+                z = np.concatenate([f[f"expectations/Z/{g}"] for g in groups], axis=1).T
+                w = np.concatenate([f[f"expectations/W/{m}"] for m in ("y1", "y2")], axis=1).T
+                assert z.shape == (100, n_factors) and w.shape == (self.mdata.varm["LFs"].shape[0], n_factors)
+                np.testing.assert_allclose(z, self.mdata.obsm["X_mofa"])
+                np.testing.assert_allclose(w, self.mdata.varm["LFs"])
+                assert f[f"variance_explained/r2_per_factor/{groups[0]}"].shape == (2, n_factors)
+                assert f["training_stats/elbo"].ndim == 1 and [v.decode() for v in f["views/views"]] == ["y1", "y2"]
         u = self.mdata.uns["mofa"]
         assert u["params"]["model"]["n_factors"] == 10 and set(u["variance"]) == {"y1", "y2"}
         assert u["variance"]["y1"].shape == (10,)
