@@ -216,7 +216,59 @@ class HipBackend:
         return out
 
     def to_host(self, t: torch.Tensor) -> np.ndarray:
-        return t.detach().cpu().numpy()
+        """Device tensor -> host array.  Big 1-d tensors (the TF-IDF values of a whole experiment are GBs) come down
+        through the pinned staging buffers of the upload path, chunk by chunk, a few host threads copying one chunk
+        out while the next is on the bus: `.cpu()` on pageable memory ran at 11 GB/s in the API benchmark (r04,
+        `bench.py --workload c3_api`)."""
+        t = t.detach()
+        if t.ndim == 1 and t.is_cuda and t.is_contiguous() and t.numel() * t.element_size() >= self._UPLOAD_PIPELINE_MIN:
+            return self._download_pipelined(t)
+        return t.cpu().numpy()
+
+    def _download_pipelined(self, t: torch.Tensor) -> np.ndarray:
+        from concurrent.futures import ThreadPoolExecutor
+
+        n = t.numel()
+        out = np.empty((n,), dtype=torch.empty((0,), dtype=t.dtype).numpy().dtype)
+        item = t.element_size()
+        per = max(1, self._UPLOAD_CHUNK // item)
+        st = self.__dict__.get("_upload_state")
+        if st is None:
+            bufs = [torch.empty((self._UPLOAD_CHUNK,), dtype=torch.uint8).pin_memory() for _ in range(3)]
+            st = self._upload_state = {"bufs": bufs, "stream": torch.cuda.Stream(self.device),
+                                       "pool": ThreadPoolExecutor(self._UPLOAD_THREADS)}
+        copy_stream, pool = st["stream"], st["pool"]
+        bufs = [b[: per * item].view(t.dtype) for b in st["bufs"]]
+        nps = [b.numpy() for b in bufs]
+        T = self._UPLOAD_THREADS
+        cur = torch.cuda.current_stream(self.device)
+        copy_stream.wait_stream(cur)  # the tensor's producers are queued on the current stream
+        chunks = [(lo, min(n, lo + per)) for lo in range(0, n, per)]
+        events = [None] * len(chunks)
+
+        def start(i):
+            lo, hi = chunks[i]
+            with torch.cuda.stream(copy_stream):
+                bufs[i % 3][: hi - lo].copy_(t[lo:hi], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            events[i] = ev
+
+        def drain(i):
+            lo, hi = chunks[i]
+            events[i].synchronize()
+            m = hi - lo
+            cuts = [m * k // T for k in range(T + 1)]
+            list(pool.map(lambda k: np.copyto(out[lo + cuts[k]:lo + cuts[k + 1]], nps[i % 3][cuts[k]:cuts[k + 1]]), range(T)))
+
+        for i in range(min(2, len(chunks))):  # two chunks on the bus / being copied out, a third buffer idle-safe
+            start(i)
+        for i in range(len(chunks)):
+            drain(i)
+            if i + 2 < len(chunks):
+                start(i + 2)  # reuses the buffer of chunk i - 1, drained in the previous turn
+        t.record_stream(copy_stream)
+        return out
 
     def upload_csr(self, indptr, indices, values, shape, values_dtype=None) -> DeviceCSR:
         """Host CSR -> HBM.  Index arrays become int64 / int32 and the values ``values_dtype`` on the
