@@ -202,6 +202,21 @@ int mu_spmm_stream_f64(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
                        int accumulate, void* stream);
 
 
+/* ---- narrow-block SpMM on a sliced-ELL operand (r04; csrc/spmm_ell.hip) -------------------------------------
+ * Y[n, 16] = X Q for the <= 16-column factor blocks of MOFA's sparse views (A = Y (tau o W), B = Y^T Z: the Z / W node
+ * updates of mofapy2's ent.run(), /root/reference/muon/_core/tools.py:583-585), on an operand laid out once per fit:
+ * positions in launch order (d_perm[p] = row at position p, -1 none), 16 positions = a group = the rows of one wave,
+ * columns in slabs of 1024.  The entries of (group, slab) are steps - one entry of each of the 16 rows, padded to the
+ * longest row - stored as windows of 4 steps (384 bytes: value[64] f32, then offset[64] u16; slot 4 r + j = row r's
+ * step 4 w + j, offset = byte offset of the Q row inside the slab = column % 1024 * 64; padding = (0.0, 0)).
+ * A group's windows are contiguous from d_wave_base[group], slab after slab; d_hdr[group][slab] is the number of
+ * windows.  d_ent needs eight windows of slack (the kernel reads that far ahead).  A workgroup = `waves` (1 .. 15)
+ * consecutive groups plus one wave that copies the Q slabs; mu_spmm_ell16_waves picks it for a row count so that
+ * full rounds of workgroups cover the chip - it is a launch parameter, not part of the layout. */
+int mu_spmm_ell16_waves(int64_t n_rows);
+int mu_spmm_ell16_f32(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr, const int64_t* d_wave_base,
+                      const void* d_ent, const int32_t* d_perm, const float* d_Q, float* d_Y, void* stream);
+
 /* ---- matrix-core SpMM of the LSI iteration (r04; csrc/spmm_mfma.hip) --------------------------------------
  * Replaces, like mu_spmm_stream_f32, the csr_matvec / csr_matvecs calls of ARPACK's reverse-communication loop
  * behind scipy.sparse.linalg.svds (/root/reference/muon/_atac/tools.py:53, scipy _svds.py:441-466,516), for
@@ -245,7 +260,7 @@ int mu_probe_mfma16(const void* d_a, const void* d_b, float* d_d, void* stream);
  *   "spmm_pipe"  software pipelining level of the packed SpMM
  *   "spmm_mode"  timing ablations of the packed SpMM (bit mask; results are then WRONG)
  *   "mfma_mode"  timing ablations of the matrix-core SpMM (1 no MFMA, 2 no gathers, 4 no masks; WRONG results)
- *   "mfma_trmap" lane -> (row, piece) assignment of the transpose read (0 = lane 4 j + c, what ships) */
+ *   "ell_mode"   timing ablation of the sliced-ELL SpMM (1 no gathers / FMAs; WRONG results) */
 int mu_tune_set(const char* key, int value);
 int mu_tune_get(const char* key);
 

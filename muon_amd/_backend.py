@@ -98,6 +98,24 @@ class DeviceCells:
     cache: dict = None
 
 
+@dataclass
+class DeviceEll:
+    """Sliced-ELL operand of the narrow-block SpMM (csrc/spmm_ell.hip, include/muon_amd.h): rows in launch order
+    (``perm``: position -> row, -1 none), groups of 16 positions (one wave each), columns in slabs of 1024;
+    ``hdr[group, slab]`` = the windows (4 steps of 16 entries; 384 bytes: 64 f32 values | 64 u16 offsets) of the
+    group in that slab;
+    ``wave_base[group]`` = the group's first window in ``ent``.  SpMM-only, B = 16."""
+
+    hdr: torch.Tensor
+    wave_base: torch.Tensor
+    ent: torch.Tensor
+    perm: torch.Tensor
+    shape: Tuple[int, int]
+    nnz: int
+    slots: int = 0
+    waves: int = 15  # row-owning waves per workgroup of the launch (mu_spmm_ell16_waves; not part of the layout)
+
+
 _NULL_CTX = contextlib.nullcontext()
 
 
@@ -120,6 +138,47 @@ def pick_block(width: int) -> int:
     raise NotImplementedError(
         f"block width {width} > 64 is not supported yet (n_comps + oversample must be <= 64)"
     )
+
+
+def ell16_layout(X: DeviceCSR, waves: int = 15) -> "DeviceEll":
+    """The sliced-ELL layout of csrc/spmm_ell.hip as tensor operations on X's device (built once per fit; its cost
+    does not matter).  See DeviceEll / include/muon_amd.h for the format."""
+    n, d = X.shape
+    dev = X.indices.device
+    S = -(-d // 1024)
+    lens = X.indptr[1:] - X.indptr[:-1]
+    order = torch.argsort(lens, descending=True, stable=True)       # position -> row: alike rows share a group
+    n_groups = -(-n // 16)
+    n_pos = n_groups * 16
+    perm = torch.full((n_pos,), -1, dtype=torch.int32, device=dev)
+    perm[:n] = order.to(torch.int32)
+    inv = torch.empty((n,), dtype=torch.int64, device=dev)
+    inv[order] = torch.arange(n, device=dev)
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), lens)
+    pos = inv[rows]
+    sl = (X.indices >> 10).to(torch.int64)
+    cnt = torch.bincount(pos * S + sl, minlength=n_pos * S).view(n_pos, S)      # entries per (position, slab)
+    nwin = (cnt.view(n_groups, 16, S).amax(dim=1) + 3) // 4                       # [group, slab]: the longest row
+    flat = nwin.reshape(-1)
+    wbase = torch.zeros(flat.numel() + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(flat, 0, out=wbase[1:])
+    total = int(wbase[-1].item())
+    win_base = wbase[:-1].view(n_groups, S)
+    hdr = nwin.to(torch.int32).contiguous()
+    wave_base = win_base[:, 0].contiguous()
+    # rank of an entry inside its (row, slab): the rows are sorted by column, so slabs follow each other
+    start = torch.cumsum(cnt, dim=1) - cnt                                        # [position, slab] exclusive
+    e = torch.arange(X.nnz, device=dev)
+    rank = e - X.indptr[:-1][rows] - start[pos, sl]
+    dest = (win_base[pos // 16, sl] + rank // 4) * 64 + 4 * (pos % 16) + rank % 4
+    vals = torch.zeros(((total + 8) * 64,), dtype=torch.float32, device=dev)      # (+ 8: the ring reads ahead)
+    offs = torch.zeros(((total + 8) * 64,), dtype=torch.int16, device=dev)
+    vals[dest] = X.values
+    off = (X.indices.to(torch.int32) & 1023) << 6                                 # u16 bit pattern in an int16
+    offs[dest] = torch.where(off >= 32768, off - 65536, off).to(torch.int16)
+    ent = torch.cat([vals.view(torch.uint8).view(-1, 256), offs.view(torch.uint8).view(-1, 128)], dim=1).contiguous()
+    del vals, offs
+    return DeviceEll(hdr, wave_base, ent, perm, (n, d), X.nnz, total * 64, int(waves))
 
 
 class HipBackend:
@@ -502,6 +561,24 @@ class HipBackend:
         inv[order] = pos.to(torch.int32)
         return perm, inv, K
 
+    # -- sliced-ELL operand of the narrow-block SpMM (csrc/spmm_ell.hip) ---------------------------
+    def ell16(self, X: DeviceCSR) -> DeviceEll:
+        """Lay a canonical f32 CSR out for mu_spmm_ell16_f32 (once per fit: the operand of MOFA's sparse views is
+        multiplied hundreds of times)."""
+        assert X.values.dtype == torch.float32
+        return ell16_layout(X, int(self.lib.mu_spmm_ell16_waves(X.shape[0])))
+
+    def spmm_ell(self, E: DeviceEll, Q: torch.Tensor, out=None) -> torch.Tensor:
+        n, d = E.shape
+        if Q.shape != (d, 16) or Q.dtype != torch.float32 or not Q.is_contiguous():
+            raise TypeError("the sliced-ELL SpMM needs a contiguous f32 block of 16 columns")
+        if out is None:
+            out = self.empty((n, 16), torch.float32)
+        with self._dev_ctx():
+            check(self.lib.mu_spmm_ell16_f32(E.waves, int(E.perm.numel()), d, _p(E.hdr), _p(E.wave_base), _p(E.ent),
+                                             _p(E.perm), _p(Q), _p(out), self._stream()))
+        return out
+
     # -- matrix-core SpMM operand (csrc/spmm_mfma.hip) ------------------------------------------
     def cells_geometry(self, nset: int):
         import ctypes as C
@@ -655,6 +732,9 @@ class HipBackend:
         if isinstance(X, DeviceCells):
             assert not accumulate
             return self.spmm_cells(X, Q, out=out)
+        if isinstance(X, DeviceEll):
+            assert not accumulate
+            return self.spmm_ell(X, Q, out=out)
         if isinstance(X, DeviceStream):
             wide = Q.dtype == torch.float64
             if B not in ((16, 32) if wide else (16, 32, 64)):

@@ -225,6 +225,12 @@ class MofaEngine:
             for g, (a, b) in enumerate(self.gslice):
                 V.Y[a:b] -= mu[g] * V.pres[a:b, None]  # explicit centring of the dense block
             V.Yt = None
+        elif (self.T == torch.float32 and hasattr(be, "ell16") and _pad_block(self.G * self.K) == 16
+              and V.X.shape[0] > 0 and V.X.shape[1] > 0):
+            # f32, factor blocks of <= 16 columns: the operand of both directions never changes during a fit - laid
+            # out once as sliced ELL (csrc/spmm_ell.hip): no per-row protocol is left in the product
+            V.Xt = be.ell16(be.transpose(V.X))
+            V.Xs = be.ell16(V.X)
         elif self.T == torch.float32 and hasattr(be, "can_stream") and be.can_stream(V.X, 16):
             # f32: both directions read row streams, built once
             V.Xt = be.transpose_stream(V.X)

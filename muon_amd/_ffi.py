@@ -72,6 +72,8 @@ SIGNATURES = {
     "mu_dense_f16_worksize": (_sz, [_i64]),
     "mu_dense_to_f16": (C.c_int, [_i32, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_cells_f32": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mu_spmm_ell16_waves": (C.c_int, [_i64]),
+    "mu_spmm_ell16_f32": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_probe_tr16": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "mu_probe_mfma16": (C.c_int, [_vp, _vp, _vp, _vp]),
     "mu_tune_set": (C.c_int, [C.c_char_p, _i32]),

@@ -1,0 +1,280 @@
+// SpMM for a NARROW dense block on a sliced-ELL operand (f32, r04):  Y[n x 16] = X[n x d] * Q[d x 16].
+//
+// MOFA's sparse views multiply by a factor block of <= 16 columns twice per ELBO iteration - A = Y (tau o W) and
+// B = Y^T Z, mofapy2's Z / W node updates reached from /root/reference/muon/_core/tools.py:583-585 - and the
+// operand does not change for the hundreds of iterations of a fit.  r03's kernel for it (csrc/spmm_narrow.hip)
+// walks the row stream with a window protocol per (row, slab) visit - cursor, compare, ballot, count, re-request -
+// and r03's own ablation showed that protocol to be the bound: 1.03 of 1.21 ms per product without a single
+// gather (profiles/r03_spmm_narrow_b16.txt).  A static operand can be laid out ONCE so that nothing of that is
+// left:
+//
+//   * 16 rows x 4 dense columns fill a wave exactly: quad r (lanes 4r .. 4r+3) owns row r of a group of 16
+//     rows, lane c of the quad dense columns 4c .. 4c+3.  One step = ONE stored entry of each of the 16 rows:
+//     `ds_read_b128` of the entry's Q row (64 bytes, four lanes) and two `v_pk_fma_f32`, with two DPP quad
+//     broadcasts that hand the entry's (LDS offset, value) to its four lanes - the offset's broadcast is the
+//     address add itself (`v_add_u32_dpp`);
+//   * the operand ("sliced ELL"): the rows in launch order (sorted by length, so the 16 rows of a group are
+//     alike), the columns in slabs of 1024 (a Q slab = 64 KiB of LDS, double buffered by LDS-DMA straight from
+//     the row-major block); the entries of (group, slab) as steps padded to the longest of the 16 rows, stored
+//     in WINDOWS of 4 steps = 384 bytes (64 f32 values, then 64 u16 byte offsets of the Q row inside the slab:
+//     6 bytes a slot against the 8 of a CSR entry): slot 4r + j = row r's step 4w + j.  A wave
+//     owns one group and reads its windows - slab after slab - as ONE sequential stream, eight windows ahead; a
+//     count per (group, slab) says how many.  No cursor, no compare, no ballot;
+//   * padded slots are (offset 0, value 0): row 0 of the slab times zero.
+// The price is the padding (slots / stored entries = 1.36 on the bench view: Poisson(31) entries per row and
+// slab, the longest of 16 rows, rounded up to 4) - bytes the kernel streams instead of instructions it cannot
+// issue.  What bounds it: with four waves per SIMD the kernel is ISSUE-bound (an instruction of a 64-lane wave
+// occupies its 16-lane SIMD for four cycles), so the loop is written for instruction count: the ring slot is a
+// register NAME (eight unrolled copies, left by a counted branch, no dispatch), 18 vector instructions, four LDS
+// reads and one global load per window of 64 slots.  Sums: a row's entries are added in stored (column) order,
+// slab after slab, in one accumulator: bit-reproducible and independent of the launch shape.
+#include <type_traits>
+#include <utility>
+
+#include "common.hpp"
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"  // 32-bit LDS addresses made from integers
+
+namespace {
+
+constexpr int kESlab = 1024;              // Q rows per slab
+constexpr int kESlabBytes = kESlab * 64;  // 64 KiB, double buffered
+constexpr int kEMaxWaves = 15;            // row-owning waves of a workgroup (+ the producer wave)
+constexpr int kEDepth = 8;                // windows a wave keeps in flight (3 KiB)
+constexpr int kEWin = 384;                // bytes of a window: value[64] f32 | offset[64] u16
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void e_dma_piece(const void* base, unsigned byte_off, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(byte_off), "s"(base), "s"(lds_dst)
+      : "memory");
+}
+
+// The window ring: slot D = a[2 D], a[2 D + 1] = (LDS offset, value bits) of this lane's slot.  Loads from asm,
+// exact counted waits (hipcc answers a register ring reloaded inside a loop with `s_waitcnt vmcnt(0)`), registers
+// the compiler does not know about except through the clobber lists (which make the kernel descriptor count them).
+#define MU_EL_CLOB "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15"
+static_assert(kEDepth == 8, "the clobber list names 2 kEDepth registers");
+template <int D>
+__device__ __forceinline__ void e_request0(const unsigned char* wp, unsigned lane4, unsigned lane2) {  // (prologue)
+  asm volatile(
+      "global_load_ushort a%c0, %3, %4 offset:%c6\n\t"
+      "global_load_dword a%c1, %2, %4 offset:%c5" ::"i"(2 * D),
+      "i"(2 * D + 1), "v"(lane4), "v"(lane2), "s"(wp), "i"(kEWin * D), "i"(kEWin * D + 256)
+      : MU_EL_CLOB, "memory");
+}
+// Take slot D (all but the kEDepth - 1 younger windows' two requests each have returned), request window
+// `this + kEDepth` into it, and hand every lane of a quad the four (LDS address, value) pairs of its row: lane j of
+// the quad holds step j.  (v_accvgpr_read -> DPP read of the same register: two wait states - the loads.)
+template <int D>
+__device__ __forceinline__ void e_take(const unsigned char* ahead, unsigned lane4, unsigned lane2, unsigned base,
+                                       unsigned (&adr)[4], float (&val)[4]) {
+  unsigned off;
+  float v;
+  asm volatile(
+      "s_waitcnt vmcnt(%c[n])\n\t"
+      "v_accvgpr_read_b32 %[off], a%c[r0]\n\t"
+      "v_accvgpr_read_b32 %[v], a%c[r1]\n\t"
+      "global_load_ushort a%c[r0], %[lane2], %[ahead] offset:256\n\t"
+      "global_load_dword a%c[r1], %[lane4], %[ahead]\n\t"
+      "v_add_u32_dpp %[a0], %[off], %[base] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_u32_dpp %[a1], %[off], %[base] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_u32_dpp %[a2], %[off], %[base] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_u32_dpp %[a3], %[off], %[base] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %[v0], %[v] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %[v1], %[v] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %[v2], %[v] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %[v3], %[v] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+      : [off] "=&v"(off), [v] "=&v"(v), [a0] "=&v"(adr[0]), [a1] "=&v"(adr[1]), [a2] "=&v"(adr[2]), [a3] "=&v"(adr[3]),
+        [v0] "=&v"(val[0]), [v1] "=&v"(val[1]), [v2] "=&v"(val[2]), [v3] "=&v"(val[3])
+      : [base] "v"(base), [lane4] "v"(lane4), [lane2] "v"(lane2), [ahead] "s"(ahead), [n] "i"(2 * (kEDepth - 1)),
+        [r0] "i"(2 * D), [r1] "i"(2 * D + 1)
+      : MU_EL_CLOB, "memory");
+}
+
+// Wave 0 of the workgroup is the PRODUCER of the Q slabs and owns no rows.  The vector-memory counter retires in
+// order: a wave that issues slab pieces cannot take a window requested after them before the pieces have landed -
+// one full memory latency per slab and wave, at the same moment in all waves (they leave the barrier together).
+// With one wave doing nothing but `issue the next slab, wait, barrier`, the others never wait for anything but
+// their own windows.   MODE (timing ablations, wrong results): 1 no gathers / FMAs, 2 no slab copies.
+template <int MODE>
+__global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_pos, int64_t n_cols, int n_slabs, int cw,
+                                                                     const int32_t* __restrict__ hdr,
+                                                                     const int64_t* __restrict__ wave_base,
+                                                                     const unsigned char* __restrict__ ent,
+                                                                     const int32_t* __restrict__ perm,
+                                                                     const float* __restrict__ Q,
+                                                                     float* __restrict__ Y) {
+  __shared__ __attribute__((aligned(1024))) unsigned char slab[2 * kESlabBytes];
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform32(threadIdx.x >> 6);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&slab[0]);
+
+  if (wave == 0) {  // 64 pieces of 1 KiB per slab
+    const unsigned q_last = (unsigned)(n_cols * 64 - 16);  // (Q is n_cols rows of 64 bytes: the last slab is clamped)
+    auto whole = [&](int s, int b) {
+#pragma unroll 8
+      for (int piece = 0; piece < ((MODE & 2) ? 1 : kESlabBytes / 1024); ++piece) {
+        unsigned o = (unsigned)s * (unsigned)kESlabBytes + (unsigned)(piece * 1024 + lane * 16);
+        o = o < q_last ? o : q_last;  // past the end: never consumed
+        e_dma_piece(Q, o, lds0 + (unsigned)b * (unsigned)kESlabBytes + (unsigned)piece * 1024u);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    whole(0, 0);
+    __syncthreads();
+    for (int s = 0; s + 1 < n_slabs; ++s) {
+      whole(s + 1, (s + 1) & 1);  // (its buffer held slab s - 1: everyone is past the barrier that ended it)
+      __syncthreads();            // the end of slab s for the others
+    }
+    return;
+  }
+
+  // this wave's group of 16 positions.  The groups are in order of row length: dealt round the workgroups, so that
+  // the workgroups - whole rounds of them, one per CU - carry alike shares
+  const int64_t gwave = (int64_t)blockIdx.x + (int64_t)gridDim.x * (wave - 1);
+  const int64_t n_waves = (n_pos + 15) / 16;
+  (void)cw;
+  const bool active = gwave < n_waves;
+  const unsigned lane4 = (unsigned)lane * 4u, lane2 = (unsigned)lane * 2u;
+
+  f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("" ::: MU_EL_CLOB);
+
+  typedef __attribute__((address_space(4))) const int32_t* chdr_p;
+  const chdr_p myhdr = (chdr_p)(hdr + (active ? gwave : 0) * (int64_t)n_slabs);
+  auto counts_of = [&](int s) -> int { return active ? uniform32(myhdr[s]) : 0; };
+  const unsigned char* wp = ent + uniform64(active ? wave_base[gwave] : 0) * kEWin + kEWin * kEDepth;  // next REQUEST
+
+  unsigned base = lds0 + (unsigned)(lane & 3) * 16u;  // this lane's four columns of the current slab buffer
+  // one window: 4 steps of 16 entries
+  auto window = [&](auto dc) {
+    constexpr int D = decltype(dc)::value;
+    unsigned adr[4];
+    float val[4];
+    e_take<D>(wp, lane4, lane2, base, adr, val);
+    wp += kEWin;
+    if constexpr (MODE & 1) {
+      acc[0] += val[0] + val[1] + val[2] + val[3] + (float)(adr[0] ^ adr[1] ^ adr[2] ^ adr[3]);
+    } else {
+      typedef __attribute__((address_space(3))) const f4* lds_p;
+      const f4 q0 = *(lds_p)adr[0];
+      const f4 q1 = *(lds_p)adr[1];
+      const f4 q2 = *(lds_p)adr[2];
+      const f4 q3 = *(lds_p)adr[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = fmaf(val[0], q0[c], acc[c]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = fmaf(val[1], q1[c], acc[c]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = fmaf(val[2], q2[c], acc[c]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = fmaf(val[3], q3[c], acc[c]);
+    }
+  };
+
+  // prologue: the first kEDepth windows are requested while slab 0 lands
+  {
+    const unsigned char* w0 = wp - kEWin * kEDepth;
+    e_request0<0>(w0, lane4, lane2);
+    e_request0<1>(w0, lane4, lane2);
+    e_request0<2>(w0, lane4, lane2);
+    e_request0<3>(w0, lane4, lane2);
+    e_request0<4>(w0, lane4, lane2);
+    e_request0<5>(w0, lane4, lane2);
+    e_request0<6>(w0, lane4, lane2);
+    e_request0<7>(w0, lane4, lane2);
+  }
+  int s = 0;
+  int left = counts_of(0);  // windows of this wave in slab s still to take
+  int next_cnt = n_slabs > 1 ? counts_of(1) : 0;
+  __syncthreads();
+  // to the next slab that holds windows of this wave (a barrier per slab boundary); false: no slab is left
+  auto advance = [&]() -> bool {
+    do {
+      if (s + 1 >= n_slabs) return false;
+      __syncthreads();  // through with slab s; the producer's slab s + 1 has landed
+      ++s;
+      base = lds0 + (unsigned)(lane & 3) * 16u + (unsigned)(s & 1) * (unsigned)kESlabBytes;
+      left = next_cnt;
+      next_cnt = s + 1 < n_slabs ? counts_of(s + 1) : 0;
+    } while (left == 0);
+    return true;
+  };
+  bool more = left > 0 || advance();
+  // the ring slot of a window is a register name: eight copies of the body, left by a counted branch
+#define MU_STEP(D)                                   \
+  window(std::integral_constant<int, D>{});          \
+  if (--left == 0) {                                 \
+    if (!advance()) break;                           \
+  }
+  if (more) {
+    for (;;) {
+      MU_STEP(0)
+      MU_STEP(1)
+      MU_STEP(2)
+      MU_STEP(3)
+      MU_STEP(4)
+      MU_STEP(5)
+      MU_STEP(6)
+      MU_STEP(7)
+    }
+  }
+#undef MU_STEP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // requests still in flight target the ring registers
+
+  const int r = lane >> 2, c = lane & 3;
+  const int64_t p = gwave * 16 + r;
+  if (active && p < n_pos) {
+    const int64_t row = perm ? (int64_t)perm[p] : p;
+    if (row >= 0) *reinterpret_cast<f4*>(Y + row * 16 + 4 * c) = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mu_spmm_ell16_waves(int64_t n_rows) {
+  // row-owning waves (= groups of 16 rows) per workgroup.  The chip runs ONE workgroup per CU (128 KiB of Q
+  // slabs) and every workgroup sweeps all of Q.  One round of workgroups while the groups fit; beyond that 14
+  // waves (measured at 100k rows on 256 CUs, DESIGN.md 6: 13 / 14 / 15 waves = 0.68 / 0.64 / 0.65 ms - the
+  // groups are dealt round the workgroups in order of length, so a ragged last round costs little)
+  const int64_t cus = mu_num_cus();
+  const int64_t nw = (n_rows + 15) / 16;
+  if (nw <= cus) return 1;
+  if (nw <= cus * kEMaxWaves) return (int)((nw + cus - 1) / cus);
+  return 14;
+}
+
+int mu_spmm_ell16_f32(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr, const int64_t* d_wave_base,
+                      const void* d_ent, const int32_t* d_perm, const float* d_Q, float* d_Y, void* stream) {
+  MU_REQUIRE(waves >= 1 && waves <= kEMaxWaves, "row-owning waves per workgroup: 1 .. 15");
+  MU_REQUIRE(n_pos >= 0 && n_cols > 0 && n_cols * 64 < ((int64_t)1 << 32), "shape out of range");
+  if (n_pos == 0) return MU_OK;
+  MU_REQUIRE(d_hdr && d_wave_base && d_ent && d_Q && d_Y, "null pointer");
+  const int64_t n_slabs = (n_cols + kESlab - 1) / kESlab;
+  const int64_t n_waves = (n_pos + 15) / 16;
+  const int64_t wgs = (n_waves + waves - 1) / waves;
+  const int mode = mu_tune_get("ell_mode");
+  hipStream_t st = (hipStream_t)stream;
+#define MU_GO(MD)                                                                                          \
+  hipLaunchKernelGGL((k_spmm_ell16<MD>), dim3((unsigned)wgs), dim3(64 * (waves + 1)), 0, st, n_pos, n_cols, \
+                     (int)n_slabs, waves, d_hdr, d_wave_base, (const unsigned char*)d_ent, d_perm, d_Q, d_Y)
+  if ((mode & 3) == 1) MU_GO(1);
+  else if ((mode & 3) == 2) MU_GO(2);
+  else if ((mode & 3) == 3) MU_GO(3);
+  else MU_GO(0);
+#undef MU_GO
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+}  // extern "C"

@@ -54,7 +54,7 @@ typedef unsigned u2_t __attribute__((ext_vector_type(2)));
 constexpr int kStepBytes = 224;   // hi 64 | lo 64 | off 64 | mask 32
 constexpr int kOffPlane = 128, kMaskPlane = 192;
 constexpr int kRing = 2;          // ring slots per wave (asm-owned registers; 2 .. 5 measured alike)
-constexpr int kWavesPerWg = 16;   // ... and its waves: 4 per SIMD, 128 registers = 64 accumulators + 12 ring (AGPRs, asm-owned) + 52
+[[maybe_unused]] constexpr int kWavesPerWg = 16;   // ... and its waves: 4 per SIMD, 128 registers = 64 accumulators + 12 ring (AGPRs, asm-owned) + 52
 constexpr int kBandRows = 32;     // 4 tiles of 8 rows
 
 template <int NSET> struct Geo {

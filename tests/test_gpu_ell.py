@@ -1,0 +1,103 @@
+"""Sliced-ELL narrow SpMM (csrc/spmm_ell.hip) on the GPU, through the C-ABI: the product against f64 arithmetic
+on the same inputs (ragged and empty rows, row counts off the group size, column counts off the slab size, every
+group count, several workgroup shapes), bit-reproducibility, and agreement with the row-stream kernel at a MOFA-sized
+view."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from tests.synth import planted_topics_csr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from muon_amd._backend import get_backend
+
+    return get_backend()
+
+
+def _upload(be, m):
+    return be.upload_csr(m.indptr, m.indices, m.data, m.shape, values_dtype=np.float32)
+
+
+def _ragged(n, d, seed):
+    m = planted_topics_csr(n, d, n_topics=5, density=0.04, seed=seed).astype(np.float32)
+    m.data = np.log1p(m.data).astype(np.float32) + np.float32(0.125)
+    keep = np.ones(n)
+    keep[::7] = 0          # empty rows
+    m = sp.csr_matrix(sp.diags(keep) @ m).astype(np.float32)
+    heavy = sp.random(n, d, density=0.5, random_state=seed, format="csr", dtype=np.float32)
+    pick = np.zeros(n)
+    pick[1::13] = 1        # a few rows hundreds of entries long
+    m = sp.csr_matrix(m + sp.diags(pick) @ heavy).astype(np.float32)
+    m.eliminate_zeros()
+    m.sort_indices()
+    return m
+
+
+@pytest.mark.parametrize("shape", [(16, 40), (100, 1024), (257, 1025), (1000, 5000), (4099, 3000)])
+def test_product_matches_f64_arithmetic(be, shape):
+    from muon_amd._backend import ell16_layout
+
+    n, d = shape
+    m = _ragged(n, d, seed=n)
+    X = _upload(be, m)
+    E = ell16_layout(X)
+    assert E.nnz == m.nnz
+    rng = np.random.default_rng(n)
+    Q = rng.standard_normal((d, 16)).astype(np.float32)
+    want = m.astype(np.float64) @ Q.astype(np.float64)
+    scale = np.abs(m).astype(np.float64) @ np.abs(Q).astype(np.float64) + 1e-30
+    Qd = torch.from_numpy(Q).to(be.device)
+    first = None
+    for waves in (15, 1, 6):  # row-owning waves per workgroup: the launch shape does not touch the arithmetic
+        E.waves = waves
+        out = torch.full((n, 16), float("nan"), device=be.device, dtype=torch.float32)
+        got = be.spmm(E, Qd, out=out)
+        again = be.spmm(E, Qd)
+        g = be.to_host(got).astype(np.float64)
+        assert np.isfinite(g).all()  # every row written, the empty ones with zeros
+        assert np.max(np.abs(g - want) / scale) < 2e-6  # f32 sums of up to ~1500 terms
+        assert torch.equal(got, again)
+        if first is None:
+            first = got.clone()
+        else:
+            assert torch.equal(first, got)
+    assert np.all(g[np.diff(m.indptr) == 0] == 0)
+
+
+def test_default_layout_and_row_stream_agree_at_a_mofa_sized_view(be):
+    n, d = 30000, 20000
+    X = be.synth_counts(0, n, d, 50, 0.03, 0)
+    X = type(X)(X.indptr, X.indices, torch.log1p(X.values.to(torch.float32)), X.shape)
+    for M in (X, be.transpose(X)):
+        E = be.ell16(M)
+        assert 1 <= E.waves <= 15 and E.slots >= M.nnz
+        assert E.slots < 1.6 * M.nnz  # the padding the kernel streams
+        Q = torch.randn(M.shape[1], 16, device=be.device, dtype=torch.float32)
+        a = be.spmm(E, Q)
+        b = be.spmm(be.stream(M), Q)
+        # both add a row's products in column order, slab after slab: one fma chain per output element ...
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+        # ... and linearity in Q
+        c = be.spmm(E, 2.0 * Q)
+        assert torch.equal(c, 2.0 * a)
+
+
+def test_refusals_and_long_rows(be):
+    from muon_amd._backend import ell16_layout
+    from muon_amd._ffi import MuonAmdError
+
+    m = _ragged(64, 2000, seed=1)
+    X = _upload(be, m)
+    E = ell16_layout(X)
+    with pytest.raises((MuonAmdError, AssertionError, TypeError)):
+        be.spmm(E, torch.zeros(2000, 32, device=be.device))  # 16 columns only
+    dense = sp.csr_matrix(np.arange(1, 3 * 2100 + 1, dtype=np.float32).reshape(3, 2100) / 64)  # 256 windows per slab
+    Q = torch.randn(2100, 16, device=be.device, dtype=torch.float32)
+    got = be.to_host(be.spmm(ell16_layout(_upload(be, dense)), Q)).astype(np.float64)
+    want = dense.toarray().astype(np.float64) @ be.to_host(Q).astype(np.float64)
+    assert np.max(np.abs(got - want)) < 1e-5 * np.max(np.abs(want))
