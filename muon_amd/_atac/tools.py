@@ -392,81 +392,91 @@ def _lsi_device(
         collect_block_grams(j, grams)
         t_r = time.perf_counter()
         host["wait_ms"] += 1e3 * (t_r - t_w)
-        m = j + 1
-        Tm, Mm = assemble(Tb, m), assemble(Mb, m)
-        lam_all, C_all = _ritz(Tm, Mm, keep + 1)  # top-k pairs, the restart's `keep`, the first unwanted value
-        lam, C, rest = lam_all[:k], C_all[:, :k], lam_all[k:]
-        history.append(np.sqrt(lam))
-        enough = m * w > k  # (n_comps > block width: the first Ritz steps cannot deliver k vectors yet)
-        # Accuracy of the current top-k Ritz subspace, from the Krylov decomposition itself: every block
-        # but the newest is mapped back into the space by A = X^T X (that is how the next block was
-        # made), so the residual of a Ritz pair (theta_i, K c_i) is Q_{j+1} B_{j+1} c_i[last block] and
-        # ||r_i|| <= ||B_{j+1}|| ||c_i[last]|| - the Lanczos residual estimate, also across thick restarts
-        # (Krylov-Schur form).  B_{j+1} is not known before the next expansion; its norm is taken from
-        # the last expansion (beta_hat).  Davis-Kahan turns residuals into angles vector by vector:
-        # sin(angle_i) <~ ||r_i|| / (theta_i - theta_{k+1}); the subspace figure is their root sum of
-        # squares.  Measured against f64 ARPACK it over-estimates the largest principal angle 2-4x on
-        # gapped spectra and up to ~50x when sigma_k ~ sigma_{k+1} (never under, down to the f32 floor).
-        gap = max(lam[k - 1] - rest[0], 0.0) if enough else 0.0
-        bound = np.inf
-        if enough and beta_hat > 0 and gap > 0:
-            c_last = C[(m - 1) * w:, :]
-            bound = float(np.sqrt(np.sum((beta_hat * np.linalg.norm(c_last, axis=0)
-                                          / np.maximum(lam - rest[0], 1e-300)) ** 2)))
-        # what f32 storage of the blocks leaves, whatever the iteration does: eps ||A|| / gap
-        floor = float(_F32_EPS * lam_all[0] / gap) if gap > 0 else np.inf
-        bounds.append(bound)
-        if _debug_cb is not None:
-            _debug_cb({"Qs": Qs, "C": C, "w": w, "m": m, "bound": bound, "floor": floor,
-                       "gap_rel": float(gap / max(lam[k - 1], 1e-300))})
-        if it >= limit and enough:
-            host["ritz_ms"] += 1e3 * (time.perf_counter() - t_r)
-            if n_iter is None:
-                converged = False  # max_iter expansions without meeting angle_tol
-            break
-        stop = False
-        if n_iter is None and enough:
-            # contraction per expansion: the last measured one, not below the asymptotic Chebyshev rate
-            # computed from the Ritz values (unwanted spectrum in [0, theta_out])
-            th_k, th_out = lam[k - 1], rest[-1]
-            cheb = 0.0
-            if th_k > th_out > 0:
-                g = 1.0 + 2.0 * (th_k - th_out) / th_out
-                cheb = 1.0 / (g + np.sqrt(g * g - 1.0))
-            rho = 0.5
-            if len(bounds) >= 2 and np.isfinite(bounds[-2]) and bounds[-2] > 0:
-                rho = min(0.9, max(bound / bounds[-2], 1.5 * cheb, 1e-3))
-            # One more expansion multiplies the error by about rho again.  A wrong "final" costs an
-            # exposed Ritz step (ms), a wrong "not final" an unused SpMM (tens of ms at 1e6 rows): lean
-            # to "final" - the bound itself over-estimates 3x and more.
-            expect_final = np.isfinite(bound) and bound * rho < 100.0 * angle_tol
-            # Block Lanczos converges superlinearly once the space holds the wanted vectors (c3: bounds
-            # 1.27, 0.21, 2.7e-7 in consecutive steps), so the rate says little.  When a product costs
-            # more than the exposed Ritz step it would hide (> ~5e8 stored entries: 3 ms and up against
-            # ~6 ms of host LAPACK and launch gaps for a wrong "final"), stop speculating as soon as the
-            # vectors have started to converge.
-            if big_products and np.isfinite(bound) and bound < 1.0:
-                expect_final = True
-            if bound < angle_tol:
-                stop = True
-            elif len(bounds) >= 6 and bound > 0.7 * bounds[-5] and bound < 1e-2:
-                stop = True  # four expansions bought < 30 %: the f32 floor of an ill-conditioned subspace
-            elif not np.isfinite(bound) and gap <= 0 and len(history) >= 2 and it >= 2:
-                # no gap behind sigma_k (k beyond the rank, sigma_k = sigma_k+1): no angle can be promised;
-                # stop once the Ritz VALUES have settled to `tol` instead of running to max_iter
-                prev, cur = history[-2] ** 2, lam
-                if np.max(np.abs(cur - prev)) <= tol * max(lam_all[0], 1e-300):
+        # The Ritz step of the very first block cannot end the iteration (no residual estimate exists before the
+        # first expansion: beta_hat = 0, bound = inf) and nothing else reads its result: skipped (r04; 0.4 ms of
+        # host LAPACK per call, exposed on small inputs)
+        # (host QR - small matrices - may find the Krylov space exhausted right after this block and needs the pairs)
+        first = it == 0 and limit > 0 and len(Qs) == 1 and beta_hat == 0.0 and device_qr
+        enough = False
+        if first:
+            history.append(np.zeros(k))
+            bounds.append(np.inf)
+        else:
+            m = j + 1
+            Tm, Mm = assemble(Tb, m), assemble(Mb, m)
+            lam_all, C_all = _ritz(Tm, Mm, keep + 1)  # top-k pairs, the restart's `keep`, the first unwanted value
+            lam, C, rest = lam_all[:k], C_all[:, :k], lam_all[k:]
+            history.append(np.sqrt(lam))
+            enough = m * w > k  # (n_comps > block width: the first Ritz steps cannot deliver k vectors yet)
+            # Accuracy of the current top-k Ritz subspace, from the Krylov decomposition itself: every block
+            # but the newest is mapped back into the space by A = X^T X (that is how the next block was
+            # made), so the residual of a Ritz pair (theta_i, K c_i) is Q_{j+1} B_{j+1} c_i[last block] and
+            # ||r_i|| <= ||B_{j+1}|| ||c_i[last]|| - the Lanczos residual estimate, also across thick restarts
+            # (Krylov-Schur form).  B_{j+1} is not known before the next expansion; its norm is taken from
+            # the last expansion (beta_hat).  Davis-Kahan turns residuals into angles vector by vector:
+            # sin(angle_i) <~ ||r_i|| / (theta_i - theta_{k+1}); the subspace figure is their root sum of
+            # squares.  Measured against f64 ARPACK it over-estimates the largest principal angle 2-4x on
+            # gapped spectra and up to ~50x when sigma_k ~ sigma_{k+1} (never under, down to the f32 floor).
+            gap = max(lam[k - 1] - rest[0], 0.0) if enough else 0.0
+            bound = np.inf
+            if enough and beta_hat > 0 and gap > 0:
+                c_last = C[(m - 1) * w:, :]
+                bound = float(np.sqrt(np.sum((beta_hat * np.linalg.norm(c_last, axis=0)
+                                              / np.maximum(lam - rest[0], 1e-300)) ** 2)))
+            # what f32 storage of the blocks leaves, whatever the iteration does: eps ||A|| / gap
+            floor = float(_F32_EPS * lam_all[0] / gap) if gap > 0 else np.inf
+            bounds.append(bound)
+            if _debug_cb is not None:
+                _debug_cb({"Qs": Qs, "C": C, "w": w, "m": m, "bound": bound, "floor": floor,
+                           "gap_rel": float(gap / max(lam[k - 1], 1e-300))})
+            if it >= limit and enough:
+                host["ritz_ms"] += 1e3 * (time.perf_counter() - t_r)
+                if n_iter is None:
+                    converged = False  # max_iter expansions without meeting angle_tol
+                break
+            stop = False
+            if n_iter is None and enough:
+                # contraction per expansion: the last measured one, not below the asymptotic Chebyshev rate
+                # computed from the Ritz values (unwanted spectrum in [0, theta_out])
+                th_k, th_out = lam[k - 1], rest[-1]
+                cheb = 0.0
+                if th_k > th_out > 0:
+                    g = 1.0 + 2.0 * (th_k - th_out) / th_out
+                    cheb = 1.0 / (g + np.sqrt(g * g - 1.0))
+                rho = 0.5
+                if len(bounds) >= 2 and np.isfinite(bounds[-2]) and bounds[-2] > 0:
+                    rho = min(0.9, max(bound / bounds[-2], 1.5 * cheb, 1e-3))
+                # One more expansion multiplies the error by about rho again.  A wrong "final" costs an
+                # exposed Ritz step (ms), a wrong "not final" an unused SpMM (tens of ms at 1e6 rows): lean
+                # to "final" - the bound itself over-estimates 3x and more.
+                expect_final = np.isfinite(bound) and bound * rho < 100.0 * angle_tol
+                # Block Lanczos converges superlinearly once the space holds the wanted vectors (c3: bounds
+                # 1.27, 0.21, 2.7e-7 in consecutive steps), so the rate says little.  When a product costs
+                # more than the exposed Ritz step it would hide (> ~5e8 stored entries: 3 ms and up against
+                # ~6 ms of host LAPACK and launch gaps for a wrong "final"), stop speculating as soon as the
+                # vectors have started to converge.
+                if big_products and np.isfinite(bound) and bound < 1.0:
+                    expect_final = True
+                if bound < angle_tol:
                     stop = True
-            # ranks must leave the loop together AND speculate together (expect_final gates a product
-            # with its all-reduce): one broadcast carries both of rank 0's decisions
-            stop, expect_final = comm.agree(stop, expect_final)
-        host["ritz_ms"] += 1e3 * (time.perf_counter() - t_r)
-        if stop:
-            # "converged" is a statement about the ANGLE, not about having stopped: the Lanczos bound
-            # and the f32 floor together must be under the parity target of the north star (1e-4)
-            converged = bool(np.hypot(bound, floor) < ANGLE_TARGET)
-            wasted += Z is not None  # queued on a wrong prediction; the result is simply not used
-            break
+                elif len(bounds) >= 6 and bound > 0.7 * bounds[-5] and bound < 1e-2:
+                    stop = True  # four expansions bought < 30 %: the f32 floor of an ill-conditioned subspace
+                elif not np.isfinite(bound) and gap <= 0 and len(history) >= 2 and it >= 2:
+                    # no gap behind sigma_k (k beyond the rank, sigma_k = sigma_k+1): no angle can be promised;
+                    # stop once the Ritz VALUES have settled to `tol` instead of running to max_iter
+                    prev, cur = history[-2] ** 2, lam
+                    if np.max(np.abs(cur - prev)) <= tol * max(lam_all[0], 1e-300):
+                        stop = True
+                # ranks must leave the loop together AND speculate together (expect_final gates a product
+                # with its all-reduce): one broadcast carries both of rank 0's decisions
+                stop, expect_final = comm.agree(stop, expect_final)
+            host["ritz_ms"] += 1e3 * (time.perf_counter() - t_r)
+            if stop:
+                # "converged" is a statement about the ANGLE, not about having stopped: the Lanczos bound
+                # and the f32 floor together must be under the parity target of the north star (1e-4)
+                converged = bool(np.hypot(bound, floor) < ANGLE_TARGET)
+                wasted += Z is not None  # queued on a wrong prediction; the result is simply not used
+                break
         # expand: next Krylov block
         if Z is None:
             Z = expand_product(j)
@@ -484,9 +494,22 @@ def _lsi_device(
             Cw = C_all[:, :keep]
             Vw = combine(Qs, Cw, chunk=w)  # `keep_blocks` new blocks of w active columns
             Yw = combine(Ys, Cw, chunk=w)
+            # Grams of the new blocks, without a device pass and the host wait behind it (r04; was: recomputed
+            # from the stored blocks, one more synchronisation per restart - a third of a 10k x 30k call):
+            # the blocks are K Cw and (X K) Cw with T c_i = theta_i M c_i, c_i^T M c_j = delta_ij, so
+            # T = diag(theta), M = I and the column sums are Cw^T applied to the old ones - exact for the
+            # f64 combinations, and the f32 storage of the new blocks moves their true Grams by 2^-24
+            # relative, the same order as the storage of every other block (`floor` accounts for it)
+            cs_old = np.concatenate(css)
             Qs, Ys, css, Tb, Mb = list(Vw), list(Yw), [], {}, {}
             for jj in range(keep_blocks):
-                add_block_grams(jj)
+                blk = slice(jj * w, (jj + 1) * w)
+                Tb[(jj, jj)] = np.diag(lam_all[blk])
+                Mb[(jj, jj)] = np.diag((np.abs(Cw[:, blk]).sum(axis=0) > 0).astype(np.float64))  # (rank < keep: zero columns)
+                css.append(Cw[:, blk].T @ cs_old)
+                for ii in range(jj):
+                    Tb[(ii, jj)] = np.zeros((w, w))
+                    Mb[(ii, jj)] = np.zeros((w, w))
             C = np.zeros((keep, k))
             C[:k, :k] = np.eye(k)  # the kept Ritz vectors are the leading columns of the new blocks
             restarts += 1
