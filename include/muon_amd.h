@@ -145,11 +145,14 @@ int mu_spmm_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const i
  *   2. caller lays the output rows out and scans their lengths into row pointers
  *   3. mu_csr_tpack_fill_stream (row stream, below) or mu_csr_tpack_fill_csr with the SAME d_work
  * nnz = stored entries of X (it sizes the row blocks and tiles; pass the same value everywhere).
+ * d_slab_ptr (may be NULL): the slab pointers of the SAME index arrays if a caller still holds them - the first
+ * n_rows x (ceil(n_cols / 8192) + 1) int64 of the work buffer of mu_csr_row_col_sums (TF-IDF searches the same
+ * 8192-column slabs one call earlier: r04, the search is not repeated).
  * Stable and free of global atomics => bit-reproducible. */
 size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz);
 int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
                        const int32_t* d_indices, int64_t* d_col_nnz, void* d_work,
-                       size_t work_bytes, void* stream);
+                       size_t work_bytes, const int64_t* d_slab_ptr, void* stream);
 /* The same transposition written as a plain CSR of X^T (t_indptr int64[n_cols + 1] = exclusive scan
  * of col_nnz, t_indices int32[nnz] = cell ids ascending inside every row, t_values f32[nnz]): step 3
  * of the sequence above with the CSR arrays as the target (the fast stable transpose). */
@@ -260,7 +263,8 @@ int mu_probe_mfma16(const void* d_a, const void* d_b, float* d_d, void* stream);
  *   "spmm_pipe"  software pipelining level of the packed SpMM
  *   "spmm_mode"  timing ablations of the packed SpMM (bit mask; results are then WRONG)
  *   "mfma_mode"  timing ablations of the matrix-core SpMM (1 no MFMA, 2 no gathers, 4 no masks; WRONG results)
- *   "ell_mode"   timing ablation of the sliced-ELL SpMM (1 no gathers / FMAs; WRONG results) */
+ *   "ell_mode"   timing ablations of the sliced-ELL SpMM (1 no gathers / FMAs, 2 no Q slab copies; WRONG results)
+ *   "tfidf_wide" 1: the f32 TF-IDF scale sweep with 8192-column idf slabs (r03) instead of 32 768 (same results) */
 int mu_tune_set(const char* key, int value);
 int mu_tune_get(const char* key);
 

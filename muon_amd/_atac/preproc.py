@@ -168,9 +168,15 @@ def tfidf_device(backend, X, n_obs, flags: int, scale: float, comm=None, out=Non
     idf = backend.idf(colsum, float(n_obs), flags, X.values.dtype)
     vals, zero_count = backend.tfidf_scale(X, rowsum, idf, scale, flags, out=out)
     res = X.with_values(vals)
+    sp = backend.__dict__.pop("_last_slab_ptr", None) if hasattr(backend, "__dict__") else None
     if int(zero_count.item()) != 0:
         # scipy's SpGEMM drops entries whose product is exactly 0
         res = backend.compact_nonzero(res)
+    else:
+        # the result shares X's index arrays: the slab pointers the sweeps searched go with it, lsi's transposition
+        # cuts the same 8192-column slabs (csrc/tpack.hip) and does not search them again
+        if sp is not None:
+            res.slab_ptr = (sp, (res.indptr.data_ptr(), res.indices.data_ptr(), res.shape[0], res.shape[1]))
     return res
 
 

@@ -386,6 +386,10 @@ class HipBackend:
                                                 _p(X.values), _p(rowsum), _p(idf), float(scale), flags,
                                                 _p(out), _p(zc), _p(work), wb, int(have),
                                                 self._stream()))
+            # the slab pointers (head of the work buffer) also serve the transposition of the same index arrays
+            # one call later (transpose_stream): kept apart from the column partials that follow them
+            n_sp = n * (-(-d // 8192) + 1)
+            self._last_slab_ptr = work[:8 * n_sp].view(torch.int64).clone()
         return out, zc
 
     def compact_nonzero(self, X: DeviceCSR) -> DeviceCSR:
@@ -411,6 +415,18 @@ class HipBackend:
                                               self._stream()))
 
     # -- LSI building blocks (reference tools.py:53 -> scipy svds) ---------------------
+    @staticmethod
+    def _slab_ptr_of(X: DeviceCSR):
+        """The slab pointers the TF-IDF sweeps left with X (``tfidf_device``), if they describe X's index arrays."""
+        got = getattr(X, "slab_ptr", None)
+        if got is None:
+            return None
+        sp, key = got
+        n, d = X.shape
+        if key != (X.indptr.data_ptr(), X.indices.data_ptr(), n, d) or sp.numel() != n * (-(-d // 8192) + 1):
+            return None
+        return sp
+
     def transpose(self, X: DeviceCSR) -> DeviceCSR:
         n, d = X.shape
         nnz = X.nnz
@@ -439,7 +455,7 @@ class HipBackend:
         with self._dev_ctx():
             st = self._stream()
             check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
-                                              _p(work), wb, st))
+                                              _p(work), wb, _p(self._slab_ptr_of(X)), st))
             check(self.lib.mu_exclusive_scan_i64(d, _p(col_nnz), _p(t_indptr), st))
             check(self.lib.mu_csr_tpack_fill_csr(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
                                                  _p(t_indptr), _p(t_indices), _p(t_values), _p(work), wb, st))
@@ -492,7 +508,7 @@ class HipBackend:
         with self._dev_ctx():
             st = self._stream()
             check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
-                                              _p(work), wb, st))
+                                              _p(work), wb, _p(self._slab_ptr_of(X)), st))
             want_k = K
             perm, inv, K, n_pos = None, None, max(1, int(want_k or self.lib.mu_spmm_stream_k(d))), d
             lens = col_nnz[:d]

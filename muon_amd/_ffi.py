@@ -58,7 +58,7 @@ SIGNATURES = {
     "mu_csr_transpose": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "mu_csr_tpack_worksize": (_sz, [_i64, _i64, _i64]),
-    "mu_csr_tpack_count": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mu_csr_tpack_count": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "mu_csr_tpack_fill_csr": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_stream_k": (C.c_int, [_i64]),
     "mu_csr_tpack_phase_cycles": (C.c_int, [_vp, _i32]),

@@ -288,6 +288,87 @@ __global__ __launch_bounds__(kSweepThreads, sizeof(T) == 4 ? 8 : 4) void k_tfidf
   }
 }
 
+// The same sweep with M times wider slabs (f32: M = 4 -> 32 768 columns of idf = 128 KiB of LDS, one workgroup
+// per CU at up to 128 registers): a visit - the piece of one row inside one slab - is M times longer, so the
+// per-visit work (pointer lanes, loop set-up, the drain of the loads at its end) is paid M times less often and
+// CH chunks of 64 entries are in flight per wave.  Measured at 1e6 x 200 000 (scripts/tfidf_probe.py): M = 1 / 2 /
+// 4: 18.2 / 16.9 / 14.4 ms (4.15 / 4.5 / 5.2 TB/s); 8 chunks in flight instead of 4: no change.  The SUM sweep
+// does not gain from the same change (f64 bins: M = 2 = 128 KiB, 14.2 -> 16.6 ms: its LDS atomics want the waves).  The slab pointers are the ones of the 8192-column slabs,
+// read with stride M.  Same arithmetic, entry by entry: bit-identical results.
+template <int M, int CH>
+__global__ __launch_bounds__(kSweepThreads, 4) void k_tfidf_scale_sweep_wide(
+    int64_t n_rows, int64_t n_cols, int64_t S, const int64_t* __restrict__ indptr,
+    const int32_t* __restrict__ indices, const float* __restrict__ values,
+    const int64_t* __restrict__ sp, const double* __restrict__ rowsum, const float* __restrict__ idf,
+    float scale, int use_scale, int flags, float* __restrict__ out, unsigned long long* zero_count) {
+  __shared__ float lidf[kSlab * M];
+  __shared__ int64_t s_r[2];
+  const int g = blockIdx.x, G = gridDim.x;
+  if (threadIdx.x == 0) sweep_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
+  __syncthreads();
+  const int64_t r0 = s_r[0], r1 = s_r[1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned int zeros = 0;
+  const int64_t wg_base = uniform64(indptr[r0 < n_rows ? r0 : n_rows]);
+  const int32_t* __restrict__ ib = indices + wg_base;
+  const float* __restrict__ vb = values + wg_base;
+  float* __restrict__ ob = out + wg_base;
+  const int64_t SW = (S + M - 1) / M;
+  for (int64_t sw = 0; sw < SW; ++sw) {
+    const int64_t s_lo = sw * M, s_hi = (sw + 1) * M < S ? (sw + 1) * M : S;
+    const int32_t cbase = (int32_t)(s_lo * kSlab);
+    const int64_t ncol_here = (n_cols - (int64_t)cbase) < (int64_t)kSlab * M ? (n_cols - (int64_t)cbase) : (int64_t)kSlab * M;
+    for (int t = threadIdx.x; t < kSlab * M; t += kSweepThreads) lidf[t] = t < ncol_here ? idf[cbase + t] : 0.f;
+    __syncthreads();
+    for (int64_t strip = r0 + wave; strip < r1; strip += (int64_t)kSweepWaves * 64) {
+      const int64_t myrow = strip + (int64_t)kSweepWaves * lane;
+      int lo_l = 0, hi_l = 0;
+      float inv_l = 0.f;
+      if (myrow < r1) {
+        lo_l = (int)(sp[myrow * (S + 1) + s_lo] - wg_base);
+        hi_l = (int)(sp[myrow * (S + 1) + s_hi] - wg_base);
+        inv_l = 1.0f / (float)rowsum[myrow];  // preproc.py:94  1.0 / n_peaks
+      }
+      const int64_t left = (r1 - strip + kSweepWaves - 1) / kSweepWaves;
+      const int nrow = left < 64 ? (int)left : 64;  // wave-uniform
+      for (int l = 0; l < nrow; ++l) {
+        const int lo = __builtin_amdgcn_readlane(lo_l, l), hi = __builtin_amdgcn_readlane(hi_l, l);
+        if (lo >= hi) continue;
+        const float inv = __shfl(inv_l, l, 64);
+        for (int p0 = lo + lane; p0 < hi; p0 += 64 * CH) {
+          int32_t c[CH];
+          float x[CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int p = p0 + 64 * u;
+            const bool ok = p < hi;
+            c[u] = ok ? ib[p] : cbase;
+            x[u] = ok ? vb[p] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int p = p0 + 64 * u;
+            if (p < hi) {
+              float t = inv * x[u];                               // :96  D @ counts
+              if (use_scale) t = t * scale;                       // :101-102
+              if (flags & MU_TFIDF_LOG_TF) t = log1p_wave(t);     // :103-104
+              t = t * lidf[c[u] - cbase];                         // :110-112  tf @ diag(idf)
+              if (flags & MU_TFIDF_LOG_TFIDF) t = log1p_wave(t);  // :116-117
+              ob[p] = t;
+              zeros += (t == 0.f) ? 1u : 0u;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (zero_count) {
+    zeros = wave_sum(zeros);
+    if (lane == 0 && zeros) atomicAdd(zero_count, (unsigned long long)zeros);
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // explicit-zero compaction, scan, fill
 // ---------------------------------------------------------------------------------
@@ -551,7 +632,13 @@ int mu_tfidf_scale_sweep(int dtype, int64_t n_rows, int64_t n_cols, const int64_
   }
   const int use_scale = !(scale == 0.0 || scale == 1.0);  // preproc.py:101
   const int G = sweep_grid();
-  if (dtype == MU_DTYPE_F32)
+  // f32: idf slabs of 4 x 8192 columns, one workgroup per CU (r04: 18.2 -> 14.4 ms at 1e6 x 200k, bit-identical;
+  // tune "tfidf_wide" = 1 keeps the 8192-column kernel for comparison)
+  if (dtype == MU_DTYPE_F32 && mu_tune_get("tfidf_wide") != 1)
+    hipLaunchKernelGGL((k_tfidf_scale_sweep_wide<4, 4>), dim3(mu_num_cus()), dim3(kSweepThreads), 0, st, n_rows, n_cols,
+                       S, d_indptr, d_indices, (const float*)d_values, sp, d_rowsum, (const float*)d_idf,
+                       (float)scale, use_scale, flags, (float*)d_out, d_zero_count);
+  else if (dtype == MU_DTYPE_F32)
     hipLaunchKernelGGL(k_tfidf_scale_sweep<float>, dim3(G), dim3(kSweepThreads), 0, st, n_rows, n_cols, S,
                        d_indptr, d_indices, (const float*)d_values, sp, d_rowsum, (const float*)d_idf,
                        (float)scale, use_scale, flags, (float*)d_out, d_zero_count);

@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int kTSlab = 8192;  // columns per slab of the count pass: 32 KiB of LDS bins
+constexpr int kTSlab = 8192;  // columns per slab of the count pass: 32 KiB of LDS bins (= sweep.hpp kSlab: shared pointers)
 constexpr int kTThreads = 1024;
 constexpr int kTWaves = kTThreads / 64;
 
@@ -679,7 +679,7 @@ size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz) {
 
 int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
                        const int32_t* d_indices, int64_t* d_col_nnz, void* d_work,
-                       size_t work_bytes, void* stream) {
+                       size_t work_bytes, const int64_t* d_slab_ptr, void* stream) {
   MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative size");
   MU_REQUIRE(n_rows < ((int64_t)1 << 31), "row ids must fit int32");
   if (n_cols == 0) return MU_OK;
@@ -695,11 +695,13 @@ int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_
     int64_t blocks = (total + 255) / 256;
     const int64_t cap = (int64_t)mu_num_cus() * 32;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_t_slab_ptr, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, S, d_indptr,
-                       d_indices, w.sp);
-    MU_CHECK_LAUNCH();
+    if (!d_slab_ptr) {  // (the TF-IDF sweeps of the same index arrays searched the same slabs: sweep.hpp kSlab)
+      hipLaunchKernelGGL(k_t_slab_ptr, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, S, d_indptr,
+                         d_indices, w.sp);
+      MU_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(k_t_count, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, S, d_indptr,
-                       d_indices, w.sp, w.cnt);
+                       d_indices, d_slab_ptr ? d_slab_ptr : w.sp, w.cnt);
     MU_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(k_t_base, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, n_cols, G,

@@ -48,3 +48,24 @@ def both():
 
 t = timeit(both)
 print(f"sum sweep + scale sweep (pointers shared): {t:.2f} ms  {20 * nnz / t / 1e9:.2f} TB/s")
+
+# r04: the scale sweep's idf slabs (tune key "tfidf_wide": 1 = the 8192-column kernel, else 4 x 8192 columns)
+be.tune("tfidf_wide", 1)
+be.row_col_sums(X)
+ref, _ = be.tfidf_scale(X, rs, idf, 1e4, 3)
+for wide in (1, 0):
+    be.tune("tfidf_wide", wide)
+    be.row_col_sums(X)
+    got, _ = be.tfidf_scale(X, rs, idf, 1e4, 3)
+    same = bool(torch.equal(got, ref))
+    be.row_col_sums(X)
+    kept = be.__dict__.get("_sweep_work")
+
+    def scale_only():
+        be._sweep_work = kept
+        be.tfidf_scale(X, rs, idf, 1e4, 3, out=out)
+
+    t = timeit(scale_only) if kept is not None else float("nan")
+    t2 = timeit(both)
+    print(f"tfidf_wide {wide}: scale sweep alone {t:.2f} ms ({12 * nnz / t / 1e9:.2f} TB/s), sum + scale {t2:.2f} ms, bit-identical {same}")
+be.tune("tfidf_wide", 0)
