@@ -219,6 +219,12 @@ int mu_spmm_stream_f64(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
 int mu_spmm_ell16_waves(int64_t n_rows);
 int mu_spmm_ell16_f32(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr, const int64_t* d_wave_base,
                       const void* d_ent, const int32_t* d_perm, const float* d_Q, float* d_Y, void* stream);
+/* The same operand format against an f64 block (f64 products and sums; mofapy2's default precision): Q rows are 128
+ * bytes, so the slabs are 512 columns and offset = column % 512 * 128.  Stored values stay f32 - an f64-valued matrix
+ * is two operands, hi = fl32(v) and lo = fl32(v - hi), and two launches, the second with accumulate != 0. */
+int mu_spmm_ell16_f64(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr, const int64_t* d_wave_base,
+                      const void* d_ent, const int32_t* d_perm, const double* d_Q, double* d_Y, int accumulate,
+                      void* stream);
 
 /* ---- matrix-core SpMM of the LSI iteration (r04; csrc/spmm_mfma.hip) --------------------------------------
  * Replaces, like mu_spmm_stream_f32, the csr_matvec / csr_matvecs calls of ARPACK's reverse-communication loop

@@ -114,6 +114,20 @@ class DeviceEll:
     nnz: int
     slots: int = 0
     waves: int = 15  # row-owning waves per workgroup of the launch (mu_spmm_ell16_waves; not part of the layout)
+    slab_cols: int = 1024  # 1024: against f32 blocks (64-byte Q rows); 512: against f64 blocks (128-byte Q rows)
+
+
+@dataclass
+class SplitEll:
+    """An f64-valued matrix as sliced-ELL operands for f64 blocks: v = hi + lo, hi = fl32(v), lo = fl32(v - hi);
+    ``lo`` is None when every value is exact in f32.  SpMM-only."""
+
+    hi: DeviceEll
+    lo: Optional[DeviceEll]
+
+    @property
+    def shape(self):
+        return self.hi.shape
 
 
 _NULL_CTX = contextlib.nullcontext()
@@ -140,12 +154,16 @@ def pick_block(width: int) -> int:
     )
 
 
-def ell16_layout(X: DeviceCSR, waves: int = 15) -> "DeviceEll":
+def ell16_layout(X: DeviceCSR, waves: int = 15, slab_cols: int = 1024) -> "DeviceEll":
     """The sliced-ELL layout of csrc/spmm_ell.hip as tensor operations on X's device (built once per fit; its cost
-    does not matter).  See DeviceEll / include/muon_amd.h for the format."""
+    does not matter).  See DeviceEll / include/muon_amd.h for the format.  ``slab_cols`` = 1024 for f32 blocks, 512
+    for f64 blocks (a slab is 64 KiB of Q rows)."""
+    assert slab_cols in (1024, 512) and X.values.dtype == torch.float32
     n, d = X.shape
     dev = X.indices.device
-    S = -(-d // 1024)
+    S = -(-d // slab_cols)
+    shift = 10 if slab_cols == 1024 else 9
+    row_shift = 6 if slab_cols == 1024 else 7
     lens = X.indptr[1:] - X.indptr[:-1]
     order = torch.argsort(lens, descending=True, stable=True)       # position -> row: alike rows share a group
     n_groups = -(-n // 16)
@@ -156,7 +174,7 @@ def ell16_layout(X: DeviceCSR, waves: int = 15) -> "DeviceEll":
     inv[order] = torch.arange(n, device=dev)
     rows = torch.repeat_interleave(torch.arange(n, device=dev), lens)
     pos = inv[rows]
-    sl = (X.indices >> 10).to(torch.int64)
+    sl = (X.indices >> shift).to(torch.int64)
     cnt = torch.bincount(pos * S + sl, minlength=n_pos * S).view(n_pos, S)      # entries per (position, slab)
     nwin = (cnt.view(n_groups, 16, S).amax(dim=1) + 3) // 4                       # [group, slab]: the longest row
     flat = nwin.reshape(-1)
@@ -174,11 +192,11 @@ def ell16_layout(X: DeviceCSR, waves: int = 15) -> "DeviceEll":
     vals = torch.zeros(((total + 8) * 64,), dtype=torch.float32, device=dev)      # (+ 8: the ring reads ahead)
     offs = torch.zeros(((total + 8) * 64,), dtype=torch.int16, device=dev)
     vals[dest] = X.values
-    off = (X.indices.to(torch.int32) & 1023) << 6                                 # u16 bit pattern in an int16
+    off = (X.indices.to(torch.int32) & (slab_cols - 1)) << row_shift              # u16 bit pattern in an int16
     offs[dest] = torch.where(off >= 32768, off - 65536, off).to(torch.int16)
     ent = torch.cat([vals.view(torch.uint8).view(-1, 256), offs.view(torch.uint8).view(-1, 128)], dim=1).contiguous()
     del vals, offs
-    return DeviceEll(hdr, wave_base, ent, perm, (n, d), X.nnz, total * 64, int(waves))
+    return DeviceEll(hdr, wave_base, ent, perm, (n, d), X.nnz, total * 64, int(waves), int(slab_cols))
 
 
 class HipBackend:
@@ -578,21 +596,42 @@ class HipBackend:
         return perm, inv, K
 
     # -- sliced-ELL operand of the narrow-block SpMM (csrc/spmm_ell.hip) ---------------------------
-    def ell16(self, X: DeviceCSR) -> DeviceEll:
-        """Lay a canonical f32 CSR out for mu_spmm_ell16_f32 (once per fit: the operand of MOFA's sparse views is
-        multiplied hundreds of times)."""
-        assert X.values.dtype == torch.float32
-        return ell16_layout(X, int(self.lib.mu_spmm_ell16_waves(X.shape[0])))
+    def ell16(self, X: DeviceCSR, wide: bool = False):
+        """Lay a canonical CSR out for mu_spmm_ell16_f32 / _f64 (once per fit: the operand of MOFA's sparse views is
+        multiplied hundreds of times).  f32 values -> DeviceEll; ``wide`` (against f64 blocks): 512-column slabs,
+        and f64 values -> SplitEll (hi + lo)."""
+        waves = int(self.lib.mu_spmm_ell16_waves(X.shape[0]))
+        cols = 512 if wide else 1024
+        if X.values.dtype == torch.float32:
+            return ell16_layout(X, waves, cols)
+        assert wide and X.values.dtype == torch.float64
+        hi = X.values.to(torch.float32)
+        rest = X.values - hi.to(torch.float64)
+        e_hi = ell16_layout(X.with_values(hi), waves, cols)
+        if bool((rest != 0).any().item()):
+            return SplitEll(e_hi, ell16_layout(X.with_values(rest.to(torch.float32)), waves, cols))
+        return SplitEll(e_hi, None)
 
-    def spmm_ell(self, E: DeviceEll, Q: torch.Tensor, out=None) -> torch.Tensor:
+    def spmm_ell(self, E: DeviceEll, Q: torch.Tensor, out=None, accumulate: bool = False) -> torch.Tensor:
         n, d = E.shape
-        if Q.shape != (d, 16) or Q.dtype != torch.float32 or not Q.is_contiguous():
-            raise TypeError("the sliced-ELL SpMM needs a contiguous f32 block of 16 columns")
+        wide = Q.dtype == torch.float64
+        if Q.shape != (d, 16) or Q.dtype not in (torch.float32, torch.float64) or not Q.is_contiguous():
+            raise TypeError("the sliced-ELL SpMM needs a contiguous f32 / f64 block of 16 columns")
+        if E.slab_cols != (512 if wide else 1024):
+            raise TypeError("sliced-ELL operand laid out for the other block type (slab width)")
+        if accumulate and not wide:
+            raise TypeError("accumulating sliced-ELL products exist for f64 blocks only")
         if out is None:
-            out = self.empty((n, 16), torch.float32)
+            assert not accumulate
+            out = self.empty((n, 16), Q.dtype)
         with self._dev_ctx():
-            check(self.lib.mu_spmm_ell16_f32(E.waves, int(E.perm.numel()), d, _p(E.hdr), _p(E.wave_base), _p(E.ent),
-                                             _p(E.perm), _p(Q), _p(out), self._stream()))
+            if wide:
+                check(self.lib.mu_spmm_ell16_f64(E.waves, int(E.perm.numel()), d, _p(E.hdr), _p(E.wave_base),
+                                                 _p(E.ent), _p(E.perm), _p(Q), _p(out), int(bool(accumulate)),
+                                                 self._stream()))
+            else:
+                check(self.lib.mu_spmm_ell16_f32(E.waves, int(E.perm.numel()), d, _p(E.hdr), _p(E.wave_base),
+                                                 _p(E.ent), _p(E.perm), _p(Q), _p(out), self._stream()))
         return out
 
     # -- matrix-core SpMM operand (csrc/spmm_mfma.hip) ------------------------------------------
@@ -748,9 +787,13 @@ class HipBackend:
         if isinstance(X, DeviceCells):
             assert not accumulate
             return self.spmm_cells(X, Q, out=out)
+        if isinstance(X, SplitEll):
+            out = self.spmm_ell(X.hi, Q, out=out, accumulate=accumulate)
+            if X.lo is not None:
+                self.spmm_ell(X.lo, Q, out=out, accumulate=True)
+            return out
         if isinstance(X, DeviceEll):
-            assert not accumulate
-            return self.spmm_ell(X, Q, out=out)
+            return self.spmm_ell(X, Q, out=out, accumulate=accumulate)
         if isinstance(X, DeviceStream):
             wide = Q.dtype == torch.float64
             if B not in ((16, 32) if wide else (16, 32, 64)):

@@ -235,6 +235,12 @@ class MofaEngine:
             # f32: both directions read row streams, built once
             V.Xt = be.transpose_stream(V.X)
             V.Xs = be.stream(V.X)
+        elif (self.T == torch.float64 and hasattr(be, "ell16") and _pad_block(self.G * self.K) == 16
+              and V.X.shape[0] > 0 and V.X.shape[1] > 0):
+            # f64 (the reference's default precision), factor blocks of <= 16 columns: the same static layout with
+            # f32 stored values - one operand when the data is exact in f32, hi + lo otherwise - against f64 blocks
+            V.Xt = be.ell16(be.transpose(V.X), wide=True)
+            V.Xs = be.ell16(V.X, wide=True)
         elif (self.T == torch.float64 and hasattr(be, "split_streams") and _pad_block(self.G * self.K) <= 32
               and V.X.shape[0] > 0 and V.X.shape[1] > 0):
             # f64 (the reference's default precision): the same row streams with f32 stored values -

@@ -74,6 +74,7 @@ SIGNATURES = {
     "mu_spmm_cells_f32": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_spmm_ell16_waves": (C.c_int, [_i64]),
     "mu_spmm_ell16_f32": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mu_spmm_ell16_f64": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "mu_probe_tr16": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
     "mu_probe_mfma16": (C.c_int, [_vp, _vp, _vp, _vp]),
     "mu_tune_set": (C.c_int, [C.c_char_p, _i32]),

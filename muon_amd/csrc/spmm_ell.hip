@@ -28,6 +28,11 @@
 // register NAME (eight unrolled copies, left by a counted branch, no dispatch), 18 vector instructions, four LDS
 // reads and one global load per window of 64 slots.  Sums: a row's entries are added in stored (column) order,
 // slab after slab, in one accumulator: bit-reproducible and independent of the launch shape.
+//
+// DT = double: MOFA's default precision (tools.py:308 use_float32=False).  The stored values stay f32 (an f64
+// matrix is hi + lo, two operands and two launches, the second one accumulating - as for the row stream,
+// mu_spmm_stream_f64); Q rows are 128 bytes, so a slab is 512 columns, a lane's four columns two `ds_read_b128`
+// and four `v_fma_f64` per entry.
 #include <type_traits>
 #include <utility>
 
@@ -36,13 +41,14 @@
 
 namespace {
 
-constexpr int kESlab = 1024;              // Q rows per slab
-constexpr int kESlabBytes = kESlab * 64;  // 64 KiB, double buffered
+constexpr int kESlabBytes = 65536;        // a Q slab: 1024 rows of 16 f32 / 512 rows of 16 f64, double buffered
+template <typename DT> constexpr int slab_rows() { return kESlabBytes / (16 * (int)sizeof(DT)); }
 constexpr int kEMaxWaves = 15;            // row-owning waves of a workgroup (+ the producer wave)
 constexpr int kEDepth = 8;                // windows a wave keeps in flight (3 KiB)
 constexpr int kEWin = 384;                // bytes of a window: value[64] f32 | offset[64] u16
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void e_dma_piece(const void* base, unsigned byte_off, unsigned lds_dst) {
   unsigned keep;
@@ -104,21 +110,22 @@ __device__ __forceinline__ void e_take(const unsigned char* ahead, unsigned lane
 // one full memory latency per slab and wave, at the same moment in all waves (they leave the barrier together).
 // With one wave doing nothing but `issue the next slab, wait, barrier`, the others never wait for anything but
 // their own windows.   MODE (timing ablations, wrong results): 1 no gathers / FMAs, 2 no slab copies.
-template <int MODE>
+template <int MODE, typename DT>
 __global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_pos, int64_t n_cols, int n_slabs, int cw,
                                                                      const int32_t* __restrict__ hdr,
                                                                      const int64_t* __restrict__ wave_base,
                                                                      const unsigned char* __restrict__ ent,
                                                                      const int32_t* __restrict__ perm,
-                                                                     const float* __restrict__ Q,
-                                                                     float* __restrict__ Y) {
+                                                                     const DT* __restrict__ Q, DT* __restrict__ Y,
+                                                                     int accumulate) {
+  constexpr int kRowBytes = 16 * (int)sizeof(DT);
   __shared__ __attribute__((aligned(1024))) unsigned char slab[2 * kESlabBytes];
   const int lane = threadIdx.x & 63;
   const int wave = uniform32(threadIdx.x >> 6);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&slab[0]);
 
   if (wave == 0) {  // 64 pieces of 1 KiB per slab
-    const unsigned q_last = (unsigned)(n_cols * 64 - 16);  // (Q is n_cols rows of 64 bytes: the last slab is clamped)
+    const unsigned q_last = (unsigned)(n_cols * kRowBytes - 16);  // (the last slab is clamped to the end of Q)
     auto whole = [&](int s, int b) {
 #pragma unroll 8
       for (int piece = 0; piece < ((MODE & 2) ? 1 : kESlabBytes / 1024); ++piece) {
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_
   const bool active = gwave < n_waves;
   const unsigned lane4 = (unsigned)lane * 4u, lane2 = (unsigned)lane * 2u;
 
-  f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+  DT acc[4] = {(DT)0, (DT)0, (DT)0, (DT)0};
   asm volatile("" ::: MU_EL_CLOB);
 
   typedef __attribute__((address_space(4))) const int32_t* chdr_p;
@@ -153,7 +160,8 @@ __global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_
   auto counts_of = [&](int s) -> int { return active ? uniform32(myhdr[s]) : 0; };
   const unsigned char* wp = ent + uniform64(active ? wave_base[gwave] : 0) * kEWin + kEWin * kEDepth;  // next REQUEST
 
-  unsigned base = lds0 + (unsigned)(lane & 3) * 16u;  // this lane's four columns of the current slab buffer
+  const unsigned lane_c = (unsigned)(lane & 3) * (unsigned)(4 * sizeof(DT));
+  unsigned base = lds0 + lane_c;  // this lane's four columns of the current slab buffer
   // one window: 4 steps of 16 entries
   auto window = [&](auto dc) {
     constexpr int D = decltype(dc)::value;
@@ -162,8 +170,8 @@ __global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_
     e_take<D>(wp, lane4, lane2, base, adr, val);
     wp += kEWin;
     if constexpr (MODE & 1) {
-      acc[0] += val[0] + val[1] + val[2] + val[3] + (float)(adr[0] ^ adr[1] ^ adr[2] ^ adr[3]);
-    } else {
+      acc[0] += (DT)(val[0] + val[1] + val[2] + val[3] + (float)(adr[0] ^ adr[1] ^ adr[2] ^ adr[3]));
+    } else if constexpr (sizeof(DT) == 4) {
       typedef __attribute__((address_space(3))) const f4* lds_p;
       const f4 q0 = *(lds_p)adr[0];
       const f4 q1 = *(lds_p)adr[1];
@@ -177,6 +185,22 @@ __global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_
       for (int c = 0; c < 4; ++c) acc[c] = fmaf(val[2], q2[c], acc[c]);
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c] = fmaf(val[3], q3[c], acc[c]);
+    } else {
+      typedef __attribute__((address_space(3))) const d2* lds_p;
+      d2 q[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        q[j][0] = *(lds_p)adr[j];
+        q[j][1] = *(lds_p)(adr[j] + 16u);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double v = (double)val[j];
+        acc[0] = fma(v, q[j][0][0], acc[0]);
+        acc[1] = fma(v, q[j][0][1], acc[1]);
+        acc[2] = fma(v, q[j][1][0], acc[2]);
+        acc[3] = fma(v, q[j][1][1], acc[3]);
+      }
     }
   };
 
@@ -202,7 +226,7 @@ __global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_
       if (s + 1 >= n_slabs) return false;
       __syncthreads();  // through with slab s; the producer's slab s + 1 has landed
       ++s;
-      base = lds0 + (unsigned)(lane & 3) * 16u + (unsigned)(s & 1) * (unsigned)kESlabBytes;
+      base = lds0 + lane_c + (unsigned)(s & 1) * (unsigned)kESlabBytes;
       left = next_cnt;
       next_cnt = s + 1 < n_slabs ? counts_of(s + 1) : 0;
     } while (left == 0);
@@ -234,7 +258,11 @@ __global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_
   const int64_t p = gwave * 16 + r;
   if (active && p < n_pos) {
     const int64_t row = perm ? (int64_t)perm[p] : p;
-    if (row >= 0) *reinterpret_cast<f4*>(Y + row * 16 + 4 * c) = acc;
+    if (row >= 0) {
+      DT* y = Y + row * 16 + 4 * c;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) y[u] = accumulate ? y[u] + acc[u] : acc[u];
+    }
   }
 }
 
@@ -254,27 +282,49 @@ int mu_spmm_ell16_waves(int64_t n_rows) {
   return 14;
 }
 
-int mu_spmm_ell16_f32(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr, const int64_t* d_wave_base,
-                      const void* d_ent, const int32_t* d_perm, const float* d_Q, float* d_Y, void* stream) {
+static int ell16_launch(bool wide, int waves, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr,
+                        const int64_t* d_wave_base, const void* d_ent, const int32_t* d_perm, const void* d_Q, void* d_Y,
+                        int accumulate, void* stream) {
   MU_REQUIRE(waves >= 1 && waves <= kEMaxWaves, "row-owning waves per workgroup: 1 .. 15");
-  MU_REQUIRE(n_pos >= 0 && n_cols > 0 && n_cols * 64 < ((int64_t)1 << 32), "shape out of range");
+  const int64_t row_bytes = wide ? 128 : 64;
+  MU_REQUIRE(n_pos >= 0 && n_cols > 0 && n_cols * row_bytes < ((int64_t)1 << 32), "shape out of range");
   if (n_pos == 0) return MU_OK;
   MU_REQUIRE(d_hdr && d_wave_base && d_ent && d_Q && d_Y, "null pointer");
-  const int64_t n_slabs = (n_cols + kESlab - 1) / kESlab;
+  const int64_t slab = kESlabBytes / row_bytes;
+  const int64_t n_slabs = (n_cols + slab - 1) / slab;
   const int64_t n_waves = (n_pos + 15) / 16;
   const int64_t wgs = (n_waves + waves - 1) / waves;
-  const int mode = mu_tune_get("ell_mode");
+  const int mode = mu_tune_get("ell_mode") & 3;
   hipStream_t st = (hipStream_t)stream;
-#define MU_GO(MD)                                                                                          \
-  hipLaunchKernelGGL((k_spmm_ell16<MD>), dim3((unsigned)wgs), dim3(64 * (waves + 1)), 0, st, n_pos, n_cols, \
-                     (int)n_slabs, waves, d_hdr, d_wave_base, (const unsigned char*)d_ent, d_perm, d_Q, d_Y)
-  if ((mode & 3) == 1) MU_GO(1);
-  else if ((mode & 3) == 2) MU_GO(2);
-  else if ((mode & 3) == 3) MU_GO(3);
-  else MU_GO(0);
+#define MU_GO(MD, DT)                                                                                            \
+  hipLaunchKernelGGL((k_spmm_ell16<MD, DT>), dim3((unsigned)wgs), dim3(64 * (waves + 1)), 0, st, n_pos, n_cols,   \
+                     (int)n_slabs, waves, d_hdr, d_wave_base, (const unsigned char*)d_ent, d_perm, (const DT*)d_Q, \
+                     (DT*)d_Y, accumulate)
+  if (wide) {
+    if (mode == 1) MU_GO(1, double);
+    else if (mode == 2) MU_GO(2, double);
+    else if (mode == 3) MU_GO(3, double);
+    else MU_GO(0, double);
+  } else {
+    if (mode == 1) MU_GO(1, float);
+    else if (mode == 2) MU_GO(2, float);
+    else if (mode == 3) MU_GO(3, float);
+    else MU_GO(0, float);
+  }
 #undef MU_GO
   MU_CHECK_LAUNCH();
   return MU_OK;
+}
+
+int mu_spmm_ell16_f32(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr, const int64_t* d_wave_base,
+                      const void* d_ent, const int32_t* d_perm, const float* d_Q, float* d_Y, void* stream) {
+  return ell16_launch(false, waves, n_pos, n_cols, d_hdr, d_wave_base, d_ent, d_perm, d_Q, d_Y, 0, stream);
+}
+
+int mu_spmm_ell16_f64(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr, const int64_t* d_wave_base,
+                      const void* d_ent, const int32_t* d_perm, const double* d_Q, double* d_Y, int accumulate,
+                      void* stream) {
+  return ell16_launch(true, waves, n_pos, n_cols, d_hdr, d_wave_base, d_ent, d_perm, d_Q, d_Y, accumulate, stream);
 }
 
 }  // extern "C"

@@ -11,6 +11,7 @@ from tests.synth import planted_topics_csr
 
 
 def _walk(E):
+    slab, rb = E.slab_cols, 65536 // E.slab_cols
     """(row, col, value) of every non-padding slot, per group in consumption order"""
     hdr, base, ent, perm = E.hdr.numpy(), E.wave_base.numpy(), E.ent.numpy(), E.perm.numpy()
     n_groups, S = hdr.shape
@@ -26,14 +27,15 @@ def _walk(E):
                         v, off = vals[4 * r + j], int(offs[4 * r + j])
                         row = perm[w * 16 + r]
                         if v != 0 or off != 0:
-                            assert row >= 0 and off % 64 == 0 and off < 65536
-                            out.append((int(row), s * 1024 + off // 64, float(v)))
+                            assert row >= 0 and off % rb == 0 and off < 65536
+                            out.append((int(row), s * slab + off // rb, float(v)))
                 p += 1
     return out
 
 
+@pytest.mark.parametrize("slab", [1024, 512])
 @pytest.mark.parametrize("shape", [(70, 2500), (100, 1024), (37, 3000), (16, 90)])
-def test_layout_holds_every_entry_once_in_stored_order(shape):
+def test_layout_holds_every_entry_once_in_stored_order(shape, slab):
     m = planted_topics_csr(shape[0], shape[1], n_topics=4, density=0.06, seed=shape[0])
     m.data = (m.data + 0.5).astype(np.float32)  # no zero values: padding is recognisable
     keep = np.ones(shape[0]); keep[3] = 0  # an empty row
@@ -42,7 +44,7 @@ def test_layout_holds_every_entry_once_in_stored_order(shape):
     m.sort_indices()
     X = DeviceCSR(torch.from_numpy(m.indptr.astype(np.int64)), torch.from_numpy(m.indices.astype(np.int32)),
                   torch.from_numpy(m.data.astype(np.float32)), m.shape)
-    E = ell16_layout(X)
+    E = ell16_layout(X, 15, slab)
     got = _walk(E)
     coo = m.tocoo()
     want = sorted(zip(coo.row.tolist(), coo.col.tolist(), coo.data.tolist()))

@@ -69,6 +69,34 @@ def test_product_matches_f64_arithmetic(be, shape):
     assert np.all(g[np.diff(m.indptr) == 0] == 0)
 
 
+@pytest.mark.parametrize("shape", [(16, 40), (257, 1025), (1000, 5000)])
+@pytest.mark.parametrize("exact", [True, False])
+def test_f64_blocks_match_f64_arithmetic(be, shape, exact):
+    """f64 blocks: 512-column slabs, f32 stored values (hi + lo when the f64 values are not exact in f32)"""
+    n, d = shape
+    m = _ragged(n, d, seed=n + 3).astype(np.float64)
+    if not exact:
+        m.data = m.data * (1.0 + 1e-9 * np.arange(1, m.nnz + 1))  # not representable in f32
+    X = be.upload_csr(m.indptr, m.indices, m.data, m.shape, values_dtype=np.float64)
+    E = be.ell16(X, wide=True)
+    assert (E.lo is None) == exact and E.hi.slab_cols == 512
+    rng = np.random.default_rng(n)
+    Q = rng.standard_normal((d, 16))
+    Qd = torch.from_numpy(Q).to(be.device)
+    want = m @ Q
+    scale = np.abs(m) @ np.abs(Q) + 1e-300
+    got = be.spmm(E, Qd)
+    g = be.to_host(got)
+    assert np.max(np.abs(g - want) / scale) < (1e-14 if exact else 1e-13)  # hi + lo: exact to 2^-48 per value
+    assert torch.equal(got, be.spmm(E, Qd))
+    # accumulate: Y + X Q
+    acc = got.clone()
+    be.spmm(E, Qd, out=acc, accumulate=True)
+    assert np.max(np.abs(be.to_host(acc) - 2 * want) / scale) < 1e-12
+    with pytest.raises(TypeError):
+        be.spmm(E.hi, Qd.to(torch.float32))  # laid out for f64 blocks
+
+
 def test_default_layout_and_row_stream_agree_at_a_mofa_sized_view(be):
     n, d = 30000, 20000
     X = be.synth_counts(0, n, d, 50, 0.03, 0)
