@@ -168,7 +168,8 @@ def tfidf_device(backend, X, n_obs, flags: int, scale: float, comm=None, out=Non
     idf = backend.idf(colsum, float(n_obs), flags, X.values.dtype)
     vals, zero_count = backend.tfidf_scale(X, rowsum, idf, scale, flags, out=out)
     res = X.with_values(vals)
-    sp = backend.__dict__.pop("_last_slab_ptr", None) if hasattr(backend, "__dict__") else None
+    take = getattr(backend, "take_slab_ptr", None)  # (a method: wrappers of the backend forward it)
+    sp = take() if take is not None else None
     if int(zero_count.item()) != 0:
         # scipy's SpGEMM drops entries whose product is exactly 0
         res = backend.compact_nonzero(res)

@@ -433,6 +433,10 @@ class HipBackend:
                                               self._stream()))
 
     # -- LSI building blocks (reference tools.py:53 -> scipy svds) ---------------------
+    def take_slab_ptr(self):
+        """The slab pointers the last TF-IDF scale sweep left behind (once; None if there are none)."""
+        return self.__dict__.pop("_last_slab_ptr", None)
+
     @staticmethod
     def _slab_ptr_of(X: DeviceCSR):
         """The slab pointers the TF-IDF sweeps left with X (``tfidf_device``), if they describe X's index arrays."""

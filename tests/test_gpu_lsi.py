@@ -269,3 +269,37 @@ def test_widened_bench_records_run_small_and_hold_parity(hip):
     assert r["parity"]["elbo_max_rel"] < 1e-10 and r["parity"]["Z_max_abs"] < 1e-8 and r["elbo_monotone"]
     r = mod.run_wnn(hip, n=3000, sample=300)
     assert r["parity"]["graph_identical_fraction"] > 0.99 and r["parity"]["modality_weight_max_abs"] < 1e-4
+
+
+def test_transposition_takes_the_slab_pointers_tfidf_searched(hip):
+    """tfidf_device leaves the 8192-column slab pointers with its result; the transposition of that matrix reads them
+    instead of searching again (csrc/tpack.hip mu_csr_tpack_count d_slab_ptr) - same output, and a wrapper of the
+    backend (bench.py's TimedBackend) must not lose them"""
+    import torch
+
+    from muon_amd._atac.preproc import tfidf_device
+    from muon_amd._backend import DeviceCSR
+
+    class Wrapped:  # forwards like bench.TimedBackend
+        def __init__(self, be):
+            self._be = be
+
+        def __getattr__(self, name):
+            return getattr(self._be, name)
+
+    X = hip.synth_counts(0, 3000, 20000, 20, 0.03, 0)
+    for be in (hip, Wrapped(hip)):
+        T = tfidf_device(be, X, 3000, 3, 1e4)
+        sp_, key = T.slab_ptr
+        assert sp_.numel() == 3000 * (3 + 1) and key == (T.indptr.data_ptr(), T.indices.data_ptr(), 3000, 20000)
+        assert hip._slab_ptr_of(T) is sp_
+        plain = DeviceCSR(T.indptr, T.indices, T.values, T.shape)
+        assert hip._slab_ptr_of(plain) is None
+        a, b = hip.transpose_csr(T), hip.transpose_csr(plain)
+        assert torch.equal(a.indptr, b.indptr) and torch.equal(a.indices, b.indices) and torch.equal(a.values, b.values)
+        sa, sb = hip.transpose_stream(T), hip.transpose_stream(plain)
+        assert torch.equal(sa.sptr, sb.sptr) and torch.equal(sa.ent, sb.ent)
+    # pointers of other index arrays are not taken
+    other = DeviceCSR(T.indptr.clone(), T.indices.clone(), T.values, T.shape)
+    other.slab_ptr = T.slab_ptr
+    assert hip._slab_ptr_of(other) is None
