@@ -106,6 +106,25 @@ def _ritz(Tm: np.ndarray, Mm: np.ndarray, want: int):
     whose directions without independent content are truncated instead of inverted."""
     n = Mm.shape[0]
     Mm = (Mm + Mm.T) / 2
+    # M = I + E with E at the level of f32 rounding (orthonormalised, projected blocks: the normal case): the symmetric
+    # reduction M^-1/2 T M^-1/2 to first order, T - (E T + T E) / 2, and M^-1/2 = I - E / 2 for the vectors - two small
+    # matrix products instead of Cholesky + triangular inverse + two products (r04: 0.9 -> 0.2 ms on a 128-row pencil;
+    # the neglected terms are O(E^2) <= 1e-10 relative, far below the f32 floor of the blocks themselves)
+    E = Mm - np.eye(n)
+    if n and float(np.abs(E).max()) < 1e-5:
+        H = E @ Tm
+        Tr = Tm - (H + H.T) / 2
+        Tr = (Tr + Tr.T) / 2
+        got = min(want, n)
+        th, Wr, info_ = scipy.linalg.lapack.dsyevd(Tr, lower=1)
+        if info_ != 0:
+            th, Wr = np.linalg.eigh(Tr)
+        Wt = np.ascontiguousarray(Wr[:, n - got:][:, ::-1])
+        C = np.zeros((n, want))
+        C[:, :got] = Wt - (E @ Wt) / 2
+        lam = np.zeros(want)
+        lam[:got] = np.maximum(th[::-1][:got], 0)
+        return lam, C
     S = None
     try:
         L = np.linalg.cholesky(Mm)
@@ -284,19 +303,25 @@ def _lsi_device(
                 A[j * w:(j + 1) * w, i * w:(i + 1) * w] = G.T
         return A
 
-    def launch_block_grams(j):
-        # new row/column j of T (needs the sum over row shards) and of M (replicated); the results
-        # travel to the host asynchronously so that the caller can queue more device work first
-        Gj, cs = backend.gram(Ys[j])
-        cross = [backend.gram_cross(Ys[i], Ys[j]) for i in range(j)]
+    def launch_grams(Ynew, Yolds, Qnew, Qolds):
+        # a new row / column of T (needs the sum over row shards) and of M (replicated) against the given blocks;
+        # the results travel to the host asynchronously so that the caller can queue more device work first
+        Gj, cs = backend.gram(Ynew)
+        cross = [backend.gram_cross(Yi, Ynew) for Yi in Yolds]
         comm.all_reduce_sum(Gj, cs, *cross)
-        mq = [backend.gram(Qs[j])[0]] + [backend.gram_cross(Qs[i], Qs[j]) for i in range(j)]
+        mq = [backend.gram(Qnew)[0]] + [backend.gram_cross(Qi, Qnew) for Qi in Qolds]
         extra = [pending_g1, qr_flag] if (device_qr and pending_g1 is not None) else []
-        return backend.fetch_async([Gj, cs] + cross + mq + extra), bool(extra)
+        return backend.fetch_async([Gj, cs] + cross + mq + extra), bool(extra), len(Yolds)
 
-    def collect_block_grams(j, handle_extra):
+    def launch_block_grams(j):
+        return launch_grams(Ys[j], Ys[:j], Qs[j], Qs[:j])
+
+    def collect_block_grams(j, handle_extra, through=None):
+        """Block row / column j of T and M from a launch_grams handle.  ``through`` (an (m_old w) x (j w) coefficient
+        matrix): the launch was made against the m_old blocks of BEFORE a thick restart - the cross blocks against
+        the j kept blocks K Cw are Cw^T applied to the stacked old ones."""
         nonlocal beta_hat, pending_g1
-        handle, has_extra = handle_extra
+        handle, has_extra, n_old = handle_extra
         got = handle.wait()
         if has_extra:
             if int(got[-1].reshape(-1)[0]) != 0:
@@ -307,11 +332,18 @@ def _lsi_device(
             got = got[:-2]
         Tb[(j, j)] = got[0][:w, :w]
         css.append(got[1][:w])
-        for i in range(j):
-            Tb[(i, j)] = got[2 + i][:w, :w]
-        Mb[(j, j)] = got[2 + j][:w, :w]
-        for i in range(j):
-            Mb[(i, j)] = got[3 + j + i][:w, :w]
+        Mb[(j, j)] = got[2 + n_old][:w, :w]
+        t_old = [got[2 + i][:w, :w] for i in range(n_old)]
+        m_old = [got[3 + n_old + i][:w, :w] for i in range(n_old)]
+        if through is None:
+            assert n_old == j
+            for i in range(j):
+                Tb[(i, j)], Mb[(i, j)] = t_old[i], m_old[i]
+        else:
+            ts, ms = np.vstack(t_old), np.vstack(m_old)  # (m_old w) x w
+            for i in range(j):
+                blk = slice(i * w, (i + 1) * w)
+                Tb[(i, j)], Mb[(i, j)] = through[:, blk].T @ ts, through[:, blk].T @ ms
 
     def add_block_grams(j):
         collect_block_grams(j, launch_block_grams(j))
@@ -378,18 +410,43 @@ def _lsi_device(
         comm.all_reduce_sum(Zn)
         return Zn
 
+    # Small inputs (a product costs less than the host's Ritz step): the half of the NEXT expansion that does not need
+    # this step's Ritz pairs - projection of Z against the blocks as they are, CholeskyQR, the product X Q_{j+1} and its
+    # Grams against the present blocks - is queued before the host starts the Ritz step and runs under it (r04).  A
+    # thick restart in between only re-expresses the kept blocks as K Cw: the new block is orthogonal to their span
+    # either way, and its cross Grams are Cw^T applied to the ones computed against the old blocks (collect_block_grams
+    # `through`).  A wrong guess ("not the last step") costs the two products it queued.
+    pipeline = device_qr and not big_products and os.environ.get("MUON_AMD_LSI_PIPELINE", "1") != "0"
+
+    def speculate(Z):
+        nonlocal pending_g1
+        if w < B:
+            Z[:, w:] = 0
+        Zp = _project_out(backend, Z, Qs, passes=1)
+        Zp, G1 = _orthonormalize(backend, Zp, w, passes=2, flag=qr_flag)
+        pending_g1 = G1
+        Zp = _project_out(backend, Zp, Qs, passes=1)
+        Yn = product(X, Zp)
+        handle = launch_grams(Yn, list(Ys), Zp, list(Qs))
+        pending_g1 = None  # (travels with `handle`)
+        return Zp, Yn, handle
+
+    cur = None  # (Grams of block j already launched, coefficient matrix of a restart in between)
     while True:
         j = len(Qs) - 1
-        Ys.append(product(X, Qs[j]))
-        grams = launch_block_grams(j)
+        if cur is None:
+            Ys.append(product(X, Qs[j]))
+            cur = (launch_block_grams(j), None)
         # The host's Ritz step (a few ms of LAPACK on (m w)^2 matrices) would leave the GPU idle.
         # Unless this step is expected to be the last one, X^T Y_j - needed by every step but the
         # last - is queued BEFORE the host waits for the Grams, so the Ritz step runs under it.
         Z = None
         if it < limit and not (n_iter is None and expect_final):
             Z = expand_product(j)
+        nxt = speculate(Z) if (pipeline and Z is not None) else None
         t_w = time.perf_counter()
-        collect_block_grams(j, grams)
+        collect_block_grams(j, cur[0], through=cur[1])
+        cur = None
         t_r = time.perf_counter()
         host["wait_ms"] += 1e3 * (t_r - t_w)
         # The Ritz step of the very first block cannot end the iteration (no residual estimate exists before the
@@ -475,19 +532,23 @@ def _lsi_device(
                 # "converged" is a statement about the ANGLE, not about having stopped: the Lanczos bound
                 # and the f32 floor together must be under the parity target of the north star (1e-4)
                 converged = bool(np.hypot(bound, floor) < ANGLE_TARGET)
-                wasted += Z is not None  # queued on a wrong prediction; the result is simply not used
+                wasted += (Z is not None) + (nxt is not None)  # queued on a wrong prediction; the results are simply not used
+                if nxt is not None and hasattr(nxt[2][0], "release"):
+                    nxt[2][0].release()
                 break
         # expand: next Krylov block
         if Z is None:
             Z = expand_product(j)
         if not enough:
             expect_final = False
-        if w < B:
-            Z[:, w:] = 0
-        before = None if device_qr else float(np.trace(backend.gram(Z)[0].cpu().numpy()[:w, :w]))
-        # the next block is the part of A Q_j outside the WHOLE space built so far - also when that
-        # space is about to be compressed: the residuals of all its Ritz vectors lie in this block
-        Z = _project_out(backend, Z, Qs, passes=1)  # (the second pass follows the normalisation below)
+        if nxt is None:
+            if w < B:
+                Z[:, w:] = 0
+            before = None if device_qr else float(np.trace(backend.gram(Z)[0].cpu().numpy()[:w, :w]))
+            # the next block is the part of A Q_j outside the WHOLE space built so far - also when that
+            # space is about to be compressed: the residuals of all its Ritz vectors lie in this block
+            Z = _project_out(backend, Z, Qs, passes=1)  # (the second pass follows the normalisation below)
+        through = None
         if len(Qs) >= (early_cap if (early_cap is not None and it < 5) else max_blocks):
             # thick restart: the top-w Ritz vectors (and their images X v, linear combinations of
             # the Y_i: no SpMM) replace the blocks; the Krylov process continues from Z
@@ -513,6 +574,14 @@ def _lsi_device(
             C = np.zeros((keep, k))
             C[:k, :k] = np.eye(k)  # the kept Ritz vectors are the leading columns of the new blocks
             restarts += 1
+            through = Cw
+        if nxt is not None:
+            # the next block, its image and their Grams (against the blocks of before the restart) are under way
+            Qs.append(nxt[0])
+            Ys.append(nxt[1])
+            cur = (nxt[2], through)
+            it += 1
+            continue
         Z, G1 = _orthonormalize(backend, Z, w, passes=2, flag=qr_flag)
         if device_qr:
             pending_g1 = G1  # read with the Grams of the next step (no host round trip here)

@@ -759,21 +759,18 @@ class HipBackend:
         """Start device -> host copies of small tensors into pinned staging buffers; ``wait()`` on
         the returned handle blocks only until these copies are done - work queued on the stream
         afterwards keeps running (the host-side Ritz step of the LSI hides under the next SpMM)."""
-        pool = self.__dict__.setdefault("_pinned", {})
+        # a staging buffer belongs to ONE handle until its wait() has copied the data out (several fetches can be in
+        # flight: the pipelined LSI loop starts the next block's fetch before it reads the current one)
+        pool = self.__dict__.setdefault("_pinned_free", {})
         bufs = []
-        used = {}
         for t in tensors:
-            key = (tuple(t.shape), t.dtype)
-            n = used.get(key, 0)
-            used[key] = n + 1
-            slot = pool.setdefault(key, [])
-            if len(slot) <= n:
-                slot.append(torch.empty(t.shape, dtype=t.dtype, pin_memory=True))
-            bufs.append(slot[n])
-            bufs[-1].copy_(t, non_blocking=True)
+            free = pool.setdefault((tuple(t.shape), t.dtype), [])
+            buf = free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            bufs.append(buf)
+            buf.copy_(t, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        return _Fetch(bufs, ev)
+        return _Fetch(bufs, ev, pool)
 
     def tune(self, key: str, value: int) -> None:
         check(self.lib.mu_tune_set(key.encode(), int(value)))
@@ -1050,12 +1047,25 @@ class HipBackend:
 
 
 class _Fetch:
-    def __init__(self, bufs, event):
-        self.bufs, self.event = bufs, event
+    def __init__(self, bufs, event, pool=None):
+        self.bufs, self.event, self.pool = bufs, event, pool
 
     def wait(self):
         self.event.synchronize()
-        return [b.numpy().copy() for b in self.bufs]
+        out = [b.numpy().copy() for b in self.bufs]
+        if self.pool is not None:  # the staging buffers go back to the pool (an abandoned handle keeps its own)
+            for b in self.bufs:
+                self.pool.setdefault((tuple(b.shape), b.dtype), []).append(b)
+            self.bufs, self.pool = [], None
+        return out
+
+    def release(self):
+        """Give the staging buffers back without reading them (an abandoned fetch).  Safe without waiting: the next
+        copy into a buffer is queued on the same stream behind this one, and its reader waits for its own event."""
+        if self.pool is not None:
+            for b in self.bufs:
+                self.pool.setdefault((tuple(b.shape), b.dtype), []).append(b)
+            self.bufs, self.pool = [], None
 
 
 _default_backend = None

@@ -119,6 +119,26 @@ class CpuTestBackend:
             return out
         return r
 
+    def chol_rinv(self, G, w, flag):
+        """what mu_chol_rinv_f64 computes: R^-1 (f32, B x B) of the leading w x w block of G = R^T R; a pivot that
+        is not safely positive sets ``flag`` (and is replaced by the threshold, like the kernel does)"""
+        Bw = G.shape[0]
+        g = G.numpy()[:w, :w].astype(np.float64).copy()
+        dmax = float(np.max(np.diag(g))) if w else 0.0
+        tiny = dmax * 1e-13 if dmax > 0 else 1.0
+        L = np.zeros((w, w))
+        for k in range(w):  # (unblocked, pivots clamped)
+            piv = g[k, k] - L[k, :k] @ L[k, :k]
+            if not piv > tiny:
+                flag[0] = 1
+                piv = tiny
+            L[k, k] = np.sqrt(piv)
+            L[k + 1:, k] = (g[k + 1:, k] - L[k + 1:, :k] @ L[k, :k]) / L[k, k]
+        M = np.zeros((Bw, Bw), dtype=np.float32)
+        if w:
+            M[:w, :w] = np.linalg.inv(L).T.astype(np.float32)
+        return torch.from_numpy(M)
+
     def project_out_block(self, Q, C, Z):
         Z -= self.apply(Q, C.to(torch.float32).contiguous())
         return Z

@@ -338,3 +338,35 @@ def test_lsi_more_components_than_rank_stops_with_exact_values():
     want = np.linalg.svd(X.toarray().astype(np.float64), compute_uv=False)
     np.testing.assert_allclose(s[:20], want[:20], rtol=1e-5)
     assert np.all(s[20:] < 1e-4 * s[0]) and info["iterations"] <= 3 and info["spmm"] <= 7
+
+
+@pytest.mark.parametrize("n_comps,max_blocks", [(8, 2), (8, 12), (70, None)])
+def test_lsi_pipelined_expansions_give_the_same_answer(monkeypatch, n_comps, max_blocks):
+    """r04: with the device-side CholeskyQR the C-independent half of the next expansion is queued before the host's
+    Ritz step (tools.py `speculate`), across thick restarts (cross Grams transformed by Cw on the host).  Same
+    subspace, same singular values, same number of expansions as the unpipelined loop; the speculation that turns
+    out wrong at the last step is reported."""
+    from muon_amd._atac.tools import lsi_device
+
+    if n_comps > 64:
+        X = planted_topics_csr(2000, 1500, n_topics=70, density=0.06, seed=5, dtype=np.float32)
+    else:
+        X = planted_topics_csr(600, 400, n_topics=8, density=0.08, seed=11, dtype=np.float32)
+    T, Xd = _device_tfidf(X)
+    ref = lsi_oracle.lsi(T, n_comps=n_comps)
+    kw = dict(n_comps=n_comps, return_info=True, device_qr=True)
+    if max_blocks is not None:
+        kw.update(oversample=8, max_blocks=max_blocks)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MUON_AMD_LSI_PIPELINE", mode)
+        _, sd, V, info = lsi_device(BE, Xd, **kw)
+        assert info["converged"]
+        assert lsi_oracle.max_subspace_angle(V.numpy(), ref["LSI"]) < 1e-4
+        np.testing.assert_allclose(sd, ref["stdev"], rtol=1e-5)
+        out[mode] = (sd, V.numpy(), info)
+    a, b = out["0"], out["1"]
+    assert a[2]["iterations"] == b[2]["iterations"] and a[2]["restarts"] == b[2]["restarts"]
+    assert lsi_oracle.max_subspace_angle(a[1], b[1]) < 2e-5
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-6)
+    assert a[2]["spmm_unused"] <= 1 and b[2]["spmm_unused"] <= 2  # the pipelined loop runs ahead by two products
