@@ -368,6 +368,13 @@ int mu_mofa_rowstats(int dtype, int64_t r0, int64_t r1, int K, const void* d_E, 
 int mu_knn_filter_f64(int64_t n_q, int64_t c_lo, int64_t c_hi, int p_pad, const double* d_Xq, const double* d_Xc,
                       const double* d_sqq, const double* d_sqc, const double* d_thr, const int32_t* d_self_pos,
                       int cap, int32_t* d_buf_pos, double* d_buf_d, int32_t* d_cnt, void* stream);
+/* The merge after a filter pass (r04): for every query the kc smallest (distance, position) pairs of its list [kc] and
+ * the first min(cnt, cap) buffer entries, ascending, ties by position, and d_thr = the kc-th distance - what the
+ * reference's NN-descent keeps per point as its heap (pynndescent behind /root/reference/muon/_core/preproc.py:366-373,
+ * 517-523).  kc + cap <= 1024; not in place.  A row with cnt > cap is the caller's to redo. */
+int mu_knn_merge_f64(int64_t n_q, int kc, int cap, const double* d_cur_d, const int64_t* d_cur_p, const double* d_buf_d,
+                     const int32_t* d_buf_pos, const int32_t* d_cnt, double* d_out_d, int64_t* d_out_p, double* d_thr,
+                     void* stream);
 
 /* ---- kernel bandwidths of muon.pp.neighbors (/root/reference/muon/_core/preproc.py:400-472): csigma[i] = mean
  * Euclidean distance from cell i to the n_bw cells whose neighbour sets overlap its own least (but do), ties

@@ -961,6 +961,17 @@ class HipBackend:
                                              _p(sqq), _p(sqc), _p(thr), _p(self_pos), int(buf_pos.shape[1]),
                                              _p(buf_pos), _p(buf_d), _p(cnt), self._stream()))
 
+    def knn_merge(self, cur_d, cur_p, buf_d, buf_pos, cnt):
+        """list ++ buffer -> (the kc smallest distances ascending, their positions, the new thresholds)
+        (include/muon_amd.h mu_knn_merge_f64)."""
+        n, kc = cur_d.shape
+        out_d, out_p = torch.empty_like(cur_d), torch.empty_like(cur_p)
+        thr = self.empty((n,), torch.float64)
+        with self._dev_ctx():
+            check(self.lib.mu_knn_merge_f64(int(n), int(kc), int(buf_d.shape[1]), _p(cur_d), _p(cur_p), _p(buf_d),
+                                            _p(buf_pos), _p(cnt), _p(out_d), _p(out_p), _p(thr), self._stream()))
+        return out_d, out_p, thr
+
     def densify_rows(self, X: DeviceCSR, lo: int, hi: int) -> torch.Tensor:
         """Rows [lo, hi) of a device CSR as a dense chunk (include/muon_amd.h)."""
         out = self.empty((hi - lo, X.shape[1]), X.values.dtype)

@@ -192,21 +192,28 @@ def _candidates_filtered(be, Xn: torch.Tensor, sq: torch.Tensor, kc: int, chunk_
     cnt = torch.empty((n,), dtype=torch.int32, device=dev)
     slot = torch.arange(cap, device=dev)[None, :]
     c_lo = p0
+    fused = hasattr(be, "knn_merge") and kc + cap <= 1024
+    thr = cur_d.amax(dim=1).contiguous()
     while c_lo < n:
         c_hi = min(n, 2 * c_lo)
-        thr = cur_d.amax(dim=1).contiguous()
         be.knn_filter(Xq, Xc, sq, sqc, thr, self_pos, c_lo, c_hi, buf_pos, buf_d, cnt)
-        valid = slot < cnt[:, None]
-        d_all = torch.cat([cur_d, torch.where(valid, buf_d, torch.full_like(buf_d, float("inf")))], dim=1)
-        p_all = torch.cat([cur_p, buf_pos.long()], dim=1)
-        t = torch.topk(d_all, kc, dim=1, largest=False)
-        new_d, new_p = t.values, torch.gather(p_all, 1, t.indices)
+        if fused:  # list ++ buffer -> the kc smallest and the new threshold, a wave per query (csrc/knn.hip)
+            new_d, new_p, thr = be.knn_merge(cur_d.contiguous(), cur_p.contiguous(), buf_d, buf_pos, cnt)
+        else:
+            valid = slot < cnt[:, None]
+            d_all = torch.cat([cur_d, torch.where(valid, buf_d, torch.full_like(buf_d, float("inf")))], dim=1)
+            p_all = torch.cat([cur_p, buf_pos.long()], dim=1)
+            t = torch.topk(d_all, kc, dim=1, largest=False)
+            new_d, new_p = t.values, torch.gather(p_all, 1, t.indices)
         over = torch.nonzero(cnt > cap)[:, 0]
         if over.numel():  # (rare) more candidates than the buffer holds: those rows again, densely, over all seen
             for lo in range(0, over.numel(), max(1, chunk_elems // c_hi)):
                 r = over[lo:lo + max(1, chunk_elems // c_hi)]
                 t = torch.topk(dense(r, 0, c_hi), kc, dim=1, largest=False)
                 new_d[r], new_p[r] = t.values, t.indices
+            thr = new_d.amax(dim=1).contiguous()
+        elif not fused:
+            thr = new_d.amax(dim=1).contiguous()
         cur_d, cur_p = new_d, new_p
         c_lo = c_hi
     return perm[cur_p], cur_d
@@ -309,17 +316,32 @@ def fuzzy_simplicial_set(knn_idx: torch.Tensor, knn_dist: torch.Tensor, n_obs: i
 
 
 def _symmetrise(knn_idx: torch.Tensor, val: torch.Tensor, n_obs: int):
-    """P + P^T - P o P^T of the membership strengths (set_op_mix_ratio = 1), as a CSR for .obsp."""
+    """P + P^T - P o P^T of the membership strengths (set_op_mix_ratio = 1), as a CSR for .obsp.  On the tensors'
+    device (r04; was scipy on the host: transpose, multiply, add, subtract = 86 ms per graph of 100 000 x 20): the
+    entries of P and P^T as keys row * n + column, one `unique`, and per key the sum s1 and the sum of squares s2
+    of its one or two values - a + b - a b = s1 - (s1^2 - s2) / 2, and a single value a gives a exactly."""
     n, k = val.shape
-    r = np.repeat(np.arange(n), k)
-    c = knn_idx.reshape(-1).cpu().numpy()
-    v = val.reshape(-1).cpu().numpy()
-    res = csr_matrix((v, (r, c)), shape=(n_obs, n_obs))
-    res.eliminate_zeros()
-    t = res.T.tocsr()
-    out = (res + t - res.multiply(t)).tocsr()
-    out.eliminate_zeros()
-    return out
+    dev = val.device
+    r = torch.arange(n, device=dev, dtype=torch.int64).repeat_interleave(k)
+    c = knn_idx.reshape(-1).to(torch.int64)
+    v = val.reshape(-1).to(torch.float64)
+    keep = v != 0
+    r, c, v = r[keep], c[keep], v[keep]
+    key = torch.cat([r * n_obs + c, c * n_obs + r])
+    vv = torch.cat([v, v])
+    uk, inv = torch.unique(key, return_inverse=True)  # sorted: row-major, columns ascending
+    s1 = torch.zeros(uk.numel(), dtype=torch.float64, device=dev).scatter_add_(0, inv, vv)
+    s2 = torch.zeros(uk.numel(), dtype=torch.float64, device=dev).scatter_add_(0, inv, vv * vv)
+    out = s1 - (s1 * s1 - s2) / 2.0
+    nz = out != 0
+    uk, out = uk[nz], out[nz]
+    rows = torch.div(uk, n_obs, rounding_mode="floor")
+    cols = (uk - rows * n_obs).to(torch.int32)
+    indptr = torch.zeros(n_obs + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.bincount(rows, minlength=n_obs), 0, out=indptr[1:])
+    m = csr_matrix((out.cpu().numpy(), cols.cpu().numpy(), indptr.cpu().numpy()), shape=(n_obs, n_obs))
+    m.has_sorted_indices = True
+    return m
 
 
 def knn(adata, n_neighbors: int = 15, use_rep: Optional[str] = None, n_pcs: Optional[int] = None,
@@ -527,11 +549,14 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
                 "Make sure to subset before calculating nearest neighbors."
             )
         graphs_local[m] = g
-        coo = g.tocoo()
-        graphs[m] = csr_matrix((coo.data, (pos[m][coo.row], pos[m][coo.col])), shape=(n, n))
+        if len(pos[m]) == n and np.array_equal(pos[m], np.arange(n)):
+            graphs[m] = g  # the modality has every cell in mdata's order (the usual case): nothing to remap
+        else:
+            coo = g.tocoo()
+            graphs[m] = csr_matrix((coo.data, (pos[m][coo.row], pos[m][coo.col])), shape=(n, n))
     pres_d = {m: torch.as_tensor(pres[m], device=dev) for m in modalities}
     ratios = torch.full((n, M), -float("inf"), dtype=torch.float64, device=dev)
-    sigmas = {}
+    sigmas, mean_ops = {}, {}
     ninf = torch.full((n,), -float("inf"), dtype=torch.float64, device=dev)
     for i1, m1 in enumerate(modalities):
         G1 = graphs_local[m1]
@@ -552,7 +577,12 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
                              "(duplicated cells?): the affinity ratio is undefined")
         thetas, cur = [], None
         for i2, m2 in enumerate(modalities):  # :484-506
-            S = _mean_operator(be, graphs[m2], None if pres[m1].all() else pres[m1])
+            # (the operator depends on the graph and on which cells HAVE modality m1: one per graph when every
+            #  modality has every cell)
+            op_key = (m2, None if pres[m1].all() else m1)
+            if op_key not in mean_ops:
+                mean_ops[op_key] = _mean_operator(be, graphs[m2], None if pres[m1].all() else pres[m1])
+            S = mean_ops[op_key]
             r = _graph_mean(be, S, X32[m1]).to(torch.float64)
             th = torch.exp(-torch.clamp(torch.linalg.norm(Xd[m1] - r, dim=1) - nnd, min=0) / (csig - nnd))
             both = pres_d[m1] & pres_d[m2]

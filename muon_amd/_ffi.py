@@ -98,6 +98,7 @@ SIGNATURES = {
     "mu_umap_strengths_f64": (C.c_int, [_i64, _i32, _vp, _vp, _dbl, _dbl, _vp, _vp]),
     "mu_wnn_bandwidth_f64": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _vp, _vp, _vp]),
     "mu_knn_filter_f64": (C.c_int, [_i64, _i64, _i64, _i32] + [_vp] * 6 + [_i32] + [_vp] * 4),
+    "mu_knn_merge_f64": (C.c_int, [_i64, _i32, _i32] + [_vp] * 9),
     "mu_csr_densify_rows": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_jaakkola": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_poisson_pseudo": (C.c_int, [_i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -119,6 +119,81 @@ __global__ __launch_bounds__(kKnnThreads) void k_knn_filter(
   if (tid < kKnnT && q0 + tid < n_q) cnt[q0 + tid] = s_cnt[tid];
 }
 
+
+// ---- the merge after a filter pass -------------------------------------------------------------------------------
+// list [kc] ++ buffer [min(cnt, cap)] -> the kc smallest (distance, position) pairs and the new threshold, a wave per
+// query: the pairs go to LDS, a bitonic sort over the next power of two (padding = +inf), the first kc come back.
+// (r04; was: a mask, two concatenations, torch's top-k over 4 kc columns and a gather per panel - the radix passes were
+// a quarter of a search's kernel time.)  Ties are broken by position, so the result does not depend on the order in
+// which the filter's workgroups appended to the buffer.
+constexpr int kMergeWaves = 4;
+constexpr int kMergeMax = 1024;  // kc + cap must fit
+
+__device__ __forceinline__ void merge_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64 * kMergeWaves) void k_knn_merge(int64_t n_q, int kc, int cap,
+                                                                const double* __restrict__ cur_d,
+                                                                const int64_t* __restrict__ cur_p,
+                                                                const double* __restrict__ buf_d,
+                                                                const int32_t* __restrict__ buf_pos,
+                                                                const int32_t* __restrict__ cnt,
+                                                                double* __restrict__ out_d, int64_t* __restrict__ out_p,
+                                                                double* __restrict__ thr) {
+  __shared__ double keys[kMergeWaves][kMergeMax];
+  __shared__ int vals[kMergeWaves][kMergeMax];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * kMergeWaves + wave;
+  if (q >= n_q) return;
+  double* K = keys[wave];
+  int* V = vals[wave];
+  const int c = cnt[q] < cap ? cnt[q] : cap;  // (an overflowed row is redone by the caller)
+  const int m = kc + c;
+  int P = 64;
+  while (P < m) P <<= 1;
+  for (int t = lane; t < P; t += 64) {
+    double d = __builtin_inf();
+    int v = 0x7fffffff;
+    if (t < kc) {
+      d = cur_d[q * kc + t];
+      v = (int)cur_p[q * kc + t];
+    } else if (t < m) {
+      d = buf_d[q * cap + (t - kc)];
+      v = buf_pos[q * cap + (t - kc)];
+    }
+    K[t] = d;
+    V[t] = v;
+  }
+  merge_sync();
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < P; t += 64) {
+        const int u = t ^ j;
+        if (u > t) {
+          const double a = K[t], b = K[u];
+          const int va = V[t], vb = V[u];
+          const bool gt = a > b || (a == b && va > vb);  // (no NaN: distances are finite or +inf)
+          const bool up = (t & k) == 0;
+          if (gt == up) {
+            K[t] = b;
+            K[u] = a;
+            V[t] = vb;
+            V[u] = va;
+          }
+        }
+      }
+      merge_sync();
+    }
+  }
+  for (int t = lane; t < kc; t += 64) {
+    out_d[q * kc + t] = K[t];
+    out_p[q * kc + t] = (int64_t)V[t];
+  }
+  if (lane == 0) thr[q] = K[kc - 1];
+}
+
 }  // namespace
 
 extern "C" {
@@ -138,6 +213,20 @@ int mu_knn_filter_f64(int64_t n_q, int64_t c_lo, int64_t c_hi, int p_pad, const 
   const int64_t wgs = (n_q + kKnnT - 1) / kKnnT;
   hipLaunchKernelGGL(k_knn_filter, dim3((unsigned)wgs), dim3(kKnnThreads), lds, (hipStream_t)stream, n_q, c_lo, c_hi,
                      p_pad, d_Xq, d_Xc, d_sqq, d_sqc, d_thr, d_self_pos, cap, d_buf_pos, d_buf_d, d_cnt);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_knn_merge_f64(int64_t n_q, int kc, int cap, const double* d_cur_d, const int64_t* d_cur_p, const double* d_buf_d,
+                     const int32_t* d_buf_pos, const int32_t* d_cnt, double* d_out_d, int64_t* d_out_p, double* d_thr,
+                     void* stream) {
+  MU_REQUIRE(n_q >= 0 && kc >= 1 && cap >= 1 && kc + cap <= kMergeMax, "kc + cap must be <= 1024");
+  if (n_q == 0) return MU_OK;
+  MU_REQUIRE(d_cur_d && d_cur_p && d_buf_d && d_buf_pos && d_cnt && d_out_d && d_out_p && d_thr, "null pointer");
+  MU_REQUIRE(d_out_d != d_cur_d && d_out_p != d_cur_p, "the merge is not in place");
+  const int64_t wgs = (n_q + kMergeWaves - 1) / kMergeWaves;
+  hipLaunchKernelGGL(k_knn_merge, dim3((unsigned)wgs), dim3(64 * kMergeWaves), 0, (hipStream_t)stream, n_q, kc, cap,
+                     d_cur_d, d_cur_p, d_buf_d, d_buf_pos, d_cnt, d_out_d, d_out_p, d_thr);
   MU_CHECK_LAUNCH();
   return MU_OK;
 }

@@ -193,3 +193,35 @@ def test_umap_strengths_kernel_equals_the_tensor_bisection(hip):
     want = pp.fuzzy_simplicial_set(ii, dd, n, k)
     got = pp.fuzzy_simplicial_set(ii, dd, n, k, backend=hip)
     assert got.shape == want.shape and abs(got - want).max() < 1e-6
+
+
+@pytest.mark.parametrize("kc,cap", [(28, 148), (208, 688), (5, 3), (64, 960)])
+def test_merge_kernel_selects_the_kc_smallest_pairs(kc, cap):
+    """mu_knn_merge_f64: list ++ buffer -> the kc smallest (distance, position) pairs, ascending, ties by position"""
+    import torch
+
+    from muon_amd._backend import get_backend
+
+    be = get_backend()
+    g = torch.Generator(device=be.device).manual_seed(kc)
+    n = 3000
+    cur_d = torch.rand((n, kc), generator=g, device=be.device, dtype=torch.float64)
+    cur_d[5] = 0.25  # ties inside the list
+    cur_p = torch.stack([torch.randperm(10**6, generator=g, device=be.device)[:kc] for _ in range(8)])[torch.arange(n, device=be.device) % 8].contiguous()
+    buf_d = torch.rand((n, cap), generator=g, device=be.device, dtype=torch.float64)
+    buf_d[5, :3] = 0.25
+    buf_pos = torch.randint(10**6, 2 * 10**6, (n, cap), generator=g, device=be.device, dtype=torch.int32)
+    cnt = torch.randint(0, cap + 20, (n,), generator=g, device=be.device, dtype=torch.int32)
+    cnt[0], cnt[1] = 0, cap
+    got_d, got_p, thr = be.knn_merge(cur_d, cur_p, buf_d, buf_pos, cnt)
+    c = torch.clamp(cnt, max=cap).long()
+    valid = torch.arange(cap, device=be.device)[None, :] < c[:, None]
+    d_all = torch.cat([cur_d, torch.where(valid, buf_d, torch.full_like(buf_d, float("inf")))], dim=1)
+    p_all = torch.cat([cur_p, buf_pos.long()], dim=1)
+    # reference order: by (distance, position): sort by position first, then stably by distance
+    o = torch.argsort(p_all, dim=1)
+    d_s, p_s = torch.gather(d_all, 1, o), torch.gather(p_all, 1, o)
+    o = torch.argsort(d_s, dim=1, stable=True)[:, :kc]
+    want_d, want_p = torch.gather(d_s, 1, o), torch.gather(p_s, 1, o)
+    assert torch.equal(got_d, want_d) and torch.equal(got_p, want_p)
+    assert torch.equal(thr, want_d[:, -1])

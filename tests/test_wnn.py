@@ -225,3 +225,28 @@ def test_filtered_candidate_search_redoes_rows_whose_buffer_overflowed():
     D.fill_diagonal_(float("inf"))
     want = torch.topk(D, kc, dim=1, largest=False).indices
     assert torch.equal(torch.sort(got, dim=1).values, torch.sort(want, dim=1).values)
+
+
+def test_symmetrise_matches_the_scipy_formula():
+    """P + P^T - P o P^T (umap's fuzzy union) built from keys and two scatter-adds equals the sparse-matrix expression"""
+    import scipy.sparse as sp
+    import torch
+
+    from muon_amd._core.preproc import _symmetrise
+
+    rng = np.random.default_rng(4)
+    n, k = 300, 12
+    idx = np.stack([rng.choice(n, size=k, replace=False) for _ in range(n)])
+    idx[:, 0] = np.arange(n)  # the cell itself, strength 0 (dropped)
+    val = rng.random((n, k))
+    val[:, 0] = 0.0
+    val[rng.random((n, k)) < 0.1] = 0.0  # some exact zeros
+    got = _symmetrise(torch.from_numpy(idx), torch.from_numpy(val), n)
+    P = sp.csr_matrix((val.reshape(-1), (np.repeat(np.arange(n), k), idx.reshape(-1))), shape=(n, n))
+    P.eliminate_zeros()
+    want = (P + P.T - P.multiply(P.T)).tocsr()
+    want.eliminate_zeros()
+    want.sort_indices()
+    assert got.has_sorted_indices and (got.indptr == want.indptr).all() and (got.indices == want.indices).all()
+    np.testing.assert_allclose(got.data, want.data, rtol=0, atol=1e-15)
+    assert abs(got - got.T).max() < 1e-15
