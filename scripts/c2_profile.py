@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Where a 10k x 30k tfidf + lsi call spends its time on the host (BASELINE configs[1]): ms per step,
-the host's wait / Ritz shares, cProfile of 20 calls."""
+"""Where a 10k x 30k tfidf + lsi call spends its time on the host (BASELINE configs[1]; other shapes: argv cells
+peaks): ms per step, the host's wait / Ritz shares, cProfile of 20 calls."""
 import cProfile
 import io
 import os
@@ -16,13 +16,15 @@ from muon_amd._atac.tools import lsi_device
 from muon_amd._backend import HipBackend
 
 be = HipBackend(0)
-X = be.synth_counts(0, 10000, 30000, 50, 0.03, 0)
+CELLS = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+PEAKS = int(sys.argv[2]) if len(sys.argv) > 2 else 30000
+X = be.synth_counts(0, CELLS, PEAKS, 50, 0.03, 0)
 out = torch.empty_like(X.values)
 
 
 def step():
-    T = tfidf_device(be, X, 10000, 3, 1e4, out=out)
-    return lsi_device(be, T, n_comps=50, n_obs=10000, return_info=True)
+    T = tfidf_device(be, X, CELLS, 3, 1e4, out=out)
+    return lsi_device(be, T, n_comps=50, n_obs=CELLS, return_info=True)
 
 
 for _ in range(5):
