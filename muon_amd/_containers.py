@@ -221,6 +221,11 @@ class MuData:
                     vals.append(pd.Series([np.nan] * a.n_vars, index=a.var.index))
             self.var[c] = pd.concat(vals)
 
+    def update_obs(self):
+        """mudata's MuData.update_obs(): bring .obs in line with the modalities (muon.pp.neighbors calls it last,
+        /root/reference/muon/_core/preproc.py:638); global columns are kept."""
+        self.update()
+
     @property
     def shape(self):
         return (len(self.obs), len(self.var))

@@ -1,11 +1,17 @@
 """CPU restatement of muon.pp.neighbors - weighted nearest neighbours (TEST INFRASTRUCTURE).
 
-PARITY UNPINNED: /root/reference/muon/_core/preproc.py:264-640 cannot run here (numba, umap-learn,
-pynndescent and scanpy are absent) and the reference has no test for it (tests/test_muon_preproc.py
-covers the filters only).  This file follows the reference statement by statement - every block cites
-its lines - with ONE deliberate difference: the reference finds neighbours with UMAP's NN-descent
-(approximate, seeded: `nearest_neighbors(...)`, :453-461 and :525-533), this oracle with exhaustive
-search, i.e. it is the exact answer NN-descent approximates.  numpy loops, small inputs only.
+PARITY PINNED (r04) to the reference EXECUTING, with two stated exceptions.  /root/reference/muon/_core/preproc.py
+cannot be imported as it is (numba, umap-learn, pynndescent and scanpy are absent) and the reference has no test for
+this function (tests/test_muon_preproc.py covers the filters only) - but tests/golden/make_wnn_golden.py loads the file
+where it lies with stubs for the THIRD-PARTY pieces only and runs its own `neighbors()` (:264-640) and `l2norm`
+(:182-262); tests/test_wnn.py compares this oracle with the fixture it wrote (tests/golden/wnn_golden.npz): modality
+weights 4e-16, multimodal distances 1e-16, identical neighbour sets in every row.  The exceptions: (i) the reference
+finds neighbours with UMAP's NN-descent (approximate, seeded: `nearest_neighbors(...)`, :453-461 and :525-533) - the
+stub and this oracle search exhaustively, i.e. give the exact answer NN-descent approximates; (ii) the UMAP
+connectivities come from scanpy (`_compute_connectivities_umap`, :615-622): `fuzzy_simplicial_set` below restates
+umap-learn's published algorithm and is NOT pinned.  Partial modality overlap follows the reference's intent, not its
+row indexing (see `neighbors`).  This file follows the reference statement by statement - every block cites its
+lines.  numpy loops, small inputs only.
 
 Also here: the exact k-nearest-neighbour graph + UMAP connectivities in the slots scanpy's
 `sc.pp.neighbors` writes (`.obsp["distances"]`, `.obsp["connectivities"]`, `.uns["neighbors"]`): the

@@ -225,3 +225,26 @@ def test_merge_kernel_selects_the_kc_smallest_pairs(kc, cap):
     want_d, want_p = torch.gather(d_s, 1, o), torch.gather(p_s, 1, o)
     assert torch.equal(got_d, want_d) and torch.equal(got_p, want_p)
     assert torch.equal(thr, want_d[:, -1])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_neighbors_on_the_gpu_against_the_reference_executing(golden_dir, tag):
+    """the HIP path on the inputs of tests/golden/wnn_golden.npz against what /root/reference/muon/_core/preproc.py:264-640
+    itself produced for them (tests/golden/make_wnn_golden.py: third-party search / connectivities stubbed)"""
+    from muon_amd import AnnData, MuData
+    from muon_amd._backend import get_backend
+    from muon_amd._core import preproc as pp
+    from tests.test_wnn import _golden_case, _same_graph
+
+    be = get_backend()
+    x1, x2, graphs, kw, want = _golden_case(golden_dir, tag)
+    md = MuData({"rna": AnnData(x1.copy()), "atac": AnnData(x2.copy())})
+    for m, k in zip(("rna", "atac"), want["k"]):
+        md.mod[m].obsp["distances"] = graphs[m]
+        md.mod[m].uns["neighbors"] = {"connectivities_key": "connectivities", "distances_key": "distances",
+                                      "params": {"n_neighbors": k, "method": "umap", "metric": "euclidean"}}
+    pp.neighbors(md, backend=be, **kw)
+    assert md.uns["neighbors"]["params"]["n_neighbors"] == want["n_neighbors"]
+    np.testing.assert_allclose(np.asarray(md.obs["rna:mod_weight"]), want["w_rna"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(np.asarray(md.obs["atac:mod_weight"]), want["w_atac"], rtol=0, atol=1e-6)
+    _same_graph(md.obsp["distances"], want["dist"], 1e-6)

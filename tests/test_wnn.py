@@ -250,3 +250,77 @@ def test_symmetrise_matches_the_scipy_formula():
     assert got.has_sorted_indices and (got.indptr == want.indptr).all() and (got.indices == want.indices).all()
     np.testing.assert_allclose(got.data, want.data, rtol=0, atol=1e-15)
     assert abs(got - got.T).max() < 1e-15
+
+
+# ---- reference-executed fixtures (tests/golden/make_wnn_golden.py: the reference's own neighbors() / l2norm run in the
+#      build container with stubs for numba / pynndescent / umap / scanpy only) -------------------------------------
+def _golden_case(golden_dir, tag):
+    import os
+
+    g = np.load(os.path.join(golden_dir, "wnn_golden.npz"))
+    x1, x2 = g[f"{tag}_x1"], g[f"{tag}_x2"]
+    n = x1.shape[0]
+    graphs = {m: sp.csr_matrix((g[f"{tag}_{m}_g_data"], g[f"{tag}_{m}_g_indices"], g[f"{tag}_{m}_g_indptr"]), shape=(n, n))
+              for m in ("rna", "atac")}
+    nb, nm, nn = (int(v) for v in g[f"{tag}_kw"])
+    kw = dict(n_bandwidth_neighbors=nb, n_multineighbors=nm)
+    if nn >= 0:
+        kw["n_neighbors"] = nn
+    ref = sp.csr_matrix((g[f"{tag}_dist_data"], g[f"{tag}_dist_indices"], g[f"{tag}_dist_indptr"]), shape=(n, n))
+    want = dict(dist=ref, w_rna=g[f"{tag}_rna_weight"], w_atac=g[f"{tag}_atac_weight"], n_neighbors=int(g[f"{tag}_n_neighbors"][0]),
+                k=[int(v) for v in g[f"{tag}_k"]])
+    return x1, x2, graphs, kw, want
+
+
+def _same_graph(got, want, tol):
+    n = want.shape[0]
+    k1 = int(np.diff(want.indptr)[0])
+    got = got.tocsr()
+    assert np.all(np.diff(got.indptr) == k1) and np.all(np.diff(want.indptr) == k1)
+    gd = np.sort(np.asarray(got.data).reshape(n, k1), axis=1)
+    wd = np.sort(np.asarray(want.data).reshape(n, k1), axis=1)
+    assert np.max(np.abs(gd - wd)) < tol
+    for i in range(n):  # (neighbour SETS: the reference's argsort inside a row is not stable)
+        assert set(got.indices[got.indptr[i]:got.indptr[i + 1]]) == set(want.indices[want.indptr[i]:want.indptr[i + 1]])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_is_pinned_to_the_reference_executing(golden_dir, tag):
+    """oracle/wnn_oracle.neighbors against the output of /root/reference/muon/_core/preproc.py:264-640 itself: modality
+    weights to 1e-15, the multimodal graph's distances to 1e-15, identical neighbour sets in every row"""
+    x1, x2, graphs, kw, want = _golden_case(golden_dir, tag)
+    D, _C, W, _sig, nn = wnn_oracle.neighbors({"rna": x1, "atac": x2}, graphs, **kw)
+    assert nn == want["n_neighbors"]
+    np.testing.assert_allclose(W[:, 0], want["w_rna"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(W[:, 1], want["w_atac"], rtol=0, atol=1e-14)
+    _same_graph(D, want["dist"], 1e-14)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_neighbors_against_the_reference_executing(golden_dir, tag):
+    """muon_amd.pp.neighbors (tensor formulation on the CPU operator set) on the fixture's inputs"""
+    x1, x2, graphs, kw, want = _golden_case(golden_dir, tag)
+    md = MuData({"rna": AnnData(x1.copy()), "atac": AnnData(x2.copy())})
+    for m, k in zip(("rna", "atac"), want["k"]):
+        md.mod[m].obsp["distances"] = graphs[m]
+        md.mod[m].uns["neighbors"] = {"connectivities_key": "connectivities", "distances_key": "distances",
+                                      "params": {"n_neighbors": k, "method": "umap", "metric": "euclidean"}}
+    pp.neighbors(md, backend=BE, **kw)
+    assert md.uns["neighbors"]["params"]["n_neighbors"] == want["n_neighbors"]
+    # (the neighbourhood means run through the f32 SpMM: 1e-7 in the weights, like against the oracle above)
+    np.testing.assert_allclose(np.asarray(md.obs["rna:mod_weight"]), want["w_rna"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(np.asarray(md.obs["atac:mod_weight"]), want["w_atac"], rtol=0, atol=1e-6)
+    _same_graph(md.obsp["distances"], want["dist"], 1e-6)
+
+
+def test_l2norm_against_the_reference_executing(golden_dir):
+    import os
+
+    g = np.load(os.path.join(golden_dir, "wnn_golden.npz"))
+    a = AnnData(g["l2_dense_in"].copy())
+    pp.l2norm(a)
+    np.testing.assert_allclose(a.X, g["l2_dense_out"], rtol=1e-14)
+    s = sp.csr_matrix((g["l2_csr_in_data"], g["l2_csr_in_indices"], g["l2_csr_in_indptr"]), shape=(20, 30))
+    b = AnnData(s.copy())
+    pp.l2norm(b)
+    np.testing.assert_allclose(b.X.tocsr().data, g["l2_csr_out_data"], rtol=1e-14)
