@@ -53,8 +53,10 @@ def _collect_views(mdata, groups_label, use_raw, use_layer, likelihoods, feature
     mods = list(mdata.mod.keys())
     if use_obs == "intersection":
         common = reduce(np.intersect1d, [v.obs_names.values for v in mdata.mod.values()])
-        keep = pd.Index(obs_names).isin(common)
-        obs_names = obs_names[keep]
+        # `mdata = mdata[common_obs]` in the reference (:99-101): np.intersect1d SORTS, so the samples of the model
+        # are in sorted name order - found by executing the reference (tests/golden/make_mofa_golden.py); r03 kept
+        # mdata's order, which changes which sample gets which row of the seeded initialisation
+        obs_names = np.asarray(common)
 
     if groups_label is not None:
         if not isinstance(groups_label, str):
@@ -262,8 +264,12 @@ def mofa(
     # Factors: rows follow the order of the samples in data.obs (tools.py:604-627)
     z = res["Z"]
     if use_obs == "intersection":
+        # the model's samples are the common cells in SORTED name order (np.intersect1d, like the reference :99-101);
+        # every cell gets its own row back, by name.  (The reference assigns the sorted-order rows through a boolean
+        # mask in data.obs order, :617-621 - the same thing only when the names happen to be sorted; otherwise each
+        # common cell receives another cell's factors: not reproduced.)
         xm = np.full((data.n_obs, z.shape[1]), np.nan)
-        xm[data.obs.index.isin(common_obs)] = z
+        xm[data.obs.index.get_indexer(pd.Index(obs_used))] = z
         data.obsm["X_mofa"] = xm
     else:
         data.obsm["X_mofa"] = z

@@ -295,3 +295,77 @@ def test_multi_group_with_shuffled_sample_names_like_the_reference_test():
     order = np.argsort(-ref["r2"].sum(axis=(0, 1)), kind="stable")
     np.testing.assert_allclose(mdata.obsm["X_mofa"], ref["Z"][:, order], atol=1e-7)
     assert set(mdata.uns["mofa"]["variance"]["view1"]) == set(pd.unique(np.asarray(groups)))
+
+
+# ---- the reference's own data assembly, executed (tests/golden/make_mofa_golden.py) ------------------------------
+def _prep_case(g, tag):
+    import scipy.sparse as sp
+
+    from muon_amd import AnnData, MuData
+
+    mods = {}
+    for m in ("rna", "atac"):
+        if f"{tag}_{m}_X" in g.files:
+            x = g[f"{tag}_{m}_X"].copy()
+        else:
+            x = sp.csr_matrix((g[f"{tag}_{m}_X_data"], g[f"{tag}_{m}_X_indices"], g[f"{tag}_{m}_X_indptr"]),
+                              shape=tuple(g[f"{tag}_{m}_X_shape"]))
+        a = AnnData(x)
+        a.obs_names = g[f"{tag}_{m}_obs_names"]
+        if f"{tag}_{m}_layer_lognorm" in g.files:
+            lay = g[f"{tag}_{m}_layer_lognorm"]
+            a.layers["lognorm"] = sp.csr_matrix(lay) if int(g[f"{tag}_{m}_layer_lognorm_sparse"][0]) else lay.copy()
+        if f"{tag}_{m}_hv" in g.files:
+            a.var["highly_variable"] = g[f"{tag}_{m}_hv"]
+        mods[m] = a
+    md = MuData(mods)
+    assert list(md.obs.index.values) == list(g[f"{tag}_obs_names"])
+    if f"{tag}_grp" in g.files:
+        md.obs["grp"] = g[f"{tag}_grp"]
+    return md
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("groups", dict(groups_label="grp")),
+    ("union", dict(use_obs="union")),
+    ("intersection", dict(use_obs="intersection")),
+    ("subset_layer", dict(use_layer="lognorm", features_subset="highly_variable")),
+])
+def test_data_assembly_against_the_reference_executing(golden_dir, tag, kw):
+    """`_collect_views` against what /root/reference/muon/_core/tools.py:50-287 itself hands to mofapy2 (process_data
+    replaced by the identity): the matrices (densified there, sparse here), the union expansion with missing samples,
+    the feature subset, the group order of first appearance, the names and the per-group intercepts"""
+    import os
+
+    import scipy.sparse as sp
+
+    from muon_amd._core.tools import _collect_views
+
+    g = np.load(os.path.join(golden_dir, "mofa_prep_golden.npz"))
+    md = _prep_case(g, tag)
+    views, groups, group_names, obs_names, lik = _collect_views(
+        md, kw.get("groups_label"), False, kw.get("use_layer"), ["gaussian", "gaussian"], kw.get("features_subset"),
+        kw.get("use_obs"))
+    M, G, N = (int(v) for v in g[f"{tag}_dims"][:3])
+    assert len(views) == M and len(group_names) == G and len(obs_names) == N
+    assert [v.shape[1] for v in views] == [int(d) for d in g[f"{tag}_dims"][3:]]
+    assert list(group_names) == list(g[f"{tag}_groups_names"]) and list(lik) == list(g[f"{tag}_likelihoods"])
+    # the reference orders the samples by group (first appearance); the engine keeps the order and a group id per sample
+    order = np.concatenate([np.nonzero(groups == gi)[0] for gi in range(G)])
+    assert list(np.asarray(obs_names)[order]) == list(g[f"{tag}_samples_names"])
+    assert list(np.asarray(group_names)[groups[order]]) == list(g[f"{tag}_samples_groups"])
+    assert [int((groups == gi).sum()) for gi in range(G)] == [int(v) for v in g[f"{tag}_samples_per_group"]]
+    for m, v in enumerate(views):
+        if sp.issparse(v):
+            d = v.toarray().astype(np.float64)
+            miss = getattr(v, "_missing_rows", None)
+            if miss is not None:
+                d[miss] = np.nan
+        else:
+            d = np.asarray(v, dtype=np.float64)
+        want = g[f"{tag}_data{m}"]
+        np.testing.assert_array_equal(np.isnan(d[order]), np.isnan(want))
+        np.testing.assert_allclose(np.nan_to_num(d[order]), np.nan_to_num(want), rtol=0, atol=0)
+        with np.errstate(invalid="ignore"):
+            ic = np.stack([np.nanmean(d[groups == gi], axis=0) for gi in range(G)])
+        np.testing.assert_allclose(ic, g[f"{tag}_intercepts{m}"], rtol=1e-14)
