@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 REF = os.environ.get("MUON_REFERENCE", "/root/reference")
 
+sys.dont_write_bytecode = True  # (no __pycache__ beside the fixtures: tests/test_layout.py audits this directory)
 import make_wnn_golden as wnn_stubs  # noqa: E402  (the stubs preproc.py needs: tools.py imports it)
 from muon_amd._containers import AnnData, MuData  # noqa: E402
 
