@@ -11,6 +11,15 @@ holds the matrices exactly as the reference hands them to mofapy2), runs that fu
 recording model object, and writes what it set to tests/golden/mofa_prep_golden.npz.  tests/test_mofa_host.py compares
 `muon_amd._core.tools._collect_views` with it.
 
+Second part: the WHOLE `mofa()` (:290-708) around mofapy2 - the keyword routing into `set_data_options /
+set_model_options / set_train_options`, and everything after `ent.save()`: reading the model file back, re-ordering the
+factors by sample names, NaN rows outside the intersection, zero rows of `.varm["LFs"]` for unused features, the
+`.uns["mofa"]` record and the variance table.  mofapy2's entry point is replaced by a recorder whose `save()` puts a
+SEEDED model (random Z / W / R2 of the right shapes, mofapy2's dataset layout) into an in-memory stand-in for the HDF5
+file that the stubbed `h5py.File` hands back.  The fixture (mofa_writeback_golden.npz) holds that model and what the
+reference wrote into the MuData object; tests/test_mofa_host.py feeds the same model through `muon_amd.tl.mofa`'s
+write-back.
+
 Run (in the build container):  python tests/golden/make_mofa_golden.py
 """
 import importlib.util
@@ -35,7 +44,13 @@ from muon_amd._containers import AnnData, MuData  # noqa: E402
 
 def load_reference_tools():
     wnn_stubs.load_reference()  # muon._core.preproc (for `from .preproc import _sparse_csr_fast_knn`)
-    sys.modules["h5py"] = types.ModuleType("h5py")
+    h5 = types.ModuleType("h5py")
+    h5.File = lambda name, mode="r": _FILES[name]
+    sys.modules["h5py"] = h5
+    run = types.ModuleType("mofapy2.run")
+    ep = types.ModuleType("mofapy2.run.entry_point")
+    ep.entry_point = RecordingEntryPoint
+    sys.modules.update({"mofapy2.run": run, "mofapy2.run.entry_point": ep})
     ns = types.ModuleType("natsort")
     ns.natsorted = sorted
     sys.modules["natsort"] = ns
@@ -52,6 +67,67 @@ def load_reference_tools():
     sys.modules["muon._core.tools"] = m
     spec.loader.exec_module(m)
     return m
+
+
+class _Node(dict):
+    """h5py group / dataset stand-in: nested dicts, datasets are numpy arrays (h5py datasets index like arrays)"""
+
+    def close(self):
+        pass
+
+
+_FILES = {}
+
+
+class RecordingEntryPoint:
+    """mofapy2.run.entry_point.entry_point: records the option calls; `save()` writes a seeded model of the right
+    shapes in mofapy2's layout (expectations/Z/<group> [K, n_g], expectations/W/<view> [K, D], samples/<group>,
+    views/views, groups/groups, model_options/likelihoods, variance_explained/r2_per_factor/<group> [M, K])"""
+
+    last = None
+
+    def __init__(self):
+        self.dimensionalities = {}
+        self.calls = {}
+        RecordingEntryPoint.last = self
+
+    def set_data_options(self, **kw):
+        self.calls["data"] = kw
+        self.data_opts = dict(kw)
+
+    def set_model_options(self, **kw):
+        self.calls["model"] = kw
+        self.K = kw["factors"]
+
+    def set_train_options(self, **kw):
+        self.calls["train"] = kw
+
+    def build(self):
+        self.calls["built"] = True
+
+    def run(self):
+        self.calls["ran"] = True
+
+    def save(self, outfile, save_data=True, save_parameters=False, expectations=None):
+        self.calls["save"] = dict(save_data=save_data, save_parameters=save_parameters, expectations=expectations)
+        rng = np.random.default_rng(11)
+        K = self.K
+        groups = self.data_opts["groups_names"]
+        views = self.data_opts["views_names"]
+        f = _Node()
+        f["expectations"] = _Node(Z=_Node(), W=_Node())
+        f["samples"] = _Node()
+        f["variance_explained"] = _Node(r2_per_factor=_Node())
+        for g, names in zip(groups, self.data_opts["samples_names"]):
+            f["expectations"]["Z"][g] = rng.standard_normal((K, len(names)))
+            f["samples"][g] = np.asarray(names, dtype="S")
+            f["variance_explained"]["r2_per_factor"][g] = rng.random((len(views), K)) * 10
+        for m, d in zip(views, self.dimensionalities["D"]):
+            f["expectations"]["W"][m] = rng.standard_normal((K, d))
+        f["views"] = _Node(views=np.asarray(views, dtype="S"))
+        f["groups"] = _Node(groups=np.asarray(groups, dtype="S"))
+        f["model_options"] = _Node(likelihoods=np.asarray(self.likelihoods, dtype="S"))
+        _FILES[outfile] = f
 
 
 class RecordingModel:
@@ -140,6 +216,76 @@ def main():
         print(tag, "dims", out[f"{tag}_dims"], "groups", list(out[f"{tag}_groups_names"]))
     np.savez_compressed(os.path.join(HERE, "mofa_prep_golden.npz"), **out)
     print("wrote", os.path.join(HERE, "mofa_prep_golden.npz"), sum(v.nbytes for v in out.values()), "bytes")
+    writeback(tools)
+
+
+def writeback_cases():
+    """MuData objects + mofa() keywords: groups in shuffled order with a feature subset; an intersection; a union.
+    (Cell names are zero-padded, i.e. already in sorted order: for unsorted names the reference's mask assignment of the
+    intersection case gives cells each other's factors, DESIGN.md 6 - nothing to pin there.)"""
+    rng = np.random.default_rng(21)
+    n = 24
+    names = np.array([f"cell{i:02d}" for i in range(n)])
+    y1 = rng.standard_normal((n, 7))
+    y2 = sp.random(n, 5, density=0.5, format="csr", random_state=2, dtype=np.float64)
+    out = {}
+    a1, a2 = AnnData(y1.copy()), AnnData(y2.copy())
+    a1.obs_names, a2.obs_names = names, names
+    a1.var["highly_variable"] = np.array([True, False, True, True, False, True, True])
+    a2.var["highly_variable"] = np.array([True, True, False, True, True])
+    md = MuData({"rna": a1, "atac": a2})
+    md.obs["batch"] = rng.choice(["b2", "b1"], size=n)
+    md.var["highly_variable"] = np.concatenate([a1.var["highly_variable"].values, a2.var["highly_variable"].values])
+    out["groups_subset"] = (md, dict(groups_label="batch", use_var="highly_variable", n_factors=4, likelihoods="gaussian",
+                                     n_iterations=7, convergence_mode="medium", seed=3, scale_views=True, quiet=True,
+                                     outfile="/tmp/golden_a.hdf5"))
+    b1, b2 = AnnData(y1[:18].copy()), AnnData(y2[5:].copy())
+    b1.obs_names, b2.obs_names = names[:18], names[5:]
+    out["intersection"] = (MuData({"rna": b1, "atac": b2}),
+                           dict(use_obs="intersection", use_var=None, n_factors=3, likelihoods=["gaussian", "gaussian"],
+                                quiet=True, outfile="/tmp/golden_b.hdf5"))
+    c1, c2 = AnnData(y1[:18].copy()), AnnData(y2[5:].copy())
+    c1.obs_names, c2.obs_names = names[:18], names[5:]
+    out["union"] = (MuData({"rna": c1, "atac": c2}),
+                    dict(use_obs="union", use_var=None, n_factors=3, likelihoods=["gaussian", "gaussian"], quiet=True,
+                         use_float32=True, outfile="/tmp/golden_c.hdf5"))
+    return out
+
+
+def writeback(tools):
+    out = {}
+    for tag, (md, kw) in writeback_cases().items():
+        pack_inputs(tag, md, out)
+        if "batch" in md.obs.columns:
+            out[f"{tag}_batch"] = np.asarray(md.obs["batch"].values, dtype="U")
+        tools.mofa(md, **kw)
+        ent = RecordingEntryPoint.last
+        f = _FILES[kw["outfile"]]
+        for g in f["expectations"]["Z"]:
+            out[f"{tag}_model_Z_{g}"] = f["expectations"]["Z"][g]
+            out[f"{tag}_model_samples_{g}"] = f["samples"][g].astype("U")
+            out[f"{tag}_model_r2_{g}"] = f["variance_explained"]["r2_per_factor"][g]
+        for m in f["expectations"]["W"]:
+            out[f"{tag}_model_W_{m}"] = f["expectations"]["W"][m]
+        out[f"{tag}_model_groups"] = f["groups"]["groups"].astype("U")
+        out[f"{tag}_X_mofa"] = np.asarray(md.obsm["X_mofa"])
+        out[f"{tag}_LFs"] = np.asarray(md.varm["LFs"])
+        u = md.uns["mofa"]
+        for sect in ("data", "model", "training"):
+            for k, v in u["params"][sect].items():
+                out[f"{tag}_param_{sect}_{k}"] = np.asarray("None" if v is None else v)
+        for view, v in u["variance"].items():
+            if isinstance(v, dict):
+                for g, arr in v.items():
+                    out[f"{tag}_variance_{view}_{g}"] = np.asarray(arr)
+            else:
+                out[f"{tag}_variance_{view}"] = np.asarray(v)
+        for sect in ("data", "model", "train"):
+            for k, v in ent.calls[sect].items():
+                out[f"{tag}_call_{sect}_{k}"] = np.asarray("None" if v is None else v)
+        print(tag, "X_mofa", out[f"{tag}_X_mofa"].shape, "LFs", out[f"{tag}_LFs"].shape, "calls", sorted(ent.calls))
+    np.savez_compressed(os.path.join(HERE, "mofa_writeback_golden.npz"), **out)
+    print("wrote", os.path.join(HERE, "mofa_writeback_golden.npz"), sum(v.nbytes for v in out.values()), "bytes")
 
 
 if __name__ == "__main__":

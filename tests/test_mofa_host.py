@@ -369,3 +369,107 @@ def test_data_assembly_against_the_reference_executing(golden_dir, tag, kw):
         with np.errstate(invalid="ignore"):
             ic = np.stack([np.nanmean(d[groups == gi], axis=0) for gi in range(G)])
         np.testing.assert_allclose(ic, g[f"{tag}_intercepts{m}"], rtol=1e-14)
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("groups_subset", dict(groups_label="batch", use_var="highly_variable", n_factors=4, likelihoods="gaussian",
+                           n_iterations=7, convergence_mode="medium", seed=3, scale_views=True, quiet=True)),
+    ("intersection", dict(use_obs="intersection", use_var=None, n_factors=3, likelihoods=["gaussian", "gaussian"], quiet=True)),
+    ("union", dict(use_obs="union", use_var=None, n_factors=3, likelihoods=["gaussian", "gaussian"], quiet=True,
+                   use_float32=True)),
+])
+def test_wrapper_routes_options_and_writes_back_like_the_reference_executing(golden_dir, tmp_path, monkeypatch, tag, kw):
+    """The reference's whole `mofa()` (tools.py:290-708) was executed around a recording stand-in for mofapy2 whose
+    `save()` wrote a seeded model (tests/golden/make_mofa_golden.py).  The same model fed through muon_amd.tl.mofa's
+    wrapper must leave the same .obsm["X_mofa"] (factors re-ordered by sample name, NaN outside the intersection),
+    .varm["LFs"] (zero rows for unused features), .uns["mofa"] record and variance table - and the engine must be
+    configured with the options the reference passes to mofapy2."""
+    import os
+
+    import scipy.sparse as sp
+    import torch
+
+    import muon_amd as mu
+    from muon_amd import AnnData, MuData
+    from muon_amd._core import mofa_engine
+
+    g = np.load(os.path.join(golden_dir, "mofa_writeback_golden.npz"))
+    mods = {}
+    for m in ("rna", "atac"):
+        if f"{tag}_{m}_X" in g.files:
+            x = g[f"{tag}_{m}_X"].copy()
+        else:
+            x = sp.csr_matrix((g[f"{tag}_{m}_X_data"], g[f"{tag}_{m}_X_indices"], g[f"{tag}_{m}_X_indptr"]),
+                              shape=tuple(g[f"{tag}_{m}_X_shape"]))
+        a = AnnData(x)
+        a.obs_names = g[f"{tag}_{m}_obs_names"]
+        if f"{tag}_{m}_hv" in g.files:
+            a.var["highly_variable"] = g[f"{tag}_{m}_hv"]
+        mods[m] = a
+    md = MuData(mods)
+    if f"{tag}_batch" in g.files:
+        md.obs["batch"] = g[f"{tag}_batch"]
+        md.var["highly_variable"] = np.concatenate([mods["rna"].var["highly_variable"].values,
+                                                    mods["atac"].var["highly_variable"].values])
+    seen = {}
+
+    class FakeEngine:
+        def __init__(self, backend, views, groups, n_factors, **opts):
+            seen.update(opts, n_factors=n_factors, groups=np.asarray(groups), shapes=[v.shape for v in views])
+
+        def run(self, n_iterations=1000, convergence_mode="fast", **_):
+            seen.update(n_iterations=n_iterations, convergence_mode=convergence_mode)
+
+        def results(self, sort_factors=True):
+            return seen["res"]
+
+    group_names = [str(x) for x in g[f"{tag}_model_groups"]]
+    # the seeded model of the fixture, in the engine's conventions: Z [N, K] in the wrapper's sample order
+    from muon_amd._core.tools import _collect_views
+
+    lik = kw["likelihoods"] if isinstance(kw["likelihoods"], list) else [kw["likelihoods"]] * 2
+    _v, groups, gnames, obs_used, _l = _collect_views(md, kw.get("groups_label"), False, None, lik, kw.get("use_var"),
+                                                      kw.get("use_obs"))
+    assert list(gnames) == group_names
+    K = kw["n_factors"]
+    Z = np.full((len(obs_used), K), np.nan)
+    for gname in group_names:
+        names = [str(s) for s in g[f"{tag}_model_samples_{gname}"]]
+        Z[[list(obs_used).index(s) for s in names]] = g[f"{tag}_model_Z_{gname}"].T
+    assert not np.isnan(Z).any()
+    W = [g[f"{tag}_model_W_{m}"].T for m in ("rna", "atac")]
+    r2 = np.stack([g[f"{tag}_model_r2_{gname}"] for gname in group_names], axis=1)  # [M, G, K]
+    seen["res"] = {"Z": Z, "W": W, "r2": r2, "elbo": [0.0]}
+    monkeypatch.setattr(mofa_engine, "MofaEngine", FakeEngine)
+    mu.tl.mofa(md, backend=BE, outfile=str(tmp_path / "m.hdf5"), **kw)
+
+    np.testing.assert_array_equal(np.isnan(md.obsm["X_mofa"]), np.isnan(g[f"{tag}_X_mofa"]))
+    np.testing.assert_allclose(np.nan_to_num(md.obsm["X_mofa"]), np.nan_to_num(g[f"{tag}_X_mofa"]), rtol=0, atol=0)
+    np.testing.assert_allclose(md.varm["LFs"], g[f"{tag}_LFs"], rtol=0, atol=0)
+    u = md.uns["mofa"]
+    for key in g.files:
+        pre = f"{tag}_param_"
+        if key.startswith(pre):
+            sect, name = key[len(pre):].split("_", 1)
+            want = g[key]
+            got = u["params"][sect][name]
+            got = np.asarray("None" if got is None else got)
+            assert got.shape == want.shape and np.all(got.astype(str) == want.astype(str)), (key, got, want)
+    for m in ("rna", "atac"):
+        v = u["variance"][m]
+        if len(group_names) > 1:
+            for gname in group_names:
+                np.testing.assert_allclose(v[gname], g[f"{tag}_variance_{m}_{gname}"])
+        else:
+            np.testing.assert_allclose(v, g[f"{tag}_variance_{m}"])
+    # what the reference told mofapy2 == what the engine was configured with
+    assert bool(g[f"{tag}_call_data_scale_views"]) == seen["scale_views"]
+    assert bool(g[f"{tag}_call_data_scale_groups"]) == seen["scale_groups"]
+    assert bool(g[f"{tag}_call_data_center_groups"]) == seen["center_groups"]
+    assert bool(g[f"{tag}_call_data_use_float32"]) == (seen["dtype"] == torch.float32)
+    assert int(g[f"{tag}_call_model_factors"]) == seen["n_factors"]
+    for k in ("ard_factors", "ard_weights", "spikeslab_weights"):
+        assert bool(g[f"{tag}_call_model_{k}"]) == seen[k]
+    assert int(g[f"{tag}_call_train_iter"]) == seen["n_iterations"]
+    assert str(g[f"{tag}_call_train_convergence_mode"]) == seen["convergence_mode"]
+    assert int(g[f"{tag}_call_train_seed"]) == seen["seed"]
