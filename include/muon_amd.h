@@ -422,6 +422,22 @@ int mu_mofa_jaakkola(int dtype, int64_t n, const void* d_zeta, const void* d_a, 
 int mu_mofa_poisson_pseudo(int dtype, int64_t n_rows, int64_t D, int mode, const void* d_zeta, const void* d_Y,
                            const void* d_kappa, void* d_out, void* stream);
 
+/* A poisson view WITHOUT anything of size N x D (r04, csrc/mofa_poisson.hip): for y = 0 an element of the pseudo-data
+ * depends on (z_n, w_d) only, so a pass = a dense sweep over all (n, d) that reads just the two K-column blocks, plus a
+ * correction over the stored entries.  mode 0: own = samples, other = features, out[n][k] = sum_d R[n, d] w_dk (the Z
+ * update's a = R <W>);  mode 1: own = features, other = samples, out[d][k] = sum_n R[n, d] z_nk (the W update's b = R^T
+ * <Z>), kappa indexed by own;  mode 2: out[n] = sum_d y ln(rate) - rate (the likelihood term).  R, rate as in
+ * mu_mofa_poisson_pseudo.  E_own [n_own x K], E_other [n_other x K] row-major, K <= 32.
+ * mu_mofa_poisson_dense writes PARTIAL results for column blocks of `other_block` rows of the other block
+ * (mu_mofa_poisson_blocks(n_own, n_other) picks it): d_part [ceil(n_other / other_block)][n_own][K] (mode 2: [..][n_own]),
+ * to be added in block order; mu_mofa_poisson_sparse ADDS the stored entries' terms to the summed result: (indptr,
+ * indices, values) = CSR of the view for modes 0 / 2, of its transpose for mode 1. */
+int64_t mu_mofa_poisson_blocks(int64_t n_own, int64_t n_other);
+int mu_mofa_poisson_dense(int dtype, int mode, int64_t n_own, int64_t n_other, int K, int64_t other_block,
+                          const void* d_E_own, const void* d_E_other, const void* d_kappa, void* d_part, void* stream);
+int mu_mofa_poisson_sparse(int dtype, int mode, int64_t n_own, int K, const int64_t* d_indptr, const int32_t* d_indices,
+                           const void* d_values, const void* d_E_own, const void* d_E_other, void* d_out, void* stream);
+
 /* ---- MOFA+ small nodes and the ELBO, fused (tools.py:585 ent.run(): mofapy2's Tau, AlphaW, ThetaW,
  * AlphaZ node updates and calculateELBO()).  Arithmetic in f64 for both storage types; every entry
  * ADDS its ELBO terms to the device scalar *d_elbo.  d_work: mu_mofa_elbo_work_doubles(K) doubles. */

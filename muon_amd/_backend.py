@@ -1023,6 +1023,26 @@ class HipBackend:
                                                   _p(zeta), self._stream()))
         return zeta
 
+    def mofa_poisson_pass(self, mode: int, E_own, E_other, kappa, X: DeviceCSR):
+        """One pass of a poisson view without anything N x D (csrc/mofa_poisson.hip, include/muon_amd.h): mode 0 ->
+        a = R <W> [N, K] (E_own = <Z>, E_other = <W>, X = the view), mode 1 -> b = R^T <Z> [D, K] (E_own = <W>, E_other =
+        <Z>, X = the view's transpose), mode 2 -> per-sample likelihood terms [N]."""
+        n_own, K = E_own.shape
+        n_other = E_other.shape[0]
+        assert E_own.is_contiguous() and E_other.is_contiguous() and E_other.shape[1] == K and E_own.dtype == E_other.dtype
+        assert X.shape == (n_own, n_other) and X.values.dtype == E_own.dtype
+        blk = int(self.lib.mu_mofa_poisson_blocks(n_own, n_other))
+        nb = -(-n_other // blk)
+        part = self.empty((nb, n_own) if mode == 2 else (nb, n_own, K), E_own.dtype)
+        with self._dev_ctx():
+            check(self.lib.mu_mofa_poisson_dense(_dt(E_own), int(mode), n_own, n_other, K, blk, _p(E_own), _p(E_other),
+                                                 _p(kappa), _p(part), self._stream()))
+            out = part[0] if nb == 1 else part.sum(dim=0)  # (fixed order: deterministic)
+            out = out.contiguous()
+            check(self.lib.mu_mofa_poisson_sparse(_dt(E_own), int(mode), n_own, K, _p(X.indptr), _p(X.indices),
+                                                  _p(X.values), _p(E_own), _p(E_other), _p(out), self._stream()))
+        return out
+
     def mofa_gs_update(self, Tm, b, prior, lth, l1mth, spikeslab, E, E2, gamma, Eh2, sig2):
         """Gauss-Seidel sweep over the factors of every row with row-wise K x K statistics (include/muon_amd.h);
         prior / lth / l1mth: f64 [K]."""

@@ -23,6 +23,7 @@ tau / ELBO).  Gaussian models without missing entries keep the two-pass HIP engi
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -210,6 +211,14 @@ class GeneralMofaEngine:
                         scale = scale / math.sqrt(var)
             V.mu = mu.to(T)
             V.scale = scale.to(T)
+        # a poisson view stored sparse with every sample present never needs a dense chunk: for y = 0 the pseudo-data
+        # depend on (z_n, w_d) only - dense sweeps over the two factor blocks + corrections over the stored entries
+        # (csrc/mofa_poisson.hip, r04)
+        V.fused = bool(lik == "poisson" and V.kind == "sparse" and hasattr(be, "mofa_poisson_pass") and self.K <= 32
+                       and V.X.values.dtype == T and pres.all()
+                       and os.environ.get("MUON_AMD_MOFA_FUSED_POISSON", "1") != "0")
+        if V.fused:
+            V.Xt = be.transpose(V.X)
         return V
 
     def _chunks(self, V, a, b, raw=False):
@@ -299,16 +308,21 @@ class GeneralMofaEngine:
         V, Wm, K = self.views[m], self.W[m], self.K
         Tm = torch.zeros((V.D, K * K), dtype=self.T, device=self.dev)
         b = torch.zeros((V.D, K), dtype=self.T, device=self.dev)
-        for g, (a0, b0) in enumerate(self.gslice):
-            for lo, hi, Y, M in self._chunks(V, a0, b0):
-                Zc, Z2c = self.EZ[lo:hi], self.EZ2[lo:hi]
-                Om, R, _, om_vec = self._omega_r(V, Wm, g, Y, M, Zc, Z2c)
-                P = self._outer_moments(Zc, Z2c)
-                if Om is None:
-                    Tm += om_vec[:, None] * P.sum(dim=0)[None, :]
-                else:
-                    Tm += Om.T @ P
-                b += R.T @ Zc
+        if getattr(V, "fused", False):
+            # Omega does not depend on the sample: T_d = kappa_d sum_n <z_n z_n^T>; b = R^T <Z> without R
+            Tm += V.kappa[:, None] * self._outer_moments(self.EZ, self.EZ2).sum(dim=0)[None, :]
+            b += self.be.mofa_poisson_pass(1, Wm.EW.contiguous(), self.EZ.contiguous(), V.kappa.contiguous(), V.Xt)
+        else:
+            for g, (a0, b0) in enumerate(self.gslice):
+                for lo, hi, Y, M in self._chunks(V, a0, b0):
+                    Zc, Z2c = self.EZ[lo:hi], self.EZ2[lo:hi]
+                    Om, R, _, om_vec = self._omega_r(V, Wm, g, Y, M, Zc, Z2c)
+                    P = self._outer_moments(Zc, Z2c)
+                    if Om is None:
+                        Tm += om_vec[:, None] * P.sum(dim=0)[None, :]
+                    else:
+                        Tm += Om.T @ P
+                    b += R.T @ Zc
         Tm, b = self._allreduce(Tm, b)
         Tm = Tm.reshape(V.D, K, K)
         aw64 = (Wm.alpha if self.opts["ard_weights"] else torch.ones_like(Wm.alpha)).to(torch.float64).contiguous()
@@ -342,6 +356,11 @@ class GeneralMofaEngine:
         WW = [self._outer_moments(w.EW, w.EW2) for w in self.W]
         az = (self.alpha_z if self.opts["ard_factors"] else torch.ones_like(self.alpha_z)).to(self.T)
         step = min(self._rows_per_chunk(v.D) for v in self.views)
+        # fused poisson views: a = R <W> for ALL samples at once (a sample's row depends on its own <z_n> only, which
+        # changes in its own chunk, after use) and the sample-independent S
+        fused = {m: (self.be.mofa_poisson_pass(0, self.EZ.contiguous(), self.W[m].EW.contiguous(), V.kappa.contiguous(), V.X),
+                     V.kappa @ WW[m])
+                 for m, V in enumerate(self.views) if getattr(V, "fused", False)}
         for g, (a0, b0) in enumerate(self.gslice):
             for lo in range(a0, b0, step):
                 hi = min(b0, lo + step)
@@ -349,6 +368,10 @@ class GeneralMofaEngine:
                 S = torch.zeros((hi - lo, K * K), dtype=self.T, device=self.dev)
                 a = torch.zeros((hi - lo, K), dtype=self.T, device=self.dev)
                 for m, V in enumerate(self.views):
+                    if m in fused:
+                        S += fused[m][1][None, :]
+                        a += fused[m][0][lo:hi]
+                        continue
                     for l2, h2, Y, M in self._chunks_range(V, lo, hi):
                         Om, R, _, om_vec = self._omega_r(V, self.W[m], g, Y, M, self.EZ[l2:h2], self.EZ2[l2:h2])
                         if Om is None:
@@ -382,7 +405,9 @@ class GeneralMofaEngine:
             Ngd = torch.zeros((G, V.D), dtype=f64, device=self.dev)
             part = torch.zeros((), dtype=f64, device=self.dev)
             W2, Wsq = Wm.EW2, Wm.EW ** 2
-            for g, (a0, b0) in enumerate(self.gslice):
+            if getattr(V, "fused", False):
+                part += self.be.mofa_poisson_pass(2, self.EZ.contiguous(), Wm.EW.contiguous(), None, V.X).sum(dtype=f64)
+            for g, (a0, b0) in enumerate(self.gslice if not getattr(V, "fused", False) else []):
                 for lo, hi, Y, M in self._chunks(V, a0, b0):
                     Zc, Z2c = self.EZ[lo:hi], self.EZ2[lo:hi]
                     zeta = Zc @ Wm.EW.T

@@ -102,6 +102,9 @@ SIGNATURES = {
     "mu_csr_densify_rows": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_jaakkola": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_poisson_pseudo": (C.c_int, [_i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mu_mofa_poisson_blocks": (_i64, [_i64, _i64]),
+    "mu_mofa_poisson_dense": (C.c_int, [_i32, _i32, _i64, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "mu_mofa_poisson_sparse": (C.c_int, [_i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_gs_update": (C.c_int, [_i32, _i64, _i32] + [_vp] * 5 + [_i32] + [_vp] * 6),
     "mu_mofa_elbo_work_doubles": (_sz, [_i32]),
     "mu_mofa_tau_elbo": (C.c_int, [_i32, _i64, _i32, _i32] + [_vp] * 7 + [_dbl, _dbl] + [_vp] * 5),

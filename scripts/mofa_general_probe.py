@@ -21,7 +21,8 @@ y1 = (Z @ rng.standard_normal((2000, 5)).T.astype(np.float32) + rng.standard_nor
 rate = np.logaddexp(0, Z @ (0.3 * rng.standard_normal((20000, 5))).T.astype(np.float32) - 3.0)
 y2 = sp.csr_matrix(rng.poisson(rate).astype(np.float32))
 print(f"N={N}: gaussian {y1.shape}, poisson {y2.shape} ({y2.nnz} nnz, {y2.nnz / N / 20000:.3f} dense)", flush=True)
-for dt in (torch.float32, torch.float64):
+dts = (torch.float32,) if 'f32' in sys.argv else (torch.float32, torch.float64)
+for dt in dts:
     eng = GeneralMofaEngine(be, [y1, y2], ["gaussian", "poisson"], np.zeros(N, dtype=int), 10, dtype=dt, seed=1)
     eng.step()
     torch.cuda.synchronize()

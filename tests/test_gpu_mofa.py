@@ -300,3 +300,42 @@ def test_gauss_seidel_row_kernel_matches_the_tensor_loop(hip, dt, K, spike):
         assert torch.allclose(Eh2[:, k].double(), gm * (mu * mu + 1 / prec) + (1 - gm) / prior[k], rtol=tol, atol=tol)
         assert torch.allclose(s2[:, k].double(), 1 / prec, rtol=tol, atol=tol)
         R[:, k] = E[:, k].double()  # (continue from the kernel's rounded value, as the kernel does not)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-12), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("K", [3, 10, 16, 20])
+def test_poisson_passes_without_the_dense_chunk(dt, tol, K):
+    """mu_mofa_poisson_dense + _sparse (a dense sweep over the factor blocks + the stored entries) against the
+    element-wise definition on the densified view: a = R <W>, b = R^T <Z>, the likelihood terms"""
+    import scipy.sparse as sp
+
+    from muon_amd._backend import get_backend
+
+    be = get_backend()
+    rng = np.random.default_rng(K)
+    N, D = 700, 1300
+    Z = rng.standard_normal((N, K)) * 0.7
+    W = rng.standard_normal((D, K)) * 0.5
+    W[::7] = 0
+    rate = np.logaddexp(0, Z @ W.T - 1.5)
+    Y = sp.csr_matrix(rng.poisson(rate).astype(np.float64))
+    Y.sort_indices()
+    kappa = 0.25 + 0.17 * np.asarray(Y.max(axis=0).todense()).ravel()
+    zeta = Z @ W.T
+    r = np.maximum(np.where(zeta > 20, zeta, np.log1p(np.exp(zeta))), 1e-300)
+    Yd = Y.toarray()
+    R = kappa[None, :] * zeta - 1.0 / (1.0 + np.exp(-zeta)) * (1.0 - Yd / r)
+    want = (R @ W, R.T @ Z, (Yd * np.log(r) - r).sum(axis=1))
+    X = be.upload_csr(Y.indptr, Y.indices, Y.data, Y.shape, values_dtype=np.float64)
+    X = X.with_values(X.values.to(dt))
+    Xt = be.transpose(X)
+    Zd, Wd, kd = (torch.from_numpy(a).to(be.device).to(dt).contiguous() for a in (Z, W, kappa))
+    got = (be.mofa_poisson_pass(0, Zd, Wd, kd, X), be.mofa_poisson_pass(1, Wd, Zd, kd, Xt),
+           be.mofa_poisson_pass(2, Zd, Wd, None, X))
+    for g, w in zip(got, want):
+        g = be.to_host(g).astype(np.float64)
+        assert g.shape == w.shape
+        assert np.max(np.abs(g - w)) <= tol * np.max(np.abs(w))
+    # deterministic
+    again = be.mofa_poisson_pass(0, Zd, Wd, kd, X)
+    assert torch.equal(again, got[0])
