@@ -427,7 +427,8 @@ int mu_mofa_poisson_pseudo(int dtype, int64_t n_rows, int64_t D, int mode, const
  * correction over the stored entries.  mode 0: own = samples, other = features, out[n][k] = sum_d R[n, d] w_dk (the Z
  * update's a = R <W>);  mode 1: own = features, other = samples, out[d][k] = sum_n R[n, d] z_nk (the W update's b = R^T
  * <Z>), kappa indexed by own;  mode 2: out[n] = sum_d y ln(rate) - rate (the likelihood term).  R, rate as in
- * mu_mofa_poisson_pseudo.  E_own [n_own x K], E_other [n_other x K] row-major, K <= 32.
+ * mu_mofa_poisson_pseudo.  E_own [n_own x KP], E_other [n_other x KP] row-major with the K <= 32 columns PADDED with zeros
+ * to KP = 4 / 8 / 12 / 16 / 32 (the smallest of these >= K; 16-byte aligned rows); outputs have K columns.
  * mu_mofa_poisson_dense writes PARTIAL results for column blocks of `other_block` rows of the other block
  * (mu_mofa_poisson_blocks(n_own, n_other) picks it): d_part [ceil(n_other / other_block)][n_own][K] (mode 2: [..][n_own]),
  * to be added in block order; mu_mofa_poisson_sparse ADDS the stored entries' terms to the summed result: (indptr,

@@ -1029,8 +1029,18 @@ class HipBackend:
         <Z>, X = the view's transpose), mode 2 -> per-sample likelihood terms [N]."""
         n_own, K = E_own.shape
         n_other = E_other.shape[0]
-        assert E_own.is_contiguous() and E_other.is_contiguous() and E_other.shape[1] == K and E_own.dtype == E_other.dtype
+        assert E_other.shape[1] == K and E_own.dtype == E_other.dtype and 1 <= K <= 32
         assert X.shape == (n_own, n_other) and X.values.dtype == E_own.dtype
+        KP = next(k for k in (4, 8, 12, 16, 32) if k >= K)  # rows padded to 16-byte multiples (include/muon_amd.h)
+
+        def pad(E):
+            if K == KP and E.is_contiguous():
+                return E
+            P = torch.zeros((E.shape[0], KP), dtype=E.dtype, device=E.device)
+            P[:, :K] = E
+            return P
+
+        E_own, E_other = pad(E_own), pad(E_other)
         blk = int(self.lib.mu_mofa_poisson_blocks(n_own, n_other))
         nb = -(-n_other // blk)
         part = self.empty((nb, n_own) if mode == 2 else (nb, n_own, K), E_own.dtype)

@@ -51,6 +51,21 @@ __device__ __forceinline__ double pz_softplus_sum(double z) { return pz_softplus
 template <typename T>
 __device__ __forceinline__ T pz_sigmoid(T z) { return (T)1 / ((T)1 + pz_exp(-z)); }
 
+// a row of a factor block PADDED to KP columns (16-byte aligned rows: three 16-byte loads for K = 10 instead of ten
+// dword gathers - the sparse corrections are bound by the number of gather instructions)
+template <typename T, int KP>
+__device__ __forceinline__ void pz_load_row(const T* __restrict__ p, T (&o)[KP]) {
+  constexpr int V = 16 / (int)sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  const vec_t* q = reinterpret_cast<const vec_t*>(p);
+#pragma unroll
+  for (int i = 0; i < KP / V; ++i) {
+    const vec_t v = q[i];
+#pragma unroll
+    for (int u = 0; u < V; ++u) o[i * V + u] = v[u];
+  }
+}
+
 constexpr int kPzTile = 128;     // rows of the other block per LDS tile
 constexpr int kPzThreads = 256;
 
@@ -68,10 +83,8 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_dense(int64_t n_own, int64_
   const int64_t o1 = o0 + other_block < n_other ? o0 + other_block : n_other;
   T e[KP], acc[KP];
 #pragma unroll
-  for (int k = 0; k < KP; ++k) {
-    e[k] = (own < n_own && k < K) ? E_own[own * K + k] : (T)0;
-    acc[k] = (T)0;
-  }
+  for (int k = 0; k < KP; ++k) e[k] = acc[k] = (T)0;
+  if (own < n_own) pz_load_row<T, KP>(E_own + own * KP, e);  // (padding columns are zero)
   const T kown = (MODE == 1 && own < n_own) ? kappa[own] : (T)0;
   T lsum = (T)0;
   for (int64_t t0 = o0; t0 < o1; t0 += kPzTile) {
@@ -79,7 +92,7 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_dense(int64_t n_own, int64_
     __syncthreads();
     for (int i = threadIdx.x; i < kPzTile * KP; i += kPzThreads) {
       const int r = i / KP, k = i - r * KP;
-      tile[r][k] = (r < rows && k < K) ? E_other[(t0 + r) * K + k] : (T)0;
+      tile[r][k] = r < rows ? E_other[(t0 + r) * KP + k] : (T)0;
     }
     if (MODE == 0)
       for (int i = threadIdx.x; i < kPzTile; i += kPzThreads) kap[i] = i < rows ? kappa[t0 + i] : (T)0;
@@ -121,18 +134,15 @@ __global__ __launch_bounds__(256) void k_pois_sparse(int64_t n_own, int K, const
   if (own >= n_own) return;
   T e[KP], acc[KP];
 #pragma unroll
-  for (int k = 0; k < KP; ++k) {
-    e[k] = k < K ? E_own[own * K + k] : (T)0;
-    acc[k] = (T)0;
-  }
+  for (int k = 0; k < KP; ++k) acc[k] = (T)0;
+  pz_load_row<T, KP>(E_own + own * KP, e);
   T lsum = (T)0;
   const int64_t lo = indptr[own], hi = indptr[own + 1];
   for (int64_t p = lo + lane; p < hi; p += 64) {
     const int64_t j = indices[p];
     const T y = values[p];
     T o[KP];
-#pragma unroll
-    for (int k = 0; k < KP; ++k) o[k] = k < K ? E_other[j * K + k] : (T)0;
+    pz_load_row<T, KP>(E_other + j * KP, o);
     T zeta = (T)0;
 #pragma unroll
     for (int k = 0; k < KP; ++k) zeta += e[k] * o[k];
