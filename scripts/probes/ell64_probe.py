@@ -11,7 +11,9 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from muon_amd._backend import _p, get_backend  # noqa: E402
 from muon_amd._ffi import check  # noqa: E402
 

@@ -6,7 +6,9 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from muon_amd._backend import get_backend, ell16_layout  # noqa: E402
 
 
