@@ -128,20 +128,72 @@ def l2norm(mdata, mod=None, rep=None, n_pcs=0, copy: bool = False):
 # -----------------------------------------------------------------------------------------------------
 # exhaustive k nearest neighbours on the device
 # -----------------------------------------------------------------------------------------------------
+# the `metric` values of the reference's signature (preproc.py:270-294) that scipy's cdist evaluates pair by pair;
+# "mahalanobis" / "seuclidean" take their (co)variances from the rows of each cdist call - in the reference one call per
+# cell over that cell's candidates - and "wminkowski" needs weights the signature cannot pass: not offered
+_PAIR_METRICS = ("euclidean", "sqeuclidean", "minkowski", "cityblock", "manhattan", "chebyshev", "cosine", "correlation",
+                 "braycurtis", "canberra", "jensenshannon", "hamming", "matching", "jaccard", "dice", "kulsinski",
+                 "rogerstanimoto", "russellrao", "sokalmichener", "sokalsneath", "yule")
+
+
 def _pair_dist(A: torch.Tensor, B: torch.Tensor, metric: str) -> torch.Tensor:
-    """Row-wise distances d(A_i, B_i) (same shapes [..., p]), computed directly (no expansion)."""
-    if metric in ("euclidean", "sqeuclidean"):
+    """Row-wise distances d(A_i, B_i) (same shapes [..., p]), computed directly (no expansion), with the definitions
+    of scipy.spatial.distance (what the reference's final step calls through cdist, preproc.py:596-606)."""
+    if metric in ("euclidean", "sqeuclidean", "minkowski"):  # (minkowski: scipy's default p = 2)
         d = ((A - B) ** 2).sum(dim=-1)
         return d if metric == "sqeuclidean" else torch.sqrt(d)
     if metric in ("cityblock", "manhattan"):
         return (A - B).abs().sum(dim=-1)
     if metric == "chebyshev":
         return (A - B).abs().amax(dim=-1)
-    if metric == "cosine":
+    if metric in ("cosine", "correlation"):
+        if metric == "correlation":
+            A, B = A - A.mean(dim=-1, keepdim=True), B - B.mean(dim=-1, keepdim=True)
         num = (A * B).sum(dim=-1)
         den = torch.sqrt((A * A).sum(dim=-1) * (B * B).sum(dim=-1))
         return 1.0 - num / den
-    raise NotImplementedError(f"metric '{metric}' (implemented: {_METRICS})")
+    if metric == "braycurtis":
+        return (A - B).abs().sum(dim=-1) / (A + B).abs().sum(dim=-1)
+    if metric == "canberra":
+        den = A.abs() + B.abs()
+        t = (A - B).abs() / torch.where(den > 0, den, torch.ones_like(den))
+        return torch.where(den > 0, t, torch.zeros_like(t)).sum(dim=-1)
+    if metric == "jensenshannon":
+        P, Q = A / A.sum(dim=-1, keepdim=True), B / B.sum(dim=-1, keepdim=True)
+        Mm = 0.5 * (P + Q)
+        kl = torch.xlogy(P, P / Mm).nan_to_num(0.0).sum(dim=-1) + torch.xlogy(Q, Q / Mm).nan_to_num(0.0).sum(dim=-1)
+        return torch.sqrt(torch.clamp(0.5 * kl, min=0.0))
+    if metric in ("hamming", "matching"):
+        return (A != B).to(A.dtype).mean(dim=-1)
+    if metric == "jaccard":  # (on the non-zero patterns, as scipy >= 1.15's cdist; older ones compared real values - the
+        a, b = A != 0, B != 0  # two agree on 0/1 data, what the metric is meant for)
+        den = (a | b).to(A.dtype).sum(dim=-1)
+        num = (a != b).to(A.dtype).sum(dim=-1)
+        return torch.where(den > 0, num / torch.where(den > 0, den, torch.ones_like(den)), torch.zeros_like(den))
+    if metric in ("dice", "kulsinski", "rogerstanimoto", "russellrao", "sokalmichener", "sokalsneath", "yule"):
+        a, b = A != 0, B != 0  # (scipy casts to bool)
+        f = A.dtype
+        n = float(A.shape[-1])
+        ntt = (a & b).to(f).sum(dim=-1)
+        ntf = (a & ~b).to(f).sum(dim=-1)
+        nft = (~a & b).to(f).sum(dim=-1)
+        nff = n - ntt - ntf - nft
+        if metric == "dice":
+            return (ntf + nft) / (2.0 * ntt + ntf + nft)
+        if metric == "kulsinski":
+            return (ntf + nft - ntt + n) / (ntf + nft + n)
+        if metric == "russellrao":
+            return (n - ntt) / n
+        if metric == "yule":
+            R = 2.0 * ntf * nft
+            den = ntt * nff + 0.5 * R
+            return torch.where(R > 0, R / torch.where(den > 0, den, torch.ones_like(den)), torch.zeros_like(R))
+        R = 2.0 * (ntf + nft)
+        if metric == "sokalsneath":
+            return R / (ntt + R)
+        return R / (ntt + nff + R)  # rogerstanimoto == sokalmichener
+    raise NotImplementedError(f"metric '{metric}' (implemented: {_PAIR_METRICS}; 'mahalanobis' and 'seuclidean' depend on "
+                              "the rows of each cdist call of the reference, 'wminkowski' needs weights)")
 
 
 def _candidates_filtered(be, Xn: torch.Tensor, sq: torch.Tensor, kc: int, chunk_elems: int, cap: Optional[int] = None) -> torch.Tensor:
@@ -229,8 +281,8 @@ def device_knn(X: torch.Tensor, k: int, metric: str = "euclidean", chunk_elems: 
     the order.  ``indices_only``: the caller wants the neighbour SET (the candidate union of ``neighbors``): with
     the filter path the k smallest GEMM-form distances decide and the exact re-evaluation - a gather of
     n x (k + 8) x p values - is skipped; the distances returned are then the GEMM-form ones."""
-    if metric not in _METRICS:
-        raise NotImplementedError(f"metric '{metric}' (implemented: {_METRICS})")
+    if metric not in _PAIR_METRICS:
+        _pair_dist(X[:1], X[:1], metric)  # (raises, naming what is offered)
     n, p = X.shape
     k = min(int(k), n - 1)
     kc = min(k + 8, n - 1)
@@ -249,7 +301,8 @@ def device_knn(X: torch.Tensor, k: int, metric: str = "euclidean", chunk_elems: 
             d = t.values.clamp_min(0.0)
             return torch.gather(cand_all, 1, t.indices), (d if metric == "sqeuclidean" else
                                                             torch.sqrt(d) if metric == "euclidean" else d / 2.0)
-    rows = max(1, min(n, chunk_elems // max(n if cand_all is None else kc * p, 1)))
+    tiled = gemm or metric in _METRICS  # (else: every pair through `_pair_dist`, a tile of queries x all rows x p)
+    rows = max(1, min(n, chunk_elems // max((n if tiled else n * p) if cand_all is None else kc * p, 1)))
     for lo in range(0, n, rows):
         hi = min(n, lo + rows)
         if cand_all is not None:
@@ -257,8 +310,11 @@ def device_knn(X: torch.Tensor, k: int, metric: str = "euclidean", chunk_elems: 
         else:
             if gemm:
                 D = sq[lo:hi, None] + sq[None, :] - 2.0 * (Xn[lo:hi] @ Xn.T)
-            else:
+            elif tiled:
                 D = torch.cdist(X[lo:hi], X, p=1.0 if metric in ("cityblock", "manhattan") else float("inf"))
+            else:
+                D = _pair_dist(X[lo:hi, None, :].expand(hi - lo, n, p), X[None, :, :].expand(hi - lo, n, p), metric)
+                D = torch.where(torch.isnan(D), torch.full_like(D, float("inf")), D)
             D[ar[lo:hi] - lo, ar[lo:hi]] = float("inf")  # not the row itself
             cand = torch.topk(D, kc, dim=1, largest=False).indices
             del D
