@@ -321,6 +321,13 @@ int mu_skinny_nn(int dtype, int64_t n_rows, int64_t D, int64_t ldY, const void* 
                  void* d_out, void* stream);
 int mu_skinny_tn(int dtype, int64_t n_rows, int64_t D, int64_t ldY, const void* d_Y, const void* d_Z,
                  void* d_C, void* d_work, size_t work_bytes, void* stream);
+/* The same two products in f64 with Y STORED in f32 (r04): a dense view whose values are exact in f32 - AnnData's
+ * default dtype, tools.py:308 converts to float64 for the default use_float32=False - streams half the bytes and is
+ * widened in registers; every product and sum is the f64 one.  (work: mu_skinny_tn_worksize(MU_DTYPE_F64, ..).) */
+int mu_skinny_nn_f64_f32(int64_t n_rows, int64_t D, int64_t ldY, const float* d_Y, const double* d_T, double* d_out,
+                         void* stream);
+int mu_skinny_tn_f64_f32(int64_t n_rows, int64_t D, int64_t ldY, const float* d_Y, const double* d_Z, double* d_C,
+                         void* d_work, size_t work_bytes, void* stream);
 
 /* ---- MOFA+ coordinate updates (tools.py:585 ent.run(): mofapy2's W and Z node updates) ---- */
 /* Spike-and-slab + ARD update of the weights of ONE view, one thread per feature, Gauss-Seidel

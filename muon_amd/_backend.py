@@ -907,26 +907,37 @@ class HipBackend:
         return out
 
     # -- MOFA+: tall-skinny products of a dense view with 16-column factor blocks ------------------
+    skinny_mixed = True  # f64 products of a dense view stored in f32 (mu_skinny_*_f64_f32)
+
     def skinny_nn(self, Y: torch.Tensor, T16: torch.Tensor) -> torch.Tensor:
-        """Y [n x D] (row slice of a row-major matrix) times T16 [D x 16] -> [n x 16]."""
+        """Y [n x D] (row slice of a row-major matrix) times T16 [D x 16] -> [n x 16].  Y may be stored in f32
+        under an f64 block: the product is the f64 one."""
         n, D = Y.shape
-        assert T16.shape == (D, 16) and T16.dtype == Y.dtype and T16.is_contiguous() and Y.stride(1) == 1
-        out = self.empty((n, 16), Y.dtype)
+        mixed = Y.dtype == torch.float32 and T16.dtype == torch.float64
+        assert T16.shape == (D, 16) and (mixed or T16.dtype == Y.dtype) and T16.is_contiguous() and Y.stride(1) == 1
+        out = self.empty((n, 16), T16.dtype)
+        ld = Y.stride(0) if n > 1 else D
         with self._dev_ctx():
-            check(self.lib.mu_skinny_nn(_dt(Y), n, D, Y.stride(0) if n > 1 else D, _p(Y), _p(T16), _p(out),
-                                        self._stream()))
+            if mixed:
+                check(self.lib.mu_skinny_nn_f64_f32(n, D, ld, _p(Y), _p(T16), _p(out), self._stream()))
+            else:
+                check(self.lib.mu_skinny_nn(_dt(Y), n, D, ld, _p(Y), _p(T16), _p(out), self._stream()))
         return out
 
     def skinny_tn(self, Y: torch.Tensor, Z16: torch.Tensor) -> torch.Tensor:
-        """Y^T [D x n] times Z16 [n x 16] -> [D x 16]."""
+        """Y^T [D x n] times Z16 [n x 16] -> [D x 16] (Y stored in f32 under an f64 block: the f64 product)."""
         n, D = Y.shape
-        assert Z16.shape == (n, 16) and Z16.dtype == Y.dtype and Z16.is_contiguous() and Y.stride(1) == 1
-        out = self.empty((D, 16), Y.dtype)
-        wb = int(self.lib.mu_skinny_tn_worksize(_dt(Y), n, D))
+        mixed = Y.dtype == torch.float32 and Z16.dtype == torch.float64
+        assert Z16.shape == (n, 16) and (mixed or Z16.dtype == Y.dtype) and Z16.is_contiguous() and Y.stride(1) == 1
+        out = self.empty((D, 16), Z16.dtype)
+        wb = int(self.lib.mu_skinny_tn_worksize(_dt(Z16), n, D))
         work = self.empty((wb,), torch.uint8)
+        ld = Y.stride(0) if n > 1 else D
         with self._dev_ctx():
-            check(self.lib.mu_skinny_tn(_dt(Y), n, D, Y.stride(0) if n > 1 else D, _p(Y), _p(Z16), _p(out),
-                                        _p(work), wb, self._stream()))
+            if mixed:
+                check(self.lib.mu_skinny_tn_f64_f32(n, D, ld, _p(Y), _p(Z16), _p(out), _p(work), wb, self._stream()))
+            else:
+                check(self.lib.mu_skinny_tn(_dt(Y), n, D, ld, _p(Y), _p(Z16), _p(out), _p(work), wb, self._stream()))
         return out
 
     # -- MOFA+ coordinate updates (reference tools.py:585 -> mofapy2 node updates) -----------

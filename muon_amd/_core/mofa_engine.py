@@ -129,6 +129,19 @@ class MofaEngine:
         t = self.be.to_device(np.ascontiguousarray(arr))
         return t.to(dtype or self.T)
 
+    def _f32_storage_ok(self, scale_views, scale_groups):
+        """f64 fit, dense view whose values are exact in f32 (AnnData's default dtype; tools.py:308 widens it for the
+        default use_float32=False): the view stays in f32 in HBM - half the bytes of the two passes over it per
+        iteration, the bound of the f64 fit - and is widened in registers (mu_skinny_*_f64_f32); products and sums
+        are the f64 ones.  The centred values are not exact in f32, so the centring moves into the products, as for
+        the sparse views: Y (tau o W) - pres (mu^T (tau o W)) and Y^T Z - mu (pres^T Z).  Against centring first the
+        result differs by rounding only (a few ulp of the uncentred products: |mu| / std digits at most).  Not with
+        view / group scaling (the scaled values are not exact in f32 either)."""
+        be = self.be
+        return (self.T == torch.float64 and not scale_views and not scale_groups and self.K <= 16
+                and getattr(be, "skinny_mixed", False) and hasattr(be, "skinny_nn") and hasattr(be, "mofa_rowstats")
+                and os.environ.get("MUON_AMD_MOFA_F32_STORAGE", "1") != "0")
+
     def _prepare_view(self, v, center_groups, scale_views, scale_groups):
         be, T, G = self.be, self.T, self.G
         V = _View()
@@ -146,7 +159,11 @@ class MofaEngine:
                 V.X = v.with_values(v.values.to(T, copy=True))  # centring / scaling work in place:
             else:                                               # never on the caller's tensors
                 V.kind = "dense"
-                V.Y = v.to(T, copy=True)
+                if self._f32_storage_ok(scale_views, scale_groups) and v.dtype == torch.float32:
+                    V.Y = v.contiguous()  # read-only from here on: no copy (see _f32_storage_ok)
+                    V.implicit = True
+                else:
+                    V.Y = v.to(T, copy=True)
         elif issparse(v):
             m = v.tocsr()[self.perm]
             m.sort_indices()
@@ -166,7 +183,13 @@ class MofaEngine:
                 raise NotImplementedError("element-wise missing values are not supported")
             pres = ~nanrow
             V.kind = "dense"
-            V.Y = self._dev(np.where(pres[:, None], a, 0.0))
+            a = np.where(pres[:, None], a, 0.0)
+            a32 = a.astype(np.float32)
+            if self._f32_storage_ok(scale_views, scale_groups) and np.array_equal(a32.astype(np.float64), a):
+                V.Y = self._dev(a32, torch.float32)
+                V.implicit = True
+            else:
+                V.Y = self._dev(a)
         V.pres = self._dev(pres.astype(np.float64))
         V.Ngm = self._allreduce(torch.tensor([float(pres[a:b].sum()) for a, b in self.gslice],
                                              dtype=torch.float64))
@@ -174,7 +197,12 @@ class MofaEngine:
         s1 = torch.zeros((G, D), dtype=T, device=V.pres.device)
         s2 = torch.zeros((G, D), dtype=T, device=V.pres.device)
         for g, (a, b) in enumerate(self.gslice):
-            if V.kind == "dense":
+            if V.kind == "dense" and getattr(V, "implicit", False):
+                for c0 in range(a, b, 16384):  # (f64 moments of the f32-stored block, a slab of rows at a time)
+                    blk = V.Y[c0:min(b, c0 + 16384)].to(T)
+                    s1[g] += blk.sum(dim=0)
+                    s2[g] += (blk * blk).sum(dim=0)
+            elif V.kind == "dense":
                 s1[g] = V.Y[a:b].sum(dim=0)
                 s2[g] = (V.Y[a:b] ** 2).sum(dim=0)
             else:
@@ -221,7 +249,9 @@ class MofaEngine:
             yy = yy * scale[:, None] ** 2
         V.yy = yy
         V.mu = mu
-        if V.kind == "dense":
+        if V.kind == "dense" and getattr(V, "implicit", False):
+            V.Yt = None  # centred in the products, like the sparse views: Y stays what it was (exact in f32)
+        elif V.kind == "dense":
             for g, (a, b) in enumerate(self.gslice):
                 V.Y[a:b] -= mu[g] * V.pres[a:b, None]  # explicit centring of the dense block
             V.Yt = None
@@ -375,7 +405,7 @@ class MofaEngine:
             B = B.contiguous()
             Gz, Z2, Zs = Gz.clone(), Z2.clone(), Zs.clone()  # (shared between views: reduce copies)
             self.comm.all_reduce_sum(Gz, Z2, Zs, B)
-        if V.kind == "sparse":
+        if V.kind == "sparse" or getattr(V, "implicit", False):
             B = B - V.mu[:, :, None] * Zs[:, None, :]  # implicit centring
         return Gz, Z2, B.contiguous()
 
@@ -434,6 +464,10 @@ class MofaEngine:
                 if V.kind == "sparse":
                     be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, self._rs_work, aux=V.mu[g], out_pad=V.TWs, col0=g * K,
                                      s1=self._corr[m, g], **kw)
+                elif hasattr(V, "T16") and getattr(V, "implicit", False):
+                    be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, self._rs_work, aux=V.mu[g], out_pad=V.T16[g],
+                                     s1=self._corr[m, g], **kw)  # (the centring term goes into the sweep: corr)
+                    A[m, a:b] = be.skinny_nn(V.Y[a:b], V.T16[g])[:, :K]
                 elif hasattr(V, "T16"):
                     be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, self._rs_work, out_pad=V.T16[g], **kw)
                     A[m, a:b] = be.skinny_nn(V.Y[a:b], V.T16[g])[:, :K]

@@ -90,6 +90,8 @@ SIGNATURES = {
     "mu_skinny_tn_worksize": (_sz, [_i32, _i64, _i64]),
     "mu_skinny_nn": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mu_skinny_tn": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mu_skinny_nn_f64_f32": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "mu_skinny_tn_f64_f32": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_mofa_update_w": (C.c_int, [_i32, _i64, _i32, _i32] + [_vp] * 7 + [_i32] + [_vp] * 6),
     "mu_mofa_update_z": (C.c_int, [_i32, _i64, _i32, _i32, _i32] + [_vp] * 11),
     "mu_mofa_rowstats_work_doubles": (_sz, [_i32]),

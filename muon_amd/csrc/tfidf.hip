@@ -2,7 +2,19 @@
 // /root/reference/muon/_atac/preproc.py:92-117 (two reductions, two diag x CSR
 // SpGEMMs, a scalar multiply and a sparse log1p) by one reduction sweep and one
 // fused scale pass.  HBM-bound: 8 B/nnz (sweep) + 12 B/nnz (scale).
+#include <type_traits>
+#include <utility>
+
 #include "sweep.hpp"
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
 
 // ---------------------------------------------------------------------------------
 // slab pointers
@@ -115,6 +127,169 @@ __global__ __launch_bounds__(kSweepThreads, sizeof(T) == 4 ? 8 : 4) void k_row_c
     }
     __syncthreads();
     const int64_t ncol_here = (n_cols - (int64_t)cbase) < kSlab ? (n_cols - (int64_t)cbase) : kSlab;
+    double* dst = partial + (int64_t)g * n_cols + cbase;
+    for (int t = threadIdx.x; t < ncol_here; t += kSweepThreads) dst[t] = bins[t];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// the same two sweeps, software pipelined (r04)
+// ---------------------------------------------------------------------------------
+// What the compiler made of the loops above: the predicated loads (`ok ? ib[q] : -1`) became branches with the
+// value's conversion - and an `s_waitcnt vmcnt(0)` - inside, so the sum sweep's "four chunks in flight" were three
+// full memory round trips per iteration; and in both sweeps a wave has ONE iteration in flight: it issues its
+// loads, waits for all of them (on gfx9 the stores of the iteration before count in the same counter), works,
+// and only then asks for more - with four (scale) or eight (sums) waves per SIMD the CU's requests in flight are
+// a few tens of KiB, and the sweeps run at the memory latency, not at its bandwidth (4.15 / 5.2 of ~6.3 TB/s).
+// Here the visits of a wave's strip of rows are walked as ONE flat sequence of iterations (a row's piece inside
+// the slab, 64 CH entries at a time, then the next row's), every load is unconditional with a clamped position
+// (no branch for the compiler to hide a wait in; a lane past the end re-reads the piece's last entry: the same
+// line), and the loads of iteration i + 1 are issued before iteration i is worked on: two register sets, the
+// loop unrolled by two, so the waits the compiler inserts are counted ones.  Same arithmetic in the same order,
+// entry by entry and row by row: bit-identical row sums and values.
+// The loads of the pipelined f32 sweeps are issued and awaited from asm: left to the compiler, the two register sets
+// of the unrolled loop came back with `s_waitcnt vmcnt(1)` in front of every other set of loads (a write-after-write
+// wait on registers whose loads had long been consumed), i.e. with half of the overlap.  The compiler does not know
+// that these registers are pending: `pipe_wait` takes them as read-write operands, so every use is ordered behind
+// it, and the ISA was checked for copies between a load and its wait (none).  Counts: a set is 2 CH loads, issued
+// in chunk order; the wait for chunk u of a set allows the loads issued after it - the rest of its own set and the
+// whole next set - to be outstanding: 2 (CH - 1 - u) + 2 CH.  (Stores of the scale sweep issued in between only
+// make the wait stricter.)  Offsets are 32-bit byte offsets from the row block's first entry (host: < 2^30 entries).
+__device__ __forceinline__ void pipe_load(const int32_t* ib, const float* vb, unsigned off, int32_t& c, float& v) {
+  asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %4"
+               : "=&v"(c), "=&v"(v)
+               : "v"(off), "s"(ib), "s"(vb)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void pipe_wait(int32_t& c, float& v) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(c), "+v"(v) : "n"(N) : "memory");
+}
+// The walk ends with one set of loads that nobody reads (issued for an iteration that does not exist): its registers
+// stay operands of this wait, so the compiler cannot hand them to anything else while the loads are in flight.
+template <typename A, typename B>
+__device__ __forceinline__ void pipe_drain(A (&c0)[4], B (&v0)[4], A (&c1)[4], B (&v1)[4]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]),
+                 "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]), "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]), "+v"(v1[3])
+               :
+               : "memory");
+}
+
+struct FlatWalk {
+  int l, pb, hi, nrow, step;
+  // the next iteration: false when the strip is through (wave-uniform: every member lives in scalar registers)
+  __device__ __forceinline__ bool advance(int lo_l, int hi_l) {
+    pb += step;
+    while (pb >= hi) {
+      if (++l >= nrow) return false;
+      pb = __builtin_amdgcn_readlane(lo_l, l);
+      hi = __builtin_amdgcn_readlane(hi_l, l);
+    }
+    return true;
+  }
+};
+
+// ABL (timing ablations, wrong results; tune "tfidf_abl"): 1 no LDS atomics, 2 f32 atomics
+// M: bins of M x 8192 columns (M = 2: 128 KiB, one workgroup per CU - pieces of a row twice as long: 14.3 -> 13.1 ms
+// at 1e6 x 200k now that a wave keeps two iterations in flight; r04's first try of M = 2, on the unpipelined kernel,
+// lost 17 %).
+// (r04 also built the slab pointer search INTO this sweep - the lane that owns a row finds the ends of its next
+// pieces from the end of the last one - to drop k_slab_ptr's 3.0 ms: the dependent loads, un-overlapped inside a
+// wave, cost the sweep 4.3 ms.  Deleted; what the search costs is its 64-byte sectors, wherever it runs.)
+template <typename T, int CH, int ABL = 0, int M = 1>
+__global__ __launch_bounds__(kSweepThreads, (sizeof(T) == 4 && M == 1) ? 8 : 4) void k_row_col_sums_pipe(  // (CH = 4: pipe_drain)
+    int64_t n_rows, int64_t n_cols, int64_t S, const int64_t* __restrict__ indptr,
+    const int32_t* __restrict__ indices, const T* __restrict__ values,
+    const int64_t* __restrict__ sp, double* __restrict__ rowsum, double* __restrict__ partial) {
+  __shared__ double bins[kSlab * M];  // 64 KiB x M
+  __shared__ int64_t s_r[2];
+  const int g = blockIdx.x, G = gridDim.x;
+  if (threadIdx.x == 0) sweep_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
+  __syncthreads();
+  const int64_t r0 = uniform64(s_r[0]), r1 = uniform64(s_r[1]);
+  const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t wg_base = uniform64(indptr[r0 < n_rows ? r0 : n_rows]);
+  const int32_t* __restrict__ ib = indices + wg_base;
+  const T* __restrict__ vb = values + wg_base;
+  constexpr bool kAsm = std::is_same<T, float>::value;
+  for (int64_t s = 0; s < S; s += M) {
+    for (int t = threadIdx.x; t < kSlab * M; t += kSweepThreads) bins[t] = 0.0;
+    __syncthreads();
+    const int32_t cbase = (int32_t)(s * kSlab);
+    const int64_t s_hi = s + M < S ? s + M : S;
+    for (int64_t strip = r0 + wave; strip < r1; strip += (int64_t)kSweepWaves * 64) {
+      const int64_t myrow = strip + (int64_t)kSweepWaves * lane;
+      int lo_l = 0, hi_l = 0;
+      if (myrow < r1) {
+        lo_l = (int)(sp[myrow * (S + 1) + s] - wg_base);
+        hi_l = (int)(sp[myrow * (S + 1) + s_hi] - wg_base);
+      }
+      const int64_t left = (r1 - strip + kSweepWaves - 1) / kSweepWaves;
+      FlatWalk w{-1, 0, 0, left < 64 ? (int)left : 64, 64 * CH};
+      double racc = 0.0, rs = 0.0;
+      int32_t ca[CH], cb[CH];
+      T va[CH], vb_[CH];
+      auto load = [&](int32_t (&c)[CH], T (&v)[CH], int pb, int hi) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          int q = pb + lane + 64 * u;
+          q = q < hi ? q : hi - 1;
+          if constexpr (kAsm) {
+            pipe_load(ib, vb, (unsigned)q * 4u, c[u], v[u]);
+          } else {
+            c[u] = ib[q];
+            v[u] = vb[q];
+          }
+        }
+      };
+      auto work = [&](int32_t (&c)[CH], T (&v)[CH], int pb, int hi, int l, bool row_ends) {
+        // no branch around a chunk: a register that was loaded but not read on some path makes the compiler wait
+        // for it - with `vmcnt(0)`, i.e. for the loads just issued - before the register is written again.  A lane
+        // past the end adds 0.0 to a bin of its own (no conflict, no effect)
+        static_for<CH>([&](auto uc) {
+          constexpr int u = decltype(uc)::value;
+          if constexpr (kAsm) pipe_wait<2 * (CH - 1 - u) + 2 * CH>(c[u], v[u]);
+        });
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const bool ok = pb + lane + 64 * u < hi;
+          const double x = ok ? (double)v[u] : 0.0;
+          if constexpr (ABL == 0) atomicAdd(&bins[ok ? c[u] - cbase : lane], x);
+          if constexpr (ABL == 1) rs += (double)(c[u] & 1);
+          if constexpr (ABL == 2) atomicAdd(reinterpret_cast<float*>(bins) + (ok ? c[u] - cbase : lane), (float)x);
+          rs += x;
+        }
+        if (row_ends) {  // (uniform)
+          const double tot = __shfl(wave_sum(rs), 0, 64);
+          if (lane == l) racc = tot;
+          rs = 0.0;
+        }
+      };
+      if (w.advance(lo_l, hi_l)) {
+        int a_pb = w.pb, a_hi = w.hi, a_l = w.l, b_pb, b_hi, b_l;
+        load(ca, va, a_pb, a_hi);
+        for (;;) {
+          bool more = w.advance(lo_l, hi_l);
+          b_pb = more ? w.pb : a_pb, b_hi = more ? w.hi : a_hi, b_l = w.l;  // (nothing left: a harmless re-read)
+          load(cb, vb_, b_pb, b_hi);
+          work(ca, va, a_pb, a_hi, a_l, b_l != a_l);
+          if (!more) break;
+          more = w.advance(lo_l, hi_l);
+          a_pb = more ? w.pb : b_pb, a_hi = more ? w.hi : b_hi, a_l = w.l;
+          load(ca, va, a_pb, a_hi);
+          work(cb, vb_, b_pb, b_hi, b_l, a_l != b_l);
+          if (!more) break;
+        }
+        if constexpr (kAsm) pipe_drain(ca, va, cb, vb_);
+      }
+      if (myrow < r1) {
+        if (s == 0) rowsum[myrow] = racc; else rowsum[myrow] += racc;
+      }
+    }
+    __syncthreads();
+    const int64_t ncol_here = (n_cols - (int64_t)cbase) < kSlab * M ? (n_cols - (int64_t)cbase) : kSlab * M;
     double* dst = partial + (int64_t)g * n_cols + cbase;
     for (int t = threadIdx.x; t < ncol_here; t += kSweepThreads) dst[t] = bins[t];
     __syncthreads();
@@ -369,6 +544,104 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_tfidf_scale_sweep_wide(
   }
 }
 
+// k_tfidf_scale_sweep_wide, software pipelined (see k_row_col_sums_pipe).  A lane past the end of a piece holds
+// the piece's LAST entry and stores its value again: same address, same bits - no branch around the store either.
+template <int M, int CH, int ABL = 0>  // ABL (timing ablations, tune "tfidf_abl"): 3 no arithmetic, 4 no stores
+__global__ __launch_bounds__(kSweepThreads, 4) void k_tfidf_scale_sweep_pipe(
+    int64_t n_rows, int64_t n_cols, int64_t S, const int64_t* __restrict__ indptr,
+    const int32_t* __restrict__ indices, const float* __restrict__ values,
+    const int64_t* __restrict__ sp, const double* __restrict__ rowsum, const float* __restrict__ idf,
+    float scale, int use_scale, int flags, float* __restrict__ out, unsigned long long* zero_count) {
+  __shared__ float lidf[kSlab * M];
+  __shared__ int64_t s_r[2];
+  const int g = blockIdx.x, G = gridDim.x;
+  if (threadIdx.x == 0) sweep_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
+  __syncthreads();
+  const int64_t r0 = uniform64(s_r[0]), r1 = uniform64(s_r[1]);
+  const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  unsigned int zeros = 0;
+  const int64_t wg_base = uniform64(indptr[r0 < n_rows ? r0 : n_rows]);
+  const int32_t* __restrict__ ib = indices + wg_base;
+  const float* __restrict__ vb = values + wg_base;
+  float* __restrict__ ob = out + wg_base;
+  const int64_t SW = (S + M - 1) / M;
+  for (int64_t sw = 0; sw < SW; ++sw) {
+    const int64_t s_lo = sw * M, s_hi = (sw + 1) * M < S ? (sw + 1) * M : S;
+    const int32_t cbase = (int32_t)(s_lo * kSlab);
+    const int64_t ncol_here = (n_cols - (int64_t)cbase) < (int64_t)kSlab * M ? (n_cols - (int64_t)cbase) : (int64_t)kSlab * M;
+    for (int t = threadIdx.x; t < kSlab * M; t += kSweepThreads) lidf[t] = t < ncol_here ? idf[cbase + t] : 0.f;
+    __syncthreads();
+    for (int64_t strip = r0 + wave; strip < r1; strip += (int64_t)kSweepWaves * 64) {
+      const int64_t myrow = strip + (int64_t)kSweepWaves * lane;
+      int lo_l = 0, hi_l = 0;
+      float inv_l = 0.f;
+      if (myrow < r1) {
+        lo_l = (int)(sp[myrow * (S + 1) + s_lo] - wg_base);
+        hi_l = (int)(sp[myrow * (S + 1) + s_hi] - wg_base);
+        inv_l = 1.0f / (float)rowsum[myrow];  // preproc.py:94  1.0 / n_peaks
+      }
+      const int64_t left = (r1 - strip + kSweepWaves - 1) / kSweepWaves;
+      FlatWalk w{-1, 0, 0, left < 64 ? (int)left : 64, 64 * CH};
+      int32_t ca[CH], cb[CH];
+      float xa[CH], xb[CH];
+      auto load = [&](int32_t (&c)[CH], float (&x)[CH], int pb, int hi) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          int q = pb + lane + 64 * u;
+          q = q < hi ? q : hi - 1;
+          pipe_load(ib, vb, (unsigned)q * 4u, c[u], x[u]);
+        }
+      };
+      auto work = [&](int32_t (&c)[CH], float (&x)[CH], int pb, int hi, int l) {
+        const float inv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_l), l));
+        static_for<CH>([&](auto uc) {
+          constexpr int u = decltype(uc)::value;
+          pipe_wait<2 * (CH - 1 - u) + 2 * CH>(c[u], x[u]);
+        });
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          // (no branch around a chunk, see k_row_col_sums_pipe: a chunk with nothing in it stores the last value again)
+          const int p = pb + lane + 64 * u;
+          const int q = p < hi ? p : hi - 1;
+          float t = inv * x[u];                               // :96  D @ counts
+          if constexpr (ABL != 3) {
+            if (use_scale) t = t * scale;                       // :101-102
+            if (flags & MU_TFIDF_LOG_TF) t = log1p_wave(t);     // :103-104
+            t = t * lidf[c[u] - cbase];                         // :110-112  tf @ diag(idf)
+            if (flags & MU_TFIDF_LOG_TFIDF) t = log1p_wave(t);  // :116-117
+          } else {
+            t += (float)c[u];
+          }
+          if constexpr (ABL != 4) ob[q] = t;
+          zeros += (p < hi && t == 0.f) ? 1u : 0u;
+        }
+      };
+      if (w.advance(lo_l, hi_l)) {
+        int a_pb = w.pb, a_hi = w.hi, a_l = w.l, b_pb, b_hi, b_l;
+        load(ca, xa, a_pb, a_hi);
+        for (;;) {
+          bool more = w.advance(lo_l, hi_l);
+          b_pb = more ? w.pb : a_pb, b_hi = more ? w.hi : a_hi, b_l = more ? w.l : a_l;
+          load(cb, xb, b_pb, b_hi);
+          work(ca, xa, a_pb, a_hi, a_l);
+          if (!more) break;
+          more = w.advance(lo_l, hi_l);
+          a_pb = more ? w.pb : b_pb, a_hi = more ? w.hi : b_hi, a_l = more ? w.l : b_l;
+          load(ca, xa, a_pb, a_hi);
+          work(cb, xb, b_pb, b_hi, b_l);
+          if (!more) break;
+        }
+        pipe_drain(ca, xa, cb, xb);
+      }
+    }
+    __syncthreads();
+  }
+  if (zero_count) {
+    zeros = wave_sum(zeros);
+    if (lane == 0 && zeros) atomicAdd(zero_count, (unsigned long long)zeros);
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // explicit-zero compaction, scan, fill
 // ---------------------------------------------------------------------------------
@@ -555,17 +828,36 @@ int mu_csr_row_col_sums(int dtype, int64_t n_rows, int64_t n_cols, const int64_t
   int64_t* sp = (int64_t*)d_work;
   size_t off = ((size_t)(n_rows * (S + 1)) * sizeof(int64_t) + 255) & ~(size_t)255;
   double* partial = (double*)((char*)d_work + off);
+  // software-pipelined walk (r04); tune "tfidf_pipe" = 1: the kernels of before, for comparison.  f32 matrices of
+  // 100 000 rows and more: 16 384-column bins, one workgroup per CU (tune "tfidf_sum_m" = 1: never, 2: whatever
+  // the size (tests))
+  const bool pipe = mu_tune_get("tfidf_pipe") != 1;
+  const int abl = mu_tune_get("tfidf_abl"), sum_m = mu_tune_get("tfidf_sum_m");
+  const bool big = dtype == MU_DTYPE_F32 && pipe && abl == 0 && sum_m != 1 && (n_rows >= 100000 || sum_m == 2);
   int rc = launch_slab_ptr(n_rows, n_cols, d_indptr, d_indices, sp, st);
   if (rc) return rc;
-  if (dtype == MU_DTYPE_F32)
+  if (big)
+    hipLaunchKernelGGL((k_row_col_sums_pipe<float, 4, 0, 2>), dim3(mu_num_cus()), dim3(kSweepThreads), 0, st, n_rows,
+                       n_cols, S, d_indptr, d_indices, (const float*)d_values, sp, d_rowsum, partial);
+  else if (dtype == MU_DTYPE_F32 && pipe && abl == 1)
+    hipLaunchKernelGGL((k_row_col_sums_pipe<float, 4, 1>), dim3(G), dim3(kSweepThreads), 0, st, n_rows, n_cols, S,
+                       d_indptr, d_indices, (const float*)d_values, sp, d_rowsum, partial);
+  else if (dtype == MU_DTYPE_F32 && pipe && abl == 2)
+    hipLaunchKernelGGL((k_row_col_sums_pipe<float, 4, 2>), dim3(G), dim3(kSweepThreads), 0, st, n_rows, n_cols, S,
+                       d_indptr, d_indices, (const float*)d_values, sp, d_rowsum, partial);
+  else if (dtype == MU_DTYPE_F32 && pipe)
+    hipLaunchKernelGGL((k_row_col_sums_pipe<float, 4>), dim3(G), dim3(kSweepThreads), 0, st, n_rows, n_cols, S,
+                       d_indptr, d_indices, (const float*)d_values, sp, d_rowsum, partial);
+  else if (dtype == MU_DTYPE_F32)
     hipLaunchKernelGGL(k_row_col_sums<float>, dim3(G), dim3(kSweepThreads), 0, st, n_rows, n_cols, S,
                        d_indptr, d_indices, (const float*)d_values, sp, d_rowsum, partial);
-  else
+  else  // (f64 values: the kernel of before - the pipelined walk is asm for f32 loads)
     hipLaunchKernelGGL(k_row_col_sums<double>, dim3(G), dim3(kSweepThreads), 0, st, n_rows, n_cols,
                        S, d_indptr, d_indices, (const double*)d_values, sp, d_rowsum, partial);
   MU_CHECK_LAUNCH();
+  const int G_used = big ? mu_num_cus() : G;
   hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st,
-                     n_cols, G, partial, d_colsum);
+                     n_cols, G_used, partial, d_colsum);
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
@@ -634,7 +926,20 @@ int mu_tfidf_scale_sweep(int dtype, int64_t n_rows, int64_t n_cols, const int64_
   const int G = sweep_grid();
   // f32: idf slabs of 4 x 8192 columns, one workgroup per CU (r04: 18.2 -> 14.4 ms at 1e6 x 200k, bit-identical;
   // tune "tfidf_wide" = 1 keeps the 8192-column kernel for comparison)
-  if (dtype == MU_DTYPE_F32 && mu_tune_get("tfidf_wide") != 1)
+  const int abl = mu_tune_get("tfidf_abl");
+  if (dtype == MU_DTYPE_F32 && mu_tune_get("tfidf_wide") != 1 && mu_tune_get("tfidf_pipe") != 1 && abl == 3)
+    hipLaunchKernelGGL((k_tfidf_scale_sweep_pipe<4, 4, 3>), dim3(mu_num_cus()), dim3(kSweepThreads), 0, st, n_rows, n_cols,
+                       S, d_indptr, d_indices, (const float*)d_values, sp, d_rowsum, (const float*)d_idf,
+                       (float)scale, use_scale, flags, (float*)d_out, d_zero_count);
+  else if (dtype == MU_DTYPE_F32 && mu_tune_get("tfidf_wide") != 1 && mu_tune_get("tfidf_pipe") != 1 && abl == 4)
+    hipLaunchKernelGGL((k_tfidf_scale_sweep_pipe<4, 4, 4>), dim3(mu_num_cus()), dim3(kSweepThreads), 0, st, n_rows, n_cols,
+                       S, d_indptr, d_indices, (const float*)d_values, sp, d_rowsum, (const float*)d_idf,
+                       (float)scale, use_scale, flags, (float*)d_out, d_zero_count);
+  else if (dtype == MU_DTYPE_F32 && mu_tune_get("tfidf_wide") != 1 && mu_tune_get("tfidf_pipe") != 1)
+    hipLaunchKernelGGL((k_tfidf_scale_sweep_pipe<4, 4>), dim3(mu_num_cus()), dim3(kSweepThreads), 0, st, n_rows, n_cols,
+                       S, d_indptr, d_indices, (const float*)d_values, sp, d_rowsum, (const float*)d_idf,
+                       (float)scale, use_scale, flags, (float*)d_out, d_zero_count);
+  else if (dtype == MU_DTYPE_F32 && mu_tune_get("tfidf_wide") != 1)
     hipLaunchKernelGGL((k_tfidf_scale_sweep_wide<4, 4>), dim3(mu_num_cus()), dim3(kSweepThreads), 0, st, n_rows, n_cols,
                        S, d_indptr, d_indices, (const float*)d_values, sp, d_rowsum, (const float*)d_idf,
                        (float)scale, use_scale, flags, (float*)d_out, d_zero_count);

@@ -69,3 +69,18 @@ for wide in (1, 0):
     t2 = timeit(both)
     print(f"tfidf_wide {wide}: scale sweep alone {t:.2f} ms ({12 * nnz / t / 1e9:.2f} TB/s), sum + scale {t2:.2f} ms, bit-identical {same}")
 be.tune("tfidf_wide", 0)
+
+# r04: software-pipelined walks (tune key "tfidf_pipe": 1 = the kernels of before)
+be.tune("tfidf_pipe", 1)
+rs_ref, cs_ref = be.row_col_sums(X)
+val_ref, _ = be.tfidf_scale(X, rs_ref, idf, 1e4, 3)
+for pipe in (1, 0, 1, 0):
+    be.tune("tfidf_pipe", pipe)
+    rs2, cs2 = be.row_col_sums(X)
+    got, _ = be.tfidf_scale(X, rs2, idf, 1e4, 3)
+    same = (bool(torch.equal(rs2, rs_ref)), bool(torch.equal(cs2, cs_ref)), bool(torch.equal(got, val_ref)))
+    t1 = timeit(lambda: be.row_col_sums(X))
+    t2 = timeit(both)
+    print(f"tfidf_pipe {pipe}: sum sweep (+ pointers) {t1:.2f} ms ({8 * nnz / t1 / 1e9:.2f} TB/s), sum + scale {t2:.2f} ms "
+          f"({20 * nnz / t2 / 1e9:.2f} TB/s), row sums / column sums / values bit-identical {same}")
+be.tune("tfidf_pipe", 0)

@@ -439,6 +439,28 @@ def test_skinny_products(hip, dt, n, D):
     assert torch.equal(hip.skinny_tn(Yd, hip.to_device(Z16)), hip.skinny_tn(Yd, hip.to_device(Z16)))
 
 
+@pytest.mark.parametrize("n,D", [(1, 1), (5, 3), (33, 130), (1000, 257), (4099, 2000), (20000, 301)])
+def test_skinny_products_of_an_f32_stored_view_are_the_f64_ones(hip, n, D):
+    """r04: mu_skinny_*_f64_f32 - Y in f32 in memory, blocks, products and sums in f64 - against the f64 kernels
+    on the widened copy of the same values: the same instruction sequence after the conversion, so the same bits."""
+    rng = np.random.default_rng(n * 7 + D)
+    Y32 = rng.standard_normal((n + 3, D)).astype(np.float32)
+    T16 = np.zeros((D, 16)); T16[:, :10] = rng.standard_normal((D, 10))
+    Z16 = np.zeros((n, 16)); Z16[:, :10] = rng.standard_normal((n, 10))
+    Yd32 = hip.to_device(Y32)[2:2 + n]
+    Yd64 = hip.to_device(Y32.astype(np.float64))[2:2 + n]
+    Td, Zd = hip.to_device(T16), hip.to_device(Z16)
+    A, A64 = hip.skinny_nn(Yd32, Td), hip.skinny_nn(Yd64, Td)
+    Bm, B64 = hip.skinny_tn(Yd32, Zd), hip.skinny_tn(Yd64, Zd)
+    assert A.dtype == torch.float64 and Bm.dtype == torch.float64
+    refA = Y32[2:2 + n].astype(np.float64) @ T16
+    refB = Y32[2:2 + n].astype(np.float64).T @ Z16
+    assert np.max(np.abs(hip.to_host(A) - refA)) <= 1e-11 * (1 + np.abs(refA).max())
+    assert np.max(np.abs(hip.to_host(Bm) - refB)) <= 1e-11 * (1 + np.abs(refB).max())
+    assert torch.equal(Bm, B64)  # (tn: the same tiles and order; nn tiles 32 columns of f32 against 16 of f64)
+    assert float((A - A64).abs().max()) <= 1e-12 * (1 + np.abs(refA).max())
+
+
 @pytest.mark.parametrize("B", [16, 32])
 @pytest.mark.parametrize("n,d,dens", [(5, 255, 0.3), (513, 700, 0.05), (3000, 20000, 0.01)])
 def test_spmm_stream_narrow_blocks(hip, B, n, d, dens):

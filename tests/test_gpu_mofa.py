@@ -47,6 +47,44 @@ def test_engine_matches_oracle_f64(hip, case):
     np.testing.assert_allclose(res["r2"], ref["r2"], atol=1e-6)
 
 
+@pytest.mark.parametrize("case", ["plain", "groups_missing", "offset"])
+def test_f64_fit_of_an_f32_valued_dense_view_streams_f32(hip, case, monkeypatch):
+    """r04: a dense view whose values are exact in f32 (AnnData's default dtype) stays in f32 on the device under the
+    f64 fit and is centred inside the products (like the sparse views).  Against the oracle (centres first, all f64)
+    and against the same engine with the f64 copy (MUON_AMD_MOFA_F32_STORAGE=0): rounding differences only."""
+    rng = np.random.default_rng(12)
+    N, K0 = 600, 5
+    Z = rng.standard_normal((N, K0))
+    W1 = rng.standard_normal((300, K0)) * (rng.random((300, K0)) < 0.4)
+    W2 = rng.standard_normal((170, K0)) * (rng.random((170, K0)) < 0.4)
+    y1 = (Z @ W1.T + rng.standard_normal((N, 300))).astype(np.float32).astype(np.float64)
+    y2 = (Z @ W2.T + rng.standard_normal((N, 170))).astype(np.float32).astype(np.float64)
+    groups = np.zeros(N, dtype=int)
+    if case == "groups_missing":
+        groups = rng.integers(0, 3, N)
+        y1[500:] = np.nan  # samples missing from view 1
+    if case == "offset":
+        y1 = (y1 + 40.0).astype(np.float32).astype(np.float64)  # |mean| = 40 std: the cancellation case
+    ref = mofa_oracle.run([y1, y2], groups=groups if case == "groups_missing" else None, n_factors=6, n_iterations=20,
+                          convergence_mode="slow")
+    eng = MofaEngine(hip, [y1, y2], groups, 6, seed=1)
+    assert all(v.Y.dtype == torch.float32 and v.implicit for v in eng.views)
+    eng.run(20, "slow")
+    res = eng.results(sort_factors=False)
+    monkeypatch.setenv("MUON_AMD_MOFA_F32_STORAGE", "0")
+    eng64 = MofaEngine(hip, [y1, y2], groups, 6, seed=1)
+    assert all(v.Y.dtype == torch.float64 and not getattr(v, "implicit", False) for v in eng64.views)
+    eng64.run(20, "slow")
+    tol = 1e-8 if case != "offset" else 1e-7
+    np.testing.assert_allclose(res["elbo"], ref["elbo"][:len(res["elbo"])], rtol=tol)
+    np.testing.assert_allclose(eng.elbo, eng64.elbo, rtol=tol)
+    np.testing.assert_allclose(res["Z"], ref["Z"], atol=1e-6)
+    for a, b in zip(res["W"], ref["W"]):
+        np.testing.assert_allclose(a, b, atol=1e-6)
+    for a, b in zip(res["intercepts"], eng64.results(sort_factors=False)["intercepts"]):
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12)
+
+
 def test_engine_f32_and_larger_sparse_view(hip):
     rng = np.random.default_rng(5)
     N, K0 = 3000, 6

@@ -178,6 +178,47 @@ def test_scale_sweep_equals_gather_kernel(hip, dt, flags):
     assert int(za.item()) == int(zc.item()) == int(zb.item())
 
 
+@pytest.mark.parametrize("shape", [(3000, 20000), (700, 5000), (2000, 40001), (130, 16384)])
+def test_sum_sweep_variants_agree(hip, shape):
+    """r04: the f32 sum sweep exists in three forms - the kernel of r03 (tune tfidf_pipe = 1), the software-pipelined
+    walk with 8192-column bins (tfidf_sum_m = 1) and the one for large matrices with 16 384-column bins, one
+    workgroup per CU (tfidf_sum_m = 2: whatever the size).  Same row sums (same order of additions), same column
+    sums on count data, the same pointer table, the same values out of the scale sweep."""
+    import torch
+    rng = np.random.default_rng(11)
+    n, d = shape
+    m = sp.random(n, d, density=0.02, format="csr", random_state=rng, dtype=np.float64)
+    m.data[:] = rng.integers(1, 6, m.nnz)
+    keep = np.ones(n)
+    keep[[5, 6, n - 1]] = 0  # empty rows, the last one too
+    m = (sp.diags(keep) @ m).tolil()
+    m[7, 10:min(d, 17000):2] = 3  # a long row across slabs
+    m[9, d - 1] = 4               # a row that ends in the last column
+    m = m.tocsr().astype(np.float32)
+    m.eliminate_zeros()
+    m.sort_indices()
+    X = hip.upload_csr(m.indptr, m.indices, m.data, m.shape)
+    n_sp = n * (-(-d // 8192) + 1)
+    got = {}
+    try:
+        for name, keys in (("r03", {"tfidf_pipe": 1}), ("pipe", {"tfidf_sum_m": 1}), ("wide", {"tfidf_sum_m": 2})):
+            for k in ("tfidf_pipe", "tfidf_sum_m"):
+                hip.tune(k, keys.get(k, 0))
+            rs, cs = hip.row_col_sums(X)
+            table = hip._sweep_work[0][:8 * n_sp].view(torch.int64).clone()
+            idf = hip.idf(cs, n, 3, torch.float32)
+            vals, _ = hip.tfidf_scale(X, rs, idf, 1e4, 3)
+            got[name] = (rs, cs, table, vals)
+    finally:
+        hip.tune("tfidf_pipe", 0)
+        hip.tune("tfidf_sum_m", 0)
+    np.testing.assert_array_equal(hip.to_host(got["r03"][0]), np.asarray(m.sum(axis=1)).ravel())
+    np.testing.assert_array_equal(hip.to_host(got["r03"][1]), np.asarray(m.sum(axis=0)).ravel())
+    for name in ("pipe", "wide"):
+        for a, b, what in zip(got[name], got["r03"], ("row sums", "column sums", "slab pointers", "values")):
+            assert torch.equal(a, b), f"{name}: {what}"
+
+
 def test_column_compressed_input_goes_through_the_device_transpose():
     X = planted_topics_csr(4000, 3000, n_topics=10, density=0.03, seed=6, dtype=np.float32)
     a = AnnData(X.copy())
