@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kGramThreads) void k_gram_partial(int64_t n_rows,
   constexpr int T = B / 16;
   constexpr int NT = T * (T + 1) / 2;  // upper-triangular tiles only
   __shared__ double red[B * B + B];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = uniform32(threadIdx.x >> 6);
   const int lr = lane >> 4, lc = lane & 15;
 
   d4 acc[NT];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kGramThreads) void k_gram_cross_partial(int64_t n_r
                                                                      double* __restrict__ partial) {
   constexpr int T = B / 16;
   __shared__ double red[B * B + B];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = uniform32(threadIdx.x >> 6);
   const int lr = lane >> 4, lc = lane & 15;
   d4 acc[T * T];
 #pragma unroll
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_dense_apply(int64_t n_rows, const float
                                                      float* __restrict__ Out) {
   constexpr int T = B / 16;   // output column tiles
   constexpr int KS = B / 4;   // k steps
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = uniform32(threadIdx.x >> 6);
   const int lr = lane >> 4, lc = lane & 15;
   float bm[KS][T];
 #pragma unroll
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_dense_project(int64_t n_rows, const flo
                                                        float* __restrict__ Z) {
   constexpr int T = B / 16;
   constexpr int KS = B / 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = uniform32(threadIdx.x >> 6);
   const int lr = lane >> 4, lc = lane & 15;
   float bm[KS][T];
 #pragma unroll

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64 * kMergeWaves) void k_knn_merge(int64_t n_q, int
                                                                 double* __restrict__ thr) {
   __shared__ double keys[kMergeWaves][kMergeMax];
   __shared__ int vals[kMergeWaves][kMergeMax];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = uniform32(threadIdx.x >> 6);
   const int64_t q = (int64_t)blockIdx.x * kMergeWaves + wave;
   if (q >= n_q) return;
   double* K = keys[wave];

@@ -41,8 +41,8 @@ template <> struct Mma<float> {
 // line-lookup rate (measured 5.0 ms for 8 GB in f32, 1.6 TB/s), so a wave stages a 16-row x
 // 128-byte tile through LDS instead: two coalesced global_load_dwordx4 per tile (8 rows x one full
 // line each), ds_write_b128, then the transposed operand reads (row stride 144 B: conflict free).
-// r03: a workgroup owns kSub = 4 such tiles (64 rows) and its four waves split the columns in quarters
-// (partial products, added up through LDS in a fixed order): per wave the eight loads of the NEXT step
+// r03: a workgroup owns kSub = 4 such tiles (64 rows) and its four waves split the columns (r04: every fourth tile
+// each; partial products, added up through LDS in a fixed order): per wave the eight loads of the NEXT step
 // over d are in flight while the 4 x CW/4 MFMAs of this one run (r02 had one tile per wave in flight
 // and wrote it to LDS right behind its loads: no overlap inside a wave, 3.6 TB/s in f64), the CW/4
 // operands of Tm (D x 16, a few MB: L2) are loaded once per 64 rows instead of once per 16, one step
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_skinny_nn(int64_t n_rows, int64_t D, in
 // grid its width; partial blocks are reduced in a fixed order (bit-reproducible).
 constexpr int kCT = 8;
 
-template <typename T, typename TY = T, bool PIPE = true>
+template <typename T, typename TY = T, bool PIPE = false>
 __global__ __launch_bounds__(256) void k_skinny_tn_partial(int64_t n_rows, int64_t D, int64_t ldY,
                                                            const TY* __restrict__ Y,
                                                            const T* __restrict__ Z, int n_splits,
@@ -225,8 +225,9 @@ __global__ __launch_bounds__(256) void k_skinny_tn_partial(int64_t n_rows, int64
     coff[t] = c < D ? c : D - 1;
   }
   const int64_t last_row = n_rows - 1;
-  // two steps in flight per wave: the loads of step i + 1 are issued before the MFMAs of step i (two register sets,
-  // the loop unrolled by two; a set loaded for a step that does not exist re-reads the last one and is not used)
+  // PIPE (tune tn_pipe = 1; NOT the default): two steps in flight per wave - the loads of step i + 1 issued before the
+  // MFMAs of step i, two register sets, the loop unrolled by two.  It costs 50 registers (170-182 against 119-128:
+  // two waves per SIMD instead of four) and measured 1-3 % slower on c4 in all three instances.
   TY xa[kCT], xb[kCT];
   T za, zb;
   auto load = [&](TY (&x)[kCT], T& z, int64_t grp) {
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void k_skinny_tn_partial(int64_t n_rows, int64
     for (int t = 0; t < kCT; ++t) acc[t] = Mma<T>::fma((T)x[t], z, acc[t]);
   };
   int64_t grp = g0 + wave;
-  if constexpr (!PIPE) {  // (tune tn_pipe = 1: one step in flight, fewer registers - for comparison)
+  if constexpr (!PIPE) {
     for (; grp < g1; grp += 4) {
       load(xa, za, grp);
       mma(xa, za);
@@ -375,7 +376,7 @@ int mu_skinny_tn_f64_f32(int64_t n_rows, int64_t D, int64_t ldY, const float* d_
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = D * 16;
   if (mu_tune_get("tn_pipe") == 1)
-    hipLaunchKernelGGL((k_skinny_tn_partial<double, float, false>), dim3((unsigned)cbs, (unsigned)S), dim3(256), 0, st,
+    hipLaunchKernelGGL((k_skinny_tn_partial<double, float, true>), dim3((unsigned)cbs, (unsigned)S), dim3(256), 0, st,
                        n_rows, D, ldY, d_Y, d_Z, S, (double*)d_work);
   else
     hipLaunchKernelGGL((k_skinny_tn_partial<double, float>), dim3((unsigned)cbs, (unsigned)S), dim3(256), 0, st, n_rows, D,
@@ -398,10 +399,10 @@ int mu_skinny_tn(int dtype, int64_t n_rows, int64_t D, int64_t ldY, const void* 
   const int64_t cbs = (D + 16 * kCT - 1) / (16 * kCT);
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = D * 16;
-  const bool simple = mu_tune_get("tn_pipe") == 1;
+  const bool piped = mu_tune_get("tn_pipe") == 1;
   if (dtype == MU_DTYPE_F64) {
-    if (simple)
-      hipLaunchKernelGGL((k_skinny_tn_partial<double, double, false>), dim3((unsigned)cbs, (unsigned)S), dim3(256), 0, st,
+    if (piped)
+      hipLaunchKernelGGL((k_skinny_tn_partial<double, double, true>), dim3((unsigned)cbs, (unsigned)S), dim3(256), 0, st,
                          n_rows, D, ldY, (const double*)d_Y, (const double*)d_Z, S, (double*)d_work);
     else
       hipLaunchKernelGGL(k_skinny_tn_partial<double>, dim3((unsigned)cbs, (unsigned)S), dim3(256), 0, st,
@@ -410,8 +411,8 @@ int mu_skinny_tn(int dtype, int64_t n_rows, int64_t D, int64_t ldY, const void* 
     hipLaunchKernelGGL(k_skinny_tn_reduce<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        total, S, (const double*)d_work, (double*)d_C);
   } else {
-    if (simple)
-      hipLaunchKernelGGL((k_skinny_tn_partial<float, float, false>), dim3((unsigned)cbs, (unsigned)S), dim3(256), 0, st,
+    if (piped)
+      hipLaunchKernelGGL((k_skinny_tn_partial<float, float, true>), dim3((unsigned)cbs, (unsigned)S), dim3(256), 0, st,
                          n_rows, D, ldY, (const float*)d_Y, (const float*)d_Z, S, (float*)d_work);
     else
       hipLaunchKernelGGL(k_skinny_tn_partial<float>, dim3((unsigned)cbs, (unsigned)S), dim3(256), 0, st,

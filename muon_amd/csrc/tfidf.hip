@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kSweepThreads, sizeof(T) == 4 ? 8 : 4) void k_row_c
   if (threadIdx.x == 0) sweep_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
   __syncthreads();
   const int64_t r0 = s_r[0], r1 = s_r[1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
   // Pointers are 32-bit offsets from the row block's first entry.  A wave takes its rows (r0 + wave,
   // + 16, ...) 64 at a time: lane l fetches the slab pointers of the strip's l-th row once, the visits
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kSweepThreads, sizeof(T) == 4 ? 8 : 4) void k_tfidf
   if (threadIdx.x == 0) sweep_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
   __syncthreads();
   const int64_t r0 = s_r[0], r1 = s_r[1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
   unsigned int zeros = 0;
   // (strips of 64 rows with the slab pointers and 1 / row sum in lanes, as in the sum sweep)
   const int64_t wg_base = uniform64(indptr[r0 < n_rows ? r0 : n_rows]);
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_tfidf_scale_sweep_wide(
   if (threadIdx.x == 0) sweep_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
   __syncthreads();
   const int64_t r0 = s_r[0], r1 = s_r[1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
   unsigned int zeros = 0;
   const int64_t wg_base = uniform64(indptr[r0 < n_rows ? r0 : n_rows]);
   const int32_t* __restrict__ ib = indices + wg_base;

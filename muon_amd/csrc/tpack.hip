@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_count(int64_t n_rows, int64_t n
   if (threadIdx.x == 0) t_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
   __syncthreads();
   const int64_t r0 = s_r[0], r1 = s_r[1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
   for (int64_t s = 0; s < S; ++s) {
     for (int t = threadIdx.x; t < kTSlab; t += kTThreads) bins[t] = 0u;
     __syncthreads();
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill2(int64_t n_rows, int64_t n
   if (threadIdx.x == 0) t_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
   __syncthreads();
   const int64_t r0 = s_r[0], r1 = s_r[1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int64_t rw = (r1 - r0 + kTWaves - 1) / kTWaves;  // rows per wave
   const int64_t wrow0 = (r0 + wave * rw) < r1 ? (r0 + wave * rw) : r1;
   const int64_t wrow1 = (wrow0 + rw) < r1 ? (wrow0 + rw) : r1;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
   for (int t = threadIdx.x; t < kTWaves * kF3Cols; t += kTThreads) (&wcnt_all[0][0])[t] = (uint16_t)0;
   __syncthreads();
   const int64_t r0 = s_r[0], r1 = s_r[1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int64_t rw = (r1 - r0 + kTWaves - 1) / kTWaves;  // rows per wave
   const int64_t wrow0 = (r0 + wave * rw) < r1 ? (r0 + wave * rw) : r1;
   const int64_t wrow1 = (wrow0 + rw) < r1 ? (wrow0 + rw) : r1;

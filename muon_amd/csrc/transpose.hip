@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_col_count(
   if (threadIdx.x == 0) sweep_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
   __syncthreads();
   const int64_t r0 = s_r[0], r1 = s_r[1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
   for (int64_t s = 0; s < S; ++s) {
     for (int t = threadIdx.x; t < kSlab; t += kSweepThreads) bins[t] = 0u;
     __syncthreads();
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_transpose_fill(
   if (threadIdx.x == 0) sweep_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
   __syncthreads();
   const int64_t r0 = s_r[0], r1 = s_r[1];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t wbit = 1u << wave;
   const uint32_t* mybase = base + (int64_t)g * n_cols;
 

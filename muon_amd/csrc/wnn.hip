@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64 * kBwWaves) void k_wnn_bandwidth(
     const int32_t* __restrict__ g_idx, const int64_t* __restrict__ r_ptr, const int32_t* __restrict__ r_idx,
     int n_bw, double bbox, double* __restrict__ csigma, int32_t* __restrict__ overflow) {
   __shared__ BwLds lds[kBwWaves];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = uniform32(threadIdx.x >> 6);
   BwLds& L = lds[wave];
   const int64_t n_waves = (int64_t)gridDim.x * kBwWaves;
   for (int64_t cell = (int64_t)blockIdx.x * kBwWaves + wave; cell < n; cell += n_waves) {
