@@ -251,10 +251,6 @@ def _lsi_device(
     if mfma:
         Xt = backend.transpose_stream(X)
         X = backend.cells(X)
-    elif pack and getattr(X, "stream", None) is not None:
-        Xs = X.stream  # written by the TF-IDF scale pass of the same call sequence
-        Xt = backend.transpose_stream(X)
-        X = Xs
     elif pack:
         X, Xt = backend.stream_both(X)
     elif Xt is None:

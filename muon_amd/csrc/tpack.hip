@@ -408,15 +408,81 @@ __device__ __forceinline__ uint32_t cur_fetch_inc(uint16_t* wcur, int i) {
   return (old >> sh) & 0xffffu;
 }
 
-template <int PHASE, bool NARROW>
-__device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, int first,
+// ---- the batch loads of the third-generation walk, from asm (r04) -----------------------------------------------
+// f2_load's predicated loads (`in ? indices_b[p] : 0x7fffffff`) are conditional blocks to the compiler, and a wait
+// behind conditional loads cannot be a counted one: k_t_fill3 carried 94 `s_waitcnt vmcnt(0)` and not one counted wait -
+// one in front of every batch's loads and one right behind them, i.e. the batch "requested before the current one is
+// processed" was awaited before the current one was processed, and a wave walked its rows one memory latency per
+// batch of eight.  Here every load is unconditional (a lane past its row's end reads a clamped position and is
+// masked when the batch is taken), issued from asm, and the batch is taken behind a counted wait that leaves the
+// next batch's loads in flight.
+template <int PHASE>
+__device__ __forceinline__ void f3_load_asm(F2Batch& b, int cur, int first, int last,
+                                            const int32_t* indices_b, const float* values_b) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < kF2Rows; ++j) {
+    const int src = (first + j) & 63;
+    int p = __builtin_amdgcn_readlane(cur, src) + lane;
+    p = p < last ? p : last;
+    const unsigned off = (unsigned)p * 4u;
+    if (PHASE == 1)
+      asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %4"
+                   : "=&v"(b.ci[j]), "=&v"(b.cv[j])
+                   : "v"(off), "s"(indices_b), "s"(values_b)
+                   : "memory");
+    else
+      asm volatile("global_load_dword %0, %1, %2" : "=&v"(b.ci[j]) : "v"(off), "s"(indices_b) : "memory");
+  }
+}
+// The reloads inside a take (a row with more than 64 entries in the tile; the look-ahead past a full window) are
+// rare, but a compiler-visible load in the row loop puts the compiler's own `s_waitcnt vmcnt(0)` at the loop's head -
+// on EVERY row, where it drains the prefetched batch.  They load and wait inside one asm instead.
+template <bool WITH_VALUE>
+__device__ __forceinline__ void f3_reload_asm(int32_t& c, float& v, int p, int last, const int32_t* indices_b,
+                                              const float* values_b) {
+  p = p < last ? p : last;
+  const unsigned off = (unsigned)p * 4u;
+  if (WITH_VALUE)
+    asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %4\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(c), "=&v"(v)
+                 : "v"(off), "s"(indices_b), "s"(values_b)
+                 : "memory");
+  else
+    asm volatile("global_load_dword %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(c) : "v"(off), "s"(indices_b) : "memory");
+}
+
+template <int PHASE, int N>
+__device__ __forceinline__ void f3_wait_asm(F2Batch& b) {
+  static_assert(kF2Rows == 8, "the operand list names 8 rows");
+  if (PHASE == 1)
+    asm volatile("s_waitcnt vmcnt(%16)"
+                 : "+v"(b.ci[0]), "+v"(b.ci[1]), "+v"(b.ci[2]), "+v"(b.ci[3]), "+v"(b.ci[4]), "+v"(b.ci[5]), "+v"(b.ci[6]),
+                   "+v"(b.ci[7]), "+v"(b.cv[0]), "+v"(b.cv[1]), "+v"(b.cv[2]), "+v"(b.cv[3]), "+v"(b.cv[4]), "+v"(b.cv[5]),
+                   "+v"(b.cv[6]), "+v"(b.cv[7])
+                 : "n"(N)
+                 : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(b.ci[0]), "+v"(b.ci[1]), "+v"(b.ci[2]), "+v"(b.ci[3]), "+v"(b.ci[4]), "+v"(b.ci[5]), "+v"(b.ci[6]),
+                   "+v"(b.ci[7])
+                 : "n"(N)
+                 : "memory");
+}
+
+// STAGED: 1 / 0 = the tile is / is not staged in LDS, known at compile time (the asm walk is instantiated for both: the
+// per-row code loses its branches on flags that do not change during a walk); -1 = the run-time flag `staged_rt`
+template <int PHASE, bool NARROW, bool ASM = false, int STAGED = -1>
+__device__ __forceinline__ void f3_process(F2Batch& b, int& cur, int end, int first,
                                            int64_t row0, int32_t cbase, int32_t cend, int32_t cend2,
                                            const int32_t* __restrict__ indices_b,
                                            const float* __restrict__ values_b, uint16_t* wcur,
                                            uint16_t* wcnt, uint32_t* wcur32, const int64_t* gdst,
-                                           unsigned long long* stage, bool staged,
-                                           const TOut& ent) {
+                                           unsigned long long* stage, bool staged_rt,
+                                           const TOut& ent, int last = 0) {
   const int lane = threadIdx.x & 63;
+  const bool staged = STAGED < 0 ? staged_rt : (STAGED == 1);
+  if constexpr (ASM) f3_wait_asm<PHASE, (PHASE == 1 ? 2 : 1) * kF2Rows>(b);  // (the next batch's loads stay in flight)
 #pragma unroll
   for (int j = 0; j < kF2Rows; ++j) {
     if (first + j >= 64) break;  // uniform
@@ -425,6 +491,11 @@ __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, 
     int ws = c0;  // where the loaded window starts
     int32_t c = b.ci[j];
     float v = (PHASE == 1) ? b.cv[j] : 0.f;
+    if constexpr (ASM) {  // (the unconditional load read a clamped position for the lanes past the row's end)
+      const bool in = c0 + lane < e0;
+      c = in ? c : 0x7fffffff;
+      if (PHASE == 1) v = in ? v : 0.f;
+    }
     while (true) {
       const bool valid = c < cend;  // sorted rows: a prefix of the 64 loaded entries
       const int n = __popcll(__ballot(valid));
@@ -460,8 +531,14 @@ __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, 
         ws = c0;
         const int p = c0 + lane;
         const bool in = p < e0;
-        c = in ? indices_b[p] : 0x7fffffff;
-        if (PHASE == 1) v = in ? values_b[p] : 0.f;
+        if constexpr (ASM) {
+          f3_reload_asm<PHASE == 1>(c, v, p, last, indices_b, values_b);
+          c = in ? c : 0x7fffffff;
+          if (PHASE == 1) v = in ? v : 0.f;
+        } else {
+          c = in ? indices_b[p] : 0x7fffffff;
+          if (PHASE == 1) v = in ? values_b[p] : 0.f;
+        }
         continue;
       }
       if (PHASE == 1) {
@@ -469,7 +546,13 @@ __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, 
         while (__popcll(__ballot(c < cend2)) == 64) {
           ws += 64;
           const int p = ws + lane;
-          c = (p < e0) ? indices_b[p] : 0x7fffffff;
+          if constexpr (ASM) {
+            float unused;
+            f3_reload_asm<false>(c, unused, p, last, indices_b, values_b);
+            c = (p < e0) ? c : 0x7fffffff;
+          } else {
+            c = (p < e0) ? indices_b[p] : 0x7fffffff;
+          }
           if (c < cend2) cnt_add(wcnt, c - cend);
         }
       }
@@ -479,7 +562,7 @@ __device__ __forceinline__ void f3_process(const F2Batch& b, int& cur, int end, 
   }
 }
 
-template <int PHASE, bool NARROW>
+template <int PHASE, bool NARROW, bool ASM = false, int STAGED = -1>
 __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cbase, int32_t cend,
                                         int32_t cend2, int64_t wg_base,
                                         const int64_t* __restrict__ indptr,
@@ -487,7 +570,7 @@ __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cb
                                         const float* __restrict__ values, int64_t* __restrict__ curs,
                                         uint16_t* wcur, uint16_t* wcnt, uint32_t* wcur32,
                                         const int64_t* gdst, unsigned long long* stage, bool staged,
-                                        const TOut& ent) {
+                                        const TOut& ent, int last = 0) {
   const int lane = threadIdx.x & 63;
   const int32_t* __restrict__ indices_b = indices + wg_base;
   const float* __restrict__ values_b = values + wg_base;
@@ -499,6 +582,29 @@ __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cb
       end = (int)(indptr[sb + lane + 1] - wg_base);
     }
     F2Batch ba, bb;
+    if constexpr (ASM) {
+      asm volatile("" ::"v"(cur), "v"(end));  // (a use: the compiler's wait for these two loads sits here, not inside a take)
+      // Every load is issued whether or not its batch exists (a batch past the strip reads the positions its lanes'
+      // cursors name - valid addresses, never taken): the number of loads behind a batch is then the same on every
+      // path, ONE counted wait serves all takes, and there is no conditional definition of a batch register for the
+      // compiler to merge with a copy (a copy of a register whose load is still in flight reads garbage: the first
+      // version, with `if (more) load`, had sixteen of them in front of its wait).  What is in flight at the end is
+      // drained with the registers as operands.
+      f3_load_asm<PHASE>(ba, cur, 0, last, indices_b, values_b);
+      for (int first = 0; first < nr; first += 2 * kF2Rows) {
+        f3_load_asm<PHASE>(bb, cur, first + kF2Rows, last, indices_b, values_b);
+        f3_process<PHASE, NARROW, true, STAGED>(ba, cur, end, first, sb, cbase, cend, cend2, indices_b, values_b, wcur, wcnt,
+                                        wcur32, gdst, stage, staged, ent, last);
+        if (first + kF2Rows >= nr) break;
+        f3_load_asm<PHASE>(ba, cur, first + 2 * kF2Rows, last, indices_b, values_b);
+        f3_process<PHASE, NARROW, true, STAGED>(bb, cur, end, first + kF2Rows, sb, cbase, cend, cend2, indices_b, values_b,
+                                        wcur, wcnt, wcur32, gdst, stage, staged, ent, last);
+      }
+      f3_wait_asm<PHASE, 0>(ba);
+      f3_wait_asm<PHASE, 0>(bb);
+      if (PHASE == 1 && lane < nr) curs[sb + lane] = wg_base + (int64_t)cur;
+      continue;
+    }
     f2_load<PHASE>(ba, cur, end, 0, indices_b, values_b);
     for (int first = 0; first < nr; first += 2 * kF2Rows) {
       if (first + kF2Rows < nr) f2_load<PHASE>(bb, cur, end, first + kF2Rows, indices_b, values_b);
@@ -514,7 +620,7 @@ __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cb
   }
 }
 
-template <bool NARROW>
+template <bool NARROW, bool ASM = false>
 __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n_cols, int C, int dbg,
                                                        const int64_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ indices,
@@ -548,6 +654,10 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
   const int64_t wrow0 = (r0 + wave * rw) < r1 ? (r0 + wave * rw) : r1;
   const int64_t wrow1 = (wrow0 + rw) < r1 ? (wrow0 + rw) : r1;
   const int64_t wg_base = uniform64(indptr[r0 < n_rows ? r0 : n_rows]);
+  // (ASM: the last position an unconditional load may read, relative to the block's first entry, as a 30-bit offset)
+  int64_t last64 = uniform64(indptr[n_rows]) - 1 - wg_base;
+  last64 = last64 < 0 ? 0 : (last64 > ((1ll << 30) - 1) ? ((1ll << 30) - 1) : last64);
+  const int last = (int)last64;
   const uint32_t* base_g = base + (int64_t)g * n_cols;
   const uint32_t* base_n = (g + 1 < G) ? base + (int64_t)(g + 1) * n_cols : nullptr;
   bool have = false;  // wcnt_all holds the counts of the tile about to be processed (uniform)
@@ -602,9 +712,9 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
     }
     mark(0);
     if (!have)
-      f3_walk<0, NARROW>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs,
-                         reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_all[wave], wcur32_all[wave], gdst, stage,
-                         staged, ent);
+      f3_walk<0, NARROW, ASM>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs,
+                              reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_all[wave], wcur32_all[wave], gdst, stage,
+                              staged, ent, last);  // (the count walk does not look at `staged`)
     __syncthreads();
     mark(1);
     // per column: exclusive prefix of the wave counts = first slot of every wave inside the run;
@@ -623,9 +733,18 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
     }
     __syncthreads();
     mark(2);
-    f3_walk<1, NARROW>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs,
-                       reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_all[wave], wcur32_all[wave], gdst, stage,
-                       staged, ent);
+    if (ASM && staged)
+      f3_walk<1, NARROW, ASM, ASM ? 1 : -1>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs,
+                                           reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_all[wave], wcur32_all[wave],
+                                           gdst, stage, staged, ent, last);
+    else if (ASM)
+      f3_walk<1, NARROW, ASM, ASM ? 0 : -1>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs,
+                                           reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_all[wave], wcur32_all[wave],
+                                           gdst, stage, staged, ent, last);
+    else
+      f3_walk<1, NARROW, ASM>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs,
+                              reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_all[wave], wcur32_all[wave], gdst, stage,
+                              staged, ent, last);
     have = true;
     mark(3);
     __syncthreads();
@@ -737,14 +856,16 @@ static int tpack_fill_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const in
     if (mu_tune_get("tpack_c") > 0) C = mu_tune_get("tpack_c");
     if (v3) {
       if (C > kF3Cols) C = kF3Cols;
-      if (narrow)
-        hipLaunchKernelGGL(k_t_fill3<true>, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,
-                           mu_tune_get("tpack_dbg"), d_indptr, d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt,
-                           w.coltot, out);
-      else
-        hipLaunchKernelGGL(k_t_fill3<false>, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,
-                           mu_tune_get("tpack_dbg"), d_indptr, d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt,
-                           w.coltot, out);
+      const bool asm_loads = mu_tune_get("tpack_asm") != 1;  // (tune tpack_asm = 1: the compiler's loads, for comparison)
+#define MU_FILL3(NARROW_, ASM_)                                                                                    \
+  hipLaunchKernelGGL((k_t_fill3<NARROW_, ASM_>), dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,          \
+                     mu_tune_get("tpack_dbg"), d_indptr, d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt, w.coltot, \
+                     out)
+      if (narrow && asm_loads) MU_FILL3(true, true);
+      else if (narrow) MU_FILL3(true, false);
+      else if (asm_loads) MU_FILL3(false, true);
+      else MU_FILL3(false, false);
+#undef MU_FILL3
     } else {
       hipLaunchKernelGGL(k_t_fill2, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,
                          mu_tune_get("tpack_abl"), d_indptr, d_indices, d_values, w.curs, d_cptr, d_inv,
