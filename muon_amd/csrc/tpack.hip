@@ -621,7 +621,7 @@ __device__ __forceinline__ void f3_walk(int64_t wrow0, int64_t wrow1, int32_t cb
 }
 
 template <bool NARROW, bool ASM = false>
-__global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n_cols, int C, int dbg,
+__global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n_cols, int C, int flags,
                                                        const int64_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ indices,
                                                        const float* __restrict__ values,
@@ -650,16 +650,34 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
   __syncthreads();
   const int64_t r0 = s_r[0], r1 = s_r[1];
   const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int64_t rw = (r1 - r0 + kTWaves - 1) / kTWaves;  // rows per wave
-  const int64_t wrow0 = (r0 + wave * rw) < r1 ? (r0 + wave * rw) : r1;
-  const int64_t wrow1 = (wrow0 + rw) < r1 ? (wrow0 + rw) : r1;
   const int64_t wg_base = uniform64(indptr[r0 < n_rows ? r0 : n_rows]);
+  // A wave owns a contiguous range of the block's rows - any contiguous split keeps the fill stable.  r04: ranges of
+  // alike ENTRY counts instead of alike row counts (the waves meet at four barriers per tile; flags bit 1: equal row
+  // counts, for comparison - and whenever a range could exceed the 65 535 rows a 16-bit count stands for)
+  int64_t wrow0, wrow1;
+  if ((flags & 2) || r1 - r0 > 65535) {
+    const int64_t rw = (r1 - r0 + kTWaves - 1) / kTWaves;  // rows per wave
+    wrow0 = (r0 + wave * rw) < r1 ? (r0 + wave * rw) : r1;
+    wrow1 = (wrow0 + rw) < r1 ? (wrow0 + rw) : r1;
+  } else {
+    const int64_t e0 = wg_base, e1 = uniform64(indptr[r1 < n_rows ? r1 : n_rows]);
+    auto cut = [&](int w) -> int64_t {
+      if (w <= 0) return r0;
+      if (w >= kTWaves) return r1;
+      const int64_t key = e0 + ((e1 - e0) / kTWaves) * w + (((e1 - e0) % kTWaves) * w) / kTWaves;
+      const int64_t r = lower_bound_i64(indptr, r0, r1, key);
+      return r > r1 ? r1 : r;
+    };
+    wrow0 = uniform64(cut(wave));
+    wrow1 = uniform64(cut(wave + 1));
+  }
   // (ASM: the last position an unconditional load may read, relative to the block's first entry, as a 30-bit offset)
   int64_t last64 = uniform64(indptr[n_rows]) - 1 - wg_base;
   last64 = last64 < 0 ? 0 : (last64 > ((1ll << 30) - 1) ? ((1ll << 30) - 1) : last64);
   const int last = (int)last64;
   const uint32_t* base_g = base + (int64_t)g * n_cols;
   const uint32_t* base_n = (g + 1 < G) ? base + (int64_t)(g + 1) * n_cols : nullptr;
+  const bool dbg = flags & 1;  // (phase accounting)
   bool have = false;  // wcnt_all holds the counts of the tile about to be processed (uniform)
   unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long t_prev = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -749,6 +767,10 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
     mark(3);
     __syncthreads();
     mark(4);
+    // (r04: the write-out as flat passes - the run headers of all of a group's columns first, then the first 16 pairs
+    //  of every run, then the next 16: a few LDS round trips per tile instead of four per column - measured SLOWER,
+    //  73.3 -> 77.7 ms: the two halves of a 176-byte run then reach the memory side ten stores apart instead of back
+    //  to back.  The write-out is bound by its partial-line stores, not by the LDS chain.)
     if (staged) {
       const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
       for (int cl = grp; cl < cend - cbase; cl += kTThreads / 16) {
@@ -859,8 +881,8 @@ static int tpack_fill_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const in
       const bool asm_loads = mu_tune_get("tpack_asm") != 1;  // (tune tpack_asm = 1: the compiler's loads, for comparison)
 #define MU_FILL3(NARROW_, ASM_)                                                                                    \
   hipLaunchKernelGGL((k_t_fill3<NARROW_, ASM_>), dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, (int)C,          \
-                     mu_tune_get("tpack_dbg"), d_indptr, d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt, w.coltot, \
-                     out)
+                     (mu_tune_get("tpack_dbg") ? 1 : 0) | (mu_tune_get("tpack_split") == 1 ? 2 : 0), d_indptr,      \
+                     d_indices, d_values, w.curs, d_cptr, d_inv, w.cnt, w.coltot, out)
       if (narrow && asm_loads) MU_FILL3(true, true);
       else if (narrow) MU_FILL3(true, false);
       else if (asm_loads) MU_FILL3(false, true);
