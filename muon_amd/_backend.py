@@ -769,10 +769,14 @@ class HipBackend:
             wg = int(os.environ.get("MUON_AMD_PACK_WG", "2"))  # (A/B on one box, c3: 32 -> 451, 4 -> 449, 2 -> 441 ms per step)
             with torch.cuda.stream(side):
                 self.tune("pack_wg", wg)  # few workgroups per CU: the fill's 1024-thread groups must fit next to them
+                # ... and the unpipelined loop: the pipelined copy is faster alone (22.5 -> 20-21.6 ms at 1e6 x 200k) and
+                # costs the fill more next to it (both together 87 -> 95 ms; scripts/probes/stream_pipe_probe.py)
+                self.tune("stream_pipe", 1)
                 try:
                     got.append(self.stream(X))
                 finally:
                     self.tune("pack_wg", 0)
+                    self.tune("stream_pipe", 0)
 
         Xt = self.transpose_stream(X, before_fill=start_copy)
         Xs = got[0]

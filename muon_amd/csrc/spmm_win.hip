@@ -680,6 +680,83 @@ __global__ __launch_bounds__(256) void k_stream_fill(int64_t n_pos, const int32_
   }
 }
 
+// The same copy, software pipelined (r04).  What the compiler made of the loop above: the predicated loads became
+// branches with an `s_waitcnt vmcnt(0)` behind every second one - the "four chunks in flight" were four round trips per
+// 256 entries.  Here the loads are unconditional (a lane past the row's end re-reads the row's last entry and stores it
+// again: same address, same bits), issued from asm, two iterations in flight per wave; the wait for a set leaves
+// the next set's eight loads outstanding.  Same bytes out.
+__device__ __forceinline__ void sf_load(const int32_t* ib, const float* vb, unsigned off, int32_t& c, float& v) {
+  asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %4"
+               : "=&v"(c), "=&v"(v)
+               : "v"(off), "s"(ib), "s"(vb)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void sf_wait(int32_t (&c)[4], float (&v)[4]) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])
+               : "n"(N)
+               : "memory");
+}
+__global__ __launch_bounds__(256) void k_stream_fill_pipe(int64_t n_pos, const int32_t* __restrict__ perm,
+                                                          const int64_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ indices,
+                                                          const float* __restrict__ values,
+                                                          const int64_t* __restrict__ sptr,
+                                                          unsigned long long* __restrict__ ent) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = uniform64(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t pos = wave0; pos < n_pos; pos += n_waves) {
+    const int64_t row = perm ? (int64_t)uniform32(perm[pos]) : pos;
+    if (row < 0) continue;
+    const int64_t lo = uniform64(indptr[row]), hi = uniform64(indptr[row + 1]);
+    const int64_t len64 = hi - lo;
+    if (len64 <= 0) continue;
+    if (len64 >= (1ll << 29)) {  // (32-bit byte offsets below: a row of 5e8 entries takes the plain loop)
+      const int64_t o0 = uniform64(sptr[pos]);
+      for (int64_t j = lane; j < len64; j += 64)
+        ent[o0 + j] = (unsigned long long)(unsigned)indices[lo + j] |
+                      ((unsigned long long)__builtin_bit_cast(unsigned, values[lo + j]) << 32);
+      continue;
+    }
+    const int len = (int)len64;
+    const int32_t* ib = indices + lo;
+    const float* vb = values + lo;
+    unsigned long long* ob = ent + uniform64(sptr[pos]);
+    int32_t ca[4], cb[4];
+    float va[4], vb_[4];
+    auto load = [&](int32_t (&c)[4], float (&v)[4], int j0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int q = j0 + lane + 64 * u;
+        q = q < len ? q : len - 1;
+        sf_load(ib, vb, (unsigned)q * 4u, c[u], v[u]);
+      }
+    };
+    auto store = [&](int32_t (&c)[4], float (&v)[4], int j0) {
+      sf_wait<8>(c, v);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int q = j0 + lane + 64 * u;
+        q = q < len ? q : len - 1;
+        ob[q] = (unsigned long long)(unsigned)c[u] | ((unsigned long long)__builtin_bit_cast(unsigned, v[u]) << 32);
+      }
+    };
+    load(ca, va, 0);
+    for (int j0 = 0;; j0 += 512) {
+      load(cb, vb_, j0 + 256);  // (past the end: clamped, not stored)
+      store(ca, va, j0);
+      if (j0 + 256 >= len) break;
+      load(ca, va, j0 + 512);
+      store(cb, vb_, j0 + 256);
+      if (j0 + 512 >= len) break;
+    }
+    sf_wait<0>(ca, va);  // what is still in flight targets these registers
+    sf_wait<0>(cb, vb_);
+  }
+}
+
 // K row-sets per wave: the smallest number of full-chip rounds R whose 64*K-row blocks fit the
 // register budget (K <= kKMax); one workgroup per CU (128 KiB of LDS at B = 64).
 int pick_k(int64_t n_rows) {
@@ -762,8 +839,12 @@ int mu_csr_stream_fill(int64_t n_pos, const int32_t* d_perm, const int64_t* d_in
   const int per_cu = mu_tune_get("pack_wg") > 0 ? mu_tune_get("pack_wg") : 32;
   const int64_t cap = (int64_t)mu_num_cus() * per_cu;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(k_stream_fill, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_pos,
-                     d_perm, d_indptr, d_indices, d_values, d_sptr, (unsigned long long*)d_ent);
+  if (mu_tune_get("stream_pipe") == 1)  // (the loop of before, for comparison)
+    hipLaunchKernelGGL(k_stream_fill, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_pos,
+                       d_perm, d_indptr, d_indices, d_values, d_sptr, (unsigned long long*)d_ent);
+  else
+    hipLaunchKernelGGL(k_stream_fill_pipe, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_pos,
+                       d_perm, d_indptr, d_indices, d_values, d_sptr, (unsigned long long*)d_ent);
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
