@@ -119,6 +119,99 @@ __global__ __launch_bounds__(kTThreads) void k_t_count(int64_t n_rows, int64_t n
 
 // cnt[g][c] <- sum_{g' < g} cnt[g'][c];  coltot[c] = sum_g cnt[g][c] (also handed to the caller,
 // who sorts the output rows by it and lays them out: muon_amd/_backend.py launch_layout)
+// The count sweep, software pipelined (r04; csrc/tfidf.hip's k_row_col_sums_pipe has the story): the pieces of a wave's
+// strip of 64 rows as one flat sequence of iterations, unconditional clamped loads from asm, two iterations in
+// flight, bins of M x 8192 columns (M = 4: 128 KiB of u32, one workgroup per CU).  Same counts.
+struct TFlatWalk {
+  int l, pb, hi, nrow, step;
+  __device__ __forceinline__ bool advance(int lo_l, int hi_l) {
+    pb += step;
+    while (pb >= hi) {
+      if (++l >= nrow) return false;
+      pb = __builtin_amdgcn_readlane(lo_l, l);
+      hi = __builtin_amdgcn_readlane(hi_l, l);
+    }
+    return true;
+  }
+};
+template <int N>
+__device__ __forceinline__ void tc_wait(int32_t (&c)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : "n"(N) : "memory");
+}
+template <int M>
+__global__ __launch_bounds__(kTThreads) void k_t_count_pipe(int64_t n_rows, int64_t n_cols, int64_t S,
+                                                            const int64_t* __restrict__ indptr,
+                                                            const int32_t* __restrict__ indices,
+                                                            const int64_t* __restrict__ sp,
+                                                            uint32_t* __restrict__ cnt) {
+  __shared__ uint32_t bins[kTSlab * M];
+  __shared__ int64_t s_r[2];
+  const int g = blockIdx.x, G = gridDim.x;
+  if (threadIdx.x == 0) t_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
+  __syncthreads();
+  const int64_t r0 = uniform64(s_r[0]), r1 = uniform64(s_r[1]);
+  const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t wg_base = uniform64(indptr[r0 < n_rows ? r0 : n_rows]);
+  const int32_t* ib = indices + wg_base;  // (32-bit byte offsets from here: the host keeps a block under 2^29 entries)
+  for (int64_t s = 0; s < S; s += M) {
+    for (int t = threadIdx.x; t < kTSlab * M; t += kTThreads) bins[t] = 0u;
+    __syncthreads();
+    const int32_t cbase = (int32_t)(s * kTSlab);
+    const int64_t s_hi = s + M < S ? s + M : S;
+    for (int64_t strip = r0 + wave; strip < r1; strip += (int64_t)kTWaves * 64) {
+      const int64_t myrow = strip + (int64_t)kTWaves * lane;
+      int lo_l = 0, hi_l = 0;
+      if (myrow < r1) {
+        lo_l = (int)(sp[myrow * (S + 1) + s] - wg_base);
+        hi_l = (int)(sp[myrow * (S + 1) + s_hi] - wg_base);
+      }
+      asm volatile("" ::"v"(lo_l), "v"(hi_l));  // (the compiler's wait for these loads: here, not inside the walk)
+      const int64_t left = (r1 - strip + kTWaves - 1) / kTWaves;
+      TFlatWalk w{-1, 0, 0, left < 64 ? (int)left : 64, 256};
+      int32_t ca[4], cb[4];
+      auto load = [&](int32_t (&c)[4], int pb, int hi) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int q = pb + lane + 64 * u;
+          q = q < hi ? q : hi - 1;
+          asm volatile("global_load_dword %0, %1, %2" : "=&v"(c[u]) : "v"((unsigned)q * 4u), "s"(ib) : "memory");
+        }
+      };
+      auto work = [&](int32_t (&c)[4], int pb, int hi) {
+        tc_wait<4>(c);  // (the next iteration's four loads stay in flight)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = pb + lane + 64 * u < hi;  // a lane past the end adds 0 to a bin of its own
+          atomicAdd(&bins[ok ? c[u] - cbase : lane], ok ? 1u : 0u);
+        }
+      };
+      if (w.advance(lo_l, hi_l)) {
+        int a_pb = w.pb, a_hi = w.hi, b_pb, b_hi;
+        load(ca, a_pb, a_hi);
+        for (;;) {
+          bool more = w.advance(lo_l, hi_l);
+          b_pb = more ? w.pb : a_pb, b_hi = more ? w.hi : a_hi;
+          load(cb, b_pb, b_hi);
+          work(ca, a_pb, a_hi);
+          if (!more) break;
+          more = w.advance(lo_l, hi_l);
+          a_pb = more ? w.pb : b_pb, a_hi = more ? w.hi : b_hi;
+          load(ca, a_pb, a_hi);
+          work(cb, b_pb, b_hi);
+          if (!more) break;
+        }
+        tc_wait<0>(ca);
+        tc_wait<0>(cb);
+      }
+    }
+    __syncthreads();
+    const int64_t here = (n_cols - (int64_t)cbase) < kTSlab * M ? (n_cols - (int64_t)cbase) : kTSlab * M;
+    uint32_t* dst = cnt + (int64_t)g * n_cols + cbase;
+    for (int t = threadIdx.x; t < here; t += kTThreads) dst[t] = bins[t];
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void k_t_base(int64_t n_cols, int G, uint32_t* __restrict__ cnt,
                                                 int64_t* __restrict__ coltot,
                                                 int64_t* __restrict__ col_nnz) {
@@ -841,7 +934,13 @@ int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_
                          d_indices, w.sp);
       MU_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_t_count, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, S, d_indptr,
+    // pipelined sweep with 32 768-column bins (r04); tune "tcount_pipe" = 1 or a row block of 2^29 entries and more
+    // (32-bit byte offsets): the sweep of before
+    if (mu_tune_get("tcount_pipe") != 1 && nnz / G < (1ll << 29) - (1ll << 24))
+      hipLaunchKernelGGL((k_t_count_pipe<4>), dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, S, d_indptr, d_indices,
+                         d_slab_ptr ? d_slab_ptr : w.sp, w.cnt);
+    else
+      hipLaunchKernelGGL(k_t_count, dim3(G), dim3(kTThreads), 0, st, n_rows, n_cols, S, d_indptr,
                        d_indices, d_slab_ptr ? d_slab_ptr : w.sp, w.cnt);
     MU_CHECK_LAUNCH();
   }

@@ -17,9 +17,9 @@ X = be.synth_counts(0, cells, 200000, 50, 0.03, 0)
 T = tfidf_device(be, X, cells, 3, 1e4)
 NAMES = ["header+scan", "count walk", "prefix", "place walk", "wait others", "write-out"]
 ref = None
-for mode, split in ((1, 1), (0, 1), (0, 0), (0, 1), (0, 0)):
+for mode, split in ((0, 1), (0, 0), (0, 1), (0, 0)):
     be.tune("tpack_asm", mode)
-    be.tune("tpack_split", split)
+    be.tune("tcount_pipe", split)
     P = be.transpose_stream(T)
     torch.cuda.synchronize()
     if ref is None:
@@ -40,7 +40,7 @@ for mode, split in ((1, 1), (0, 1), (0, 0), (0, 1), (0, 0)):
     be.lib.mu_csr_tpack_phase_cycles(ctypes.cast(out, ctypes.c_void_p), 0)
     be.tune("tpack_dbg", 0)
     tot = sum(out)
-    print(f"split {'rows' if split else 'entries'}, tpack_asm {mode} ({'compiler loads' if mode else 'asm loads, counted waits'}): {ms:.2f} ms (count + layout + scan + fill), "
+    print(f"count sweep {'r03' if split else 'pipelined'}, tpack_asm {mode} ({'compiler loads' if mode else 'asm loads, counted waits'}): {ms:.2f} ms (count + layout + scan + fill), "
           f"same bytes {same}; " + ", ".join(f"{n} {100.0 * v / tot:.1f} %" for n, v in zip(NAMES, out)), flush=True)
 be.tune("tpack_asm", 0)
-be.tune("tpack_split", 0)
+be.tune("tcount_pipe", 0)
