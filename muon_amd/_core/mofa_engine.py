@@ -335,7 +335,11 @@ class MofaEngine:
                     V.TWs = torch.zeros((V.D, V.ld), dtype=T, device=dev)
                 elif K <= 16 and hasattr(self.be, "skinny_tn"):
                     V.ld = 16
-                    if T == torch.float64 and hasattr(self.be, "skinny_nn"):
+                    # f32: the library GEMM for A = Y (tau o W) had been 3 % ahead of mu_skinny_nn; with the branch-free,
+                    # asm-prefetching build of r04 (views of whole 128-byte tiles) the kernel is 2 % ahead of it
+                    # (c4: 0.465 against 0.475 s; MUON_AMD_MOFA_F32_NN=blas brings the library back)
+                    own_f32 = V.D % 32 == 0 and os.environ.get("MUON_AMD_MOFA_F32_NN", "") != "blas"
+                    if (T == torch.float64 or own_f32) and hasattr(self.be, "skinny_nn"):
                         V.T16 = [torch.zeros((V.D, 16), dtype=T, device=dev) for _ in range(G)]
                     else:
                         V.TWt = [torch.zeros((K, V.D), dtype=T, device=dev) for _ in range(G)]

@@ -17,7 +17,7 @@ X = be.synth_counts(0, cells, 200000, 50, 0.03, 0)
 T = tfidf_device(be, X, cells, 3, 1e4)
 NAMES = ["header+scan", "count walk", "prefix", "place walk", "wait others", "write-out"]
 ref = None
-for mode, split in ((0, 1), (0, 0), (0, 1), (0, 0)):
+for mode, split in ((1, 1), (0, 1), (0, 0), (1, 1), (0, 1), (0, 0)):
     be.tune("tpack_asm", mode)
     be.tune("tcount_pipe", split)
     P = be.transpose_stream(T)
