@@ -252,6 +252,15 @@ class CpuTestBackend:
             elbo += self._gamma_kl(a0, b0, a, b, az, laz).sum()
         elbo += (0.5 * laz * n - 0.5 * az * zs[:, 0] + 0.5 * zs[:, 1] + 0.5 * n).sum()
 
+    # the tall-skinny products of a dense view (csrc/skinny.hip); Y may be stored in f32 under an f64 block
+    skinny_mixed = True
+
+    def skinny_nn(self, Y, T16):
+        return Y.to(T16.dtype) @ T16
+
+    def skinny_tn(self, Y, Z16):
+        return Y.to(Z16.dtype).T @ Z16
+
     def mofa_rowstats_work(self, K):
         return torch.zeros((1,), dtype=torch.float64)
 

@@ -70,6 +70,43 @@ def test_engine_matches_oracle_iteration_by_iteration(case):
     np.testing.assert_allclose(res["r2"], ref["r2"], atol=1e-7)
 
 
+@pytest.mark.parametrize("case", ["plain", "groups_missing", "offset"])
+def test_f32_valued_dense_views_are_centred_inside_the_products(case, monkeypatch):
+    """r04: under the f64 fit a dense view whose values are exact in f32 stays f32 and is centred inside the
+    products (mofa_engine._f32_storage_ok), like the sparse views.  Host logic on the CPU operator set against the
+    oracle, which centres first; the GPU twin is tests/test_gpu_mofa.py."""
+    import torch
+    from muon_amd._core.mofa_engine import MofaEngine
+    from tests.cpu_backend import CpuTestBackend
+
+    rng = np.random.default_rng(12)
+    N, K0 = 300, 4
+    Z = rng.standard_normal((N, K0))
+    W1 = rng.standard_normal((96, K0)) * (rng.random((96, K0)) < 0.4)
+    W2 = rng.standard_normal((50, K0)) * (rng.random((50, K0)) < 0.4)
+    y1 = (Z @ W1.T + rng.standard_normal((N, 96))).astype(np.float32).astype(np.float64)
+    y2 = (Z @ W2.T + rng.standard_normal((N, 50))).astype(np.float32).astype(np.float64)
+    groups = np.zeros(N, dtype=int)
+    if case == "groups_missing":
+        groups = rng.integers(0, 3, N)
+        y1[250:] = np.nan
+    if case == "offset":
+        y1 = (y1 + 40.0).astype(np.float32).astype(np.float64)
+    ref = mofa_oracle.run([y1, y2], groups=groups if case == "groups_missing" else None, n_factors=5, n_iterations=15,
+                          convergence_mode="slow")
+    eng = MofaEngine(CpuTestBackend(), [y1, y2], groups, 5, seed=1)
+    assert all(v.Y.dtype == torch.float32 and v.implicit for v in eng.views)
+    eng.run(15, "slow")
+    res = eng.results(sort_factors=False)
+    np.testing.assert_allclose(res["elbo"], ref["elbo"][:len(res["elbo"])], rtol=1e-8 if case != "offset" else 1e-7)
+    np.testing.assert_allclose(res["Z"], ref["Z"], atol=1e-6)
+    for a, b in zip(res["W"], ref["W"]):
+        np.testing.assert_allclose(a, b, atol=1e-6)
+    monkeypatch.setenv("MUON_AMD_MOFA_F32_STORAGE", "0")
+    eng64 = MofaEngine(CpuTestBackend(), [y1, y2], groups, 5, seed=1)
+    assert all(v.Y.dtype == torch.float64 and not getattr(v, "implicit", False) for v in eng64.views)
+
+
 def test_scaling_options_match_oracle():
     y1, y2 = simple_views()
     y2 = y2 * 7.0
