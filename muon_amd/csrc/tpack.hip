@@ -603,6 +603,15 @@ __device__ __forceinline__ void f3_process(F2Batch& b, int& cur, int end, int fi
         //  instructions and two results to wait for.)
         const bool nxt = !valid && c < cend2;
         uint32_t k = 0;   // absolute slot in the staging buffer (run-relative when not staged)
+        if constexpr (NARROW && ASM && STAGED == 1) {
+          // cursors and counts of a wave are one array (k_t_fill3): column c of this tile or the next is entry c - cbase
+          if (valid || nxt) k = cur_fetch_inc(wcur, c - cbase);
+          if (valid) {
+            const unsigned long long e = (unsigned long long)(unsigned)(row0 + first + j) |
+                                         ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32);
+            stage[k] = e;
+          }
+        } else {
         if (valid) {
           // NARROW, staged: 16-bit absolute staging slots; a tile that does not fit the staging
           // buffer keeps 32-bit run-relative cursors in the (then unused) staging memory.  Wide
@@ -617,6 +626,7 @@ __device__ __forceinline__ void f3_process(F2Batch& b, int& cur, int end, int fi
                                        ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32);
           if (staged) stage[k] = e;
           else t_store(ent, gdst[c - cbase] + k, e);
+        }
         }
       }
       c0 += n;
@@ -727,19 +737,32 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
   constexpr int kF3Cap = NARROW ? kF3CapNarrow : kF3CapWide;
   typedef typename std::conditional<NARROW, uint16_t, uint32_t>::type CurT;
   __shared__ unsigned long long stage[kF3Cap];     // 112 / 80 KiB
-  __shared__ CurT wcur_all[kTWaves][kF3Cols];      // 20 / 40 KiB: per (wave, column) cursor of this tile
-  __shared__ uint16_t wcnt_all[kTWaves][kF3Cols];  // 20 KiB: per (wave, column) count of the tile in the making
+  // per (wave, column): the cursor of this tile and the count of the tile in the making.  Narrow build: ONE 16-bit array
+  // per wave, cursors at [0, C), counts at [C, 2 C) - column c of either tile is entry c - cbase, so a row visit updates
+  // both with one packed atomic (r04; two index computations and two LDS atomics before).  Wide build: 32-bit cursors
+  // and 16-bit counts apart.
+  __shared__ CurT wcur_all[kTWaves][NARROW ? 2 * kF3Cols : kF3Cols];  // 40 KiB
+  __shared__ uint16_t wcnt_wide[NARROW ? 1 : kTWaves][NARROW ? 1 : kF3Cols];  // (wide build: 20 KiB)
+  auto wcnt_of = [&](int w) -> uint16_t* {
+    if constexpr (NARROW) return reinterpret_cast<uint16_t*>(&wcur_all[w][0]) + C;
+    else return &wcnt_wide[w][0];
+  };
   __shared__ uint16_t lcount[kF3Cols], lpos[kF3Cols];  // staged tiles only (<= kF3Cap pairs)
   __shared__ int64_t gdst[kF3Cols];
   static_assert(sizeof(uint32_t) * kTWaves * kF3Cols <= sizeof(unsigned long long) * kF3Cap, "direct-mode cursors live in the staging buffer");
   // 32-bit cursors: the wide build's own array; the narrow build's direct-mode cursors (staging memory)
   uint32_t(*wcur32_all)[kF3Cols] = NARROW ? reinterpret_cast<uint32_t(*)[kF3Cols]>(stage)
                                           : reinterpret_cast<uint32_t(*)[kF3Cols]>(&wcur_all[0][0]);
+  static_assert(NARROW || sizeof(wcur_all) == sizeof(uint32_t) * kTWaves * kF3Cols, "wide build: 32-bit cursors in wcur_all");
   __shared__ uint32_t wsum[kTWaves];
   __shared__ int64_t s_r[2];
   const int g = blockIdx.x, G = gridDim.x;
   if (threadIdx.x == 0) t_row_range(indptr, n_rows, g, G, s_r[0], s_r[1]);
-  for (int t = threadIdx.x; t < kTWaves * kF3Cols; t += kTThreads) (&wcnt_all[0][0])[t] = (uint16_t)0;
+  if constexpr (NARROW) {
+    for (int t = threadIdx.x; t < kTWaves * 2 * kF3Cols; t += kTThreads) (&wcur_all[0][0])[t] = (CurT)0;
+  } else {
+    for (int t = threadIdx.x; t < kTWaves * kF3Cols; t += kTThreads) (&wcnt_wide[0][0])[t] = (uint16_t)0;
+  }
   __syncthreads();
   const int64_t r0 = s_r[0], r1 = s_r[1];
   const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -824,19 +847,20 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
     mark(0);
     if (!have)
       f3_walk<0, NARROW, ASM>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs,
-                              reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_all[wave], wcur32_all[wave], gdst, stage,
+                              reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_of(wave), wcur32_all[wave], gdst, stage,
                               staged, ent, last);  // (the count walk does not look at `staged`)
     __syncthreads();
     mark(1);
     // per column: exclusive prefix of the wave counts = first slot of every wave inside the run;
     // the counts are consumed (zeroed) for the next tile
-    if (threadIdx.x < kF3Cols) {
+    if (threadIdx.x < (NARROW ? C : kF3Cols)) {  // (narrow build: entries C .. of the cursor half are the counts)
       // a staged tile's cursors are absolute staging slots (no lpos lookup in the walk), a direct
       // one's are relative to the column's run in the output
       uint32_t run = staged ? my_lpos : 0u;
       for (int w = 0; w < kTWaves; ++w) {
-        const uint32_t t = wcnt_all[w][threadIdx.x];
-        wcnt_all[w][threadIdx.x] = (uint16_t)0;
+        uint16_t* wc = wcnt_of(w);
+        const uint32_t t = wc[threadIdx.x];
+        wc[threadIdx.x] = (uint16_t)0;
         if (NARROW && staged) wcur_all[w][threadIdx.x] = (CurT)run;
         else wcur32_all[w][threadIdx.x] = run;
         run += t;
@@ -846,15 +870,15 @@ __global__ __launch_bounds__(kTThreads) void k_t_fill3(int64_t n_rows, int64_t n
     mark(2);
     if (ASM && staged)
       f3_walk<1, NARROW, ASM, ASM ? 1 : -1>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs,
-                                           reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_all[wave], wcur32_all[wave],
+                                           reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_of(wave), wcur32_all[wave],
                                            gdst, stage, staged, ent, last);
     else if (ASM)
       f3_walk<1, NARROW, ASM, ASM ? 0 : -1>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs,
-                                           reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_all[wave], wcur32_all[wave],
+                                           reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_of(wave), wcur32_all[wave],
                                            gdst, stage, staged, ent, last);
     else
       f3_walk<1, NARROW, ASM>(wrow0, wrow1, cbase, cend, cend2, wg_base, indptr, indices, values, curs,
-                              reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_all[wave], wcur32_all[wave], gdst, stage,
+                              reinterpret_cast<uint16_t*>(wcur_all[wave]), wcnt_of(wave), wcur32_all[wave], gdst, stage,
                               staged, ent, last);
     have = true;
     mark(3);
