@@ -130,7 +130,8 @@ def l2norm(mdata, mod=None, rep=None, n_pcs=0, copy: bool = False):
 # -----------------------------------------------------------------------------------------------------
 # the `metric` values of the reference's signature (preproc.py:270-294) that scipy's cdist evaluates pair by pair;
 # "mahalanobis" / "seuclidean" take their (co)variances from the rows of each cdist call - in the reference one call per
-# cell over that cell's candidates - and "wminkowski" needs weights the signature cannot pass: not offered
+# cell over that cell's candidates: `_cell_dist`, in the final step of `neighbors` only - and "wminkowski" needs weights
+# the signature cannot pass (and is gone from scipy): not offered
 _PAIR_METRICS = ("euclidean", "sqeuclidean", "minkowski", "cityblock", "manhattan", "chebyshev", "cosine", "correlation",
                  "braycurtis", "canberra", "jensenshannon", "hamming", "matching", "jaccard", "dice", "kulsinski",
                  "rogerstanimoto", "russellrao", "sokalmichener", "sokalsneath", "yule")
@@ -192,8 +193,59 @@ def _pair_dist(A: torch.Tensor, B: torch.Tensor, metric: str) -> torch.Tensor:
         if metric == "sokalsneath":
             return R / (ntt + R)
         return R / (ntt + nff + R)  # rogerstanimoto == sokalmichener
-    raise NotImplementedError(f"metric '{metric}' (implemented: {_PAIR_METRICS}; 'mahalanobis' and 'seuclidean' depend on "
-                              "the rows of each cdist call of the reference, 'wminkowski' needs weights)")
+    raise NotImplementedError(f"metric '{metric}' (implemented pair by pair: {_PAIR_METRICS}; 'mahalanobis' and 'seuclidean' "
+                              "depend on the rows of each cdist call: offered for the final step of `neighbors` only; "
+                              "'wminkowski' needs weights)")
+
+
+def _cell_dist(X: torch.Tensor, ri: torch.Tensor, ci: torch.Tensor, ok: torch.Tensor, present: torch.Tensor,
+               metric: str, step: int = 1 << 20) -> torch.Tensor:
+    """`seuclidean` / `mahalanobis` distances of the candidate pairs (ri, ci) (sorted by ri), as the reference gets
+    them: ONE cdist call per cell, `cdist(rep[None, cell], rep[nz])` (preproc.py:596-606), so scipy takes the
+    variances V (ddof = 1) / the covariance of THAT call's rows - the cell and its candidates.  Here: segment
+    statistics over the pairs of a cell (two passes: means, then centred sums).  `ok`: both ends present in this
+    modality (other pairs get 0 and do not count).  mahalanobis needs more rows than dimensions in every call, like
+    scipy (ValueError)."""
+    n, p = X.shape
+    a, b = ri[ok], ci[ok]
+    one = torch.ones(a.numel(), dtype=X.dtype, device=X.device)
+    cnt = present.to(X.dtype).clone()  # (the cell's own row)
+    cnt.index_add_(0, a, one)
+    S1 = X * present[:, None].to(X.dtype)
+    for lo in range(0, a.numel(), step):
+        S1.index_add_(0, a[lo:lo + step], X[b[lo:lo + step]])
+    mean = S1 / cnt.clamp(min=1.0)[:, None]
+    out = torch.zeros(ri.numel(), dtype=X.dtype, device=X.device)
+    sel = torch.nonzero(ok).reshape(-1)
+    if metric == "seuclidean":
+        SS = (X - mean) ** 2 * present[:, None].to(X.dtype)
+        for lo in range(0, a.numel(), step):
+            aa, bb = a[lo:lo + step], b[lo:lo + step]
+            SS.index_add_(0, aa, (X[bb] - mean[aa]) ** 2)
+        V = SS / (cnt - 1.0).clamp(min=1.0)[:, None]
+        for lo in range(0, a.numel(), step):
+            aa, bb = a[lo:lo + step], b[lo:lo + step]
+            out[sel[lo:lo + step]] = torch.sqrt((((X[aa] - X[bb]) ** 2) / V[aa]).sum(dim=1))
+        return out
+    if bool(((cnt <= p) & present).any()):
+        raise ValueError("The number of observations (m) is too small; the covariance matrix is singular. For observations "
+                         f"with {p} dimensions, at least {p + 1} observations are required.")  # (scipy's cdist)
+    Xc = (X - mean) * present[:, None].to(X.dtype)
+    C = Xc[:, :, None] * Xc[:, None, :]
+    sub = max(1, min(step, (1 << 27) // max(p * p, 1)))
+    for lo in range(0, a.numel(), sub):
+        aa, bb = a[lo:lo + sub], b[lo:lo + sub]
+        d = X[bb] - mean[aa]
+        C.index_add_(0, aa, d[:, :, None] * d[:, None, :])
+    C = C / (cnt - 1.0).clamp(min=1.0)[:, None, None]
+    eye = torch.eye(p, dtype=X.dtype, device=X.device)
+    C = torch.where(present[:, None, None], C, eye)  # (absent cells: no pairs, any invertible matrix)
+    VI = torch.linalg.inv(C)
+    for lo in range(0, a.numel(), sub):
+        aa, bb = a[lo:lo + sub], b[lo:lo + sub]
+        d = X[aa] - X[bb]
+        out[sel[lo:lo + sub]] = torch.sqrt(torch.clamp(torch.einsum("np,npq,nq->n", d, VI[aa], d), min=0.0))
+    return out
 
 
 def _candidates_filtered(be, Xn: torch.Tensor, sq: torch.Tensor, kc: int, chunk_elems: int, cap: Optional[int] = None) -> torch.Tensor:
@@ -663,6 +715,12 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
     step = 1 << 22
     for i, m in enumerate(modalities):  # :579-609
         X = Xd[m]
+        if metric in ("seuclidean", "mahalanobis"):  # (their (co)variances are those of each cell's own cdist call)
+            both = pres_d[m][ri] & pres_d[m][ci]
+            d = _cell_dist(X, ri, ci, both, pres_d[m], metric)
+            term = torch.exp(-d / sigmas[m][ri]) * weights[ri, i]
+            aff += torch.where(both, term, torch.zeros_like(term))
+            continue
         for lo in range(0, key.numel(), step):
             a, b = ri[lo:lo + step], ci[lo:lo + step]
             term = torch.exp(-_pair_dist(X[a], X[b], metric) / sigmas[m][a]) * weights[a, i]

@@ -186,6 +186,15 @@ def neighbors(reps, graphs, graph_metrics=None, n_neighbors=None, n_bandwidth_ne
     aff = np.zeros((n, n))
     for i, m in enumerate(mods):  # :579-609
         X = np.asarray(reps[m], dtype=np.float64)
+        if metric in ("seuclidean", "mahalanobis"):
+            # scipy takes V / VI from the rows of EACH call, and the reference calls once per cell over that cell's
+            # candidates (:596-606): the same loop here (candidates absent from the modality left out)
+            for cell in np.nonzero(pres[m])[0]:
+                cols = np.nonzero(pattern[cell] & pres[m])[0]
+                if len(cols):
+                    d = cdist(X[None, cell, :], X[cols, :], metric=metric)[0]
+                    aff[cell, cols] += np.exp(-d / sigmas[m][cell]) * weights[cell, i]
+            continue
         D = cdist(X, X, metric=metric)
         term = np.exp(-D / sigmas[m][:, None]) * weights[:, i][:, None]
         aff += np.where(pres[m][:, None] & pres[m][None, :], term, 0.0)

@@ -88,7 +88,7 @@ def test_pair_distances_follow_scipy():
             ok = np.isfinite(want)
         np.testing.assert_allclose(got[ok], want[ok], rtol=1e-12, atol=1e-14, err_msg=metric)
         assert np.array_equal(np.isnan(got), np.isnan(want)), metric
-    for metric in ("mahalanobis", "seuclidean", "wminkowski"):
+    for metric in ("mahalanobis", "seuclidean", "wminkowski"):  # (the first two: per cell, `_cell_dist`)
         with pytest.raises(NotImplementedError):
             pp._pair_dist(torch.from_numpy(real_a), torch.from_numpy(real_b), metric)
 
@@ -121,7 +121,9 @@ def _run_both(n=140, seed=0, **kw):
 @pytest.mark.parametrize("kw", [dict(n_multineighbors=40), dict(n_multineighbors=30, n_neighbors=10, n_bandwidth_neighbors=12),
                                 dict(n_multineighbors=40, metric="cityblock"),
                                 dict(n_multineighbors=40, metric="correlation"),
-                                dict(n_multineighbors=40, metric="braycurtis")])
+                                dict(n_multineighbors=40, metric="braycurtis"),
+                                dict(n_multineighbors=40, metric="seuclidean"),
+                                dict(n_multineighbors=40, metric="mahalanobis")])
 def test_wnn_matches_oracle(kw):
     lab, md, (D, C, W, sig, k) = _run_both(**kw)
     got = md.obsp["distances"]
