@@ -447,6 +447,14 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     sec[name] = {"error": repr(e)}
             out["secondary"] = sec
+        if default_line and out is not None:
+            # the two figures the driver's view of the line (known keys + a 4 KB tail) otherwise does not show, mirrored
+            # under `config`: the 10k x 30k record's step time and the c3 sample parity
+            c2 = sec.get("c2") or {}
+            out["config"]["c2_ms_per_step"] = c2.get("ms_per_step")
+            par = out.get("parity") or {}
+            out["config"]["parity_summary"] = {k: par.get(k) for k in ("tfidf_pattern_identical", "tfidf_values_max_rel",
+                                                                         "lsi_angle_rad", "lsi_stdev_max_rel")}
     if rank == 0 and out is not None:
         print(json.dumps(out))
     if world > 1 or force_dist:

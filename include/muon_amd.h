@@ -193,6 +193,11 @@ int mu_csr_tpack_fill_stream(int64_t n_rows, int64_t n_cols, int64_t nnz, const 
                              const int32_t* d_indices, const float* d_values, const int64_t* d_sptr,
                              const int32_t* d_inv, void* d_ent, void* d_work, size_t work_bytes,
                              void* stream);
+/* B = 64 / 32: k_spmm_win (csrc/spmm_win.hip).  B = 16: k_spmm_narrow (csrc/spmm_narrow.hip: 16 stored entries x 4
+ * columns per wave step) - the DEFAULT kernel of every 16-column product on a row stream: lsi with n_comps <= 2, the
+ * neighbourhood means of mu.pp.neighbors on embeddings of <= 16 dimensions, MOFA f32 views whose operand is not laid
+ * out as sliced ELL (tests/test_gpu_kernels.py runs it against scipy at B = 16).  MOFA's default for <= 16 stacked
+ * factor columns is mu_spmm_ell16_* below. */
 int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, const void* d_ent,
                        const int32_t* d_perm, int k_layout, const float* d_Q, int B, float* d_Y,
                        void* stream);
@@ -226,7 +231,12 @@ int mu_spmm_ell16_f64(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d
                       const void* d_ent, const int32_t* d_perm, const double* d_Q, double* d_Y, int accumulate,
                       void* stream);
 
-/* ---- matrix-core SpMM of the LSI iteration (r04; csrc/spmm_mfma.hip) --------------------------------------
+/* ---- EXPERIMENTAL (not on any default path; MUON_AMD_LSI_MFMA=1 opts in and logs a warning) -------------------
+ * mu_cells_geometry / mu_cells_cut / mu_dense_to_f16 / mu_spmm_cells_f32 and the two mu_probe_* entries below:
+ * the r04 matrix-core SpMM experiment.  Faster than mu_spmm_stream_f32 (3.3 vs 4.0 ms at 125k x 200k) and NOT
+ * accurate enough for the LSI parity bar (the Krylov basis is rounded to f16: ~1e-4 rad).  Kept
+ * tested (tests/test_gpu_mfma.py) as the record of that experiment; the entry points may change or go.
+ * ---- matrix-core SpMM of the LSI iteration (r04; csrc/spmm_mfma.hip) --------------------------------------
  * Replaces, like mu_spmm_stream_f32, the csr_matvec / csr_matvecs calls of ARPACK's reverse-communication loop
  * behind scipy.sparse.linalg.svds (/root/reference/muon/_atac/tools.py:53, scipy _svds.py:441-466,516), for
  * 64-column blocks: rows of the dense operand are gathered from LDS with ds_read_b64_tr_b16 and summed per

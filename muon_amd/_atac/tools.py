@@ -249,6 +249,9 @@ def _lsi_device(
     mfma = (pack and hasattr(backend, "can_cells") and os.environ.get("MUON_AMD_LSI_MFMA", "0") == "1"
             and backend.can_cells(X, B))
     if mfma:
+        logger.warning("MUON_AMD_LSI_MFMA=1: X Q_j runs on the matrix cores with the Krylov basis rounded to f16 - an "
+                       "experiment (DESIGN.md 4.3) that leaves the top-k subspace about 1e-4 rad from the f32 path's, "
+                       "at the edge of the parity bar")
         Xt = backend.transpose_stream(X)
         X = backend.cells(X)
     elif pack:

@@ -127,9 +127,14 @@ def _sort_rows(backend, X):
     key = key[order]
     vals = X.values[order]
     if bool((key[1:] == key[:-1]).any()):
-        # duplicate (row, column) pairs: one entry each, values summed (in stored order: deterministic)
-        ukey, inv = torch.unique_consecutive(key, return_inverse=True)
-        uvals = torch.zeros(ukey.numel(), dtype=vals.dtype, device=vals.device).index_add_(0, inv, vals)
+        # duplicate (row, column) pairs: one entry each, values summed as a segmented reduction - differences of the
+        # f64 running sum at the segment ends (a scan: the same result run to run; index_add_ is atomics in arbitrary
+        # order - ADVICE r04), exact for counts
+        ukey, seg = torch.unique_consecutive(key, return_counts=True)
+        run = torch.cumsum(vals.to(torch.float64), 0)
+        ends = torch.cumsum(seg, 0) - 1
+        tot = run[ends]
+        uvals = (tot - torch.cat([tot.new_zeros(1), tot[:-1]])).to(vals.dtype)
         cnt = torch.bincount(torch.div(ukey, int(d), rounding_mode="floor"), minlength=n)
         indptr = torch.zeros(n + 1, dtype=torch.int64, device=key.device)
         torch.cumsum(cnt, 0, out=indptr[1:])

@@ -48,6 +48,16 @@ def _pad_block(w: int) -> int:
     raise NotImplementedError("n_groups * n_factors must be <= 64 for sparse views")
 
 
+def _can_ell16(be, X, wide: bool) -> bool:
+    """The sliced-ELL kernels address both dense operands with 32-bit byte offsets (64-byte rows of an f32 block, 128-byte
+    rows of an f64 one): X and X^T must both stay under 4 GiB of dense rows, else the row-stream path is taken."""
+    fn = getattr(be, "can_ell16", None)
+    if fn is not None:
+        return bool(fn(X, wide))
+    row = 128 if wide else 64
+    return max(X.shape) * row < (1 << 32)
+
+
 class _View:
     pass
 
@@ -112,6 +122,13 @@ class MofaEngine:
             t = t.to(dev)
         return t
 
+    def _all_ranks(self, flag: bool) -> bool:
+        """True iff ``flag`` holds on EVERY rank (a per-shard property that selects a code path with collectives)."""
+        if self.comm.world_size == 1:
+            return bool(flag)
+        bad = self._allreduce(torch.tensor([0.0 if flag else 1.0], dtype=torch.float64))
+        return float(bad.item()) == 0.0
+
     def _pad16(self, A: torch.Tensor) -> torch.Tensor:
         out = torch.zeros((A.shape[0], 16), dtype=A.dtype, device=A.device)
         out[:, : A.shape[1]] = A
@@ -156,10 +173,16 @@ class MofaEngine:
             pres = np.ones(N, dtype=bool)
             if isinstance(v, DeviceCSR):
                 V.kind = "sparse"
+                if v.nnz >= 2 and hasattr(be, "lib"):
+                    # the operand layouts below rank an entry inside its (row, slab) by position: rows must be sorted
+                    # by column (a caller's device-resident CSR is not canonicalised anywhere else - ADVICE r04)
+                    from .io import canonicalize
+
+                    v = canonicalize(be, v)
                 V.X = v.with_values(v.values.to(T, copy=True))  # centring / scaling work in place:
             else:                                               # never on the caller's tensors
                 V.kind = "dense"
-                if self._f32_storage_ok(scale_views, scale_groups) and v.dtype == torch.float32:
+                if self._all_ranks(self._f32_storage_ok(scale_views, scale_groups) and v.dtype == torch.float32):
                     V.Y = v.contiguous()  # read-only from here on: no copy (see _f32_storage_ok)
                     V.implicit = True
                 else:
@@ -185,7 +208,9 @@ class MofaEngine:
             V.kind = "dense"
             a = np.where(pres[:, None], a, 0.0)
             a32 = a.astype(np.float32)
-            if self._f32_storage_ok(scale_views, scale_groups) and np.array_equal(a32.astype(np.float64), a):
+            # (the storage mode is ONE decision for all ranks: a shard that is exact in f32 next to one that is not would
+            #  all-reduce uncentred Y^T Z contributions with centred ones - ADVICE r04)
+            if self._all_ranks(self._f32_storage_ok(scale_views, scale_groups) and np.array_equal(a32.astype(np.float64), a)):
                 V.Y = self._dev(a32, torch.float32)
                 V.implicit = True
             else:
@@ -256,7 +281,7 @@ class MofaEngine:
                 V.Y[a:b] -= mu[g] * V.pres[a:b, None]  # explicit centring of the dense block
             V.Yt = None
         elif (self.T == torch.float32 and hasattr(be, "ell16") and _pad_block(self.G * self.K) == 16
-              and V.X.shape[0] > 0 and V.X.shape[1] > 0):
+              and V.X.shape[0] > 0 and V.X.shape[1] > 0 and _can_ell16(be, V.X, wide=False)):
             # f32, factor blocks of <= 16 columns: the operand of both directions never changes during a fit - laid
             # out once as sliced ELL (csrc/spmm_ell.hip): no per-row protocol is left in the product
             V.Xt = be.ell16(be.transpose(V.X))
@@ -266,7 +291,7 @@ class MofaEngine:
             V.Xt = be.transpose_stream(V.X)
             V.Xs = be.stream(V.X)
         elif (self.T == torch.float64 and hasattr(be, "ell16") and _pad_block(self.G * self.K) == 16
-              and V.X.shape[0] > 0 and V.X.shape[1] > 0):
+              and V.X.shape[0] > 0 and V.X.shape[1] > 0 and _can_ell16(be, V.X, wide=True)):
             # f64 (the reference's default precision), factor blocks of <= 16 columns: the same static layout with
             # f32 stored values - one operand when the data is exact in f32, hi + lo otherwise - against f64 blocks
             V.Xt = be.ell16(be.transpose(V.X), wide=True)

@@ -591,6 +591,9 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
     """
     if not is_mudata(mdata):
         raise TypeError("Expected a MuData object")
+    if metric not in _PAIR_METRICS + ("seuclidean", "mahalanobis"):
+        # (at entry, not after the bandwidth and weight work - ADVICE r04; the message names what is offered)
+        _pair_dist(torch.zeros((1, 1)), torch.zeros((1, 1)), metric)
     be = _backend(backend)
     mdata = mdata.copy() if copy else mdata
     if neighbor_keys is None:
@@ -680,9 +683,8 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
                              "the modality's graph")
         csig = torch.ones(n, dtype=torch.float64, device=dev)
         csig[pos_d[m1]] = cs_local
-        if bool(((csig - nnd)[pres_d[m1]] == 0).any()):
-            raise ValueError(f"modality '{m1}': a cell's kernel bandwidth equals its nearest-neighbour distance "
-                             "(duplicated cells?): the affinity ratio is undefined")
+        # (a bandwidth equal to the nearest-neighbour distance - duplicated cells - is not an error by itself: the
+        #  reference's exp(-x / 0) is 0 for x > 0, a valid ratio; only 0 / 0 is undefined, caught where it happens)
         thetas, cur = [], None
         for i2, m2 in enumerate(modalities):  # :484-506
             # (the operator depends on the graph and on which cells HAVE modality m1: one per graph when every
@@ -694,6 +696,11 @@ def neighbors(mdata, n_neighbors: Optional[int] = None, n_bandwidth_neighbors: i
             r = _graph_mean(be, S, X32[m1]).to(torch.float64)
             th = torch.exp(-torch.clamp(torch.linalg.norm(Xd[m1] - r, dim=1) - nnd, min=0) / (csig - nnd))
             both = pres_d[m1] & pres_d[m2]
+            undefined = both & torch.isnan(th)
+            if bool(undefined.any()):
+                raise ValueError(f"modality '{m1}': the affinity ratio of cell {int(torch.nonzero(undefined)[0])} is 0 / 0 (its "
+                                 "kernel bandwidth equals its nearest-neighbour distance and the neighbourhood mean "
+                                 f"in '{m2}' sits on the cell itself: duplicated cells?)")
             th = torch.where(both, th, ninf)
             if i1 == i2:
                 cur = th

@@ -256,7 +256,11 @@ def mofa(
     res = eng.results(sort_factors=True)
 
     logger.info("Saving the model...")
-    written = _save_model(outfile, res, list(mdata.mod.keys()), group_names, obs_used, groups, expectations)
+    try:
+        written = _save_model(outfile, res, list(mdata.mod.keys()), group_names, obs_used, groups, expectations)
+    except Exception as e:  # noqa: BLE001  (a failing save must not lose the fit: the slots below are still written)
+        warn(f"Cannot save the model to {outfile}: {e!r}")
+        written = None
 
     if copy:
         data = data.copy()
@@ -340,15 +344,18 @@ def _model_datasets(res, view_names, group_names, obs_names, groups):
     (/root/reference/muon/_core/tools.py:604-641: expectations/Z/<group> [factors, samples], expectations/W/<view>
     [factors, features], samples/<group>) plus views/views, groups/groups, variance_explained/r2_per_factor/<group>
     [views, factors] and training_stats/elbo.  Both writers below store exactly this mapping."""
+    def _bytes(names):  # UTF-8 byte strings (h5py / mofapy2's convention; `.astype("S")` raises on non-ASCII names)
+        return np.char.encode(np.asarray(names).astype(str), "utf-8") if len(names) else np.asarray([], dtype="S1")
+
     d = {}
     for gi, g in enumerate(group_names):
         d[f"expectations/Z/{g}"] = np.ascontiguousarray(res["Z"][groups == gi].T)
-        d[f"samples/{g}"] = np.asarray(obs_names)[groups == gi].astype("S")
+        d[f"samples/{g}"] = _bytes(np.asarray(obs_names)[groups == gi])
         d[f"variance_explained/r2_per_factor/{g}"] = np.ascontiguousarray(res["r2"][:, gi, :])
     for m, w in zip(view_names, res["W"]):
         d[f"expectations/W/{m}"] = np.ascontiguousarray(np.asarray(w).T)
-    d["views/views"] = np.asarray(view_names, dtype="S")
-    d["groups/groups"] = np.asarray(group_names, dtype="S")
+    d["views/views"] = _bytes(view_names)
+    d["groups/groups"] = _bytes(group_names)
     d["training_stats/elbo"] = np.asarray(res["elbo"])
     return d
 

@@ -63,6 +63,15 @@ def _worker(rank, world, port, q):
         eng.run(12, "slow")
         res = eng.results(sort_factors=False)
         Zall = comm.all_gather_rows(torch.from_numpy(res["Z"]))
+        # rank 0's shard of the dense view exact in f32, rank 1's not: the f32-storage / implicit-centring mode must be
+        # ONE decision of all ranks (per-rank modes all-reduce centred with uncentred statistics)
+        y1x = y1.copy()
+        y1x[:55] = y1x[:55].astype(np.float32)
+        engx = MofaEngine(be, [y1x[a:b], sp.csr_matrix(y2[a:b])], groups[a:b], 6, seed=1, comm=comm,
+                          row_offset=a, n_total=120)
+        modes = [bool(getattr(v, "implicit", False)) for v in engx.views]
+        engx.run(6, "slow")
+        elbo_x = engx.results(sort_factors=False)["elbo"]
         # the element-wise-precision engine (poisson counts, sparse; gaussian view with NaN entries)
         from muon_amd._core.mofa_general import GeneralMofaEngine
 
@@ -77,6 +86,7 @@ def _worker(rank, world, port, q):
         if rank == 0:
             q.put({"tfidf": T.values.numpy(), "U": Uall.numpy(), "stdev": stdev, "V": V.numpy(),
                    "elbo": res["elbo"], "Z": Zall.numpy(), "W": res["W"], "iters": info["iterations"],
+                   "elbo_x": elbo_x, "modes_x": modes,
                    "g_elbo": gres["elbo"], "g_Z": gZ.numpy(), "g_W": gres["W"], "g_r2": gres["r2"]})
     finally:
         dist.destroy_process_group()
@@ -130,6 +140,13 @@ def test_world_size_2_matches_single_process():
     np.testing.assert_allclose(got["Z"], res["Z"], atol=1e-8)
     for a, b in zip(got["W"], res["W"]):
         np.testing.assert_allclose(a, b, atol=1e-8)
+
+    y1x = y1.copy()
+    y1x[:55] = y1x[:55].astype(np.float32)
+    engx = MofaEngine(be, [y1x, sp.csr_matrix(y2)], groups, 6, seed=1)
+    engx.run(6, "slow")
+    assert got["modes_x"] == [False, False]
+    np.testing.assert_allclose(got["elbo_x"], engx.results(sort_factors=False)["elbo"], rtol=1e-9)
 
     # general engine: the same model on the whole data in one process, and the oracle
     from muon_amd._core.mofa_general import GeneralMofaEngine
