@@ -182,6 +182,41 @@ int mu_csr_tpack_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int
  * accumulated in column order with one fmaf chain per dense column, whatever the layout =>
  * bit-reproducible and layout-independent. */
 int mu_spmm_stream_k(int64_t n_rows);
+
+/* ---- r05: the row stream of the TF-IDF result from the scale sweep, and the transposition that reads it ------------
+ * mu_tfidf_scale_sweep_stream = mu_tfidf_scale_sweep for f32 values that ALSO writes the row stream of its result:
+ * pair i of row r - (column int32, value f32), 8 bytes - goes to d_ent[d_row_dst[r] + i], i.e. the caller lays the
+ * rows out in the launch order of mu_spmm_stream_f32 beforehand (row lengths are known before the values are) and
+ * the streaming copy mu_csr_stream_fill is not needed (replaces, with the values array it still writes,
+ * /root/reference/muon/_atac/preproc.py:96-117; the stream is the matvec operand of scipy svds, _svds.py:441-466).
+ *
+ * mu_tpack4_*: X^T as a row stream (or CSR) straight from X, fourth generation (csrc/tpack4.hip) - same output bytes
+ * as mu_csr_tpack_fill_stream / _csr.  Source: the row stream of X when d_x_ent != NULL (d_x_row_dst[r] = pair index of
+ * row r's first pair; d_indptr gives the row lengths) - rows are read as contiguous pairs - else the CSR arrays.
+ * Row blocks are fixed row ranges (mu_tpack4_geometry: 16 waves x <= 32 rows), d_work is shared by _count and _fill,
+ * d_slab_ptr as in mu_csr_tpack_count.  mu_tpack4_supported: 0 for shapes that need mu_csr_tpack_* (2^31 rows, a
+ * row block of 2^29 entries).  mu_tpack4_status reads the fill's error word (0 = fine; synchronises: tests). */
+int mu_tfidf_scale_sweep_stream(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
+                                const float* d_values, const double* d_rowsum, const float* d_idf, double scale,
+                                int flags, float* d_out, unsigned long long* d_zero_count, void* d_work,
+                                size_t work_bytes, int have_slab_ptr, const int64_t* d_row_dst, void* d_ent,
+                                void* stream);
+int mu_tpack4_supported(int64_t n_rows, int64_t n_cols, int64_t nnz);
+int mu_tpack4_geometry(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t* rows_per_block, int* n_blocks,
+                       int* tile_cols);
+size_t mu_tpack4_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz);
+int mu_tpack4_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr, const int32_t* d_indices,
+                    int64_t* d_col_nnz, void* d_work, size_t work_bytes, const int64_t* d_slab_ptr, void* stream);
+int mu_tpack4_fill_stream(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
+                          const int32_t* d_indices, const float* d_values, const int64_t* d_x_row_dst,
+                          const void* d_x_ent, const int64_t* d_sptr, const int32_t* d_inv, void* d_ent, void* d_work,
+                          size_t work_bytes, void* stream);
+int mu_tpack4_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr, const int32_t* d_indices,
+                       const float* d_values, const int64_t* d_x_row_dst, const void* d_x_ent,
+                       const int64_t* d_t_indptr, int32_t* d_t_indices, float* d_t_values, void* d_work,
+                       size_t work_bytes, void* stream);
+int mu_tpack4_status(const void* d_work, int64_t n_rows, int64_t n_cols, int64_t nnz, int* h_err);
+int mu_tpack4_phase_cycles(unsigned long long* h_out6, int reset);
 /* diagnostics (scripts/tpack_probe.py): see csrc/tpack.hip */
 int mu_csr_tpack_phase_cycles(unsigned long long* h_out6, int reset);
 int mu_csr_stream_len(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr, int64_t* d_len,

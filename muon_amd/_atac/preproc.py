@@ -156,7 +156,7 @@ def canonical_csr(counts) -> csr_matrix:
     return m
 
 
-def tfidf_device(backend, X, n_obs, flags: int, scale: float, comm=None, out=None):
+def tfidf_device(backend, X, n_obs, flags: int, scale: float, comm=None, out=None, emit_stream: bool = True):
     """Device-resident TF-IDF of a (row shard of a) CSR.  Returns a DeviceCSR that shares
     indptr / indices with ``X`` unless zeros had to be dropped.
 
@@ -166,7 +166,16 @@ def tfidf_device(backend, X, n_obs, flags: int, scale: float, comm=None, out=Non
     rowsum, colsum = backend.row_col_sums(X)
     comm.all_reduce_sum(colsum)
     idf = backend.idf(colsum, float(n_obs), flags, X.values.dtype)
-    vals, zero_count = backend.tfidf_scale(X, rowsum, idf, scale, flags, out=out)
+    # r05: the scale sweep also writes the ROW STREAM of the result - the operand layout of lsi's products - while it has
+    # every entry in registers (the layout needs the row lengths only); lsi then skips its streaming copy of X and
+    # transposes from the stream.  Operator sets without the kernel (CPU tests) simply do not offer it.
+    emit = None
+    can = getattr(backend, "can_emit_stream", None)
+    if emit_stream and can is not None and can(X):
+        emit = backend.stream_layout(X)
+        vals, zero_count = backend.tfidf_scale(X, rowsum, idf, scale, flags, out=out, emit=emit)
+    else:
+        vals, zero_count = backend.tfidf_scale(X, rowsum, idf, scale, flags, out=out)
     res = X.with_values(vals)
     take = getattr(backend, "take_slab_ptr", None)  # (a method: wrappers of the backend forward it)
     sp = take() if take is not None else None
@@ -178,6 +187,9 @@ def tfidf_device(backend, X, n_obs, flags: int, scale: float, comm=None, out=Non
         # cuts the same 8192-column slabs (csrc/tpack.hip) and does not search them again
         if sp is not None:
             res.slab_ptr = (sp, (res.indptr.data_ptr(), res.indices.data_ptr(), res.shape[0], res.shape[1]))
+        if emit is not None:  # (keyed by the arrays it mirrors: a result whose zeros were compacted has no stream)
+            res.xstream = (emit[0], emit[1], (res.indptr.data_ptr(), res.indices.data_ptr(), res.values.data_ptr(),
+                                              res.shape[0], res.shape[1], res.nnz))
     return res
 
 
@@ -286,7 +298,9 @@ def tfidf(
     if n_obs is None:
         n_obs = comm.sum_scalar(adata.shape[0])
     flags = _flags(log_tf, log_idf, log_tfidf)
-    R = tfidf_device(backend, X, n_obs, flags, _effective_scale(scale_factor), comm=comm)
+    # (the result's row stream - lsi's operand - is only worth its 8 bytes per entry when the device copy stays attached)
+    R = tfidf_device(backend, X, n_obs, flags, _effective_scale(scale_factor), comm=comm,
+                     emit_stream=keep_on_device and not (match_scipy_order and log_tf and not log_tfidf))
 
     vals = backend.to_host(R.values)
     if host is not None and R.indices is X.indices:

@@ -408,13 +408,62 @@ class HipBackend:
                                         self._stream()))
         return out
 
-    def tfidf_scale(self, X: DeviceCSR, rowsum, idf, scale: float, flags: int, out=None):
+    def can_emit_stream(self, X: DeviceCSR) -> bool:
+        """The TF-IDF scale sweep can write the row stream of its result (f32, a shape the stream SpMM takes)."""
+        return (X.values.dtype == torch.float32 and X.nnz > 0 and self.can_stream(X, 64)
+                and os.environ.get("MUON_AMD_TFIDF_STREAM", "1") != "0" and self.lib.mu_tune_get(b"scale_stream_off") != 1)
+
+    def stream_layout(self, X: DeviceCSR, K: Optional[int] = None):
+        """Where the rows of X go in its row stream (launch_layout: needs the row LENGTHS only, so it can be made before
+        the values exist) and an empty stream to fill: (DeviceStream, row_dst) with row_dst[r] = pair index of row r's
+        first pair."""
+        n, d = X.shape
+        lens = X.indptr[1:] - X.indptr[:-1]
+        perm, inv, K = self.launch_layout(lens, K)
+        n_pos = int(perm.numel())
+        plens = torch.zeros((n_pos,), dtype=torch.int64, device=self.device)
+        plens[inv.long()] = lens
+        with self._dev_ctx():
+            sptr = self._stream_sptr(plens, K)
+        ent = self.empty((max(X.nnz, 1),), torch.int64)
+        row_dst = sptr[inv.long()].contiguous()
+        return DeviceStream(sptr, ent, (n, d), X.nnz, perm, K), row_dst
+
+    @staticmethod
+    def _xstream_of(X: DeviceCSR):
+        """(row stream, row_dst) the TF-IDF scale sweep left with X, if they describe X's arrays as they are."""
+        got = getattr(X, "xstream", None)
+        if got is None:
+            return None
+        xs, row_dst, key = got
+        n, d = X.shape
+        if key != (X.indptr.data_ptr(), X.indices.data_ptr(), X.values.data_ptr(), n, d, X.nnz):
+            return None
+        return xs, row_dst
+
+    def tfidf_scale(self, X: DeviceCSR, rowsum, idf, scale: float, flags: int, out=None, emit=None):
+        """``emit`` = (DeviceStream, row_dst) from stream_layout: the sweep also writes the result's row stream."""
         if out is None:
             out = torch.empty_like(X.values)
         zc = self.zeros((1,), torch.int64)
         n, d = X.shape
         kept = self.__dict__.pop("_sweep_work", None)
         key = (X.indptr.data_ptr(), X.indices.data_ptr(), n, d)
+        if emit is not None:
+            assert X.values.dtype == torch.float32
+            have = kept is not None and kept[2] == key
+            if have:
+                work, wb = kept[0], kept[1]
+            else:
+                wb = int(self.lib.mu_csr_row_col_sums_worksize(n, d))
+                work = self.empty((wb,), torch.uint8)
+            with self._dev_ctx():
+                check(self.lib.mu_tfidf_scale_sweep_stream(n, d, _p(X.indptr), _p(X.indices), _p(X.values), _p(rowsum),
+                                                           _p(idf), float(scale), flags, _p(out), _p(zc), _p(work), wb,
+                                                           int(have), _p(emit[1]), _p(emit[0].ent), self._stream()))
+            n_sp = n * (-(-d // 8192) + 1)
+            self._last_slab_ptr = work[:8 * n_sp].view(torch.int64).clone()
+            return out, zc
         with self._dev_ctx():
             if self.__dict__.get("_scale_gather"):  # comparison / tests: the per-lane gather kernel
                 check(self.lib.mu_tfidf_scale(_dt(X.values), n, _p(X.indptr), _p(X.indices),
@@ -499,6 +548,18 @@ class HipBackend:
         t_indptr = self.zeros((d + 1,), torch.int64)
         t_indices = self.empty((max(X.nnz, 1),), torch.int32)[:X.nnz]
         t_values = self.empty((max(X.nnz, 1),), torch.float32)[:X.nnz]
+        if self._use_tpack4(X):
+            wb = int(self.lib.mu_tpack4_worksize(n, d, X.nnz))
+            work = self.empty((wb,), torch.uint8)
+            with self._dev_ctx():
+                st = self._stream()
+                check(self.lib.mu_tpack4_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz), _p(work), wb,
+                                               _p(self._slab_ptr_of(X)), st))
+                check(self.lib.mu_exclusive_scan_i64(d, _p(col_nnz), _p(t_indptr), st))
+                check(self.lib.mu_tpack4_fill_csr(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values), None, None,
+                                                  _p(t_indptr), _p(t_indices), _p(t_values), _p(work), wb, st))
+            self._tpack4_work = (work, (n, d, X.nnz))
+            return DeviceCSR(t_indptr, t_indices, t_values, (d, n))
         wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
         work = self.empty((wb,), torch.uint8)
         with self._dev_ctx():
@@ -545,13 +606,58 @@ class HipBackend:
                                               _p(sptr), _p(ent), st))
         return DeviceStream(sptr, ent, (n, d), X.nnz, perm, K)
 
+    def _use_tpack4(self, X: DeviceCSR) -> bool:
+        """The fourth-generation transposition (csrc/tpack4.hip) unless the shape needs the third (or tune tpack_v3 = 1)."""
+        n, d = X.shape
+        return (self.lib.mu_tune_get(b"tpack_v3") != 1 and os.environ.get("MUON_AMD_TPACK_V3", "0") != "1"
+                and bool(self.lib.mu_tpack4_supported(n, d, X.nnz)))
+
+    def tpack4_status(self) -> int:
+        """Error word of the last fourth-generation fill (0 = fine; synchronises: tests and probes)."""
+        import ctypes as C
+
+        got = self.__dict__.get("_tpack4_work")
+        if got is None:
+            return 0
+        work, (n, d, nnz) = got
+        err = C.c_int(0)
+        check(self.lib.mu_tpack4_status(_p(work), n, d, nnz, C.byref(err)))
+        return int(err.value)
+
     def transpose_stream(self, X: DeviceCSR, sort_rows: bool = True, before_fill=None,
-                         K: Optional[int] = None) -> DeviceStream:
-        """Row stream of X^T straight from the CSR of X (no CSR of X^T; stable: cells ascending inside
-        every row).  ``before_fill``: called once the count phase is done and before the fill is queued."""
+                         K: Optional[int] = None, src=None) -> DeviceStream:
+        """Row stream of X^T straight from X (no CSR of X^T; stable: cells ascending inside every row).
+        ``src`` = (row stream of X, row_dst): the rows are read from the stream as contiguous pairs instead of from
+        the CSR arrays (r05).  ``before_fill``: called once the count phase is done and before the fill is queued."""
         n, d = X.shape
         assert X.values.dtype == torch.float32
         col_nnz = self.empty((max(d, 1),), torch.int64)
+        if self._use_tpack4(X):
+            wb = int(self.lib.mu_tpack4_worksize(n, d, X.nnz))
+            work = self.empty((wb,), torch.uint8)
+            with self._dev_ctx():
+                st = self._stream()
+                check(self.lib.mu_tpack4_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz), _p(work), wb,
+                                               _p(self._slab_ptr_of(X)), st))
+                want_k = K
+                perm, inv, K, n_pos = None, None, max(1, int(want_k or self.lib.mu_spmm_stream_k(d))), d
+                lens = col_nnz[:d]
+                if sort_rows and d > 0:
+                    perm, inv, K = self.launch_layout(lens, want_k)
+                    n_pos = int(perm.numel())
+                    plens = torch.zeros((n_pos,), dtype=torch.int64, device=self.device)
+                    plens[inv.long()] = lens
+                else:
+                    plens = lens.contiguous()
+                sptr = self._stream_sptr(plens, K)
+                ent = self.empty((max(X.nnz, 1),), torch.int64)
+                if before_fill is not None:
+                    before_fill()
+                xs_ent, xs_dst = (src[0].ent, src[1]) if src is not None else (None, None)
+                check(self.lib.mu_tpack4_fill_stream(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
+                                                     _p(xs_dst), _p(xs_ent), _p(sptr), _p(inv), _p(ent), _p(work), wb, st))
+            self._tpack4_work = (work, (n, d, X.nnz))
+            return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K)
         wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
         work = self.empty((wb,), torch.uint8)
         with self._dev_ctx():
@@ -756,6 +862,11 @@ class HipBackend:
         """(row stream of X, row stream of X^T).  The two builders are independent; the streaming
         copy of X (HBM bound) runs on a second stream under the transposition, whose fill is
         instruction bound and leaves half of every CU's wave slots free."""
+        have = self._xstream_of(X)
+        if have is not None and self._use_tpack4(X):
+            # r05: the TF-IDF scale sweep wrote X's stream already; the transposition reads its rows from there
+            Xs, row_dst = have
+            return Xs, self.transpose_stream(X, src=(Xs, row_dst))
         cur = torch.cuda.current_stream(self.device)
         side = self.__dict__.get("_side_stream")
         if side is None:

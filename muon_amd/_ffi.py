@@ -61,6 +61,16 @@ SIGNATURES = {
     "mu_csr_tpack_count": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "mu_csr_tpack_fill_csr": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_stream_k": (C.c_int, [_i64]),
+    "mu_tfidf_scale_sweep_stream": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _dbl, _i32, _vp, _vp, _vp, _sz, _i32,
+                                              _vp, _vp, _vp]),
+    "mu_tpack4_supported": (C.c_int, [_i64, _i64, _i64]),
+    "mu_tpack4_geometry": (C.c_int, [_i64, _i64, _i64, C.POINTER(_i64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mu_tpack4_worksize": (_sz, [_i64, _i64, _i64]),
+    "mu_tpack4_count": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "mu_tpack4_fill_stream": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mu_tpack4_fill_csr": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mu_tpack4_status": (C.c_int, [_vp, _i64, _i64, _i64, C.POINTER(C.c_int)]),
+    "mu_tpack4_phase_cycles": (C.c_int, [_vp, _i32]),
     "mu_csr_tpack_phase_cycles": (C.c_int, [_vp, _i32]),
     "mu_csr_stream_len": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "mu_csr_stream_fill": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

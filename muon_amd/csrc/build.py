@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["runtime.hip", "tfidf.hip", "transpose.hip", "spmm.hip", "spmm_win.hip", "spmm_narrow.hip", "spmm_mfma.hip", "spmm_ell.hip", "tpack.hip", "dense.hip", "skinny.hip", "synth.hip", "mofa.hip", "mofa_elbo.hip", "mofa_stats.hip", "mofa_poisson.hip", "knn.hip", "wnn.hip"]
+SOURCES = ["runtime.hip", "tfidf.hip", "transpose.hip", "spmm.hip", "spmm_win.hip", "spmm_narrow.hip", "spmm_mfma.hip", "spmm_ell.hip", "tpack.hip", "tpack4.hip", "dense.hip", "skinny.hip", "synth.hip", "mofa.hip", "mofa_elbo.hip", "mofa_stats.hip", "mofa_poisson.hip", "knn.hip", "wnn.hip"]
 HEADERS = ["common.hpp", "sweep.hpp", os.path.join(ROOT, "include", "muon_amd.h")]
 # (spmm_mfma.hip names a64+ in asm clobber lists: the backend calls them "reserved" at 1024 threads per workgroup -
 #  it splits the 128 registers of a wave evenly - and still allocates them: next_free_vgpr covers a[0:87])

@@ -31,13 +31,13 @@ int mu_num_cus() {
 static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "spmm_waves", "spmm_pipe",
                                         "tpack_abl", "tpack_c", "gram_wg", "tpack_v2", "pack_wg",
                                         "tpack_dbg", "tpack_rows", "tpack_narrow", "spmm_narrow_off",
-                                        "mfma_mode", "ell_mode", "tfidf_wide", "tfidf_pipe", "nn_interleave", "tfidf_abl", "tfidf_sum_m", "tn_pipe", "nn_fast_off", "tpack_asm", "tpack_split", "stream_pipe", "tcount_pipe"};
+                                        "mfma_mode", "ell_mode", "tfidf_wide", "tfidf_pipe", "nn_interleave", "tfidf_abl", "tfidf_sum_m", "tn_pipe", "nn_fast_off", "tpack_asm", "tpack_split", "stream_pipe", "tcount_pipe", "tpack4_m", "tpack4_c", "tpack_v3", "scale_stream_off"};
 constexpr int kTuneN = sizeof(kTuneKeys) / sizeof(kTuneKeys[0]);
 static int g_tune[kTuneN] = {};
 
 extern "C" {
 
-int mu_version(void) { return 400; }  // r04: matrix-core SpMM (mu_cells_*, mu_dense_to_f16, mu_spmm_cells_f32, probes);  // r03: mu_mofa_rowstats, mu_mofa_gs_update, mu_mofa_poisson_pseudo, mu_mofa_jaakkola, mu_csr_densify_rows, mu_knn_filter_f64, mu_wnn_bandwidth_f64, mu_umap_strengths_f64 added, mu_mofa_update_z takes d_corr, mu_spmm_ws_* removed
+int mu_version(void) { return 500; }  // r05: mu_tfidf_scale_sweep_stream, mu_tpack4_* (the transposition on the row stream);  // r04: matrix-core SpMM (mu_cells_*, mu_dense_to_f16, mu_spmm_cells_f32, probes);  // r03: mu_mofa_rowstats, mu_mofa_gs_update, mu_mofa_poisson_pseudo, mu_mofa_jaakkola, mu_csr_densify_rows, mu_knn_filter_f64, mu_wnn_bandwidth_f64, mu_umap_strengths_f64 added, mu_mofa_update_z takes d_corr, mu_spmm_ws_* removed
 
 int mu_tune_set(const char* key, int value) {
   MU_REQUIRE(key, "null key");

@@ -546,12 +546,17 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_tfidf_scale_sweep_wide(
 
 // k_tfidf_scale_sweep_wide, software pipelined (see k_row_col_sums_pipe).  A lane past the end of a piece holds
 // the piece's LAST entry and stores its value again: same address, same bits - no branch around the store either.
-template <int M, int CH, int ABL = 0>  // ABL (timing ablations, tune "tfidf_abl"): 3 no arithmetic, 4 no stores
+// STREAM (r05): the sweep also writes the ROW STREAM of the result - the (column, value) pairs of every row, 8 bytes each,
+// contiguous from pair row_dst[row] of `ent`, i.e. in the launch order of the SpMM that lsi() runs next (csrc/spmm_win.hip)
+// - while it has every entry in registers.  lsi's streaming copy of X (8 bytes read + 8 written per entry, next to the
+// transposition's fill) disappears, and the transposition reads rows as contiguous pairs (csrc/tpack4.hip).
+template <int M, int CH, int ABL = 0, bool STREAM = false>  // ABL (timing ablations, tune "tfidf_abl"): 3 no arithmetic, 4 no stores
 __global__ __launch_bounds__(kSweepThreads, 4) void k_tfidf_scale_sweep_pipe(
     int64_t n_rows, int64_t n_cols, int64_t S, const int64_t* __restrict__ indptr,
     const int32_t* __restrict__ indices, const float* __restrict__ values,
     const int64_t* __restrict__ sp, const double* __restrict__ rowsum, const float* __restrict__ idf,
-    float scale, int use_scale, int flags, float* __restrict__ out, unsigned long long* zero_count) {
+    float scale, int use_scale, int flags, float* __restrict__ out, unsigned long long* zero_count,
+    const int64_t* __restrict__ row_dst = nullptr, unsigned long long* __restrict__ ent = nullptr) {
   __shared__ float lidf[kSlab * M];
   __shared__ int64_t s_r[2];
   const int g = blockIdx.x, G = gridDim.x;
@@ -575,10 +580,16 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_tfidf_scale_sweep_pipe(
       const int64_t myrow = strip + (int64_t)kSweepWaves * lane;
       int lo_l = 0, hi_l = 0;
       float inv_l = 0.f;
+      int dlo_l = 0, dhi_l = 0;  // STREAM: pair index in `ent` of the entry at offset 0 from wg_base, for this lane's row
       if (myrow < r1) {
         lo_l = (int)(sp[myrow * (S + 1) + s_lo] - wg_base);
         hi_l = (int)(sp[myrow * (S + 1) + s_hi] - wg_base);
         inv_l = 1.0f / (float)rowsum[myrow];  // preproc.py:94  1.0 / n_peaks
+        if constexpr (STREAM) {
+          const int64_t d = row_dst[myrow] - (indptr[myrow] - wg_base);
+          dlo_l = (int)(unsigned)(d & 0xffffffffll);
+          dhi_l = (int)(d >> 32);
+        }
       }
       const int64_t left = (r1 - strip + kSweepWaves - 1) / kSweepWaves;
       FlatWalk w{-1, 0, 0, left < 64 ? (int)left : 64, 64 * CH};
@@ -594,6 +605,12 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_tfidf_scale_sweep_pipe(
       };
       auto work = [&](int32_t (&c)[CH], float (&x)[CH], int pb, int hi, int l) {
         const float inv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv_l), l));
+        unsigned long long* eb = nullptr;
+        if constexpr (STREAM) {
+          const unsigned dlo = (unsigned)__builtin_amdgcn_readlane(dlo_l, l);
+          const int dhi = __builtin_amdgcn_readlane(dhi_l, l);
+          eb = ent + (((int64_t)dhi << 32) | (int64_t)dlo);
+        }
         static_for<CH>([&](auto uc) {
           constexpr int u = decltype(uc)::value;
           pipe_wait<2 * (CH - 1 - u) + 2 * CH>(c[u], x[u]);
@@ -613,6 +630,8 @@ __global__ __launch_bounds__(kSweepThreads, 4) void k_tfidf_scale_sweep_pipe(
             t += (float)c[u];
           }
           if constexpr (ABL != 4) ob[q] = t;
+          if constexpr (STREAM)  // (a lane past the piece's end stores the piece's last pair again: same address, same bits)
+            eb[q] = (unsigned long long)(unsigned)c[u] | ((unsigned long long)__builtin_bit_cast(unsigned, t) << 32);
           zeros += (p < hi && t == 0.f) ? 1u : 0u;
         }
       };
@@ -951,6 +970,35 @@ int mu_tfidf_scale_sweep(int dtype, int64_t n_rows, int64_t n_cols, const int64_
     hipLaunchKernelGGL(k_tfidf_scale_sweep<double>, dim3(G), dim3(kSweepThreads), 0, st, n_rows, n_cols,
                        S, d_indptr, d_indices, (const double*)d_values, sp, d_rowsum,
                        (const double*)d_idf, scale, use_scale, flags, (double*)d_out, d_zero_count);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+/* mu_tfidf_scale_sweep for f32 that ALSO writes the row stream of the result (see k_tfidf_scale_sweep_pipe): pair i
+ * of row r goes to d_ent[d_row_dst[r] + i].  Same values out, bit for bit. */
+int mu_tfidf_scale_sweep_stream(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
+                                const float* d_values, const double* d_rowsum, const float* d_idf, double scale,
+                                int flags, float* d_out, unsigned long long* d_zero_count, void* d_work,
+                                size_t work_bytes, int have_slab_ptr, const int64_t* d_row_dst, void* d_ent,
+                                void* stream) {
+  MU_REQUIRE(!((flags & MU_TFIDF_LOG_TFIDF) && (flags & (MU_TFIDF_LOG_TF | MU_TFIDF_LOG_IDF))),
+             "log_tfidf excludes log_tf / log_idf (preproc.py:69-73)");
+  MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative shape");
+  hipStream_t st = (hipStream_t)stream;
+  if (d_zero_count) MU_CHECK_HIP(hipMemsetAsync(d_zero_count, 0, sizeof(unsigned long long), st));
+  if (n_rows == 0 || n_cols == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_rowsum && d_idf && d_out && d_row_dst && d_ent, "null pointer");
+  MU_REQUIRE(d_work && work_bytes >= mu_csr_row_col_sums_worksize(n_rows, n_cols), "work buffer too small");
+  const int64_t S = num_slabs(n_cols);
+  int64_t* sp = (int64_t*)d_work;  // same place as in mu_csr_row_col_sums
+  if (!have_slab_ptr) {
+    int rc = launch_slab_ptr(n_rows, n_cols, d_indptr, d_indices, sp, st);
+    if (rc) return rc;
+  }
+  const int use_scale = !(scale == 0.0 || scale == 1.0);  // preproc.py:101
+  hipLaunchKernelGGL((k_tfidf_scale_sweep_pipe<4, 4, 0, true>), dim3(mu_num_cus()), dim3(kSweepThreads), 0, st, n_rows,
+                     n_cols, S, d_indptr, d_indices, d_values, sp, d_rowsum, d_idf, (float)scale, use_scale, flags,
+                     d_out, d_zero_count, d_row_dst, (unsigned long long*)d_ent);
   MU_CHECK_LAUNCH();
   return MU_OK;
 }

@@ -1,0 +1,738 @@
+// X^T as a row stream (or CSR) from X - fourth generation of the transposition's fill (r05).
+//
+// Same job, same output bytes as csrc/tpack.hip (the rmatvec operand of scipy svds, _svds.py:441-466, reached from
+// /root/reference/muon/_atac/tools.py:53): a workgroup stages a (row block x column tile) in LDS sorted by (column, cell)
+// and writes every column's run with consecutive lanes; stable, no global atomics.  What changed is how a tile is
+// sorted, because of what bounded the third generation: its row visits fetched 64 (column, value)
+// entries = 3 + 3 lines of 128 bytes from two arrays to use the ~20 that fall into the tile (it needed the NEXT
+// tile's entries inside the window for its look-ahead count), one row per wave step, in a chain of LDS atomic round
+// trips - 250 GB through the fabric for 50 GB of input at 1e6 x 200k.
+//
+//   * Source: the ROW STREAM of X ((column, value) pairs, 8 bytes each, one row contiguous - what the TF-IDF scale
+//     sweep now writes, csrc/tfidf.hip) or, for callers without one, the CSR arrays.
+//   * A wave owns 32 consecutive rows of the block and has ALL of them in flight: 16 load instructions, each the next
+//     32 pairs of TWO rows (lanes 0-31 / 32-63, EXEC-masked to the entries the row still has; 256 contiguous bytes =
+//     2-3 lines per row and visit), issued one tile ahead into registers the compiler never sees (v94..v127).
+//   * No count walk and no look-ahead: a tile is ranked with a BITMAP.  Phase 1: every entry of the tile sets the bit
+//     of its row in word (wave, column) - `ds_or_rtn_b32`, 16 independent ones in flight, the returned word holds the
+//     wave's earlier rows with that column = the entry's rank inside the wave.  Phase 2: a thread per column turns the
+//     16 words of its column into the waves' first staging slots (prefix of popcounts).  Phase 3: slot = word + rank,
+//     pair -> staging buffer - from the window registers, nothing is fetched twice.  Phase 4: runs written out.
+//   * A row with more than 32 entries in the tile (rare by the host's choice of the tile width: ~4 sigma) takes the
+//     wave's one overflow slot (two rows, one more window each); anything beyond that - or a tile that does not fit the
+//     staging buffer - retries the tile at half its width (a 16-column tile of 512 rows always fits).
+#include <type_traits>
+#include <utility>
+
+#include "common.hpp"
+#pragma clang diagnostic ignored "-Winline-asm"
+
+namespace {
+
+constexpr int kT = 1024, kNW = 16;   // threads / waves of a workgroup
+constexpr int kRW = 32;              // rows of a wave: one bit each in a 32-bit word
+constexpr int kMaxC = 768;           // widest tile (columns)
+constexpr int kCap = 12288;          // staged pairs: 96 KiB
+constexpr int kW0 = 94;              // asm-owned registers v[kW0 ..]: slot j = (v[kW0 + 2j] column, v[kW0 + 2j + 1] value bits)
+constexpr int kSlotX = 16;           // the overflow slot
+constexpr int kCountSlab = 8192;     // = sweep.hpp kSlab = tpack.hip kTSlab: the slab pointers are shared
+
+#define MU_T4_CLOB                                                                                                  \
+  "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",  \
+      "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", \
+      "v123", "v124", "v125", "v126", "v127"
+
+struct T4Out {
+  unsigned long long* ent;
+  int32_t* idx;
+  float* val;
+};
+__device__ __forceinline__ void t4_store(const T4Out& o, int64_t pos, unsigned long long e) {
+  if (o.idx) {
+    o.idx[pos] = (int32_t)(unsigned)e;
+    o.val[pos] = __builtin_bit_cast(float, (unsigned)(e >> 32));
+  } else {
+    o.ent[pos] = e;
+  }
+}
+
+// lane `L` of v <- the wave-uniform x (this clang has no writelane builtin)
+template <int L>
+__device__ __forceinline__ int writelane_c(int v, int x) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(x), "n"(L));
+  return v;
+}
+__device__ __forceinline__ int writelane_s(int v, int x, int l) {  // (lane select in M0: one SGPR operand per instruction)
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(x), "s"(l) : "m0");
+  return v;
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// ---- count: entries per (row block, column), row blocks of `rpb` consecutive rows ------------------------------------
+// (csrc/tpack.hip k_t_count_pipe with fixed row blocks: the pieces of a wave's strip of rows as one flat sequence of
+//  iterations, unconditional clamped loads from asm, two iterations in flight, bins of M x 8192 columns)
+struct T4Walk {
+  int l, pb, hi, nrow, step;
+  __device__ __forceinline__ bool advance(int lo_l, int hi_l) {
+    pb += step;
+    while (pb >= hi) {
+      if (++l >= nrow) return false;
+      pb = __builtin_amdgcn_readlane(lo_l, l);
+      hi = __builtin_amdgcn_readlane(hi_l, l);
+    }
+    return true;
+  }
+};
+template <int N>
+__device__ __forceinline__ void t4c_wait(int32_t (&c)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : "n"(N) : "memory");
+}
+template <int M>
+__global__ __launch_bounds__(kT) void k_t4_count(int64_t n_rows, int64_t n_cols, int64_t S, int64_t rpb,
+                                                 const int64_t* __restrict__ indptr,
+                                                 const int32_t* __restrict__ indices,
+                                                 const int64_t* __restrict__ sp, uint32_t* __restrict__ cnt) {
+  __shared__ uint32_t bins[kCountSlab * M];
+  const int g = blockIdx.x;
+  const int64_t r0 = (int64_t)g * rpb;
+  const int64_t r1 = (r0 + rpb) < n_rows ? (r0 + rpb) : n_rows;
+  const int wave = uniform32(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t wg_base = uniform64(indptr[r0 < n_rows ? r0 : n_rows]);
+  const int32_t* ib = indices + wg_base;  // (32-bit byte offsets from here: the host keeps a block under 2^29 entries)
+  for (int64_t s = 0; s < S; s += M) {
+    for (int t = threadIdx.x; t < kCountSlab * M; t += kT) bins[t] = 0u;
+    __syncthreads();
+    const int32_t cbase = (int32_t)(s * kCountSlab);
+    const int64_t s_hi = s + M < S ? s + M : S;
+    for (int64_t strip = r0 + wave; strip < r1; strip += (int64_t)kNW * 64) {
+      const int64_t myrow = strip + (int64_t)kNW * lane;
+      int lo_l = 0, hi_l = 0;
+      if (myrow < r1) {
+        lo_l = (int)(sp[myrow * (S + 1) + s] - wg_base);
+        hi_l = (int)(sp[myrow * (S + 1) + s_hi] - wg_base);
+      }
+      asm volatile("" ::"v"(lo_l), "v"(hi_l));  // (the compiler's wait for these loads: here, not inside the walk)
+      const int64_t left = (r1 - strip + kNW - 1) / kNW;
+      T4Walk w{-1, 0, 0, left < 64 ? (int)left : 64, 256};
+      int32_t ca[4], cb[4];
+      auto load = [&](int32_t (&c)[4], int pb, int hi) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int q = pb + lane + 64 * u;
+          q = q < hi ? q : hi - 1;
+          asm volatile("global_load_dword %0, %1, %2" : "=&v"(c[u]) : "v"((unsigned)q * 4u), "s"(ib) : "memory");
+        }
+      };
+      auto work = [&](int32_t (&c)[4], int pb, int hi) {
+        t4c_wait<4>(c);  // (the next iteration's four loads stay in flight)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = pb + lane + 64 * u < hi;  // a lane past the end adds 0 to a bin of its own
+          atomicAdd(&bins[ok ? c[u] - cbase : lane], ok ? 1u : 0u);
+        }
+      };
+      if (w.advance(lo_l, hi_l)) {
+        int a_pb = w.pb, a_hi = w.hi, b_pb, b_hi;
+        load(ca, a_pb, a_hi);
+        for (;;) {
+          bool more = w.advance(lo_l, hi_l);
+          b_pb = more ? w.pb : a_pb, b_hi = more ? w.hi : a_hi;
+          load(cb, b_pb, b_hi);
+          work(ca, a_pb, a_hi);
+          if (!more) break;
+          more = w.advance(lo_l, hi_l);
+          a_pb = more ? w.pb : b_pb, a_hi = more ? w.hi : b_hi;
+          load(ca, a_pb, a_hi);
+          work(cb, b_pb, b_hi);
+          if (!more) break;
+        }
+        t4c_wait<0>(ca);
+        t4c_wait<0>(cb);
+      }
+    }
+    __syncthreads();
+    const int64_t here = (n_cols - (int64_t)cbase) < kCountSlab * M ? (n_cols - (int64_t)cbase) : kCountSlab * M;
+    uint32_t* dst = cnt + (int64_t)g * n_cols + cbase;
+    for (int t = threadIdx.x; t < here; t += kT) dst[t] = bins[t];
+    __syncthreads();
+  }
+}
+
+// cnt[g][c] <- sum_{g' < g} cnt[g'][c];  coltot[c] = col_nnz[c] = sum_g cnt[g][c]
+__global__ __launch_bounds__(256) void k_t4_base(int64_t n_cols, int G, uint32_t* __restrict__ cnt,
+                                                 int64_t* __restrict__ coltot, int64_t* __restrict__ col_nnz) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cols) return;
+  uint32_t run = 0;
+  for (int g = 0; g < G; ++g) {
+    const uint32_t t = cnt[(int64_t)g * n_cols + c];
+    cnt[(int64_t)g * n_cols + c] = run;
+    run += t;
+  }
+  cnt[(int64_t)G * n_cols + c] = run;  // row G: the totals (the last block's "next block")
+  coltot[c] = (int64_t)run;
+  col_nnz[c] = (int64_t)run;
+}
+
+// cdst[c] = first pair of column c's output row in the target (the header of a tile then has no dependent load)
+__global__ __launch_bounds__(256) void k_t4_cdst(int64_t n_cols, const int64_t* __restrict__ cptr,
+                                                 const int32_t* __restrict__ inv, int64_t* __restrict__ cdst) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n_cols) cdst[c] = cptr[inv ? (int64_t)inv[c] : c];
+}
+
+// ---- the window registers ----------------------------------------------------------------------------------------
+// Slot j holds the next 32 pairs of two rows: lanes 0-31 row a, lanes 32-63 row b; a lane past its row's end keeps
+// the padding column.  Always exactly the same instructions whatever the masks (a VMEM instruction with EXEC = 0 is
+// issued and counted in order on gfx950: scripts/probes/exec0_vmcnt.hip).
+template <int J>
+__device__ __forceinline__ void t4_issue_pairs(uint64_t a0, uint64_t a1, int n0, int n1, unsigned sub8) {
+  unsigned long long save, m0, m1;
+  int t0, t1;
+  // (the clamps of the two counts to 0 .. 32 as scalar instructions in here: written in C++ they came back as v_med3
+  //  into VGPRs, which s_bfm cannot read)
+  asm volatile(
+      "s_max_i32 %[t0], %[n0], 0\n\t"
+      "s_max_i32 %[t1], %[n1], 0\n\t"
+      "s_min_i32 %[t0], %[t0], 32\n\t"
+      "s_min_i32 %[t1], %[t1], 32\n\t"
+      "s_bfm_b64 %[m0], %[t0], 0\n\t"
+      "s_bfm_b64 %[m1], %[t1], 32\n\t"
+      "s_mov_b64 %[save], exec\n\t"
+      "v_mov_b32 v%c[C], 0x7fffffff\n\t"
+      "s_mov_b64 exec, %[m0]\n\t"
+      "global_load_dwordx2 v[%c[C]:%c[V]], %[off], %[a0]\n\t"
+      "s_mov_b64 exec, %[m1]\n\t"
+      "global_load_dwordx2 v[%c[C]:%c[V]], %[off], %[a1]\n\t"
+      "s_mov_b64 exec, %[save]"
+      : [save] "=&s"(save), [m0] "=&s"(m0), [m1] "=&s"(m1), [t0] "=&s"(t0), [t1] "=&s"(t1)
+      : [off] "v"(sub8), [a0] "s"(a0), [a1] "s"(a1), [n0] "s"(n0), [n1] "s"(n1), [C] "i"(kW0 + 2 * J),
+        [V] "i"(kW0 + 2 * J + 1)
+      : MU_T4_CLOB, "memory", "scc");
+}
+// the same from the CSR arrays: i0 / i1 = address of the row's next column index, v0 / v1 = of its next value
+template <int J>
+__device__ __forceinline__ void t4_issue_csr(uint64_t i0, uint64_t v0, uint64_t i1, uint64_t v1, int n0, int n1,
+                                             unsigned sub4) {
+  unsigned long long save, m0, m1;
+  int t0, t1;
+  asm volatile(
+      "s_max_i32 %[t0], %[n0], 0\n\t"
+      "s_max_i32 %[t1], %[n1], 0\n\t"
+      "s_min_i32 %[t0], %[t0], 32\n\t"
+      "s_min_i32 %[t1], %[t1], 32\n\t"
+      "s_bfm_b64 %[m0], %[t0], 0\n\t"
+      "s_bfm_b64 %[m1], %[t1], 32\n\t"
+      "s_mov_b64 %[save], exec\n\t"
+      "v_mov_b32 v%c[C], 0x7fffffff\n\t"
+      "s_mov_b64 exec, %[m0]\n\t"
+      "global_load_dword v%c[C], %[off], %[i0]\n\t"
+      "global_load_dword v%c[V], %[off], %[v0]\n\t"
+      "s_mov_b64 exec, %[m1]\n\t"
+      "global_load_dword v%c[C], %[off], %[i1]\n\t"
+      "global_load_dword v%c[V], %[off], %[v1]\n\t"
+      "s_mov_b64 exec, %[save]"
+      : [save] "=&s"(save), [m0] "=&s"(m0), [m1] "=&s"(m1), [t0] "=&s"(t0), [t1] "=&s"(t1)
+      : [off] "v"(sub4), [i0] "s"(i0), [v0] "s"(v0), [i1] "s"(i1), [v1] "s"(v1), [n0] "s"(n0), [n1] "s"(n1),
+        [C] "i"(kW0 + 2 * J), [V] "i"(kW0 + 2 * J + 1)
+      : MU_T4_CLOB, "memory", "scc");
+}
+__device__ __forceinline__ void t4_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: MU_T4_CLOB, "memory"); }
+template <int J>
+__device__ __forceinline__ int t4_col() {
+  int c;
+  asm volatile("v_mov_b32 %0, v%c1" : "=v"(c) : "i"(kW0 + 2 * J) : MU_T4_CLOB);
+  return c;
+}
+template <int J>
+__device__ __forceinline__ unsigned t4_val() {
+  unsigned v;
+  asm volatile("v_mov_b32 %0, v%c1" : "=v"(v) : "i"(kW0 + 2 * J + 1) : MU_T4_CLOB);
+  return v;
+}
+
+template <int... I, class F>
+__device__ __forceinline__ void t4_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void t4_for(F&& f) {
+  t4_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+__device__ unsigned long long g_t4_phase[8];  // tune tpack_dbg: cycles of header / phase 1 / 2 / 3 / write-out / retries
+
+// PAIRS: the source is the row stream of X (src0 = ent, row_dst[row] = pair index of the row's first pair);
+// otherwise the CSR arrays (src0 = indices, src1 = values).  rw = rows of a wave (<= 32), rpb = 16 rw rows per block.
+template <bool PAIRS, bool DBG = false>
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_fill(
+    int64_t n_rows, int64_t n_cols, int C, int rw, int flags, const int64_t* __restrict__ indptr,
+    const int64_t* __restrict__ row_dst, const void* __restrict__ src0, const void* __restrict__ src1,
+    const int64_t* __restrict__ cdst, const uint32_t* __restrict__ base, const int64_t* __restrict__ coltot,
+    T4Out out, int* __restrict__ err) {
+  __shared__ unsigned long long stage[kCap];  // 96 KiB
+  __shared__ uint32_t bm[kNW][kMaxC];         // 48 KiB: (wave, column): bitmap of the wave's rows, then its first slot
+  __shared__ uint16_t lcount[kMaxC], lpos[kMaxC];
+  __shared__ int64_t gdst[kMaxC];
+  __shared__ uint32_t wsum[kNW];
+  __shared__ int s_flag;
+  const int g = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform32(tid >> 6);
+  const int half = lane >> 5, sub = lane & 31;
+  const int64_t rpb = (int64_t)kNW * rw;
+  const int64_t r0 = (int64_t)g * rpb;
+  const int64_t r1 = (r0 + rpb) < n_rows ? (r0 + rpb) : n_rows;
+  const int64_t wr0 = r0 + (int64_t)wave * rw;  // this wave's first row
+  uint32_t* bmw = &bm[wave][0];
+  for (int t = tid; t < kNW * kMaxC; t += kT) (&bm[0][0])[t] = 0u;
+  if (tid == 0) s_flag = 0;
+
+  // lane l < 32: the state of row wr0 + l - address of its next entry and the entries it has left
+  uint64_t A = 0, A2 = 0;
+  int rem = 0;
+  {
+    const int64_t row = wr0 + sub;
+    const bool ok = sub < rw && row < r1;
+    const int64_t p0 = ok ? indptr[row] : 0;
+    rem = ok ? (int)(indptr[row + 1] - p0) : 0;
+    if (PAIRS) {
+      A = (uint64_t)src0 + 8ull * (uint64_t)(ok ? row_dst[row] : 0);
+    } else {
+      A = (uint64_t)src0 + 4ull * (uint64_t)p0;
+      A2 = (uint64_t)src1 + 4ull * (uint64_t)p0;
+    }
+  }
+  const unsigned subo = (unsigned)sub * (PAIRS ? 8u : 4u);
+  auto issue_all = [&]() {
+    t4_for<16>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      const int n0 = __builtin_amdgcn_readlane(rem, 2 * J), n1 = __builtin_amdgcn_readlane(rem, 2 * J + 1);
+      if constexpr (PAIRS)
+        t4_issue_pairs<J>(readlane_u64(A, 2 * J), readlane_u64(A, 2 * J + 1), n0, n1, subo);
+      else
+        t4_issue_csr<J>(readlane_u64(A, 2 * J), readlane_u64(A2, 2 * J), readlane_u64(A, 2 * J + 1),
+                        readlane_u64(A2, 2 * J + 1), n0, n1, subo);
+    });
+  };
+  issue_all();
+  __syncthreads();
+
+  // (the count array has G + 1 rows - row G holds the column totals - so a tile's header is three independent loads)
+  const uint32_t* base_g = base + (int64_t)g * n_cols;
+  const uint32_t* base_n = base + (int64_t)(g + 1) * n_cols;
+  constexpr bool dbg = DBG;  // (phase accounting: its own instance, the counters cost registers)
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto mark = [&](int i) {
+    if constexpr (DBG) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      ph[i] += t - t_prev;
+      t_prev = t;
+    }
+  };
+
+  int Ct = C;
+  for (int64_t cb = 0; cb < n_cols;) {
+    const int32_t cbase = (int32_t)cb;
+    const int32_t cend = (int32_t)((cb + Ct) < n_cols ? (cb + Ct) : n_cols);
+    // (the per-slot constants made from `half` - row bit, row id, rank mask - are two instructions each: recomputed per
+    //  tile, not kept in 50 registers across the loop, which is what loop-invariant code motion did and spilled for)
+    int hf = half;
+    asm volatile("" : "+v"(hf));
+    // ---- header: this block's pairs per column of the tile, their exclusive scan, where the runs go ----------------
+    uint32_t mine = 0;
+    int64_t gd = 0;
+    if (tid < Ct && cbase + tid < cend) {
+      const int64_t c = (int64_t)cbase + tid;
+      const uint32_t b0 = base_g[c];
+      const uint32_t b1 = base_n[c];
+      const int64_t cd = cdst[c];
+      mine = b1 - b0;
+      gd = cd + (int64_t)b0;
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    mark(0);
+
+    // ---- phase 1: the tile's entries set their row's bit in (wave, column); ranks inside the wave come back ----------
+    t4_wait_all();
+    uint32_t old[17];  // per slot: the wave's word of the entry's column
+    int cntv = 0;          // lane r < 32: entries of row r consumed by this tile
+    unsigned full = 0;     // bit r: the window of row r was used up
+    t4_for<16>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      const int c = t4_col<J>();
+      const bool valid = c < cend;  // sorted rows: a prefix of each half; padding lanes hold INT_MAX
+      const unsigned long long m = __ballot(valid);
+      const int c0 = __popc((unsigned)m), c1 = __popc((unsigned)(m >> 32));
+      // (no result asked for: sixteen of these go out back to back; the two rows of a slot may share a column - the
+      //  same word in one instruction - which an OR does not mind)
+      if (valid)
+        __hip_atomic_fetch_or(&bmw[c - cbase], (1u << (2 * J)) << hf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      cntv = writelane_c<2 * J>(cntv, c0);
+      cntv = writelane_c<2 * J + 1>(cntv, c1);
+      full |= (c0 == 32 ? 1u << (2 * J) : 0u) | (c1 == 32 ? 1u << (2 * J + 1) : 0u);
+    });
+    // rows whose window was used up and that have entries left: more of them may fall into this tile (not when the tile
+    // has 32 columns or fewer: a row has at most one entry per column)
+    int xa = -1, xb = -1;
+    old[16] = 0u;
+    {
+      unsigned ov = full & (unsigned)__ballot(half == 0 && rem > 32);
+      if (Ct <= 32) ov = 0u;
+      if (ov) {
+        xa = __builtin_ctz(ov);
+        ov &= ov - 1u;
+        if (ov) {
+          xb = __builtin_ctz(ov);
+          ov &= ov - 1u;
+        }
+        if (ov) {  // more than two such rows in one wave: retry the tile at half its width
+          if (lane == 0) s_flag = 1;
+          xa = xb = -1;
+        } else {
+          const unsigned step = PAIRS ? 256u : 128u;
+          const int na = __builtin_amdgcn_readlane(rem, xa) - 32;
+          const int nb = xb >= 0 ? __builtin_amdgcn_readlane(rem, xb) - 32 : 0;
+          const int lb = xb >= 0 ? xb : xa;
+          if constexpr (PAIRS)
+            t4_issue_pairs<kSlotX>(readlane_u64(A, xa) + step, readlane_u64(A, lb) + step, na, nb, subo);
+          else
+            t4_issue_csr<kSlotX>(readlane_u64(A, xa) + step, readlane_u64(A2, xa) + step, readlane_u64(A, lb) + step,
+                                 readlane_u64(A2, lb) + step, na, nb, subo);
+          t4_wait_all();  // (exposed: rare by the choice of the tile width)
+          const int c = t4_col<kSlotX>();
+          const bool valid = c < cend;
+          const unsigned long long m = __ballot(valid);
+          const int c0 = __popc((unsigned)m), c1 = __popc((unsigned)(m >> 32));
+          if (valid)
+            __hip_atomic_fetch_or(&bmw[c - cbase], 1u << (hf ? lb : xa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          cntv = writelane_s(cntv, __builtin_amdgcn_readlane(cntv, xa) + c0, xa);
+          if (xb >= 0) cntv = writelane_s(cntv, __builtin_amdgcn_readlane(cntv, xb) + c1, xb);
+          // 64 entries of one row in the tile and more to come: half the width
+          if ((c0 == 32 && na > 32) || (c1 == 32 && nb > 32)) {
+            if (lane == 0) s_flag = 1;
+          }
+        }
+      }
+    }
+    // the wave's finished words of its entries' columns (LDS operations of a wave execute in order: every OR above has
+    // landed): the bits below an entry's own row are its rank among the wave's rows
+    t4_for<16>([&](auto jc) {
+      constexpr int J = decltype(jc)::value;
+      const int c = t4_col<J>();
+      old[J] = c < cend ? bmw[c - cbase] : 0u;
+    });
+    if (xa >= 0) {
+      const int c = t4_col<kSlotX>();
+      old[16] = c < cend ? bmw[c - cbase] : 0u;
+    }
+    mark(1);
+    __syncthreads();  // B1: wsum, every wave's bitmap rows, s_flag
+    uint32_t wpre = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kNW; ++w) {
+      const uint32_t t = wsum[w];
+      if (w < wave) wpre += t;
+      total += t;
+    }
+    const uint32_t my_lpos = wpre + incl - mine;
+    const bool retry = (s_flag != 0) || total > (uint32_t)kCap;
+    if (retry || total == 0) {
+      // (nothing of this block in the tile: next tile.  Retry: the bitmap rows are cleared and the same windows are
+      //  looked at again against a tile of half the width; a 16-column tile always fits)
+      if (retry)
+        for (int t = lane; t < Ct; t += 64) bmw[t] = 0u;
+      __syncthreads();
+      if (tid == 0) s_flag = 0;
+      if (retry) {
+        if (Ct <= 16) {  // cannot happen (16 columns x 512 rows fit, a row has <= 16 entries): do not spin
+          if (tid == 0) atomicOr(err, 2);
+          cb += Ct;
+          Ct = C;
+        } else {
+          Ct = ((Ct / 2) / 16) * 16;
+          if (Ct < 16) Ct = 16;
+        }
+        if (DBG && tid == 0) ph[5] += 1;
+      } else {
+        cb += Ct;
+        Ct = C;
+      }
+      __syncthreads();
+      continue;
+    }
+    if (tid < Ct) {
+      lcount[tid] = (uint16_t)mine;
+      lpos[tid] = (uint16_t)my_lpos;
+      gdst[tid] = gd;
+    }
+    // ---- phase 2: per column, the waves' first staging slots (exclusive prefix of the popcounts over the waves) ------
+    if (tid < Ct) {
+      uint32_t run = my_lpos;
+#pragma unroll
+      for (int w = 0; w < kNW; ++w) {
+        const uint32_t x = bm[w][tid];
+        bm[w][tid] = run;
+        run += (uint32_t)__popc(x);
+      }
+      if (run - my_lpos != mine) atomicOr(err, 1);  // the bitmap and the count pass disagree: never
+    }
+    mark(2);
+    __syncthreads();  // B2
+    // ---- phase 3: every entry to its slot, from the window registers -------------------------------------------------
+    // (eight slots at a time: their eight words first - one LDS round trip - then the eight stores; slot by slot the
+    //  compiler had each store wait for its own read)
+    auto first_slot = [&](auto jc) -> uint32_t {
+      constexpr int J = decltype(jc)::value;
+      const int c = t4_col<J>();
+      return bmw[c < cend ? c - cbase : 0];
+    };
+    auto place = [&](auto jc, int ra, int rb, uint32_t first) {
+      constexpr int J = decltype(jc)::value;
+      const int c = t4_col<J>();
+      const unsigned v = t4_val<J>();
+      if (c < cend) {
+        const int rloc = hf ? rb : ra;
+        const uint32_t below = (1u << rloc) - 1u;  // (rloc <= 31)
+        const uint32_t slot = first + (uint32_t)__popc(old[J] & below);
+        stage[slot] = (unsigned long long)(unsigned)(wr0 + rloc) | ((unsigned long long)v << 32);
+      }
+    };
+    {
+      uint32_t fs[8];
+      t4_for<8>([&](auto jc) { fs[decltype(jc)::value] = first_slot(jc); });
+      t4_for<8>([&](auto jc) { place(jc, 2 * decltype(jc)::value, 2 * decltype(jc)::value + 1, fs[decltype(jc)::value]); });
+      t4_for<8>([&](auto jc) { fs[decltype(jc)::value] = first_slot(std::integral_constant<int, 8 + decltype(jc)::value>{}); });
+      t4_for<8>([&](auto jc) {
+        constexpr int J = 8 + decltype(jc)::value;
+        place(std::integral_constant<int, J>{}, 2 * J, 2 * J + 1, fs[decltype(jc)::value]);
+      });
+    }
+    if (xa >= 0) place(std::integral_constant<int, kSlotX>{}, xa, xb >= 0 ? xb : xa, first_slot(std::integral_constant<int, kSlotX>{}));
+    // this wave's cursors move on; its bitmap row is cleared for the next tile; the next windows are requested
+    if (half == 0) {
+      A += (uint64_t)(unsigned)cntv * (PAIRS ? 8u : 4u);
+      if (!PAIRS) A2 += (uint64_t)(unsigned)cntv * 4u;
+      rem -= cntv;
+    }
+    for (int t = lane; t < Ct; t += 64) bmw[t] = 0u;
+    issue_all();
+    mark(3);
+    __syncthreads();  // B3: the staged tile is complete
+    // ---- phase 4: write-out, one 16-lane group per column, consecutive lanes = consecutive pairs of the run -----------
+    {
+      const int grp = tid >> 4, s16 = tid & 15;
+      for (int cl = grp; cl < cend - cbase; cl += kT / 16) {
+        const uint32_t L = lcount[cl], src = lpos[cl];
+        const int64_t dst = gdst[cl];
+        for (uint32_t i = s16; i < L; i += 16) t4_store(out, dst + i, stage[src + i]);
+      }
+    }
+    mark(4);
+    cb += Ct;
+    Ct = C;
+    __syncthreads();  // B4: staging buffer and run tables are free
+  }
+  t4_wait_all();  // (the windows requested for a tile that does not exist)
+  if (DBG && tid == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_t4_phase[i], ph[i]);
+}
+
+inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+struct T4Geo {
+  int rw;        // rows of a wave
+  int64_t rpb;   // rows of a block
+  int G;         // blocks
+  int C;         // tile width
+};
+inline T4Geo t4_geometry(int64_t n_rows, int64_t n_cols, int64_t nnz) {
+  T4Geo q;
+  const int64_t cus = mu_num_cus();
+  int64_t rw = (n_rows + kNW * cus - 1) / (kNW * cus);
+  if (rw < 1) rw = 1;
+  if (rw > kRW) rw = kRW;
+  q.rw = (int)rw;
+  q.rpb = kNW * rw;
+  q.G = (int)((n_rows + q.rpb - 1) / q.rpb);
+  if (q.G < 1) q.G = 1;
+  // tile width: the block's pairs of a tile fill ~88 % of the staging buffer, and a row has ~m entries in a tile
+  // (tune tpack4_m, default 18: 32-entry windows then overflow at ~3.3 sigma of a Poisson count)
+  const double per_col = (double)nnz / (double)q.G / (double)(n_cols > 0 ? n_cols : 1);
+  double Cc = per_col > 0 ? 0.88 * kCap / per_col : (double)kMaxC;
+  const int m = mu_tune_get("tpack4_m") > 0 ? mu_tune_get("tpack4_m") : 18;
+  const double row_avg = (double)nnz / (double)(n_rows > 0 ? n_rows : 1);
+  const double Cm = row_avg > 0 ? (double)m * (double)n_cols / row_avg : (double)kMaxC;
+  if (Cm < Cc) Cc = Cm;
+  int64_t C = (int64_t)Cc;
+  C = (C / 32) * 32;
+  if (C < 32) C = 32;
+  if (C > kMaxC) C = kMaxC;
+  if (mu_tune_get("tpack4_c") > 0) C = mu_tune_get("tpack4_c");
+  if (C > kMaxC) C = kMaxC;
+  if (C < 16) C = 16;
+  q.C = (int)C;
+  return q;
+}
+struct T4Work {
+  int64_t* sp;
+  uint32_t* cnt;
+  int64_t* coltot;
+  int64_t* cdst;
+  int* err;
+};
+inline size_t t4_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz) {
+  const int64_t S = (n_cols + kCountSlab - 1) / kCountSlab;
+  const T4Geo q = t4_geometry(n_rows, n_cols, nnz);
+  return al((size_t)(n_rows * (S + 1)) * sizeof(int64_t)) + al((size_t)(q.G + 1) * (size_t)n_cols * sizeof(uint32_t)) +
+         2 * al((size_t)n_cols * sizeof(int64_t)) + 256 + 256;
+}
+inline T4Work t4_carve(void* work, int64_t n_rows, int64_t n_cols, int64_t nnz) {
+  const int64_t S = (n_cols + kCountSlab - 1) / kCountSlab;
+  const T4Geo q = t4_geometry(n_rows, n_cols, nnz);
+  char* w = (char*)work;
+  T4Work t;
+  t.sp = (int64_t*)w;
+  w += al((size_t)(n_rows * (S + 1)) * sizeof(int64_t));
+  t.cnt = (uint32_t*)w;
+  w += al((size_t)(q.G + 1) * (size_t)n_cols * sizeof(uint32_t));
+  t.coltot = (int64_t*)w;
+  w += al((size_t)n_cols * sizeof(int64_t));
+  t.cdst = (int64_t*)w;
+  w += al((size_t)n_cols * sizeof(int64_t));
+  t.err = (int*)w;
+  return t;
+}
+
+int t4_fill_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr, const int32_t* d_indices,
+                 const float* d_values, const int64_t* d_row_dst, const void* d_x_ent, const int64_t* d_cptr,
+                 const int32_t* d_inv, T4Out out, void* d_work, hipStream_t st) {
+  const T4Geo q = t4_geometry(n_rows, n_cols, nnz);
+  const T4Work w = t4_carve(d_work, n_rows, n_cols, nnz);
+  hipLaunchKernelGGL(k_t4_cdst, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, n_cols, d_cptr, d_inv,
+                     w.cdst);
+  MU_CHECK_LAUNCH();
+  const bool dbg = mu_tune_get("tpack_dbg") > 0;
+#define MU_T4_LAUNCH(PAIRS_, DBG_, RD_, S0_, S1_)                                                                      \
+  hipLaunchKernelGGL((k_t4_fill<PAIRS_, DBG_>), dim3(q.G), dim3(kT), 0, st, n_rows, n_cols, q.C, q.rw, 0, d_indptr, RD_, \
+                     (const void*)(S0_), (const void*)(S1_), w.cdst, w.cnt, w.coltot, out, w.err)
+  if (d_x_ent && dbg) MU_T4_LAUNCH(true, true, d_row_dst, d_x_ent, nullptr);
+  else if (d_x_ent) MU_T4_LAUNCH(true, false, d_row_dst, d_x_ent, nullptr);
+  else if (dbg) MU_T4_LAUNCH(false, true, (const int64_t*)nullptr, d_indices, d_values);
+  else MU_T4_LAUNCH(false, false, (const int64_t*)nullptr, d_indices, d_values);
+#undef MU_T4_LAUNCH
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+}  // namespace
+
+int launch_slab_ptr(int64_t n_rows, int64_t n_cols, const int64_t* indptr, const int32_t* indices, int64_t* sp,
+                    hipStream_t stream);  // csrc/tfidf.hip (the same 8192-column slabs)
+
+extern "C" {
+
+/* 1 when the fourth-generation transposition can take the shape: row ids and block-relative offsets in 32 bits */
+int mu_tpack4_supported(int64_t n_rows, int64_t n_cols, int64_t nnz) {
+  if (n_rows <= 0 || n_cols <= 0 || nnz <= 0) return 0;
+  if (n_rows >= ((int64_t)1 << 31) || n_cols >= ((int64_t)1 << 31) - 1) return 0;
+  const T4Geo q = t4_geometry(n_rows, n_cols, nnz);
+  // the count sweep addresses a block's entries with 32-bit byte offsets
+  if ((double)q.rpb * (double)n_cols >= (double)((int64_t)1 << 29) && nnz >= ((int64_t)1 << 29)) return 0;
+  return 1;
+}
+
+int mu_tpack4_geometry(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t* rows_per_block, int* n_blocks,
+                       int* tile_cols) {
+  const T4Geo q = t4_geometry(n_rows, n_cols, nnz);
+  if (rows_per_block) *rows_per_block = q.rpb;
+  if (n_blocks) *n_blocks = q.G;
+  if (tile_cols) *tile_cols = q.C;
+  return MU_OK;
+}
+
+size_t mu_tpack4_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz) { return t4_worksize(n_rows, n_cols, nnz); }
+
+int mu_tpack4_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr, const int32_t* d_indices,
+                    int64_t* d_col_nnz, void* d_work, size_t work_bytes, const int64_t* d_slab_ptr, void* stream) {
+  MU_REQUIRE(mu_tpack4_supported(n_rows, n_cols, nnz), "shape out of range (mu_tpack4_supported)");
+  MU_REQUIRE(d_indptr && d_indices && d_col_nnz && d_work, "null pointer");
+  MU_REQUIRE(work_bytes >= t4_worksize(n_rows, n_cols, nnz), "work buffer too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t S = (n_cols + kCountSlab - 1) / kCountSlab;
+  const T4Geo q = t4_geometry(n_rows, n_cols, nnz);
+  const T4Work w = t4_carve(d_work, n_rows, n_cols, nnz);
+  MU_CHECK_HIP(hipMemsetAsync(w.err, 0, sizeof(int), st));
+  if (!d_slab_ptr) {
+    const int rc = launch_slab_ptr(n_rows, n_cols, d_indptr, d_indices, w.sp, st);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL((k_t4_count<4>), dim3(q.G), dim3(kT), 0, st, n_rows, n_cols, S, q.rpb, d_indptr, d_indices,
+                     d_slab_ptr ? d_slab_ptr : w.sp, w.cnt);
+  MU_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_t4_base, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, n_cols, q.G, w.cnt, w.coltot,
+                     d_col_nnz);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_tpack4_fill_stream(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
+                          const int32_t* d_indices, const float* d_values, const int64_t* d_x_row_dst,
+                          const void* d_x_ent, const int64_t* d_sptr, const int32_t* d_inv, void* d_ent, void* d_work,
+                          size_t work_bytes, void* stream) {
+  MU_REQUIRE(mu_tpack4_supported(n_rows, n_cols, nnz), "shape out of range (mu_tpack4_supported)");
+  MU_REQUIRE(d_indptr && d_sptr && d_ent && d_work, "null pointer");
+  MU_REQUIRE((d_x_ent && d_x_row_dst) || (d_indices && d_values), "neither a row stream nor CSR arrays to read");
+  MU_REQUIRE(work_bytes >= t4_worksize(n_rows, n_cols, nnz), "work buffer too small");
+  const T4Out out{(unsigned long long*)d_ent, nullptr, nullptr};
+  return t4_fill_impl(n_rows, n_cols, nnz, d_indptr, d_indices, d_values, d_x_row_dst, d_x_ent, d_sptr, d_inv, out,
+                      d_work, (hipStream_t)stream);
+}
+
+int mu_tpack4_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr, const int32_t* d_indices,
+                       const float* d_values, const int64_t* d_x_row_dst, const void* d_x_ent,
+                       const int64_t* d_t_indptr, int32_t* d_t_indices, float* d_t_values, void* d_work,
+                       size_t work_bytes, void* stream) {
+  MU_REQUIRE(mu_tpack4_supported(n_rows, n_cols, nnz), "shape out of range (mu_tpack4_supported)");
+  MU_REQUIRE(d_indptr && d_t_indptr && d_t_indices && d_t_values && d_work, "null pointer");
+  MU_REQUIRE((d_x_ent && d_x_row_dst) || (d_indices && d_values), "neither a row stream nor CSR arrays to read");
+  MU_REQUIRE(work_bytes >= t4_worksize(n_rows, n_cols, nnz), "work buffer too small");
+  const T4Out out{nullptr, d_t_indices, d_t_values};
+  return t4_fill_impl(n_rows, n_cols, nnz, d_indptr, d_indices, d_values, d_x_row_dst, d_x_ent, d_t_indptr, nullptr,
+                      out, d_work, (hipStream_t)stream);
+}
+
+/* the fill's error word (0 = fine; 1: bitmap and count pass disagreed, 2: a tile could not be narrowed) - synchronises */
+int mu_tpack4_status(const void* d_work, int64_t n_rows, int64_t n_cols, int64_t nnz, int* h_err) {
+  MU_REQUIRE(d_work && h_err, "null pointer");
+  const T4Work w = t4_carve(const_cast<void*>(d_work), n_rows, n_cols, nnz);
+  MU_CHECK_HIP(hipDeviceSynchronize());
+  MU_CHECK_HIP(hipMemcpy(h_err, w.err, sizeof(int), hipMemcpyDeviceToHost));
+  return MU_OK;
+}
+
+/* tune tpack_dbg = 1: cycles (s_memtime, wave 0 of every block) of header / phase 1 / 2 / 3 / write-out, [5] = retried tiles */
+int mu_tpack4_phase_cycles(unsigned long long* h_out6, int reset) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (reset) {
+    MU_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_t4_phase), z, sizeof(z)));
+    return MU_OK;
+  }
+  MU_CHECK_HIP(hipDeviceSynchronize());
+  MU_CHECK_HIP(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_t4_phase), sizeof(z)));
+  for (int i = 0; i < 6; ++i) h_out6[i] = z[i];
+  return MU_OK;
+}
+
+}  // extern "C"

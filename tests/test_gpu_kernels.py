@@ -340,13 +340,15 @@ def test_transpose_stream_tile_overflow_falls_back(hip):
     mt = m.T.tocsr()
     mt.sort_indices()
     sptr, ent = _stream_ref(mt)
-    for v2 in (0, 1):
+    for v2 in (0, 1, 2):  # third generation, second generation, fourth (the default)
         try:
-            hip.tune("tpack_v2", v2)
+            hip.tune("tpack_v3", 0 if v2 == 2 else 1)
+            hip.tune("tpack_v2", 1 if v2 == 1 else 0)
             P = hip.transpose_stream(X, sort_rows=False)
             Ps = hip.transpose_stream(X)
         finally:
             hip.tune("tpack_v2", 0)
+            hip.tune("tpack_v3", 0)
         assert np.array_equal(hip.to_host(P.sptr), sptr)
         assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
         _check_stream(hip, Ps, mt)
@@ -371,6 +373,7 @@ def test_transpose_stream_both_cursor_widths(hip, build):
         mt.sort_indices()
         sptr, ent = _stream_ref(mt)
         try:
+            hip.tune("tpack_v3", 1)
             hip.tune("tpack_narrow", build)
             hip.tune("tpack_c", C)
             P = hip.transpose_stream(_up(hip, m), sort_rows=False)
@@ -378,6 +381,7 @@ def test_transpose_stream_both_cursor_widths(hip, build):
         finally:
             hip.tune("tpack_narrow", 0)
             hip.tune("tpack_c", 0)
+            hip.tune("tpack_v3", 0)
         assert np.array_equal(hip.to_host(P.sptr), sptr)
         assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
         _check_stream(hip, Ps, mt)
@@ -406,6 +410,7 @@ def test_transpose_stream_count_rides_on_previous_tile(hip, C):
     mt.sort_indices()
     sptr, ent = _stream_ref(mt)
     try:
+        hip.tune("tpack_v3", 1)
         hip.tune("tpack_c", C)
         P = hip.transpose_stream(X, sort_rows=False)
         hip.tune("tpack_v2", 1)
@@ -413,6 +418,7 @@ def test_transpose_stream_count_rides_on_previous_tile(hip, C):
     finally:
         hip.tune("tpack_c", 0)
         hip.tune("tpack_v2", 0)
+        hip.tune("tpack_v3", 0)
     assert np.array_equal(hip.to_host(P.sptr), sptr)
     assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
     assert torch.equal(P2.ent[: ent.size], P.ent[: ent.size])
