@@ -558,7 +558,7 @@ class HipBackend:
                 check(self.lib.mu_exclusive_scan_i64(d, _p(col_nnz), _p(t_indptr), st))
                 check(self.lib.mu_tpack4_fill_csr(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values), None, None,
                                                   _p(t_indptr), _p(t_indices), _p(t_values), _p(work), wb, st))
-            self._tpack4_work = (work, (n, d, X.nnz))
+            self._note_tpack4(work, n, d, X.nnz)
             return DeviceCSR(t_indptr, t_indices, t_values, (d, n))
         wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
         work = self.empty((wb,), torch.uint8)
@@ -612,6 +612,13 @@ class HipBackend:
         return (self.lib.mu_tune_get(b"tpack_v3") != 1 and os.environ.get("MUON_AMD_TPACK_V3", "0") != "1"
                 and bool(self.lib.mu_tpack4_supported(n, d, X.nnz)))
 
+    keep_tpack4_work = False  # tests / probes: keep the last fill's work buffer so that tpack4_status() can read its error word
+
+    def _note_tpack4(self, work, n, d, nnz) -> None:
+        # (never by default: a work buffer kept across calls is a second 1.8 GB block at 1e6 x 200k - the next call's
+        #  allocation then misses the caching allocator's pool: a hipMalloc inside every step, measured at 300 ms)
+        self._tpack4_work = (work, (n, d, nnz)) if self.keep_tpack4_work else None
+
     def tpack4_status(self) -> int:
         """Error word of the last fourth-generation fill (0 = fine; synchronises: tests and probes)."""
         import ctypes as C
@@ -656,7 +663,7 @@ class HipBackend:
                 xs_ent, xs_dst = (src[0].ent, src[1]) if src is not None else (None, None)
                 check(self.lib.mu_tpack4_fill_stream(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
                                                      _p(xs_dst), _p(xs_ent), _p(sptr), _p(inv), _p(ent), _p(work), wb, st))
-            self._tpack4_work = (work, (n, d, X.nnz))
+            self._note_tpack4(work, n, d, X.nnz)
             return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K)
         wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
         work = self.empty((wb,), torch.uint8)

@@ -31,14 +31,15 @@ namespace {
 
 constexpr int kT = 1024, kNW = 16;   // threads / waves of a workgroup
 constexpr int kRW = 32;              // rows of a wave: one bit each in a 32-bit word
-constexpr int kMaxC = 768;           // widest tile (columns)
-constexpr int kCap = 12288;          // staged pairs: 96 KiB
+constexpr int kMaxC = 512;           // widest tile (columns): 16 waves x 512 columns x (bitmap word, first slot) = 64 KiB
+constexpr int kCap = 10240;          // staged pairs: 80 KiB
+constexpr int kH0 = 90;              // asm-owned v[90..93]: the next tile's header (base of this block, of the next, run start)
 constexpr int kW0 = 94;              // asm-owned registers v[kW0 ..]: slot j = (v[kW0 + 2j] column, v[kW0 + 2j + 1] value bits)
 constexpr int kSlotX = 16;           // the overflow slot
 constexpr int kCountSlab = 8192;     // = sweep.hpp kSlab = tpack.hip kTSlab: the slab pointers are shared
 
 #define MU_T4_CLOB                                                                                                  \
-  "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",  \
+  "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",  \
       "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", \
       "v123", "v124", "v125", "v126", "v127"
 
@@ -256,6 +257,28 @@ __device__ __forceinline__ unsigned t4_val() {
   return v;
 }
 
+// A tile's header - this block's count prefix of the tile's columns (b0), the next block's (b1), where the columns' runs
+// start in the target (cd) - is requested ONE TILE AHEAD into v[kH0 .. kH0 + 3] (three loads by every thread, clamped
+// inside the arrays) and taken at the tile's top behind the wait that the windows need anyway.
+__device__ __forceinline__ void t4_issue_header(const uint32_t* bg, const uint32_t* bn, const int64_t* cd, unsigned off4) {
+  asm volatile(
+      "global_load_dword v%c4, %0, %1\n\t"
+      "global_load_dword v%c5, %0, %2\n\t"
+      "v_lshlrev_b32 v%c6, 1, %0\n\t"
+      "global_load_dwordx2 v[%c6:%c7], v%c6, %3"
+      :
+      : "v"(off4), "s"(bg), "s"(bn), "s"(cd), "i"(kH0), "i"(kH0 + 1), "i"(kH0 + 2), "i"(kH0 + 3)
+      : MU_T4_CLOB, "memory");
+}
+__device__ __forceinline__ void t4_take_header(uint32_t& b0, uint32_t& b1, int64_t& cd) {
+  unsigned lo, hi;
+  asm volatile("v_mov_b32 %0, v%c4\n\tv_mov_b32 %1, v%c5\n\tv_mov_b32 %2, v%c6\n\tv_mov_b32 %3, v%c7"
+               : "=v"(b0), "=v"(b1), "=v"(lo), "=v"(hi)
+               : "i"(kH0), "i"(kH0 + 1), "i"(kH0 + 2), "i"(kH0 + 3)
+               : MU_T4_CLOB);
+  cd = (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
 template <int... I, class F>
 __device__ __forceinline__ void t4_for_impl(std::integer_sequence<int, I...>, F&& f) {
   (f(std::integral_constant<int, I>{}), ...);
@@ -270,18 +293,30 @@ __device__ unsigned long long g_t4_phase[8];  // tune tpack_dbg: cycles of heade
 // PAIRS: the source is the row stream of X (src0 = ent, row_dst[row] = pair index of the row's first pair);
 // otherwise the CSR arrays (src0 = indices, src1 = values).  rw = rows of a wave (<= 32), rpb = 16 rw rows per block.
 template <bool PAIRS, bool DBG = false>
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_fill(
-    int64_t n_rows, int64_t n_cols, int C, int rw, int flags, const int64_t* __restrict__ indptr,
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_fill(
+    int64_t n_rows, int64_t n_cols, int C, int rw, int G, const int64_t* __restrict__ indptr,
     const int64_t* __restrict__ row_dst, const void* __restrict__ src0, const void* __restrict__ src1,
     const int64_t* __restrict__ cdst, const uint32_t* __restrict__ base, const int64_t* __restrict__ coltot,
-    T4Out out, int* __restrict__ err) {
-  __shared__ unsigned long long stage[kCap];  // 96 KiB
-  __shared__ uint32_t bm[kNW][kMaxC];         // 48 KiB: (wave, column): bitmap of the wave's rows, then its first slot
-  __shared__ uint16_t lcount[kMaxC], lpos[kMaxC];
+    T4Out out, int* __restrict__ err, int abl) {
+  __shared__ unsigned long long stage[kCap];  // 80 KiB
+  __shared__ uint2 bm[kNW][kMaxC];            // 64 KiB: (wave, column): .x bitmap of the wave's rows, .y its first slot
+  __shared__ uint32_t lrun[kMaxC];            // per column of the tile: pairs << 16 | first staging slot
   __shared__ int64_t gdst[kMaxC];
   __shared__ uint32_t wsum[kNW];
   __shared__ int s_flag;
-  const int g = blockIdx.x;
+  // Workgroup -> row block, XCD-aware: workgroup w runs on XCD w % 8 (observed dispatch order; for speed only), and the
+  // 32 CUs of an XCD get CONSECUTIVE row blocks.  The runs that neighbouring row blocks write for one column are
+  // neighbours in the output row (~120 bytes each): written through the same L2 at about the same time - the blocks of
+  // an XCD walk the column tiles in step - they leave it as whole lines instead of one partial line per block and XCD.
+  // (G < 0: the plain order, for comparison.)
+  int g = blockIdx.x;
+  if (G > 0) {
+    const int per = (G + 7) / 8;
+    g = (g % 8) * per + (g / 8);
+    if (g >= G) return;
+  } else {
+    G = -G;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uniform32(tid >> 6);
   const int half = lane >> 5, sub = lane & 31;
@@ -289,8 +324,8 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_
   const int64_t r0 = (int64_t)g * rpb;
   const int64_t r1 = (r0 + rpb) < n_rows ? (r0 + rpb) : n_rows;
   const int64_t wr0 = r0 + (int64_t)wave * rw;  // this wave's first row
-  uint32_t* bmw = &bm[wave][0];
-  for (int t = tid; t < kNW * kMaxC; t += kT) (&bm[0][0])[t] = 0u;
+  uint2* bmw = &bm[wave][0];
+  for (int t = tid; t < kNW * kMaxC; t += kT) (&bm[0][0])[t] = make_uint2(0u, 0u);
   if (tid == 0) s_flag = 0;
 
   // lane l < 32: the state of row wr0 + l - address of its next entry and the entries it has left
@@ -338,6 +373,7 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_
   };
 
   int Ct = C;
+  int64_t hdr_cb = -1;  // the tile (its first column) whose header sits in / is on its way to v[kH0 ..]
   for (int64_t cb = 0; cb < n_cols;) {
     const int32_t cbase = (int32_t)cb;
     const int32_t cend = (int32_t)((cb + Ct) < n_cols ? (cb + Ct) : n_cols);
@@ -346,15 +382,25 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_
     int hf = half;
     asm volatile("" : "+v"(hf));
     // ---- header: this block's pairs per column of the tile, their exclusive scan, where the runs go ----------------
+    // (requested one tile ahead - see t4_issue_header; a retried tile or the first one asks now.  The wait covers the
+    //  windows of phase 1 too: everything this wave has in flight was issued at least a phase ago)
+    if (hdr_cb != cb) {
+      int64_t ofs = n_cols - 1 - cb;
+      ofs = ofs < 0 ? 0 : ofs;
+      const unsigned o4 = (unsigned)((int64_t)tid < ofs ? (int64_t)tid : ofs) * 4u;
+      t4_issue_header(base_g + cb, base_n + cb, cdst + cb, o4);
+    }
+    t4_wait_all();
     uint32_t mine = 0;
     int64_t gd = 0;
-    if (tid < Ct && cbase + tid < cend) {
-      const int64_t c = (int64_t)cbase + tid;
-      const uint32_t b0 = base_g[c];
-      const uint32_t b1 = base_n[c];
-      const int64_t cd = cdst[c];
-      mine = b1 - b0;
-      gd = cd + (int64_t)b0;
+    {
+      uint32_t b0, b1;
+      int64_t cd;
+      t4_take_header(b0, b1, cd);
+      if (tid < Ct && cbase + tid < cend) {
+        mine = b1 - b0;
+        gd = cd + (int64_t)b0;
+      }
     }
     uint32_t incl = mine;
 #pragma unroll
@@ -365,9 +411,7 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_
     if (lane == 63) wsum[wave] = incl;
     mark(0);
 
-    // ---- phase 1: the tile's entries set their row's bit in (wave, column); ranks inside the wave come back ----------
-    t4_wait_all();
-    uint32_t old[17];  // per slot: the wave's word of the entry's column
+    // ---- phase 1: the tile's entries set their row's bit in word (wave, column) ---------------------------------------
     int cntv = 0;          // lane r < 32: entries of row r consumed by this tile
     unsigned full = 0;     // bit r: the window of row r was used up
     t4_for<16>([&](auto jc) {
@@ -379,7 +423,7 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_
       // (no result asked for: sixteen of these go out back to back; the two rows of a slot may share a column - the
       //  same word in one instruction - which an OR does not mind)
       if (valid)
-        __hip_atomic_fetch_or(&bmw[c - cbase], (1u << (2 * J)) << hf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or(&bmw[c - cbase].x, (1u << (2 * J)) << hf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       cntv = writelane_c<2 * J>(cntv, c0);
       cntv = writelane_c<2 * J + 1>(cntv, c1);
       full |= (c0 == 32 ? 1u << (2 * J) : 0u) | (c1 == 32 ? 1u << (2 * J + 1) : 0u);
@@ -387,7 +431,6 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_
     // rows whose window was used up and that have entries left: more of them may fall into this tile (not when the tile
     // has 32 columns or fewer: a row has at most one entry per column)
     int xa = -1, xb = -1;
-    old[16] = 0u;
     {
       unsigned ov = full & (unsigned)__ballot(half == 0 && rem > 32);
       if (Ct <= 32) ov = 0u;
@@ -417,7 +460,7 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_
           const unsigned long long m = __ballot(valid);
           const int c0 = __popc((unsigned)m), c1 = __popc((unsigned)(m >> 32));
           if (valid)
-            __hip_atomic_fetch_or(&bmw[c - cbase], 1u << (hf ? lb : xa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_or(&bmw[c - cbase].x, 1u << (hf ? lb : xa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           cntv = writelane_s(cntv, __builtin_amdgcn_readlane(cntv, xa) + c0, xa);
           if (xb >= 0) cntv = writelane_s(cntv, __builtin_amdgcn_readlane(cntv, xb) + c1, xb);
           // 64 entries of one row in the tile and more to come: half the width
@@ -426,17 +469,6 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_
           }
         }
       }
-    }
-    // the wave's finished words of its entries' columns (LDS operations of a wave execute in order: every OR above has
-    // landed): the bits below an entry's own row are its rank among the wave's rows
-    t4_for<16>([&](auto jc) {
-      constexpr int J = decltype(jc)::value;
-      const int c = t4_col<J>();
-      old[J] = c < cend ? bmw[c - cbase] : 0u;
-    });
-    if (xa >= 0) {
-      const int c = t4_col<kSlotX>();
-      old[16] = c < cend ? bmw[c - cbase] : 0u;
     }
     mark(1);
     __syncthreads();  // B1: wsum, every wave's bitmap rows, s_flag
@@ -453,7 +485,7 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_
       // (nothing of this block in the tile: next tile.  Retry: the bitmap rows are cleared and the same windows are
       //  looked at again against a tile of half the width; a 16-column tile always fits)
       if (retry)
-        for (int t = lane; t < Ct; t += 64) bmw[t] = 0u;
+        for (int t = lane; t < Ct; t += 64) bmw[t].x = 0u;
       __syncthreads();
       if (tid == 0) s_flag = 0;
       if (retry) {
@@ -474,17 +506,25 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_
       continue;
     }
     if (tid < Ct) {
-      lcount[tid] = (uint16_t)mine;
-      lpos[tid] = (uint16_t)my_lpos;
+      lrun[tid] = (mine << 16) | my_lpos;  // (both < 2^14: the tile fits the staging buffer)
       gdst[tid] = gd;
+    }
+    {  // the next tile's header, one tile ahead (the registers were taken at the top)
+      const int64_t ncb = cb + Ct;
+      if (ncb < n_cols) {
+        int64_t ofs = n_cols - 1 - ncb;
+        const unsigned o4 = (unsigned)((int64_t)tid < ofs ? (int64_t)tid : ofs) * 4u;
+        t4_issue_header(base_g + ncb, base_n + ncb, cdst + ncb, o4);
+      }
+      hdr_cb = ncb;
     }
     // ---- phase 2: per column, the waves' first staging slots (exclusive prefix of the popcounts over the waves) ------
     if (tid < Ct) {
       uint32_t run = my_lpos;
 #pragma unroll
       for (int w = 0; w < kNW; ++w) {
-        const uint32_t x = bm[w][tid];
-        bm[w][tid] = run;
+        const uint32_t x = bm[w][tid].x;
+        bm[w][tid].y = run;
         run += (uint32_t)__popc(x);
       }
       if (run - my_lpos != mine) atomicOr(err, 1);  // the bitmap and the count pass disagree: never
@@ -492,42 +532,42 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_
     mark(2);
     __syncthreads();  // B2
     // ---- phase 3: every entry to its slot, from the window registers -------------------------------------------------
-    // (eight slots at a time: their eight words first - one LDS round trip - then the eight stores; slot by slot the
-    //  compiler had each store wait for its own read)
-    auto first_slot = [&](auto jc) -> uint32_t {
+    // (eight slots at a time: their eight (bitmap, first slot) pairs first - one LDS round trip - then the eight stores.
+    //  The bits below an entry's own row in its wave's word are its rank among the wave's rows with that column)
+    auto word_of = [&](auto jc) -> uint2 {
       constexpr int J = decltype(jc)::value;
       const int c = t4_col<J>();
       return bmw[c < cend ? c - cbase : 0];
     };
-    auto place = [&](auto jc, int ra, int rb, uint32_t first) {
+    auto place = [&](auto jc, int ra, int rb, uint2 wd) {
       constexpr int J = decltype(jc)::value;
       const int c = t4_col<J>();
       const unsigned v = t4_val<J>();
       if (c < cend) {
         const int rloc = hf ? rb : ra;
         const uint32_t below = (1u << rloc) - 1u;  // (rloc <= 31)
-        const uint32_t slot = first + (uint32_t)__popc(old[J] & below);
+        const uint32_t slot = wd.y + (uint32_t)__popc(wd.x & below);
         stage[slot] = (unsigned long long)(unsigned)(wr0 + rloc) | ((unsigned long long)v << 32);
       }
     };
     {
-      uint32_t fs[8];
-      t4_for<8>([&](auto jc) { fs[decltype(jc)::value] = first_slot(jc); });
+      uint2 fs[8];
+      t4_for<8>([&](auto jc) { fs[decltype(jc)::value] = word_of(jc); });
       t4_for<8>([&](auto jc) { place(jc, 2 * decltype(jc)::value, 2 * decltype(jc)::value + 1, fs[decltype(jc)::value]); });
-      t4_for<8>([&](auto jc) { fs[decltype(jc)::value] = first_slot(std::integral_constant<int, 8 + decltype(jc)::value>{}); });
+      t4_for<8>([&](auto jc) { fs[decltype(jc)::value] = word_of(std::integral_constant<int, 8 + decltype(jc)::value>{}); });
       t4_for<8>([&](auto jc) {
         constexpr int J = 8 + decltype(jc)::value;
         place(std::integral_constant<int, J>{}, 2 * J, 2 * J + 1, fs[decltype(jc)::value]);
       });
     }
-    if (xa >= 0) place(std::integral_constant<int, kSlotX>{}, xa, xb >= 0 ? xb : xa, first_slot(std::integral_constant<int, kSlotX>{}));
+    if (xa >= 0) place(std::integral_constant<int, kSlotX>{}, xa, xb >= 0 ? xb : xa, word_of(std::integral_constant<int, kSlotX>{}));
     // this wave's cursors move on; its bitmap row is cleared for the next tile; the next windows are requested
     if (half == 0) {
       A += (uint64_t)(unsigned)cntv * (PAIRS ? 8u : 4u);
       if (!PAIRS) A2 += (uint64_t)(unsigned)cntv * 4u;
       rem -= cntv;
     }
-    for (int t = lane; t < Ct; t += 64) bmw[t] = 0u;
+    for (int t = lane; t < Ct; t += 64) bmw[t].x = 0u;
     issue_all();
     mark(3);
     __syncthreads();  // B3: the staged tile is complete
@@ -535,9 +575,12 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(47))) void k_t4_
     {
       const int grp = tid >> 4, s16 = tid & 15;
       for (int cl = grp; cl < cend - cbase; cl += kT / 16) {
-        const uint32_t L = lcount[cl], src = lpos[cl];
+        const uint32_t lr = lrun[cl];
+        const uint32_t L = lr >> 16, src = lr & 0xffffu;
         const int64_t dst = gdst[cl];
-        for (uint32_t i = s16; i < L; i += 16) t4_store(out, dst + i, stage[src + i]);
+        if (abl & 2) continue;  // (timing ablations, tune tpack4_abl: 2 no stores, 4 every run to the start of the target)
+        const int64_t dd = (abl & 4) ? (int64_t)(cl & 63) * 16 : dst;
+        for (uint32_t i = s16; i < L; i += 16) t4_store(out, dd + i, stage[src + i]);
       }
     }
     mark(4);
@@ -568,10 +611,11 @@ inline T4Geo t4_geometry(int64_t n_rows, int64_t n_cols, int64_t nnz) {
   q.G = (int)((n_rows + q.rpb - 1) / q.rpb);
   if (q.G < 1) q.G = 1;
   // tile width: the block's pairs of a tile fill ~88 % of the staging buffer, and a row has ~m entries in a tile
-  // (tune tpack4_m, default 18: 32-entry windows then overflow at ~3.3 sigma of a Poisson count)
+  // (tune tpack4_m, default 16: measured on the bench matrix - whose rows are burstier than Poisson - 14 / 16 / 18
+  //  entries per row and tile retry 0.1 / 3 / 50 % of the tiles)
   const double per_col = (double)nnz / (double)q.G / (double)(n_cols > 0 ? n_cols : 1);
   double Cc = per_col > 0 ? 0.88 * kCap / per_col : (double)kMaxC;
-  const int m = mu_tune_get("tpack4_m") > 0 ? mu_tune_get("tpack4_m") : 18;
+  const int m = mu_tune_get("tpack4_m") > 0 ? mu_tune_get("tpack4_m") : 16;
   const double row_avg = (double)nnz / (double)(n_rows > 0 ? n_rows : 1);
   const double Cm = row_avg > 0 ? (double)m * (double)n_cols / row_avg : (double)kMaxC;
   if (Cm < Cc) Cc = Cm;
@@ -624,9 +668,12 @@ int t4_fill_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_i
                      w.cdst);
   MU_CHECK_LAUNCH();
   const bool dbg = mu_tune_get("tpack_dbg") > 0;
+  const bool xcd = mu_tune_get("tpack4_plain") != 1;  // (tune tpack4_plain = 1: workgroup = row block, for comparison)
+  const unsigned grid = xcd ? (unsigned)(8 * ((q.G + 7) / 8)) : (unsigned)q.G;
 #define MU_T4_LAUNCH(PAIRS_, DBG_, RD_, S0_, S1_)                                                                      \
-  hipLaunchKernelGGL((k_t4_fill<PAIRS_, DBG_>), dim3(q.G), dim3(kT), 0, st, n_rows, n_cols, q.C, q.rw, 0, d_indptr, RD_, \
-                     (const void*)(S0_), (const void*)(S1_), w.cdst, w.cnt, w.coltot, out, w.err)
+  hipLaunchKernelGGL((k_t4_fill<PAIRS_, DBG_>), dim3(grid), dim3(kT), 0, st, n_rows, n_cols, q.C, q.rw,                 \
+                     xcd ? q.G : -q.G, d_indptr, RD_, (const void*)(S0_), (const void*)(S1_), w.cdst, w.cnt, w.coltot,  \
+                     out, w.err, mu_tune_get("tpack4_abl"))
   if (d_x_ent && dbg) MU_T4_LAUNCH(true, true, d_row_dst, d_x_ent, nullptr);
   else if (d_x_ent) MU_T4_LAUNCH(true, false, d_row_dst, d_x_ent, nullptr);
   else if (dbg) MU_T4_LAUNCH(false, true, (const int64_t*)nullptr, d_indices, d_values);

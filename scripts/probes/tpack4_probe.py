@@ -14,6 +14,7 @@ from muon_amd._atac.preproc import tfidf_device
 from muon_amd._backend import HipBackend
 
 be = HipBackend(0)
+be.keep_tpack4_work = True
 cells = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 125000
 peaks = 200000
 X = be.synth_counts(0, cells, peaks, 50, 0.03, 0)
@@ -111,7 +112,7 @@ msc, _ = timed(lambda: be.lib.mu_tpack4_count(cells, peaks, T.nnz, T.indptr.data
 print(f"v4: count + base alone: {msc:.2f} ms", flush=True)
 del work
 
-NAMES = ["header", "phase 1 (bits)", "phase 2 (prefix) + B1", "phase 3 (place) + B2", "write-out + B3", "retried tiles"]
+NAMES = ["top wait + header", "phase 1 (bits)", "B1 + phase 2 (prefix)", "B2 + phase 3 (place) + next loads", "B3 + write-out", "retried tiles"]
 
 
 def phases(label):
@@ -127,8 +128,14 @@ def phases(label):
 
 
 phases("phase share of the fill (thread 0 of every block)")
+be.tune("tpack4_plain", 1)
+ms, r_ = timed(lambda: be.stream_both(T))
+del r_
+print(f"v4 with workgroup = row block (no XCD-aware order): {ms:.2f} ms", flush=True)
+phases("plain order")
+be.tune("tpack4_plain", 0)
 if "--sweep" in sys.argv:
-    for m in (12, 14, 16, 20, 22, 24):
+    for m in (14, 15, 17):
         be.tune("tpack4_m", m)
         ms, r_ = timed(lambda: be.stream_both(T))
         del r_

@@ -12,6 +12,14 @@ from tests.test_gpu_kernels import _check_stream, _heavy_rows_csr, _stream_ref, 
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _keep_work(hip):
+    hip.keep_tpack4_work = True  # the tests read the fill's error word
+    yield
+    hip.keep_tpack4_work = False
+    hip._tpack4_work = None
+
+
 def _t_ref(m):
     mt = m.T.tocsr()
     mt.sort_indices()
