@@ -61,7 +61,11 @@ int mu_free(void* d_ptr);
 int mu_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
 int mu_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
 int mu_memset(void* d_dst, int value, size_t bytes, void* stream);
-int mu_stream_sync(void* stream); /* blocks the host */
+int mu_stream_sync(void* stream);
+/* 64-bit change-detecting digest of a HOST byte range on n_threads cores (16 MiB chunks, XXH64-style lanes, chunk
+ * digests folded in order): the fingerprint of the API path's resident-copy check (the matrices `adata.X` that
+ * /root/reference/muon/_atac/preproc.py:81-129 and tools.py:50-53 read), which a Python-level hash computes on one core. */
+int mu_host_hash64(const void* h_ptr, size_t n_bytes, int n_threads, uint64_t seed, uint64_t* h_out); /* blocks the host */
 
 /* ---- TF-IDF (preproc.py:92-119) ------------------------------------------- */
 /* Bytes of scratch mu_csr_row_col_sums needs for this shape (d_work). */
@@ -199,8 +203,23 @@ int mu_spmm_stream_k(int64_t n_rows);
 int mu_tfidf_scale_sweep_stream(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
                                 const float* d_values, const double* d_rowsum, const float* d_idf, double scale,
                                 int flags, float* d_out, unsigned long long* d_zero_count, void* d_work,
-                                size_t work_bytes, int have_slab_ptr, const int64_t* d_row_dst, void* d_ent,
-                                void* stream);
+                                size_t work_bytes, int have_slab_ptr, const int64_t* d_slab_ptr,
+                                const int64_t* d_row_dst, void* d_ent, void* stream);
+/* The slab pointers of a CSR (first entry of every row at or behind every 8192-column boundary; int64[n_rows *
+ * (ceil(n_cols / 8192) + 1)]) depend on the index arrays alone, which do not change between ingest, binarize, tfidf
+ * and lsi: built ONCE where the device CSR is made (upload, 10x ingest) instead of searched by every tfidf call (26
+ * binary searches per row at 200 000 columns: 3.0 ms of a 1e6-cell step).  The _sp entries take the table
+ * (mu_tfidf_scale_sweep_stream and mu_csr_tpack_count / mu_tpack4_count have a d_slab_ptr argument of their own);
+ * NULL = search as before.  Replaces nothing in the reference by itself: bookkeeping of preproc.py:92-117's kernels. */
+int mu_csr_slab_ptr(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices, int64_t* d_sp,
+                    void* stream);
+int mu_csr_row_col_sums_sp(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                           const int32_t* d_indices, const void* d_values, double* d_rowsum, double* d_colsum,
+                           void* d_work, size_t work_bytes, const int64_t* d_slab_ptr, void* stream);
+int mu_tfidf_scale_sweep_sp(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                            const int32_t* d_indices, const void* d_values, const double* d_rowsum, const void* d_idf,
+                            double scale, int flags, void* d_out, unsigned long long* d_zero_count,
+                            const int64_t* d_slab_ptr, void* stream);
 int mu_tpack4_supported(int64_t n_rows, int64_t n_cols, int64_t nnz);
 int mu_tpack4_geometry(int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t* rows_per_block, int* n_blocks,
                        int* tile_cols);

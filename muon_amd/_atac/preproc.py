@@ -45,21 +45,87 @@ def _digest_fn():
 _DIGEST = None
 
 
-def _hash_array(a: np.ndarray) -> int:
-    """64-bit digest over ALL bytes of ``a`` (chunks hashed on a thread pool, digests combined in
-    order): milliseconds for the matrices that travel through the AnnData API and comparable to the
-    PCIe upload it saves at 1e9 entries."""
-    digest = _digest_fn()
-    b = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
-    if b.size <= _HASH_CHUNK:
-        return digest(b)
-    from concurrent.futures import ThreadPoolExecutor
+_POOL = None
+
+
+def _pool():
+    """One thread pool for the host-side passes over whole matrices (hashing, copies), made once: starting threads
+    costs ~12 ms each next to busy workers - r04 made a fresh 16-thread pool for every array it hashed, 0.7 s of the
+    API path at 250 000 cells (scripts/probes/api_profile.py)."""
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        _POOL = ThreadPoolExecutor(max_workers=max(4, min(32, os.cpu_count() or 4)), thread_name_prefix="muon_amd_host")
+    return _POOL
+
+
+def _host_threads() -> int:
+    """Cores this process may actually use: the affinity mask, capped by a cgroup CPU quota (a container with 256
+    visible cores and a quota of 16 runs 64 threads slower than 16)."""
     import os
 
-    cuts = list(range(0, b.size, _HASH_CHUNK))
-    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
-        parts = list(ex.map(lambda o: digest(b[o:o + _HASH_CHUNK]), cuts))
-    return digest(np.asarray(parts, dtype=np.uint64).view(np.uint8))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:  # noqa: BLE001  (no cgroup v2 file: keep the affinity count)
+        pass
+    return max(1, min(n, 32))
+
+
+def _native_hash():
+    """libmuon_amd's multi-threaded host digest (mu_host_hash64) when the library is there; None otherwise."""
+    global _NATIVE
+    if _NATIVE is None:
+        try:
+            import ctypes as C
+
+            from .. import _ffi
+
+            lib = _ffi.lib()
+            T = _host_threads()
+
+            def h(b):
+                out = C.c_uint64(0)
+                _ffi.check(lib.mu_host_hash64(b.ctypes.data, b.size, T, 0, C.byref(out)))
+                return int(out.value)
+
+            _NATIVE = h
+        except Exception:  # noqa: BLE001
+            _NATIVE = False
+    return _NATIVE or None
+
+
+_NATIVE = None
+
+
+def _hash_arrays(arrays) -> tuple:
+    """64-bit digests over ALL bytes of every array (xxh3: ~10 GB/s per thread; every 64 MiB chunk of every array is
+    one task of the shared pool, a chunk's digests are combined in order): the price of trusting a resident copy."""
+    views = [np.ascontiguousarray(a).view(np.uint8).reshape(-1) for a in arrays]
+    native = _native_hash()
+    if native is not None:
+        # one call per array, every core of the process inside it (the Python xxhash binding holds the GIL: one core,
+        # 35-39 GB/s whatever the number of threads - scripts/probes/hash_rate.py)
+        return tuple(native(b) for b in views)
+    digest = _digest_fn()
+    tasks = [(i, o) for i, b in enumerate(views) for o in range(0, max(b.size, 1), _HASH_CHUNK)]
+    if sum(b.size for b in views) <= _HASH_CHUNK:
+        parts = [digest(views[i][o:o + _HASH_CHUNK]) for i, o in tasks]
+    else:
+        parts = list(_pool().map(lambda t: digest(views[t[0]][t[1]:t[1] + _HASH_CHUNK]), tasks))
+    out = []
+    for i in range(len(views)):
+        mine = [p for (j, _o), p in zip(tasks, parts) if j == i]
+        out.append(mine[0] if len(mine) == 1 else digest(np.asarray(mine, dtype=np.uint64).view(np.uint8)))
+    return tuple(out)
+
+
+def _hash_array(a: np.ndarray) -> int:
+    return _hash_arrays([a])[0]
 
 
 def _copy_array(a: np.ndarray) -> np.ndarray:
@@ -68,13 +134,10 @@ def _copy_array(a: np.ndarray) -> np.ndarray:
     a = np.ascontiguousarray(a)
     if a.nbytes < (64 << 20):
         return a.copy()
-    from concurrent.futures import ThreadPoolExecutor
-
     out = np.empty_like(a)
-    T = 8
+    T = 16
     cuts = [a.size * k // T for k in range(T + 1)]
-    with ThreadPoolExecutor(max_workers=T) as ex:
-        list(ex.map(lambda k: np.copyto(out[cuts[k]:cuts[k + 1]], a[cuts[k]:cuts[k + 1]]), range(T)))
+    list(_pool().map(lambda k: np.copyto(out[cuts[k]:cuts[k + 1]], a[cuts[k]:cuts[k + 1]]), range(T)))
     return out
 
 
@@ -82,8 +145,8 @@ def _fingerprint(m: csr_matrix):
     """Identity of a host CSR: shape, dtype and a hash of EVERY byte of data, indices and indptr.
     Any in-place edit between two calls - a single entry, a permuted index array - invalidates the
     resident copy (r01 sampled 2^16 values and could serve stale HBM data; ADVICE r01 #1)."""
-    return (m.shape, int(m.nnz), m.data.dtype.str, m.indices.dtype.str, m.indptr.dtype.str,
-            _hash_array(m.data), _hash_array(m.indices), _hash_array(m.indptr))
+    return (m.shape, int(m.nnz), m.data.dtype.str, m.indices.dtype.str, m.indptr.dtype.str) + _hash_arrays(
+        [m.data, m.indices, m.indptr])
 
 
 def attach_device(m: csr_matrix, dev_csr, backend) -> None:
@@ -132,6 +195,39 @@ def _effective_scale(scale_factor) -> float:
     if scale_factor is None or scale_factor == 0 or scale_factor == 1:
         return 1.0
     return float(scale_factor)
+
+
+def _flags_unknown(m) -> bool:
+    """scipy caches ``has_canonical_format`` / ``has_sorted_indices`` in private attributes; a matrix that has never
+    been asked (a fresh ``.copy()``, a matrix assembled from arrays) answers with a single-threaded scan of every
+    entry - 0.34 s at 1.6e9 entries, inside every tfidf() call of r04."""
+    return getattr(m, "_has_canonical_format", None) is None
+
+
+def canonical_csr_deferred(counts):
+    """``(host CSR, checked)``: like ``canonical_csr`` but a float CSR whose canonical flags scipy has not computed yet
+    is handed on UNCHECKED (``checked`` False) - the caller uploads it and lets the device say in milliseconds whether
+    its rows are sorted and free of duplicates (``_core.io.canonicalize``), falling back to ``canonical_csr`` if not."""
+    if (issparse(counts) and counts.format == "csr" and counts.dtype in (np.float32, np.float64)
+            and _flags_unknown(counts)):
+        return counts, False
+    return canonical_csr(counts), True
+
+
+def upload_canonical(backend, counts, values_dtype=None):
+    """Host matrix -> (host canonical CSR, DeviceCSR with its slab pointers)."""
+    host, checked = canonical_csr_deferred(counts)
+    if not checked and hasattr(backend, "with_slab_ptr"):
+        from .._core.io import canonicalize
+
+        X = backend.upload_csr(host.indptr, host.indices, host.data, host.shape, values_dtype=values_dtype,
+                               slab_ptr=False)
+        if getattr(canonicalize(backend, X), "canonical_as_given", False):
+            host.has_canonical_format = True  # (verified entry by entry on the device: scipy need not scan it again)
+            return host, backend.with_slab_ptr(X)
+        del X  # unsorted rows or duplicates: the host route (it copies, sorts and sums like scipy)
+    host = canonical_csr(counts)
+    return host, backend.upload_csr(host.indptr, host.indices, host.data, host.shape, values_dtype=values_dtype)
 
 
 def canonical_csr(counts) -> csr_matrix:
@@ -185,7 +281,7 @@ def tfidf_device(backend, X, n_obs, flags: int, scale: float, comm=None, out=Non
     else:
         # the result shares X's index arrays: the slab pointers the sweeps searched go with it, lsi's transposition
         # cuts the same 8192-column slabs (csrc/tpack.hip) and does not search them again
-        if sp is not None:
+        if sp is not None and getattr(res, "slab_ptr", None) is None:  # (else: X came with its table, `with_values` kept it)
             res.slab_ptr = (sp, (res.indptr.data_ptr(), res.indices.data_ptr(), res.shape[0], res.shape[1]))
         if emit is not None:  # (keyed by the arrays it mirrors: a result whose zeros were compacted has no stream)
             res.xstream = (emit[0], emit[1], (res.indptr.data_ptr(), res.indices.data_ptr(), res.values.data_ptr(),
@@ -293,8 +389,7 @@ def tfidf(
         X = backend.transpose_csr(Xc) if fast else backend.transpose(Xc)
         host = None
     else:
-        host = canonical_csr(counts)
-        X = backend.upload_csr(host.indptr, host.indices, host.data, host.shape)
+        host, X = upload_canonical(backend, counts)
     if n_obs is None:
         n_obs = comm.sum_scalar(adata.shape[0])
     flags = _flags(log_tf, log_idf, log_tfidf)

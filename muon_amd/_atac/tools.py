@@ -30,7 +30,7 @@ import scipy.linalg
 
 from .._comm import default_comm
 from .._containers import is_anndata, is_mudata
-from .preproc import canonical_csr, resident
+from .preproc import canonical_csr, resident, upload_canonical  # noqa: F401
 
 logger = logging.getLogger("muon_amd")
 
@@ -666,8 +666,7 @@ def lsi(data, scale_embeddings=True, n_comps=50, *, comm=None, n_iter: Optional[
     X = adata.X
     Xd = resident(X, backend)  # still on the device from tfidf(): no PCIe upload
     if Xd is None:
-        host = canonical_csr(X)
-        Xd = backend.upload_csr(host.indptr, host.indices, host.data, host.shape, values_dtype=np.float32)
+        _host, Xd = upload_canonical(backend, X, values_dtype=np.float32)
     out_dtype = X.dtype if X.dtype in (np.float32, np.float64) else np.float64
 
     U, stdev, V, info = lsi_device(backend, Xd, n_comps=n_comps, scale_embeddings=scale_embeddings,

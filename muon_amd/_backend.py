@@ -40,7 +40,11 @@ class DeviceCSR:
         return self.values.dtype
 
     def with_values(self, values: torch.Tensor) -> "DeviceCSR":
-        return DeviceCSR(self.indptr, self.indices, values, self.shape)
+        out = DeviceCSR(self.indptr, self.indices, values, self.shape)
+        sp = getattr(self, "slab_ptr", None)
+        if sp is not None:  # (the slab pointers describe the index arrays, which the new object shares)
+            out.slab_ptr = sp
+        return out
 
 
 @dataclass
@@ -374,16 +378,30 @@ class HipBackend:
         t.record_stream(copy_stream)
         return out
 
-    def upload_csr(self, indptr, indices, values, shape, values_dtype=None) -> DeviceCSR:
+    def upload_csr(self, indptr, indices, values, shape, values_dtype=None, slab_ptr: bool = True) -> DeviceCSR:
         """Host CSR -> HBM.  Index arrays become int64 / int32 and the values ``values_dtype`` on the
         way (scipy keeps int64 column indices beyond 2^31 stored entries; a separate ``astype`` of
         such an array is a single-threaded pass over tens of GB)."""
-        return DeviceCSR(
+        X = DeviceCSR(
             self.to_device(indptr, np.int64),
             self.to_device(indices, np.int32),
             self.to_device(values, values_dtype),
             (int(shape[0]), int(shape[1])),
         )
+        return self.with_slab_ptr(X) if slab_ptr else X
+
+    def with_slab_ptr(self, X: DeviceCSR) -> DeviceCSR:
+        """Attach the slab pointers of X's index arrays (include/muon_amd.h mu_csr_slab_ptr): searched once where the
+        device CSR is made - inside the clock of whoever makes it (upload, ingest) - and read by every sweep of tfidf and
+        by lsi's transposition afterwards.  Needs sorted rows (every producer here uploads canonical CSR)."""
+        n, d = X.shape
+        if n == 0 or d == 0 or X.nnz == 0 or self._slab_ptr_of(X) is not None:
+            return X
+        sp = self.empty((n * (-(-d // 8192) + 1),), torch.int64)
+        with self._dev_ctx():
+            check(self.lib.mu_csr_slab_ptr(n, d, _p(X.indptr), _p(X.indices), _p(sp), self._stream()))
+        X.slab_ptr = (sp, (X.indptr.data_ptr(), X.indices.data_ptr(), n, d))
+        return X
 
     # -- TF-IDF (reference preproc.py:92-117) -----------------------------------------
     def row_col_sums(self, X: DeviceCSR):
@@ -392,12 +410,14 @@ class HipBackend:
         colsum = self.empty((d,), torch.float64)
         wb = int(self.lib.mu_csr_row_col_sums_worksize(n, d))
         work = self.empty((wb,), torch.uint8)
+        sp = self._slab_ptr_of(X)
         with self._dev_ctx():
-            check(self.lib.mu_csr_row_col_sums(_dt(X.values), n, d, _p(X.indptr), _p(X.indices),
-                                               _p(X.values), _p(rowsum), _p(colsum), _p(work), wb,
-                                               self._stream()))
-        # the row / slab pointers at the head of `work` serve the scale pass of the same matrix
-        self._sweep_work = (work, wb, (X.indptr.data_ptr(), X.indices.data_ptr(), n, d))
+            check(self.lib.mu_csr_row_col_sums_sp(_dt(X.values), n, d, _p(X.indptr), _p(X.indices),
+                                                  _p(X.values), _p(rowsum), _p(colsum), _p(work), wb, _p(sp),
+                                                  self._stream()))
+        if sp is None:
+            # the slab pointers at the head of `work` serve the scale pass of the same matrix
+            self._sweep_work = (work, wb, (X.indptr.data_ptr(), X.indices.data_ptr(), n, d))
         return rowsum, colsum
 
     def idf(self, colsum: torch.Tensor, n_obs: float, flags: int, dtype) -> torch.Tensor:
@@ -449,20 +469,31 @@ class HipBackend:
         n, d = X.shape
         kept = self.__dict__.pop("_sweep_work", None)
         key = (X.indptr.data_ptr(), X.indices.data_ptr(), n, d)
+        sp = self._slab_ptr_of(X)
         if emit is not None:
             assert X.values.dtype == torch.float32
             have = kept is not None and kept[2] == key
-            if have:
-                work, wb = kept[0], kept[1]
-            else:
-                wb = int(self.lib.mu_csr_row_col_sums_worksize(n, d))
-                work = self.empty((wb,), torch.uint8)
+            work, wb = None, 0
+            if sp is None:
+                if have:
+                    work, wb = kept[0], kept[1]
+                else:
+                    wb = int(self.lib.mu_csr_row_col_sums_worksize(n, d))
+                    work = self.empty((wb,), torch.uint8)
             with self._dev_ctx():
                 check(self.lib.mu_tfidf_scale_sweep_stream(n, d, _p(X.indptr), _p(X.indices), _p(X.values), _p(rowsum),
                                                            _p(idf), float(scale), flags, _p(out), _p(zc), _p(work), wb,
-                                                           int(have), _p(emit[1]), _p(emit[0].ent), self._stream()))
-            n_sp = n * (-(-d // 8192) + 1)
-            self._last_slab_ptr = work[:8 * n_sp].view(torch.int64).clone()
+                                                           int(have), _p(sp), _p(emit[1]), _p(emit[0].ent),
+                                                           self._stream()))
+            if sp is None:
+                n_sp = n * (-(-d // 8192) + 1)
+                self._last_slab_ptr = work[:8 * n_sp].view(torch.int64).clone()
+            return out, zc
+        if sp is not None and not self.__dict__.get("_scale_gather"):
+            with self._dev_ctx():
+                check(self.lib.mu_tfidf_scale_sweep_sp(_dt(X.values), n, d, _p(X.indptr), _p(X.indices), _p(X.values),
+                                                       _p(rowsum), _p(idf), float(scale), flags, _p(out), _p(zc), _p(sp),
+                                                       self._stream()))
             return out, zc
         with self._dev_ctx():
             if self.__dict__.get("_scale_gather"):  # comparison / tests: the per-lane gather kernel
@@ -1244,7 +1275,8 @@ class HipBackend:
             values = self.empty((nnz,), torch.float32)
             check(self.lib.mu_synth_fill(row0, n_rows, n_cols, n_topics, density, seed, _p(indptr),
                                          _p(indices), _p(values), st))
-        return DeviceCSR(indptr, indices, values, (n_rows, n_cols))
+        # (the generator stands where ingest stands: the slab pointers of its index arrays are made here, once)
+        return self.with_slab_ptr(DeviceCSR(indptr, indices, values, (n_rows, n_cols)))
 
 
 class _Fetch:

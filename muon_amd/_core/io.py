@@ -62,8 +62,12 @@ def device_csr_from_10x(matrix: Mapping, comm=None, backend=None, atac_only: boo
     ip = np.asarray(indptr[r0:r1 + 1]).astype(np.int64)
     p0, p1 = int(ip[0]), int(ip[-1])
     # only this rank's stored entries cross PCIe; index / value conversion happens on the way
-    X = backend.upload_csr(ip - p0, matrix["indices"][p0:p1], matrix["data"][p0:p1], (r1 - r0, n_feat),
-                           values_dtype=values_dtype)
+    try:
+        X = backend.upload_csr(ip - p0, matrix["indices"][p0:p1], matrix["data"][p0:p1], (r1 - r0, n_feat),
+                               values_dtype=values_dtype, slab_ptr=False)  # (made below, for the arrays that stay)
+    except TypeError:  # operator sets without the option (CPU tests)
+        X = backend.upload_csr(ip - p0, matrix["indices"][p0:p1], matrix["data"][p0:p1], (r1 - r0, n_feat),
+                               values_dtype=values_dtype)
     keep = None
     if atac_only:
         ft = feature_types
@@ -78,6 +82,12 @@ def device_csr_from_10x(matrix: Mapping, comm=None, backend=None, atac_only: boo
                 keep = np.nonzero(mask)[0]
                 X = select_columns(backend, X, mask)
     X = canonicalize(backend, X)
+    if hasattr(backend, "with_slab_ptr"):
+        # ingest is where the slab pointers of the final index arrays are searched, once (tfidf and lsi read them)
+        flag = getattr(X, "canonical_as_given", None)
+        X = backend.with_slab_ptr(X)
+        if flag is not None:
+            X.canonical_as_given = flag
     return X, keep, (r0, r1)
 
 

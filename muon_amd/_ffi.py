@@ -44,6 +44,7 @@ SIGNATURES = {
     "mu_memcpy_d2h": (C.c_int, [_vp, _vp, _sz, _vp]),
     "mu_memset": (C.c_int, [_vp, _i32, _sz, _vp]),
     "mu_stream_sync": (C.c_int, [_vp]),
+    "mu_host_hash64": (C.c_int, [_vp, _sz, _i32, _u64, C.POINTER(_u64)]),
     "mu_csr_row_col_sums_worksize": (_sz, [_i64, _i64]),
     "mu_csr_row_col_sums": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_tfidf_idf": (C.c_int, [_i32, _i64, _dbl, _vp, _i32, _vp, _vp]),
@@ -62,7 +63,10 @@ SIGNATURES = {
     "mu_csr_tpack_fill_csr": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_stream_k": (C.c_int, [_i64]),
     "mu_tfidf_scale_sweep_stream": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _dbl, _i32, _vp, _vp, _vp, _sz, _i32,
-                                              _vp, _vp, _vp]),
+                                              _vp, _vp, _vp, _vp]),
+    "mu_csr_slab_ptr": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp]),
+    "mu_csr_row_col_sums_sp": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "mu_tfidf_scale_sweep_sp": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _dbl, _i32, _vp, _vp, _vp, _vp]),
     "mu_tpack4_supported": (C.c_int, [_i64, _i64, _i64]),
     "mu_tpack4_geometry": (C.c_int, [_i64, _i64, _i64, C.POINTER(_i64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mu_tpack4_worksize": (_sz, [_i64, _i64, _i64]),

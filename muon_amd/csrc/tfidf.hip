@@ -828,9 +828,41 @@ size_t mu_csr_row_col_sums_worksize(int64_t n_rows, int64_t n_cols) {
          256;
 }
 
+static int row_col_sums_impl(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                             const int32_t* d_indices, const void* d_values, double* d_rowsum, double* d_colsum,
+                             void* d_work, size_t work_bytes, const int64_t* d_slab_ptr, void* stream);
+
 int mu_csr_row_col_sums(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
                         const int32_t* d_indices, const void* d_values, double* d_rowsum,
                         double* d_colsum, void* d_work, size_t work_bytes, void* stream) {
+  return row_col_sums_impl(dtype, n_rows, n_cols, d_indptr, d_indices, d_values, d_rowsum, d_colsum, d_work, work_bytes,
+                           nullptr, stream);
+}
+
+/* r05: the slab pointers (first entry of every row at or behind every 8192-column boundary: 26 binary searches per row
+ * at 200 000 columns, 3.0 ms of a 1e6-row step) depend on the index arrays alone, which do not change between ingest,
+ * binarize, tfidf and lsi: mu_csr_slab_ptr builds the table once where the device CSR is made (d_sp: int64[n_rows *
+ * (ceil(n_cols / 8192) + 1)]), the _sp entries read it instead of searching (d_slab_ptr == NULL: search, as before). */
+int mu_csr_slab_ptr(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices, int64_t* d_sp,
+                    void* stream) {
+  MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative shape");
+  if (n_rows == 0 || n_cols == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_sp, "null pointer");
+  return launch_slab_ptr(n_rows, n_cols, d_indptr, d_indices, d_sp, (hipStream_t)stream);
+}
+
+int mu_csr_row_col_sums_sp(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                           const int32_t* d_indices, const void* d_values, double* d_rowsum, double* d_colsum,
+                           void* d_work, size_t work_bytes, const int64_t* d_slab_ptr, void* stream) {
+  return row_col_sums_impl(dtype, n_rows, n_cols, d_indptr, d_indices, d_values, d_rowsum, d_colsum, d_work, work_bytes,
+                           d_slab_ptr, stream);
+}
+
+}  // extern "C"
+
+static int row_col_sums_impl(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                             const int32_t* d_indices, const void* d_values, double* d_rowsum, double* d_colsum,
+                             void* d_work, size_t work_bytes, const int64_t* d_slab_ptr, void* stream) {
   MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative shape");
   MU_REQUIRE(d_indptr && d_rowsum && d_colsum, "null pointer");
   MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
@@ -844,7 +876,7 @@ int mu_csr_row_col_sums(int dtype, int64_t n_rows, int64_t n_cols, const int64_t
   }
   const int64_t S = num_slabs(n_cols);
   const int G = sweep_grid();
-  int64_t* sp = (int64_t*)d_work;
+  const int64_t* sp = d_slab_ptr ? d_slab_ptr : (const int64_t*)d_work;
   size_t off = ((size_t)(n_rows * (S + 1)) * sizeof(int64_t) + 255) & ~(size_t)255;
   double* partial = (double*)((char*)d_work + off);
   // software-pipelined walk (r04); tune "tfidf_pipe" = 1: the kernels of before, for comparison.  f32 matrices of
@@ -853,8 +885,10 @@ int mu_csr_row_col_sums(int dtype, int64_t n_rows, int64_t n_cols, const int64_t
   const bool pipe = mu_tune_get("tfidf_pipe") != 1;
   const int abl = mu_tune_get("tfidf_abl"), sum_m = mu_tune_get("tfidf_sum_m");
   const bool big = dtype == MU_DTYPE_F32 && pipe && abl == 0 && sum_m != 1 && (n_rows >= 100000 || sum_m == 2);
-  int rc = launch_slab_ptr(n_rows, n_cols, d_indptr, d_indices, sp, st);
-  if (rc) return rc;
+  if (!d_slab_ptr) {
+    int rc = launch_slab_ptr(n_rows, n_cols, d_indptr, d_indices, (int64_t*)d_work, st);
+    if (rc) return rc;
+  }
   if (big)
     hipLaunchKernelGGL((k_row_col_sums_pipe<float, 4, 0, 2>), dim3(mu_num_cus()), dim3(kSweepThreads), 0, st, n_rows,
                        n_cols, S, d_indptr, d_indices, (const float*)d_values, sp, d_rowsum, partial);
@@ -880,6 +914,8 @@ int mu_csr_row_col_sums(int dtype, int64_t n_rows, int64_t n_cols, const int64_t
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
+
+extern "C" {
 
 int mu_tfidf_idf(int dtype, int64_t n_cols, double n_obs, const double* d_colsum, int flags,
                  void* d_idf, void* stream) {
@@ -921,11 +957,36 @@ int mu_tfidf_scale(int dtype, int64_t n_rows, const int64_t* d_indptr, const int
   return MU_OK;
 }
 
+static int scale_sweep_impl(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                            const int32_t* d_indices, const void* d_values, const double* d_rowsum, const void* d_idf,
+                            double scale, int flags, void* d_out, unsigned long long* d_zero_count, void* d_work,
+                            size_t work_bytes, int have_slab_ptr, const int64_t* d_slab_ptr, void* stream);
+
 int mu_tfidf_scale_sweep(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
                          const int32_t* d_indices, const void* d_values, const double* d_rowsum,
                          const void* d_idf, double scale, int flags, void* d_out,
                          unsigned long long* d_zero_count, void* d_work, size_t work_bytes,
                          int have_slab_ptr, void* stream) {
+  return scale_sweep_impl(dtype, n_rows, n_cols, d_indptr, d_indices, d_values, d_rowsum, d_idf, scale, flags, d_out,
+                          d_zero_count, d_work, work_bytes, have_slab_ptr, nullptr, stream);
+}
+
+/* the same with the slab pointers of mu_csr_slab_ptr (no work buffer needed) */
+int mu_tfidf_scale_sweep_sp(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                            const int32_t* d_indices, const void* d_values, const double* d_rowsum, const void* d_idf,
+                            double scale, int flags, void* d_out, unsigned long long* d_zero_count,
+                            const int64_t* d_slab_ptr, void* stream) {
+  MU_REQUIRE(d_slab_ptr || n_rows == 0 || n_cols == 0, "null slab pointers");
+  return scale_sweep_impl(dtype, n_rows, n_cols, d_indptr, d_indices, d_values, d_rowsum, d_idf, scale, flags, d_out,
+                          d_zero_count, nullptr, 0, 1, d_slab_ptr, stream);
+}
+
+}  // extern "C"
+
+static int scale_sweep_impl(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
+                            const int32_t* d_indices, const void* d_values, const double* d_rowsum, const void* d_idf,
+                            double scale, int flags, void* d_out, unsigned long long* d_zero_count, void* d_work,
+                            size_t work_bytes, int have_slab_ptr, const int64_t* d_slab_ptr, void* stream) {
   MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
   MU_REQUIRE(!((flags & MU_TFIDF_LOG_TFIDF) && (flags & (MU_TFIDF_LOG_TF | MU_TFIDF_LOG_IDF))),
              "log_tfidf excludes log_tf / log_idf (preproc.py:69-73)");
@@ -934,11 +995,11 @@ int mu_tfidf_scale_sweep(int dtype, int64_t n_rows, int64_t n_cols, const int64_
   if (d_zero_count) MU_CHECK_HIP(hipMemsetAsync(d_zero_count, 0, sizeof(unsigned long long), st));
   if (n_rows == 0 || n_cols == 0) return MU_OK;
   MU_REQUIRE(d_indptr && d_rowsum && d_idf && d_out, "null pointer");
-  MU_REQUIRE(d_work && work_bytes >= mu_csr_row_col_sums_worksize(n_rows, n_cols), "work buffer too small");
+  MU_REQUIRE(d_slab_ptr || (d_work && work_bytes >= mu_csr_row_col_sums_worksize(n_rows, n_cols)), "work buffer too small");
   const int64_t S = num_slabs(n_cols);
-  int64_t* sp = (int64_t*)d_work;  // same place as in mu_csr_row_col_sums
-  if (!have_slab_ptr) {
-    int rc = launch_slab_ptr(n_rows, n_cols, d_indptr, d_indices, sp, st);
+  const int64_t* sp = d_slab_ptr ? d_slab_ptr : (const int64_t*)d_work;  // (the work buffer: same place as in mu_csr_row_col_sums)
+  if (!d_slab_ptr && !have_slab_ptr) {
+    int rc = launch_slab_ptr(n_rows, n_cols, d_indptr, d_indices, (int64_t*)d_work, st);
     if (rc) return rc;
   }
   const int use_scale = !(scale == 0.0 || scale == 1.0);  // preproc.py:101
@@ -974,13 +1035,15 @@ int mu_tfidf_scale_sweep(int dtype, int64_t n_rows, int64_t n_cols, const int64_
   return MU_OK;
 }
 
+extern "C" {
+
 /* mu_tfidf_scale_sweep for f32 that ALSO writes the row stream of the result (see k_tfidf_scale_sweep_pipe): pair i
  * of row r goes to d_ent[d_row_dst[r] + i].  Same values out, bit for bit. */
 int mu_tfidf_scale_sweep_stream(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
                                 const float* d_values, const double* d_rowsum, const float* d_idf, double scale,
                                 int flags, float* d_out, unsigned long long* d_zero_count, void* d_work,
-                                size_t work_bytes, int have_slab_ptr, const int64_t* d_row_dst, void* d_ent,
-                                void* stream) {
+                                size_t work_bytes, int have_slab_ptr, const int64_t* d_slab_ptr,
+                                const int64_t* d_row_dst, void* d_ent, void* stream) {
   MU_REQUIRE(!((flags & MU_TFIDF_LOG_TFIDF) && (flags & (MU_TFIDF_LOG_TF | MU_TFIDF_LOG_IDF))),
              "log_tfidf excludes log_tf / log_idf (preproc.py:69-73)");
   MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative shape");
@@ -988,11 +1051,11 @@ int mu_tfidf_scale_sweep_stream(int64_t n_rows, int64_t n_cols, const int64_t* d
   if (d_zero_count) MU_CHECK_HIP(hipMemsetAsync(d_zero_count, 0, sizeof(unsigned long long), st));
   if (n_rows == 0 || n_cols == 0) return MU_OK;
   MU_REQUIRE(d_indptr && d_rowsum && d_idf && d_out && d_row_dst && d_ent, "null pointer");
-  MU_REQUIRE(d_work && work_bytes >= mu_csr_row_col_sums_worksize(n_rows, n_cols), "work buffer too small");
+  MU_REQUIRE(d_slab_ptr || (d_work && work_bytes >= mu_csr_row_col_sums_worksize(n_rows, n_cols)), "work buffer too small");
   const int64_t S = num_slabs(n_cols);
-  int64_t* sp = (int64_t*)d_work;  // same place as in mu_csr_row_col_sums
-  if (!have_slab_ptr) {
-    int rc = launch_slab_ptr(n_rows, n_cols, d_indptr, d_indices, sp, st);
+  const int64_t* sp = d_slab_ptr ? d_slab_ptr : (const int64_t*)d_work;  // (else: same place as in mu_csr_row_col_sums)
+  if (!d_slab_ptr && !have_slab_ptr) {
+    int rc = launch_slab_ptr(n_rows, n_cols, d_indptr, d_indices, (int64_t*)d_work, st);
     if (rc) return rc;
   }
   const int use_scale = !(scale == 0.0 || scale == 1.0);  // preproc.py:101

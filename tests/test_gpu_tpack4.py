@@ -158,3 +158,42 @@ def test_explicit_zero_result_drops_the_stream(hip):
     m.sort_indices()
     T = tfidf_device(hip, _up(hip, m), 500, 3, 1e4)
     assert T.nnz < m.nnz and hip._xstream_of(T) is None
+
+
+def test_slab_pointers_made_at_ingest_give_the_same_results(hip):
+    """upload_csr attaches the slab-pointer table of the index arrays (r05): the sweeps of tfidf and lsi's transposition read
+    it instead of searching; sums, values, stream and transposed stream are bit-identical to the searching path, also
+    through binarize's in-place rewrite of the values and for f64 counts."""
+    from muon_amd._atac.preproc import tfidf_device
+    from tests.synth import planted_topics_csr
+
+    m = planted_topics_csr(20000, 30000, n_topics=20, density=0.02, seed=9, dtype=np.float32)
+    m.sort_indices()
+    X = hip.upload_csr(m.indptr, m.indices, m.data, m.shape)
+    X0 = hip.upload_csr(m.indptr, m.indices, m.data, m.shape, slab_ptr=False)
+    assert hip._slab_ptr_of(X) is not None and hip._slab_ptr_of(X0) is None
+    # the table is what the sweeps would search: first entry of every row at or behind every 8192-column boundary
+    S = -(-m.shape[1] // 8192)
+    sp = hip.to_host(hip._slab_ptr_of(X)).reshape(m.shape[0], S + 1)
+    rows = np.random.default_rng(0).integers(0, m.shape[0], 200)
+    for r in rows:
+        cols = m.indices[m.indptr[r]:m.indptr[r + 1]]
+        want = m.indptr[r] + np.searchsorted(cols, np.arange(S) * 8192, side="left")
+        assert np.array_equal(sp[r, :S], want) and sp[r, S] == m.indptr[r + 1]
+    r1, c1 = hip.row_col_sums(X)
+    hip.__dict__.pop("_sweep_work", None)
+    r0, c0 = hip.row_col_sums(X0)
+    hip.__dict__.pop("_sweep_work", None)
+    assert torch.equal(r1, r0) and torch.equal(c1, c0)
+    T, T0 = tfidf_device(hip, X, m.shape[0], 3, 1e4), tfidf_device(hip, X0, m.shape[0], 3, 1e4)
+    assert torch.equal(T.values, T0.values)
+    assert torch.equal(T.xstream[0].ent[: T.nnz], T0.xstream[0].ent[: T.nnz])
+    assert hip._slab_ptr_of(T) is not None and hip._slab_ptr_of(T0) is not None  # (T0: the sweep's own search, handed on)
+    assert torch.equal(hip._slab_ptr_of(T), hip._slab_ptr_of(T0))
+    A, B = hip.stream_both(T), hip.stream_both(T0)
+    assert torch.equal(A[1].ent[: T.nnz], B[1].ent[: T.nnz]) and torch.equal(A[1].sptr, B[1].sptr)
+    # f64 counts: the generic sweeps with the table
+    Xd = hip.upload_csr(m.indptr, m.indices, m.data.astype(np.float64), m.shape)
+    Xd0 = hip.upload_csr(m.indptr, m.indices, m.data.astype(np.float64), m.shape, slab_ptr=False)
+    Td, Td0 = tfidf_device(hip, Xd, m.shape[0], 3, 1e4), tfidf_device(hip, Xd0, m.shape[0], 3, 1e4)
+    assert torch.equal(Td.values, Td0.values)
