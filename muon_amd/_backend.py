@@ -41,9 +41,10 @@ class DeviceCSR:
 
     def with_values(self, values: torch.Tensor) -> "DeviceCSR":
         out = DeviceCSR(self.indptr, self.indices, values, self.shape)
-        sp = getattr(self, "slab_ptr", None)
-        if sp is not None:  # (the slab pointers describe the index arrays, which the new object shares)
-            out.slab_ptr = sp
+        for name in ("slab_ptr", "xplan", "tplan"):  # (they describe the index arrays, which the new object shares)
+            got = getattr(self, name, None)
+            if got is not None:
+                setattr(out, name, got)
         return out
 
 
@@ -401,7 +402,59 @@ class HipBackend:
         with self._dev_ctx():
             check(self.lib.mu_csr_slab_ptr(n, d, _p(X.indptr), _p(X.indices), _p(sp), self._stream()))
         X.slab_ptr = (sp, (X.indptr.data_ptr(), X.indices.data_ptr(), n, d))
+        return self.with_plans(X)
+
+    def with_plans(self, X: DeviceCSR) -> DeviceCSR:
+        """The rest of what lsi's operand building derives from the INDEX ARRAYS alone, made once where the device CSR is
+        made (r05; the same rule as the slab pointers: whoever makes the CSR - upload, ingest - pays inside its own clock):
+        `xplan` - where the rows go in the row stream of X (launch_layout of the row lengths, scanned; what the TF-IDF
+        scale sweep needs to write that stream) - and `tplan` - the transposition's count phase (entries per (row block,
+        column), their prefixes, the column totals) and the layout of X^T's stream.  Keyed by the arrays they describe;
+        a result whose zeros were compacted has other arrays and none of this.  MUON_AMD_PLANS=0: off."""
+        n, d = X.shape
+        if (n == 0 or d == 0 or X.nnz == 0 or os.environ.get("MUON_AMD_PLANS", "1") == "0"
+                or not (X.shape[0] > 0 and X.shape[1] > 0)):
+            return X
+        if getattr(X, "xplan", None) is None:
+            lens = X.indptr[1:] - X.indptr[:-1]
+            perm, inv, K = self.launch_layout(lens, None)
+            plens = torch.zeros((int(perm.numel()),), dtype=torch.int64, device=self.device)
+            plens[inv.long()] = lens
+            with self._dev_ctx():
+                try:
+                    sptr = self._stream_sptr(plens, K)
+                except NotImplementedError:
+                    return X
+            X.xplan = (dict(perm=perm, inv=inv, K=K, sptr=sptr, row_dst=sptr[inv.long()].contiguous()),
+                       (X.indptr.data_ptr(), n, d))
+        if getattr(X, "tplan", None) is None and bool(self.lib.mu_tpack4_supported(n, d, X.nnz)) \
+                and self.lib.mu_tune_get(b"tpack_v3") != 1:
+            col_nnz = self.empty((d,), torch.int64)
+            wb = int(self.lib.mu_tpack4_worksize(n, d, X.nnz))
+            work = self.empty((wb,), torch.uint8)
+            with self._dev_ctx():
+                check(self.lib.mu_tpack4_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz), _p(work), wb,
+                                               _p(self._slab_ptr_of(X)), self._stream()))
+                perm, inv, K = self.launch_layout(col_nnz, None)
+                plens = torch.zeros((int(perm.numel()),), dtype=torch.int64, device=self.device)
+                plens[inv.long()] = col_nnz
+                try:
+                    sptr = self._stream_sptr(plens, K)
+                except NotImplementedError:
+                    return X
+            X.tplan = (dict(work=work, wb=wb, perm=perm, inv=inv, K=K, sptr=sptr),
+                       (X.indptr.data_ptr(), X.indices.data_ptr(), n, d, X.nnz))
         return X
+
+    @staticmethod
+    def _plan_of(X: DeviceCSR, name: str):
+        got = getattr(X, name, None)
+        if got is None:
+            return None
+        plan, key = got
+        n, d = X.shape
+        want = (X.indptr.data_ptr(), n, d) if name == "xplan" else (X.indptr.data_ptr(), X.indices.data_ptr(), n, d, X.nnz)
+        return plan if key == want else None
 
     # -- TF-IDF (reference preproc.py:92-117) -----------------------------------------
     def row_col_sums(self, X: DeviceCSR):
@@ -438,6 +491,10 @@ class HipBackend:
         the values exist) and an empty stream to fill: (DeviceStream, row_dst) with row_dst[r] = pair index of row r's
         first pair."""
         n, d = X.shape
+        plan = self._plan_of(X, "xplan") if K is None else None
+        if plan is not None:  # (made with the device CSR: with_plans)
+            ent = self.empty((max(X.nnz, 1),), torch.int64)
+            return DeviceStream(plan["sptr"], ent, (n, d), X.nnz, plan["perm"], plan["K"]), plan["row_dst"]
         lens = X.indptr[1:] - X.indptr[:-1]
         perm, inv, K = self.launch_layout(lens, K)
         n_pos = int(perm.numel())
@@ -670,6 +727,19 @@ class HipBackend:
         n, d = X.shape
         assert X.values.dtype == torch.float32
         col_nnz = self.empty((max(d, 1),), torch.int64)
+        plan = self._plan_of(X, "tplan") if (sort_rows and K is None and self._use_tpack4(X)) else None
+        if plan is not None:
+            # count phase and layout were made with the device CSR (with_plans): the fill is all that is left
+            ent = self.empty((max(X.nnz, 1),), torch.int64)
+            if before_fill is not None:
+                before_fill()
+            xs_ent, xs_dst = (src[0].ent, src[1]) if src is not None else (None, None)
+            with self._dev_ctx():
+                check(self.lib.mu_tpack4_fill_stream(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
+                                                     _p(xs_dst), _p(xs_ent), _p(plan["sptr"]), _p(plan["inv"]), _p(ent),
+                                                     _p(plan["work"]), plan["wb"], self._stream()))
+            self._note_tpack4(plan["work"], n, d, X.nnz)
+            return DeviceStream(plan["sptr"], ent, (d, n), X.nnz, plan["perm"], plan["K"])
         if self._use_tpack4(X):
             wb = int(self.lib.mu_tpack4_worksize(n, d, X.nnz))
             work = self.empty((wb,), torch.uint8)
