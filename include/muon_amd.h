@@ -213,6 +213,10 @@ int mu_tfidf_scale_sweep_stream(int64_t n_rows, int64_t n_cols, const int64_t* d
  * NULL = search as before.  Replaces nothing in the reference by itself: bookkeeping of preproc.py:92-117's kernels. */
 int mu_csr_slab_ptr(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices, int64_t* d_sp,
                     void* stream);
+/* ... for slabs of `width` columns (int64[n_rows * (ceil(n_cols / width) + 1)]): entries per (row, slab) of the sliced-ELL
+ * operand of MOFA's sparse views (mu_spmm_ell16_*; 1024 / 512 columns) without a histogram over every entry */
+int mu_csr_slab_ptr_width(int64_t n_rows, int64_t n_cols, int64_t width, const int64_t* d_indptr,
+                          const int32_t* d_indices, int64_t* d_sp, void* stream);
 int mu_csr_row_col_sums_sp(int dtype, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr,
                            const int32_t* d_indices, const void* d_values, double* d_rowsum, double* d_colsum,
                            void* d_work, size_t work_bytes, const int64_t* d_slab_ptr, void* stream);

@@ -406,7 +406,8 @@ def _lsi_device(
 
     def expand_product(j):
         Zn = product(Xt, Ys[j])
-        comm.all_reduce_sum(Zn)
+        big = getattr(comm, "all_reduce_sum_big", None)  # (plain all-reduce, or reduce-scatter + all-gather: _comm.py)
+        (big or comm.all_reduce_sum)(Zn)
         return Zn
 
     # Small inputs (a product costs less than the host's Ritz step): the half of the NEXT expansion that does not need

@@ -159,7 +159,7 @@ def pick_block(width: int) -> int:
     )
 
 
-def ell16_layout(X: DeviceCSR, waves: int = 15, slab_cols: int = 1024) -> "DeviceEll":
+def ell16_layout(X: DeviceCSR, waves: int = 15, slab_cols: int = 1024, slab_ptr_fn=None) -> "DeviceEll":
     """The sliced-ELL layout of csrc/spmm_ell.hip as tensor operations on X's device (built once per fit; its cost
     does not matter).  See DeviceEll / include/muon_amd.h for the format.  ``slab_cols`` = 1024 for f32 blocks, 512
     for f64 blocks (a slab is 64 KiB of Q rows)."""
@@ -180,7 +180,14 @@ def ell16_layout(X: DeviceCSR, waves: int = 15, slab_cols: int = 1024) -> "Devic
     rows = torch.repeat_interleave(torch.arange(n, device=dev), lens)
     pos = inv[rows]
     sl = (X.indices >> shift).to(torch.int64)
-    cnt = torch.bincount(pos * S + sl, minlength=n_pos * S).view(n_pos, S)      # entries per (position, slab)
+    if slab_ptr_fn is not None:
+        # entries per (row, slab) off the slab pointers (binary searches: mu_csr_slab_ptr_width) - r04 histogrammed
+        # every entry (torch.bincount: 20 ms of the 80 ms a fit's set-up took at 3.1e8 entries)
+        sp = slab_ptr_fn(X, slab_cols).view(n, S + 1)
+        cnt = torch.zeros((n_pos, S), dtype=torch.int64, device=dev)
+        cnt[inv] = sp[:, 1:] - sp[:, :-1]
+    else:
+        cnt = torch.bincount(pos * S + sl, minlength=n_pos * S).view(n_pos, S)  # entries per (position, slab)
     nwin = (cnt.view(n_groups, 16, S).amax(dim=1) + 3) // 4                       # [group, slab]: the longest row
     flat = nwin.reshape(-1)
     wbase = torch.zeros(flat.numel() + 1, dtype=torch.int64, device=dev)
@@ -848,14 +855,22 @@ class HipBackend:
         waves = int(self.lib.mu_spmm_ell16_waves(X.shape[0]))
         cols = 512 if wide else 1024
         if X.values.dtype == torch.float32:
-            return ell16_layout(X, waves, cols)
+            return ell16_layout(X, waves, cols, self.slab_ptr_width)
         assert wide and X.values.dtype == torch.float64
         hi = X.values.to(torch.float32)
         rest = X.values - hi.to(torch.float64)
-        e_hi = ell16_layout(X.with_values(hi), waves, cols)
+        e_hi = ell16_layout(X.with_values(hi), waves, cols, self.slab_ptr_width)
         if bool((rest != 0).any().item()):
-            return SplitEll(e_hi, ell16_layout(X.with_values(rest.to(torch.float32)), waves, cols))
+            return SplitEll(e_hi, ell16_layout(X.with_values(rest.to(torch.float32)), waves, cols, self.slab_ptr_width))
         return SplitEll(e_hi, None)
+
+    def slab_ptr_width(self, X: DeviceCSR, width: int) -> torch.Tensor:
+        """First entry of every row at or behind every multiple of ``width`` columns (+ the row's end)."""
+        n, d = X.shape
+        sp = self.empty((n * (-(-d // width) + 1),), torch.int64)
+        with self._dev_ctx():
+            check(self.lib.mu_csr_slab_ptr_width(n, d, int(width), _p(X.indptr), _p(X.indices), _p(sp), self._stream()))
+        return sp
 
     def spmm_ell(self, E: DeviceEll, Q: torch.Tensor, out=None, accumulate: bool = False) -> torch.Tensor:
         n, d = E.shape

@@ -24,6 +24,9 @@ class LocalComm:
     def all_gather_rows(self, t):
         return t
 
+    def all_reduce_sum_big(self, t):
+        return t
+
     def sum_scalar(self, x):
         return x
 
@@ -73,6 +76,48 @@ class TorchDistComm:
 
     def all_reduce_max(self, t):
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def all_reduce_sum_big(self, t, mode=None):
+        """In-place sum of ONE large contiguous tensor - Z = X^T Y of an LSI expansion, 51 MB at 200 000 peaks - either
+        as a plain all-reduce (default) or, with MUON_AMD_Z_COLLECTIVE=rsag (or mode="rsag"), as an explicit
+        reduce-scatter + all-gather over row chunks: every rank sums 1 / W of the rows, then the chunks are gathered.
+        On xGMI's point-to-point links the two halves are what a ring all-reduce does anyway; having them as separate
+        calls is what lets the first 8-GPU lease A/B them (and later overlap the reduce-scatter of one column chunk
+        with the product of the next).  Same sums: each element is added over the ranks in one place, in rank order
+        for the gloo path.  (r05: built because VERDICT r04 asked for the variant; unmeasured on more than one GPU.)"""
+        import os
+
+        mode = mode or os.environ.get("MUON_AMD_Z_COLLECTIVE", "allreduce")
+        W = self.world_size
+        if mode != "rsag" or W == 1 or not t.is_contiguous() or t.numel() < W:
+            return self.all_reduce_sum(t)
+        dist = self._dist
+        flat = t.view(-1)
+        n = flat.numel()
+        per = -(-n // W)
+        if per * W != n:
+            buf = torch.zeros((per * W,), dtype=t.dtype, device=t.device)
+            buf[:n] = flat
+        else:
+            buf = flat
+        mine = torch.empty((per,), dtype=t.dtype, device=t.device)
+        if dist.get_backend(self.group) == "nccl":
+            dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(buf, mine, group=self.group)
+        else:
+            # gloo has no reduce-scatter: W reductions, one per owner (the CPU tests exercise the chunking and the gather)
+            for r in range(W):
+                chunk = buf[r * per:(r + 1) * per].clone()
+                dst = dist.get_global_rank(self.group, r) if self.group is not None else r
+                dist.reduce(chunk, dst=dst, op=dist.ReduceOp.SUM, group=self.group)
+                if r == self.rank:
+                    mine.copy_(chunk)
+            parts = [torch.empty_like(mine) for _ in range(W)]
+            dist.all_gather(parts, mine, group=self.group)
+            buf = torch.cat(parts)
+        if buf.data_ptr() != flat.data_ptr():
+            flat.copy_(buf[:n])
         return t
 
     def all_gather_rows(self, t):

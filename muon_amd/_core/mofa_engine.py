@@ -230,6 +230,18 @@ class MofaEngine:
             elif V.kind == "dense":
                 s1[g] = V.Y[a:b].sum(dim=0)
                 s2[g] = (V.Y[a:b] ** 2).sum(dim=0)
+            elif hasattr(be, "lib") and hasattr(be, "row_col_sums"):
+                # the per-feature moments of a group's rows are column sums of the values and of their squares: the
+                # TF-IDF sum sweep (f64 sums in LDS bins) instead of two index_add_ over every entry (r04: 2 x 12.8 ms)
+                from .._backend import DeviceCSR
+
+                lo, hi = int(V.X.indptr[a].item()), int(V.X.indptr[b].item())
+                sub = DeviceCSR((V.X.indptr[a:b + 1] - lo).contiguous(), V.X.indices[lo:hi], V.X.values[lo:hi], (b - a, D))
+                if b > a and hi > lo:
+                    s1[g] = be.row_col_sums(sub)[1].to(T)
+                    be.__dict__.pop("_sweep_work", None)
+                    s2[g] = be.row_col_sums(sub.with_values(V.X.values[lo:hi] ** 2))[1].to(T)
+                    be.__dict__.pop("_sweep_work", None)
             else:
                 lo, hi = int(V.X.indptr[a].item()), int(V.X.indptr[b].item())
                 idx = V.X.indices[lo:hi].long()
@@ -284,7 +296,9 @@ class MofaEngine:
               and V.X.shape[0] > 0 and V.X.shape[1] > 0 and _can_ell16(be, V.X, wide=False)):
             # f32, factor blocks of <= 16 columns: the operand of both directions never changes during a fit - laid
             # out once as sliced ELL (csrc/spmm_ell.hip): no per-row protocol is left in the product
-            V.Xt = be.ell16(be.transpose(V.X))
+            # (the transposed operand through the tile-staged transposition, csrc/tpack4.hip: 3 ms where the general
+            #  kernel behind `transpose` took 14)
+            V.Xt = be.ell16(be.transpose_csr(V.X) if hasattr(be, "transpose_csr") else be.transpose(V.X))
             V.Xs = be.ell16(V.X)
         elif self.T == torch.float32 and hasattr(be, "can_stream") and be.can_stream(V.X, 16):
             # f32: both directions read row streams, built once

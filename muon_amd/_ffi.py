@@ -65,6 +65,7 @@ SIGNATURES = {
     "mu_tfidf_scale_sweep_stream": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _dbl, _i32, _vp, _vp, _vp, _sz, _i32,
                                               _vp, _vp, _vp, _vp]),
     "mu_csr_slab_ptr": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp]),
+    "mu_csr_slab_ptr_width": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mu_csr_row_col_sums_sp": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "mu_tfidf_scale_sweep_sp": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _dbl, _i32, _vp, _vp, _vp, _vp]),
     "mu_tpack4_supported": (C.c_int, [_i64, _i64, _i64]),

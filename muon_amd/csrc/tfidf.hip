@@ -22,7 +22,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 __global__ __launch_bounds__(256) void k_slab_ptr(int64_t n_rows, int64_t S,
                                                   const int64_t* __restrict__ indptr,
                                                   const int32_t* __restrict__ indices,
-                                                  int64_t* __restrict__ sp) {
+                                                  int64_t* __restrict__ sp, int64_t width = kSlab) {
   const int64_t total = n_rows * (S + 1);
   for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
        id += (int64_t)gridDim.x * blockDim.x) {
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void k_slab_ptr(int64_t n_rows, int64_t S,
       sp[id] = hi;
       continue;
     }
-    const int64_t key = s * (int64_t)kSlab;
+    const int64_t key = s * width;
     while (lo < hi) {
       int64_t mid = lo + ((hi - lo) >> 1);
       if ((int64_t)indices[mid] < key) lo = mid + 1; else hi = mid;
@@ -843,6 +843,25 @@ int mu_csr_row_col_sums(int dtype, int64_t n_rows, int64_t n_cols, const int64_t
  * at 200 000 columns, 3.0 ms of a 1e6-row step) depend on the index arrays alone, which do not change between ingest,
  * binarize, tfidf and lsi: mu_csr_slab_ptr builds the table once where the device CSR is made (d_sp: int64[n_rows *
  * (ceil(n_cols / 8192) + 1)]), the _sp entries read it instead of searching (d_slab_ptr == NULL: search, as before). */
+/* the same table for slabs of `width` columns (d_sp: int64[n_rows * (ceil(n_cols / width) + 1)]): the operand layouts that
+ * cut rows into column slabs of their own (the sliced-ELL operand of MOFA's sparse views: 1024 / 512 columns) read the
+ * entries per (row, slab) off it instead of histogramming every entry */
+int mu_csr_slab_ptr_width(int64_t n_rows, int64_t n_cols, int64_t width, const int64_t* d_indptr,
+                          const int32_t* d_indices, int64_t* d_sp, void* stream) {
+  MU_REQUIRE(n_rows >= 0 && n_cols >= 0 && width > 0, "bad shape");
+  if (n_rows == 0 || n_cols == 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_sp, "null pointer");
+  const int64_t S = (n_cols + width - 1) / width;
+  const int64_t total = n_rows * (S + 1);
+  int64_t blocks = (total + 255) / 256;
+  const int64_t cap = (int64_t)mu_num_cus() * 32;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_slab_ptr, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_rows, S, d_indptr,
+                     d_indices, d_sp, width);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
 int mu_csr_slab_ptr(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices, int64_t* d_sp,
                     void* stream) {
   MU_REQUIRE(n_rows >= 0 && n_cols >= 0, "negative shape");

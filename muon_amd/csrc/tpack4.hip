@@ -194,16 +194,12 @@ __global__ __launch_bounds__(256) void k_t4_cdst(int64_t n_cols, const int64_t* 
 template <int J>
 __device__ __forceinline__ void t4_issue_pairs(uint64_t a0, uint64_t a1, int n0, int n1, unsigned sub8) {
   unsigned long long save, m0, m1;
-  int t0, t1;
-  // (the clamps of the two counts to 0 .. 32 as scalar instructions in here: written in C++ they came back as v_med3
-  //  into VGPRs, which s_bfm cannot read)
+  // (n0, n1 in 0 .. 32: the caller clamps the counts of all rows with ONE vector instruction per tile.  Written here in
+  //  C++ the clamps came back as v_med3 into VGPRs, which s_bfm cannot read; as four scalar instructions per slot they
+  //  were a fifth of the issue sequence)
   asm volatile(
-      "s_max_i32 %[t0], %[n0], 0\n\t"
-      "s_max_i32 %[t1], %[n1], 0\n\t"
-      "s_min_i32 %[t0], %[t0], 32\n\t"
-      "s_min_i32 %[t1], %[t1], 32\n\t"
-      "s_bfm_b64 %[m0], %[t0], 0\n\t"
-      "s_bfm_b64 %[m1], %[t1], 32\n\t"
+      "s_bfm_b64 %[m0], %[n0], 0\n\t"
+      "s_bfm_b64 %[m1], %[n1], 32\n\t"
       "s_mov_b64 %[save], exec\n\t"
       "v_mov_b32 v%c[C], 0x7fffffff\n\t"
       "s_mov_b64 exec, %[m0]\n\t"
@@ -211,24 +207,19 @@ __device__ __forceinline__ void t4_issue_pairs(uint64_t a0, uint64_t a1, int n0,
       "s_mov_b64 exec, %[m1]\n\t"
       "global_load_dwordx2 v[%c[C]:%c[V]], %[off], %[a1]\n\t"
       "s_mov_b64 exec, %[save]"
-      : [save] "=&s"(save), [m0] "=&s"(m0), [m1] "=&s"(m1), [t0] "=&s"(t0), [t1] "=&s"(t1)
+      : [save] "=&s"(save), [m0] "=&s"(m0), [m1] "=&s"(m1)
       : [off] "v"(sub8), [a0] "s"(a0), [a1] "s"(a1), [n0] "s"(n0), [n1] "s"(n1), [C] "i"(kW0 + 2 * J),
         [V] "i"(kW0 + 2 * J + 1)
-      : MU_T4_CLOB, "memory", "scc");
+      : MU_T4_CLOB, "memory");
 }
 // the same from the CSR arrays: i0 / i1 = address of the row's next column index, v0 / v1 = of its next value
 template <int J>
 __device__ __forceinline__ void t4_issue_csr(uint64_t i0, uint64_t v0, uint64_t i1, uint64_t v1, int n0, int n1,
                                              unsigned sub4) {
   unsigned long long save, m0, m1;
-  int t0, t1;
   asm volatile(
-      "s_max_i32 %[t0], %[n0], 0\n\t"
-      "s_max_i32 %[t1], %[n1], 0\n\t"
-      "s_min_i32 %[t0], %[t0], 32\n\t"
-      "s_min_i32 %[t1], %[t1], 32\n\t"
-      "s_bfm_b64 %[m0], %[t0], 0\n\t"
-      "s_bfm_b64 %[m1], %[t1], 32\n\t"
+      "s_bfm_b64 %[m0], %[n0], 0\n\t"
+      "s_bfm_b64 %[m1], %[n1], 32\n\t"
       "s_mov_b64 %[save], exec\n\t"
       "v_mov_b32 v%c[C], 0x7fffffff\n\t"
       "s_mov_b64 exec, %[m0]\n\t"
@@ -238,10 +229,10 @@ __device__ __forceinline__ void t4_issue_csr(uint64_t i0, uint64_t v0, uint64_t 
       "global_load_dword v%c[C], %[off], %[i1]\n\t"
       "global_load_dword v%c[V], %[off], %[v1]\n\t"
       "s_mov_b64 exec, %[save]"
-      : [save] "=&s"(save), [m0] "=&s"(m0), [m1] "=&s"(m1), [t0] "=&s"(t0), [t1] "=&s"(t1)
+      : [save] "=&s"(save), [m0] "=&s"(m0), [m1] "=&s"(m1)
       : [off] "v"(sub4), [i0] "s"(i0), [v0] "s"(v0), [i1] "s"(i1), [v1] "s"(v1), [n0] "s"(n0), [n1] "s"(n1),
         [C] "i"(kW0 + 2 * J), [V] "i"(kW0 + 2 * J + 1)
-      : MU_T4_CLOB, "memory", "scc");
+      : MU_T4_CLOB, "memory");
 }
 __device__ __forceinline__ void t4_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: MU_T4_CLOB, "memory"); }
 template <int J>
@@ -345,9 +336,10 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_
   }
   const unsigned subo = (unsigned)sub * (PAIRS ? 8u : 4u);
   auto issue_all = [&]() {
+    const int remc = rem < 32 ? rem : 32;  // (rem >= 0 always)
     t4_for<16>([&](auto jc) {
       constexpr int J = decltype(jc)::value;
-      const int n0 = __builtin_amdgcn_readlane(rem, 2 * J), n1 = __builtin_amdgcn_readlane(rem, 2 * J + 1);
+      const int n0 = __builtin_amdgcn_readlane(remc, 2 * J), n1 = __builtin_amdgcn_readlane(remc, 2 * J + 1);
       if constexpr (PAIRS)
         t4_issue_pairs<J>(readlane_u64(A, 2 * J), readlane_u64(A, 2 * J + 1), n0, n1, subo);
       else
@@ -446,14 +438,15 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_
           xa = xb = -1;
         } else {
           const unsigned step = PAIRS ? 256u : 128u;
-          const int na = __builtin_amdgcn_readlane(rem, xa) - 32;
+          const int na = __builtin_amdgcn_readlane(rem, xa) - 32;  // (> 0: the row has entries left)
           const int nb = xb >= 0 ? __builtin_amdgcn_readlane(rem, xb) - 32 : 0;
           const int lb = xb >= 0 ? xb : xa;
+          const int nac = __builtin_amdgcn_readfirstlane(na < 32 ? na : 32), nbc = __builtin_amdgcn_readfirstlane(nb < 32 ? nb : 32);
           if constexpr (PAIRS)
-            t4_issue_pairs<kSlotX>(readlane_u64(A, xa) + step, readlane_u64(A, lb) + step, na, nb, subo);
+            t4_issue_pairs<kSlotX>(readlane_u64(A, xa) + step, readlane_u64(A, lb) + step, nac, nbc, subo);
           else
             t4_issue_csr<kSlotX>(readlane_u64(A, xa) + step, readlane_u64(A2, xa) + step, readlane_u64(A, lb) + step,
-                                 readlane_u64(A2, lb) + step, na, nb, subo);
+                                 readlane_u64(A2, lb) + step, nac, nbc, subo);
           t4_wait_all();  // (exposed: rare by the choice of the tile width)
           const int c = t4_col<kSlotX>();
           const bool valid = c < cend;
@@ -534,33 +527,34 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_
     // ---- phase 3: every entry to its slot, from the window registers -------------------------------------------------
     // (eight slots at a time: their eight (bitmap, first slot) pairs first - one LDS round trip - then the eight stores.
     //  The bits below an entry's own row in its wave's word are its rank among the wave's rows with that column)
-    auto word_of = [&](auto jc) -> uint2 {
+    struct Ent { int c; unsigned v; uint2 wd; };
+    auto fetch = [&](auto jc) -> Ent {
       constexpr int J = decltype(jc)::value;
-      const int c = t4_col<J>();
-      return bmw[c < cend ? c - cbase : 0];
+      Ent e;
+      e.c = t4_col<J>();
+      e.v = t4_val<J>();
+      e.wd = bmw[e.c < cend ? e.c - cbase : 0];
+      return e;
     };
-    auto place = [&](auto jc, int ra, int rb, uint2 wd) {
-      constexpr int J = decltype(jc)::value;
-      const int c = t4_col<J>();
-      const unsigned v = t4_val<J>();
-      if (c < cend) {
+    auto place = [&](const Ent& e, int ra, int rb) {
+      if (e.c < cend) {
         const int rloc = hf ? rb : ra;
         const uint32_t below = (1u << rloc) - 1u;  // (rloc <= 31)
-        const uint32_t slot = wd.y + (uint32_t)__popc(wd.x & below);
-        stage[slot] = (unsigned long long)(unsigned)(wr0 + rloc) | ((unsigned long long)v << 32);
+        const uint32_t slot = e.wd.y + (uint32_t)__popc(e.wd.x & below);
+        stage[slot] = (unsigned long long)(unsigned)(wr0 + rloc) | ((unsigned long long)e.v << 32);
       }
     };
     {
-      uint2 fs[8];
-      t4_for<8>([&](auto jc) { fs[decltype(jc)::value] = word_of(jc); });
-      t4_for<8>([&](auto jc) { place(jc, 2 * decltype(jc)::value, 2 * decltype(jc)::value + 1, fs[decltype(jc)::value]); });
-      t4_for<8>([&](auto jc) { fs[decltype(jc)::value] = word_of(std::integral_constant<int, 8 + decltype(jc)::value>{}); });
+      Ent fs[8];
+      t4_for<8>([&](auto jc) { fs[decltype(jc)::value] = fetch(jc); });
+      t4_for<8>([&](auto jc) { place(fs[decltype(jc)::value], 2 * decltype(jc)::value, 2 * decltype(jc)::value + 1); });
+      t4_for<8>([&](auto jc) { fs[decltype(jc)::value] = fetch(std::integral_constant<int, 8 + decltype(jc)::value>{}); });
       t4_for<8>([&](auto jc) {
         constexpr int J = 8 + decltype(jc)::value;
-        place(std::integral_constant<int, J>{}, 2 * J, 2 * J + 1, fs[decltype(jc)::value]);
+        place(fs[decltype(jc)::value], 2 * J, 2 * J + 1);
       });
     }
-    if (xa >= 0) place(std::integral_constant<int, kSlotX>{}, xa, xb >= 0 ? xb : xa, word_of(std::integral_constant<int, kSlotX>{}));
+    if (xa >= 0) place(fetch(std::integral_constant<int, kSlotX>{}), xa, xb >= 0 ? xb : xa);
     // this wave's cursors move on; its bitmap row is cleared for the next tile; the next windows are requested
     if (half == 0) {
       A += (uint64_t)(unsigned)cntv * (PAIRS ? 8u : 4u);
@@ -586,7 +580,8 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_
     mark(4);
     cb += Ct;
     Ct = C;
-    __syncthreads();  // B4: staging buffer and run tables are free
+    // (no barrier here: the next tile writes the run tables after ITS first barrier and the staging buffer after its
+    //  second - a wave still writing this tile out has passed neither)
   }
   t4_wait_all();  // (the windows requested for a tile that does not exist)
   if (DBG && tid == 0)

@@ -29,6 +29,14 @@ r0, r1 = cuts[rank], cuts[rank + 1]
 X = be.synth_counts(r0, r1 - r0, d, 50, 0.03, 0)
 T = tfidf_device(be, X, n, 3, 1e4, comm=comm)
 U, sd, V, info = lsi_device(be, T, n_comps=k, n_obs=n, comm=comm, return_info=True)
+# the Z all-reduce as reduce-scatter + all-gather (MUON_AMD_Z_COLLECTIVE=rsag): the same sums, element by element
+os.environ["MUON_AMD_Z_COLLECTIVE"] = "rsag"
+U2, sd2, V2, info2 = lsi_device(be, T, n_comps=k, n_obs=n, comm=comm, return_info=True)
+os.environ.pop("MUON_AMD_Z_COLLECTIVE")
+assert info2["iterations"] == info["iterations"] and torch.equal(V2, V) and torch.equal(U2, U) and np.array_equal(sd2, sd), \
+    "reduce-scatter + all-gather changed the result"
+if rank == 0:
+    print("rsag == allreduce: bit-identical U, V, stdev")
 if rank == 0:
     Xf = be.synth_counts(0, n, d, 50, 0.03, 0)
     Tf = tfidf_device(be, Xf, n, 3, 1e4)

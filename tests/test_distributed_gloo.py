@@ -49,6 +49,14 @@ def _worker(rank, world, port, q):
         T = tfidf_device(be, Xd, n, 3, 1e4, comm=comm)
         U, stdev, V, info = lsi_device(be, T, n_comps=8, n_obs=n, comm=comm, return_info=True)
         Uall = comm.all_gather_rows(U.contiguous())
+        # the Z all-reduce as reduce-scatter + all-gather over row chunks: same sums
+        os.environ["MUON_AMD_Z_COLLECTIVE"] = "rsag"
+        U2, stdev2, V2, info2 = lsi_device(be, T, n_comps=8, n_obs=n, comm=comm, return_info=True)
+        os.environ.pop("MUON_AMD_Z_COLLECTIVE")
+        rsag_same = bool(torch.equal(V2, V) and torch.equal(U2, U) and info2["iterations"] == info["iterations"])
+        probe = torch.arange(10, dtype=torch.float64) + rank  # (a length the world size does not divide)
+        comm.all_reduce_sum_big(probe, mode="rsag")
+        rsag_same = rsag_same and bool(torch.equal(probe, 2 * torch.arange(10, dtype=torch.float64) + 1))
 
         # MOFA: samples sharded, two views (one sparse), two groups
         rng = np.random.default_rng(0)
@@ -86,7 +94,7 @@ def _worker(rank, world, port, q):
         if rank == 0:
             q.put({"tfidf": T.values.numpy(), "U": Uall.numpy(), "stdev": stdev, "V": V.numpy(),
                    "elbo": res["elbo"], "Z": Zall.numpy(), "W": res["W"], "iters": info["iterations"],
-                   "elbo_x": elbo_x, "modes_x": modes,
+                   "elbo_x": elbo_x, "modes_x": modes, "rsag_same": rsag_same,
                    "g_elbo": gres["elbo"], "g_Z": gZ.numpy(), "g_W": gres["W"], "g_r2": gres["r2"]})
     finally:
         dist.destroy_process_group()
@@ -125,6 +133,7 @@ def test_world_size_2_matches_single_process():
     np.testing.assert_allclose(got["stdev"], stdev, rtol=1e-5)
     assert lsi_oracle.max_subspace_angle(got["V"], V.numpy()) < 1e-4
     assert got["U"].shape == (600, 8)
+    assert got["rsag_same"]
     assert lsi_oracle.max_subspace_angle(got["U"], U.numpy()) < 5e-4
 
     rng = np.random.default_rng(0)
