@@ -40,7 +40,17 @@ def _digest(paths):
             h.update(f.read())
     h.update(" ".join(f for f in FLAGS if not f.startswith("-I")).encode())  # paths differ per box
     h.update(repr(sorted(EXTRA.items())).encode())
+    h.update(_compiler_id().encode())  # (kernels with asm-issued loads rest on what THIS hipcc does with their registers)
     return h.hexdigest()
+
+
+def _compiler_id():
+    """First line of `hipcc --version` that names the HIP / clang build ("" if the compiler cannot be asked)."""
+    try:
+        out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, timeout=30).stdout
+        return " | ".join(l.strip() for l in out.splitlines() if "version" in l.lower())[:300]
+    except Exception:  # noqa: BLE001
+        return ""
 
 
 def build(force=False, verbose=True):

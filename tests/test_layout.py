@@ -107,3 +107,43 @@ def test_stream_spmm_isa_keeps_out_of_the_asm_owned_registers(tmp_path):
                     assert hi < 110, (name, line)
 
 
+
+
+def test_tpack4_isa_keeps_out_of_the_asm_owned_registers(tmp_path):
+    """The fourth-generation transposition (csrc/tpack4.hip) keeps the next tile's header in v[90..93] and its 17 window
+    slots in v[94..127], written by loads issued from inline asm one tile ahead: hipcc must stay below v90 (a copy or a
+    spill of a register whose load is in flight reads stale data) and must not spill at all in the production instances
+    (scratch traffic shares vmcnt with the hand-placed waits)."""
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "muon_amd", "csrc", "tpack4.hip")
+    out = tmp_path / "tpack4.s"
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "muon_amd", "csrc"), "-S", "--cuda-device-only", "-w",
+                           "-o", str(out), src])
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN[^\n:]*k_t4_fill[^\n:]*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, flags=re.S | re.M)
+    assert len(kernels) == 4  # (row stream | CSR arrays) x (production | phase accounting)
+    reg = re.compile(r"\bv(\d+)\b|v\[(\d+):(\d+)\]")
+    for name, body in kernels:
+        production = "ILb1ELb0E" in name or "ILb0ELb0E" in name
+        m = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
+        assert m and int(m.group(1)) == 128, (name, m and m.group(1))
+        if production:
+            assert "scratch_" not in body, name
+            assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body), name
+        inasm = False
+        for line in body.splitlines():
+            if "#ASMSTART" in line:
+                inasm = True
+            elif "#ASMEND" in line:
+                inasm = False
+            elif not inasm and not line.lstrip().startswith((".", ";")):
+                for a, b, c in reg.findall(line.split(";")[0]):
+                    hi = int(a) if a else int(c)
+                    assert hi < 90, (name, line)
