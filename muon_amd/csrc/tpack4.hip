@@ -283,7 +283,7 @@ __device__ unsigned long long g_t4_phase[8];  // tune tpack_dbg: cycles of heade
 
 // PAIRS: the source is the row stream of X (src0 = ent, row_dst[row] = pair index of the row's first pair);
 // otherwise the CSR arrays (src0 = indices, src1 = values).  rw = rows of a wave (<= 32), rpb = 16 rw rows per block.
-template <bool PAIRS, bool DBG = false>
+template <bool PAIRS, bool DBG = false, bool OUT_CSR = false>
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_fill(
     int64_t n_rows, int64_t n_cols, int C, int rw, int G, const int64_t* __restrict__ indptr,
     const int64_t* __restrict__ row_dst, const void* __restrict__ src0, const void* __restrict__ src1,
@@ -566,15 +566,44 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_
     mark(3);
     __syncthreads();  // B3: the staged tile is complete
     // ---- phase 4: write-out, one 16-lane group per column, consecutive lanes = consecutive pairs of the run -----------
+    // (four columns of a group at a time: their four table entries first, then the four staged pairs, then the four
+    //  stores - three LDS round trips per FOUR columns; written column by column the compiler had three per column, in
+    //  series, and addresses for both kinds of target)
     {
       const int grp = tid >> 4, s16 = tid & 15;
-      for (int cl = grp; cl < cend - cbase; cl += kT / 16) {
-        const uint32_t lr = lrun[cl];
-        const uint32_t L = lr >> 16, src = lr & 0xffffu;
-        const int64_t dst = gdst[cl];
+      const int ncol = cend - cbase;
+      auto put = [&](int64_t pos, unsigned long long e) {
+        if constexpr (OUT_CSR) {
+          out.idx[pos] = (int32_t)(unsigned)e;
+          out.val[pos] = __builtin_bit_cast(float, (unsigned)(e >> 32));
+        } else {
+          out.ent[pos] = e;
+        }
+      };
+      for (int c0 = grp; c0 < ncol; c0 += 4 * (kT / 16)) {  // (uniform trip count per wave up to the last round)
+        uint32_t lr[4];
+        int64_t gd[4];
+        unsigned long long e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int cl = c0 + u * (kT / 16);
+          const bool in = cl < ncol;
+          lr[u] = in ? lrun[in ? cl : 0] : 0u;
+          gd[u] = gdst[in ? cl : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t L = lr[u] >> 16, src = lr[u] & 0xffffu;
+          e[u] = stage[(uint32_t)s16 < L ? src + s16 : 0];
+        }
         if (abl & 2) continue;  // (timing ablations, tune tpack4_abl: 2 no stores, 4 every run to the start of the target)
-        const int64_t dd = (abl & 4) ? (int64_t)(cl & 63) * 16 : dst;
-        for (uint32_t i = s16; i < L; i += 16) t4_store(out, dd + i, stage[src + i]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t L = lr[u] >> 16, src = lr[u] & 0xffffu;
+          const int64_t dd = (abl & 4) ? (int64_t)((c0 + u) & 63) * 16 : gd[u];
+          if ((uint32_t)s16 < L) put(dd + s16, e[u]);
+          for (uint32_t i = 16 + s16; i < L; i += 16) put(dd + i, stage[src + i]);  // (a column with more than 16 pairs here)
+        }
       }
     }
     mark(4);
@@ -665,14 +694,18 @@ int t4_fill_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_i
   const bool dbg = mu_tune_get("tpack_dbg") > 0;
   const bool xcd = mu_tune_get("tpack4_plain") != 1;  // (tune tpack4_plain = 1: workgroup = row block, for comparison)
   const unsigned grid = xcd ? (unsigned)(8 * ((q.G + 7) / 8)) : (unsigned)q.G;
-#define MU_T4_LAUNCH(PAIRS_, DBG_, RD_, S0_, S1_)                                                                      \
-  hipLaunchKernelGGL((k_t4_fill<PAIRS_, DBG_>), dim3(grid), dim3(kT), 0, st, n_rows, n_cols, q.C, q.rw,                 \
+#define MU_T4_LAUNCH(PAIRS_, DBG_, CSR_, RD_, S0_, S1_)                                                                \
+  hipLaunchKernelGGL((k_t4_fill<PAIRS_, DBG_, CSR_>), dim3(grid), dim3(kT), 0, st, n_rows, n_cols, q.C, q.rw,           \
                      xcd ? q.G : -q.G, d_indptr, RD_, (const void*)(S0_), (const void*)(S1_), w.cdst, w.cnt, w.coltot,  \
                      out, w.err, mu_tune_get("tpack4_abl"))
-  if (d_x_ent && dbg) MU_T4_LAUNCH(true, true, d_row_dst, d_x_ent, nullptr);
-  else if (d_x_ent) MU_T4_LAUNCH(true, false, d_row_dst, d_x_ent, nullptr);
-  else if (dbg) MU_T4_LAUNCH(false, true, (const int64_t*)nullptr, d_indices, d_values);
-  else MU_T4_LAUNCH(false, false, (const int64_t*)nullptr, d_indices, d_values);
+  const bool csr_out = out.idx != nullptr;
+  const int64_t* no_rd = nullptr;
+  if (d_x_ent && dbg && !csr_out) MU_T4_LAUNCH(true, true, false, d_row_dst, d_x_ent, nullptr);
+  else if (d_x_ent && !csr_out) MU_T4_LAUNCH(true, false, false, d_row_dst, d_x_ent, nullptr);
+  else if (d_x_ent) MU_T4_LAUNCH(true, false, true, d_row_dst, d_x_ent, nullptr);
+  else if (dbg && !csr_out) MU_T4_LAUNCH(false, true, false, no_rd, d_indices, d_values);
+  else if (!csr_out) MU_T4_LAUNCH(false, false, false, no_rd, d_indices, d_values);
+  else MU_T4_LAUNCH(false, false, true, no_rd, d_indices, d_values);
 #undef MU_T4_LAUNCH
   MU_CHECK_LAUNCH();
   return MU_OK;
