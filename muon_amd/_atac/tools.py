@@ -200,6 +200,8 @@ def _lsi_device(
     pack: Optional[bool] = None,
     max_blocks: Optional[int] = None,
     device_qr: Optional[bool] = None,
+    start: Optional[torch.Tensor] = None,
+    return_basis: bool = False,
 ):
     """Truncated SVD of a device-resident CSR (row shard) by block Lanczos on X^T X with full
     reorthogonalisation and Rayleigh-Ritz over the whole block Krylov space.
@@ -248,6 +250,7 @@ def _lsi_device(
     # "basis"): not the default.  X^T Y_j keeps the f32 row-stream kernel either way.
     mfma = (pack and hasattr(backend, "can_cells") and os.environ.get("MUON_AMD_LSI_MFMA", "0") == "1"
             and backend.can_cells(X, B))
+    Xcsr = X  # (the CSR as it came: the warm start below cuts a row range out of it)
     if mfma:
         logger.warning("MUON_AMD_LSI_MFMA=1: X Q_j runs on the matrix cores with the Krylov basis rounded to f16 - an "
                        "experiment (DESIGN.md 4.3) that leaves the top-k subspace about 1e-4 rad from the f32 path's, "
@@ -287,10 +290,48 @@ def _lsi_device(
         device_qr = hasattr(backend, "chol_rinv") and min(n_obs, d) >= 8192
     qr_flag = backend.zeros((1,), torch.int32) if device_qr else None
     pending_g1 = None  # first Gram of the last orthonormalisation, still on the device
-    Q0 = backend.randn(d, B, seed)
+    # (`start`: a d x B block to begin with instead of Gaussian noise; it is orthonormalised like the noise)
+    Q0 = start.clone() if start is not None else backend.randn(d, B, seed)
     if w < B:
         Q0[:, w:] = 0
     Q0, _ = _orthonormalize(backend, Q0, w, passes=2, flag=qr_flag)
+    # r05 - SUBSAMPLED POWER WARM START (big inputs, row streams): before the first full product the start block takes q
+    # steps of the power iteration of the FIRST n / frac CELLS of this rank: Q0 <- orth(X_S^T (X_S Q0)), summed over the
+    # ranks.  X_S^T X_S is (n_s / n) X^T X up to sampling noise, so one such step does to the block what the first Krylov
+    # expansion would - at 2 / frac of the price of its two products plus the operands of the slice - and the block
+    # Lanczos process that follows (same stopping rule, same Ritz procedure, on the WHOLE matrix) needs one expansion
+    # less: 5 instead of 7 products at 1e6 x 200k.  Nothing about the answer changes: the iteration converges to the
+    # top-k subspace of X as before and stops on its own residual bound; a start that does not help costs its 2 q / frac
+    # products.  Measured at 1e6 x 200k (scripts/probes/lsi_warm_probe.py): cold 7 products, 319 ms per call; 1 / 16 of
+    # the cells and one step 6 products (the bound after the first expansion, 1.5, still asks for a speculative product),
+    # two steps 5 products, 264 ms; 1 / 32 and two steps 257 ms; 1 / 64: 254 ms; the top-50 subspaces of warm and cold
+    # runs 1.0e-5 rad apart (two f32 runs through different Krylov spaces: the level at which f32 ARPACK repeats
+    # itself), singular values 5e-9.  MUON_AMD_LSI_WARM = "frac:q" (default "32:2" above 5e8 stored entries per rank;
+    # "0": cold start).
+    warm_spec = os.environ.get("MUON_AMD_LSI_WARM", "32:2" if nnz_rank > 500_000_000 else "0")
+    warm_used = None
+    if (start is None and warm_spec != "0" and pack and not mfma and n_iter is None and hasattr(Xcsr, "indptr")
+            and hasattr(backend, "stream_both")):
+        frac, qsteps = (int(v) for v in (warm_spec.split(":") + ["2"])[:2])
+        # this rank's slice: 1 / frac of its cells, at least 16 384 (a shard of a few 1e5 cells still gets a slice whose
+        # top subspace means something), at most a quarter, whole 512-row blocks
+        n_s = min(max(n_local // max(frac, 1), 16384), n_local // 4)
+        n_s = (n_s // 512) * 512
+        if comm.agree(qsteps >= 1 and comm.sum_scalar(n_s) >= 8192):  # (all ranks take part in the collectives or none does)
+            Ss = St = None
+            if n_s > 0:
+                lo = int(Xcsr.indptr[n_s].item())
+                if lo > 0:
+                    Xsub = type(Xcsr)(Xcsr.indptr[: n_s + 1], Xcsr.indices[:lo], Xcsr.values[:lo], (n_s, d))
+                    Ss, St = backend.stream_both(Xsub)
+            for _ in range(qsteps):
+                Zs = backend.spmm(St, backend.spmm(Ss, Q0)) if Ss is not None else torch.zeros_like(Q0)
+                comm.all_reduce_sum(Zs)
+                if w < B:
+                    Zs[:, w:] = 0
+                Q0, _ = _orthonormalize(backend, Zs, w, passes=2, flag=qr_flag)
+            del Ss, St
+            warm_used = {"cells": n_s, "power_steps": qsteps}
     Qs, Ys, css = [Q0], [], []
     Tb, Mb = {}, {}  # (i, j), i <= j  ->  w x w f64 host blocks
 
@@ -620,8 +661,13 @@ def _lsi_device(
 
     stdev = s / np.sqrt(n_obs - 1)  # tools.py:65
     if return_info:
-        info = {"iterations": it, "converged": bool(converged), "block": B, "width": w,
-                "blocks": len(Qs), "restarts": restarts, "spmm": 2 * it + 1 + wasted,
+        basis = None
+        if return_basis:  # the top-w Ritz vectors (one full block): what a warm start of another run begins with
+            Cb = np.zeros((C_all.shape[0], w))
+            Cb[:, :min(w, C_all.shape[1])] = C_all[:, :w]
+            basis = combine(Qs, Cb)[0]
+        info = {"iterations": it, "converged": bool(converged), "block": B, "width": w, "basis": basis,
+                "blocks": len(Qs), "restarts": restarts, "spmm": 2 * it + 1 + wasted, "warm_start": warm_used,
                 "spmm_unused": wasted, "host": host,
                 "svalues": s, "history": history, "bounds": bounds,
                 "angle_bound": float(np.hypot(bound, floor)), "lanczos_bound": float(bound),

@@ -37,6 +37,17 @@ assert info2["iterations"] == info["iterations"] and torch.equal(V2, V) and torc
     "reduce-scatter + all-gather changed the result"
 if rank == 0:
     print("rsag == allreduce: bit-identical U, V, stdev")
+# the subsampled power warm start across ranks (each rank's first cells; one all-reduce per power step)
+os.environ["MUON_AMD_LSI_WARM"] = "8:2"
+Uw, sdw, Vw, infow = lsi_device(be, T, n_comps=k, n_obs=n, comm=comm, return_info=True)
+os.environ.pop("MUON_AMD_LSI_WARM")
+assert infow["warm_start"] is not None and infow["converged"] and infow["iterations"] <= info["iterations"], infow
+qa, _ = torch.linalg.qr(V.double())
+qb, _ = torch.linalg.qr(Vw.double())
+angw = float(torch.linalg.matrix_norm(qb - qa @ (qa.T @ qb), ord=2))
+assert angw < 5e-5 and float(np.max(np.abs(sdw - sd) / sd)) < 1e-6, (angw, infow["bounds"])
+if rank == 0:
+    print(f"warm start ({infow['warm_start']}): {infow['iterations']} expansions against {info['iterations']}, angle to the cold run {angw:.2e}")
 if rank == 0:
     Xf = be.synth_counts(0, n, d, 50, 0.03, 0)
     Tf = tfidf_device(be, Xf, n, 3, 1e4)

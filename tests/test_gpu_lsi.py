@@ -303,3 +303,27 @@ def test_transposition_takes_the_slab_pointers_tfidf_searched(hip):
     other = DeviceCSR(T.indptr.clone(), T.indices.clone(), T.values, T.shape)
     other.slab_ptr = T.slab_ptr
     assert hip._slab_ptr_of(other) is None
+
+
+def test_warm_start_saves_an_expansion_and_gives_the_same_subspace(hip, monkeypatch):
+    """r05: the start block takes power steps on a slice of the cells before the first full product
+    (`_lsi_device`, MUON_AMD_LSI_WARM).  Forced on a matrix below its size threshold: fewer expansions than the cold
+    run, both within the parity bar of the f64 oracle, singular values alike."""
+    from muon_amd._atac.preproc import tfidf_device
+    from muon_amd._atac.tools import lsi_device
+    from oracle import lsi_oracle, tfidf_oracle
+    from tests.synth import planted_topics_csr
+
+    X = planted_topics_csr(40000, 12000, n_topics=20, density=0.03, seed=4, dtype=np.float32)
+    Xd = hip.upload_csr(X.indptr, X.indices, X.data, X.shape)
+    T = tfidf_device(hip, Xd, X.shape[0], 3, 1e4)
+    monkeypatch.setenv("MUON_AMD_LSI_WARM", "0")
+    Uc, sdc, Vc, ic = lsi_device(hip, T, n_comps=20, n_obs=X.shape[0], return_info=True)
+    monkeypatch.setenv("MUON_AMD_LSI_WARM", "8:2")
+    Uw, sdw, Vw, iw = lsi_device(hip, T, n_comps=20, n_obs=X.shape[0], return_info=True)
+    assert ic["warm_start"] is None and iw["warm_start"] == {"cells": 9728, "power_steps": 2}
+    assert iw["converged"] and ic["converged"] and iw["iterations"] < ic["iterations"], (ic["bounds"], iw["bounds"])
+    ref = lsi_oracle.lsi(tfidf_oracle.canonical(tfidf_oracle.tfidf(X)), n_comps=20)
+    for V, sd in ((Vc, sdc), (Vw, sdw)):
+        assert lsi_oracle.max_subspace_angle(hip.to_host(V), ref["LSI"]) < 1e-4
+        assert np.max(np.abs(sd - ref["stdev"]) / ref["stdev"]) < 1e-5
