@@ -320,10 +320,24 @@ def _lsi_device(
         if comm.agree(qsteps >= 1 and comm.sum_scalar(n_s) >= 8192):  # (all ranks take part in the collectives or none does)
             Ss = St = None
             if n_s > 0:
-                lo = int(Xcsr.indptr[n_s].item())
-                if lo > 0:
-                    Xsub = type(Xcsr)(Xcsr.indptr[: n_s + 1], Xcsr.indices[:lo], Xcsr.values[:lo], (n_s, d))
+                # the slice = 16 row ranges spread evenly over this rank's cells (files list cells sample by sample:
+                # the FIRST n_s cells may be one batch; a start from an odd slice costs an expansion, never the answer)
+                chunks = 16 if n_s >= 16 * 512 else 1
+                per = n_s // chunks
+                starts = [c * (n_local // chunks) for c in range(chunks)]
+                ip = Xcsr.indptr
+                edge = ip[torch.tensor([v for st in starts for v in (st, st + per)], device=ip.device)].tolist()
+                los, his = edge[0::2], edge[1::2]
+                if sum(h - l for l, h in zip(los, his)) > 0:
+                    parts, off = [], 0
+                    for st, l, h in zip(starts, los, his):
+                        parts.append(ip[st: st + per + (1 if st == starts[-1] else 0)] - l + off)
+                        off += h - l
+                    sub_ip = torch.cat(parts) if chunks > 1 else parts[0]
+                    cat = (lambda a: torch.cat([a[l:h] for l, h in zip(los, his)])) if chunks > 1 else (lambda a: a[los[0]:his[0]])
+                    Xsub = type(Xcsr)(sub_ip.contiguous(), cat(Xcsr.indices), cat(Xcsr.values), (per * chunks, d))
                     Ss, St = backend.stream_both(Xsub)
+                    n_s = per * chunks
             for _ in range(qsteps):
                 Zs = backend.spmm(St, backend.spmm(Ss, Q0)) if Ss is not None else torch.zeros_like(Q0)
                 comm.all_reduce_sum(Zs)
