@@ -33,13 +33,14 @@ constexpr int kT = 1024, kNW = 16;   // threads / waves of a workgroup
 constexpr int kRW = 32;              // rows of a wave: one bit each in a 32-bit word
 constexpr int kMaxC = 512;           // widest tile (columns): 16 waves x 512 columns x (bitmap word, first slot) = 64 KiB
 constexpr int kCap = 10240;          // staged pairs: 80 KiB
-constexpr int kH0 = 90;              // asm-owned v[90..93]: the next tile's header (base of this block, of the next, run start)
-constexpr int kW0 = 94;              // asm-owned registers v[kW0 ..]: slot j = (v[kW0 + 2j] column, v[kW0 + 2j + 1] value bits)
-constexpr int kSlotX = 16;           // the overflow slot
+constexpr int kH0 = 88;              // asm-owned v[88..91]: the next tile's header (base of this block, of the next, run start)
+constexpr int kW0 = 92;              // asm-owned registers v[kW0 ..]: slot j = (v[kW0 + 2j] column, v[kW0 + 2j + 1] value bits)
+constexpr int kSlotP = 16;           // overflow slot of the rows PREDICTED to overflow (they did in the tile before): prefetched
+constexpr int kSlotX = 17;           // overflow slot of the rows that overflow unannounced: loaded on the spot
 constexpr int kCountSlab = 8192;     // = sweep.hpp kSlab = tpack.hip kTSlab: the slab pointers are shared
 
 #define MU_T4_CLOB                                                                                                  \
-  "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",  \
+  "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",  \
       "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", \
       "v123", "v124", "v125", "v126", "v127"
 
@@ -284,15 +285,18 @@ __device__ unsigned long long g_t4_phase[8];  // tune tpack_dbg: cycles of heade
 // PAIRS: the source is the row stream of X (src0 = ent, row_dst[row] = pair index of the row's first pair);
 // otherwise the CSR arrays (src0 = indices, src1 = values).  rw = rows of a wave (<= 32), rpb = 16 rw rows per block.
 template <bool PAIRS, bool DBG = false, bool OUT_CSR = false>
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_fill(
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(44))) void k_t4_fill(
     int64_t n_rows, int64_t n_cols, int C, int rw, int G, const int64_t* __restrict__ indptr,
     const int64_t* __restrict__ row_dst, const void* __restrict__ src0, const void* __restrict__ src1,
     const int64_t* __restrict__ cdst, const uint32_t* __restrict__ base, const int64_t* __restrict__ coltot,
     T4Out out, int* __restrict__ err, int abl) {
+  const bool late = (abl & 8) != 0;
   __shared__ unsigned long long stage[kCap];  // 80 KiB
   __shared__ uint2 bm[kNW][kMaxC];            // 64 KiB: (wave, column): .x bitmap of the wave's rows, .y its first slot
-  __shared__ uint32_t lrun[kMaxC];            // per column of the tile: pairs << 16 | first staging slot
-  __shared__ int64_t gdst[kMaxC];
+  // per column of a tile: pairs << 16 | first staging slot, and where the run goes - TWO sets: a tile is written out
+  // while the next one is being ranked (see the loop)
+  __shared__ uint32_t lrun[2][kMaxC];
+  __shared__ int64_t gdst[2][kMaxC];
   __shared__ uint32_t wsum[kNW];
   __shared__ int s_flag;
   // Workgroup -> row block, XCD-aware: workgroup w runs on XCD w % 8 (observed dispatch order; for speed only), and the
@@ -335,6 +339,7 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_
     }
   }
   const unsigned subo = (unsigned)sub * (PAIRS ? 8u : 4u);
+  int pa = -1, pb = -1;  // rows (of this wave) whose continuation window the next issue prefetches into slot kSlotP
   auto issue_all = [&]() {
     const int remc = rem < 32 ? rem : 32;  // (rem >= 0 always)
     t4_for<16>([&](auto jc) {
@@ -346,6 +351,21 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_
         t4_issue_csr<J>(readlane_u64(A, 2 * J), readlane_u64(A2, 2 * J), readlane_u64(A, 2 * J + 1),
                         readlane_u64(A2, 2 * J + 1), n0, n1, subo);
     });
+    if (pa >= 0) {
+      // the continuation windows (entries 32 .. 63 behind the cursor) of the rows that overflowed in the tile before: a
+      // row inside a dense stretch of columns overflows tile after tile, and a continuation requested only when phase 1
+      // finds it missing is a memory round trip all sixteen waves wait for (92 % of the tiles of the bench matrix)
+      const unsigned step = PAIRS ? 256u : 128u;
+      const int lb = pb >= 0 ? pb : pa;
+      int na = __builtin_amdgcn_readlane(rem, pa) - 32, nb = pb >= 0 ? __builtin_amdgcn_readlane(rem, pb) - 32 : 0;
+      na = __builtin_amdgcn_readfirstlane(na < 0 ? 0 : (na > 32 ? 32 : na));
+      nb = __builtin_amdgcn_readfirstlane(nb < 0 ? 0 : (nb > 32 ? 32 : nb));
+      if constexpr (PAIRS)
+        t4_issue_pairs<kSlotP>(readlane_u64(A, pa) + step, readlane_u64(A, lb) + step, na, nb, subo);
+      else
+        t4_issue_csr<kSlotP>(readlane_u64(A, pa) + step, readlane_u64(A2, pa) + step, readlane_u64(A, lb) + step,
+                             readlane_u64(A2, lb) + step, na, nb, subo);
+    }
   };
   issue_all();
   __syncthreads();
@@ -363,6 +383,51 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_
       t_prev = t;
     }
   };
+
+  // ---- phase 4: write-out, one 16-lane group per column, consecutive lanes = consecutive pairs of the run -----------
+  // (four columns of a group at a time: their four table entries first, then the four staged pairs, then the four
+  //  stores - three LDS round trips per FOUR columns.)  Two sets of run tables: `late` (tune tpack4_late = 1) runs it ONE
+  //  TILE LATE, between the first and the second barrier of the next tile, so that the stores have a whole tile to drain
+  //  before this wave's next `s_waitcnt vmcnt(0)`.  Measured (profiles/r05_tpack4_ablations.txt): 58.9 against 55.8 ms -
+  //  the drain leaves the top of the tile, and the window requests of phase 3 queue behind the stores instead (phase 3
+  //  160 instead of 74 hundred cycles): the stores cost their ~20 ms wherever they sit.  Not the default.
+  auto put = [&](int64_t pos, unsigned long long e) {
+    if constexpr (OUT_CSR) {
+      out.idx[pos] = (int32_t)(unsigned)e;
+      out.val[pos] = __builtin_bit_cast(float, (unsigned)(e >> 32));
+    } else {
+      out.ent[pos] = e;
+    }
+  };
+  auto write_out = [&](int set, int ncol) {
+    const int grp = tid >> 4, s16 = tid & 15;
+    for (int c0 = grp; c0 < ncol; c0 += 4 * (kT / 16)) {  // (uniform trip count per wave up to the last round)
+      uint32_t lr[4];
+      int64_t gd[4];
+      unsigned long long e[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cl = c0 + u * (kT / 16);
+        const bool in = cl < ncol;
+        lr[u] = in ? lrun[set][in ? cl : 0] : 0u;
+        gd[u] = gdst[set][in ? cl : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t L = lr[u] >> 16, src = lr[u] & 0xffffu;
+        e[u] = stage[(uint32_t)s16 < L ? src + s16 : 0];
+      }
+      if (abl & 2) continue;  // (timing ablations, tune tpack4_abl: 2 no stores, 4 every run to the start of the target)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t L = lr[u] >> 16, src = lr[u] & 0xffffu;
+        const int64_t dd = (abl & 4) ? (int64_t)((c0 + u) & 63) * 16 : gd[u];
+        if ((uint32_t)s16 < L) put(dd + s16, e[u]);
+        for (uint32_t i = 16 + s16; i < L; i += 16) put(dd + i, stage[src + i]);  // (a column with more than 16 pairs here)
+      }
+    }
+  };
+  int pend_cols = 0, pend_set = 0, tset = 0;  // the tile staged and not yet written out (its columns, its table set)
 
   int Ct = C;
   int64_t hdr_cb = -1;  // the tile (its first column) whose header sits in / is on its way to v[kH0 ..]
@@ -405,64 +470,73 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_
 
     // ---- phase 1: the tile's entries set their row's bit in word (wave, column) ---------------------------------------
     int cntv = 0;          // lane r < 32: entries of row r consumed by this tile
-    unsigned full = 0;     // bit r: the window of row r was used up
     t4_for<16>([&](auto jc) {
       constexpr int J = decltype(jc)::value;
       const int c = t4_col<J>();
       const bool valid = c < cend;  // sorted rows: a prefix of each half; padding lanes hold INT_MAX
       const unsigned long long m = __ballot(valid);
-      const int c0 = __popc((unsigned)m), c1 = __popc((unsigned)(m >> 32));
       // (no result asked for: sixteen of these go out back to back; the two rows of a slot may share a column - the
       //  same word in one instruction - which an OR does not mind)
       if (valid)
         __hip_atomic_fetch_or(&bmw[c - cbase].x, (1u << (2 * J)) << hf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      cntv = writelane_c<2 * J>(cntv, c0);
-      cntv = writelane_c<2 * J + 1>(cntv, c1);
-      full |= (c0 == 32 ? 1u << (2 * J) : 0u) | (c1 == 32 ? 1u << (2 * J + 1) : 0u);
+      cntv = writelane_c<2 * J>(cntv, __popc((unsigned)m));
+      cntv = writelane_c<2 * J + 1>(cntv, __popc((unsigned)(m >> 32)));
     });
     // rows whose window was used up and that have entries left: more of them may fall into this tile (not when the tile
     // has 32 columns or fewer: a row has at most one entry per column)
+    unsigned ov = (unsigned)__ballot(half == 0 && cntv == 32 && rem > 32);
+    if (Ct <= 32) ov = 0u;
+    const unsigned ov_all = ov;
     int xa = -1, xb = -1;
-    {
-      unsigned ov = full & (unsigned)__ballot(half == 0 && rem > 32);
-      if (Ct <= 32) ov = 0u;
+    bool again = false;  // (wave-uniform) this wave cannot finish the tile at this width
+    // one continuation window of two rows: its entries of the tile set their bits, the rows' counts grow
+    auto continuation = [&](auto jc, int ra, int rb) {
+      constexpr int J = decltype(jc)::value;
+      const int c = t4_col<J>();
+      const bool valid = c < cend;
+      const unsigned long long m = __ballot(valid);
+      const int c0 = __popc((unsigned)m), c1 = __popc((unsigned)(m >> 32));
+      const int lb = rb >= 0 ? rb : ra;
+      if (valid)
+        __hip_atomic_fetch_or(&bmw[c - cbase].x, 1u << (hf ? lb : ra), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      cntv = writelane_s(cntv, __builtin_amdgcn_readlane(cntv, ra) + c0, ra);
+      if (rb >= 0) cntv = writelane_s(cntv, __builtin_amdgcn_readlane(cntv, rb) + c1, rb);
+      // 64 entries of one row in the tile and more to come: half the width
+      if ((c0 == 32 && __builtin_amdgcn_readlane(rem, ra) > 64) || (rb >= 0 && c1 == 32 && __builtin_amdgcn_readlane(rem, rb) > 64))
+        again = true;
+    };
+    if (pa >= 0 && Ct > 32) {
+      // the prefetched continuations (they arrived with the regular windows).  A predicted row that did NOT use its
+      // window up has nothing of this tile in its continuation: sorted rows, every lane fails `c < cend`
+      continuation(std::integral_constant<int, kSlotP>{}, pa, pb);
+      ov &= ~((1u << pa) | (pb >= 0 ? 1u << pb : 0u));
+    }
+    if (ov) {  // overflowing rows nobody announced: up to two, loaded on the spot
+      xa = __builtin_ctz(ov);
+      ov &= ov - 1u;
       if (ov) {
-        xa = __builtin_ctz(ov);
+        xb = __builtin_ctz(ov);
         ov &= ov - 1u;
-        if (ov) {
-          xb = __builtin_ctz(ov);
-          ov &= ov - 1u;
-        }
-        if (ov) {  // more than two such rows in one wave: retry the tile at half its width
-          if (lane == 0) s_flag = 1;
-          xa = xb = -1;
-        } else {
-          const unsigned step = PAIRS ? 256u : 128u;
-          const int na = __builtin_amdgcn_readlane(rem, xa) - 32;  // (> 0: the row has entries left)
-          const int nb = xb >= 0 ? __builtin_amdgcn_readlane(rem, xb) - 32 : 0;
-          const int lb = xb >= 0 ? xb : xa;
-          const int nac = __builtin_amdgcn_readfirstlane(na < 32 ? na : 32), nbc = __builtin_amdgcn_readfirstlane(nb < 32 ? nb : 32);
-          if constexpr (PAIRS)
-            t4_issue_pairs<kSlotX>(readlane_u64(A, xa) + step, readlane_u64(A, lb) + step, nac, nbc, subo);
-          else
-            t4_issue_csr<kSlotX>(readlane_u64(A, xa) + step, readlane_u64(A2, xa) + step, readlane_u64(A, lb) + step,
-                                 readlane_u64(A2, lb) + step, nac, nbc, subo);
-          t4_wait_all();  // (exposed: rare by the choice of the tile width)
-          const int c = t4_col<kSlotX>();
-          const bool valid = c < cend;
-          const unsigned long long m = __ballot(valid);
-          const int c0 = __popc((unsigned)m), c1 = __popc((unsigned)(m >> 32));
-          if (valid)
-            __hip_atomic_fetch_or(&bmw[c - cbase].x, 1u << (hf ? lb : xa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          cntv = writelane_s(cntv, __builtin_amdgcn_readlane(cntv, xa) + c0, xa);
-          if (xb >= 0) cntv = writelane_s(cntv, __builtin_amdgcn_readlane(cntv, xb) + c1, xb);
-          // 64 entries of one row in the tile and more to come: half the width
-          if ((c0 == 32 && na > 32) || (c1 == 32 && nb > 32)) {
-            if (lane == 0) s_flag = 1;
-          }
-        }
+      }
+      if (ov) {  // more than that in one wave: retry the tile at half its width
+        again = true;
+        xa = xb = -1;
+      } else {
+        const unsigned step = PAIRS ? 256u : 128u;
+        const int na = __builtin_amdgcn_readlane(rem, xa) - 32;  // (> 0: the row has entries left)
+        const int nb = xb >= 0 ? __builtin_amdgcn_readlane(rem, xb) - 32 : 0;
+        const int lb = xb >= 0 ? xb : xa;
+        const int nac = __builtin_amdgcn_readfirstlane(na < 32 ? na : 32), nbc = __builtin_amdgcn_readfirstlane(nb < 32 ? nb : 32);
+        if constexpr (PAIRS)
+          t4_issue_pairs<kSlotX>(readlane_u64(A, xa) + step, readlane_u64(A, lb) + step, nac, nbc, subo);
+        else
+          t4_issue_csr<kSlotX>(readlane_u64(A, xa) + step, readlane_u64(A2, xa) + step, readlane_u64(A, lb) + step,
+                               readlane_u64(A2, lb) + step, nac, nbc, subo);
+        t4_wait_all();  // (exposed: the first tile of a dense stretch)
+        continuation(std::integral_constant<int, kSlotX>{}, xa, xb);
       }
     }
+    if (again && lane == 0) s_flag = 1;
     mark(1);
     __syncthreads();  // B1: wsum, every wave's bitmap rows, s_flag
     uint32_t wpre = 0, total = 0;
@@ -499,8 +573,8 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_
       continue;
     }
     if (tid < Ct) {
-      lrun[tid] = (mine << 16) | my_lpos;  // (both < 2^14: the tile fits the staging buffer)
-      gdst[tid] = gd;
+      lrun[tset][tid] = (mine << 16) | my_lpos;  // (both < 2^14: the tile fits the staging buffer)
+      gdst[tset][tid] = gd;
     }
     {  // the next tile's header, one tile ahead (the registers were taken at the top)
       const int64_t ncb = cb + Ct;
@@ -523,6 +597,10 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_
       if (run - my_lpos != mine) atomicOr(err, 1);  // the bitmap and the count pass disagree: never
     }
     mark(2);
+    // the tile before (staged behind ITS third barrier, untouched since: phase 3 below is the next writer of the
+    // staging buffer, behind this tile's second barrier)
+    if (pend_cols > 0) write_out(pend_set, pend_cols);
+    pend_cols = 0;
     __syncthreads();  // B2
     // ---- phase 3: every entry to its slot, from the window registers -------------------------------------------------
     // (eight slots at a time: their eight (bitmap, first slot) pairs first - one LDS round trip - then the eight stores.
@@ -554,7 +632,16 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_
         place(fs[decltype(jc)::value], 2 * J, 2 * J + 1);
       });
     }
+    if (pa >= 0 && Ct > 32) place(fetch(std::integral_constant<int, kSlotP>{}), pa, pb >= 0 ? pb : pa);
     if (xa >= 0) place(fetch(std::integral_constant<int, kSlotX>{}), xa, xb >= 0 ? xb : xa);
+    // the rows that overflowed here are the ones expected to overflow in the next tile
+    pa = pb = -1;
+    if (ov_all) {
+      unsigned o2 = ov_all;
+      pa = __builtin_ctz(o2);
+      o2 &= o2 - 1u;
+      if (o2) pb = __builtin_ctz(o2);
+    }
     // this wave's cursors move on; its bitmap row is cleared for the next tile; the next windows are requested
     if (half == 0) {
       A += (uint64_t)(unsigned)cntv * (PAIRS ? 8u : 4u);
@@ -565,53 +652,20 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(45))) void k_t4_
     issue_all();
     mark(3);
     __syncthreads();  // B3: the staged tile is complete
-    // ---- phase 4: write-out, one 16-lane group per column, consecutive lanes = consecutive pairs of the run -----------
-    // (four columns of a group at a time: their four table entries first, then the four staged pairs, then the four
-    //  stores - three LDS round trips per FOUR columns; written column by column the compiler had three per column, in
-    //  series, and addresses for both kinds of target)
-    {
-      const int grp = tid >> 4, s16 = tid & 15;
-      const int ncol = cend - cbase;
-      auto put = [&](int64_t pos, unsigned long long e) {
-        if constexpr (OUT_CSR) {
-          out.idx[pos] = (int32_t)(unsigned)e;
-          out.val[pos] = __builtin_bit_cast(float, (unsigned)(e >> 32));
-        } else {
-          out.ent[pos] = e;
-        }
-      };
-      for (int c0 = grp; c0 < ncol; c0 += 4 * (kT / 16)) {  // (uniform trip count per wave up to the last round)
-        uint32_t lr[4];
-        int64_t gd[4];
-        unsigned long long e[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int cl = c0 + u * (kT / 16);
-          const bool in = cl < ncol;
-          lr[u] = in ? lrun[in ? cl : 0] : 0u;
-          gd[u] = gdst[in ? cl : 0];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t L = lr[u] >> 16, src = lr[u] & 0xffffu;
-          e[u] = stage[(uint32_t)s16 < L ? src + s16 : 0];
-        }
-        if (abl & 2) continue;  // (timing ablations, tune tpack4_abl: 2 no stores, 4 every run to the start of the target)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t L = lr[u] >> 16, src = lr[u] & 0xffffu;
-          const int64_t dd = (abl & 4) ? (int64_t)((c0 + u) & 63) * 16 : gd[u];
-          if ((uint32_t)s16 < L) put(dd + s16, e[u]);
-          for (uint32_t i = 16 + s16; i < L; i += 16) put(dd + i, stage[src + i]);  // (a column with more than 16 pairs here)
-        }
-      }
+    // ---- phase 4: the write-out (tune tpack4_late = 1: one tile late, between the next tile's first two barriers) ----
+    if (late) {
+      pend_cols = cend - cbase;
+      pend_set = tset;
+      tset ^= 1;
+    } else {
+      write_out(tset, cend - cbase);
     }
     mark(4);
     cb += Ct;
     Ct = C;
-    // (no barrier here: the next tile writes the run tables after ITS first barrier and the staging buffer after its
-    //  second - a wave still writing this tile out has passed neither)
   }
+  // (the last staged tile; the barrier orders it behind every wave's phase 3 - it is the third barrier of that tile)
+  if (pend_cols > 0) write_out(pend_set, pend_cols);
   t4_wait_all();  // (the windows requested for a tile that does not exist)
   if (DBG && tid == 0)
     for (int i = 0; i < 6; ++i) atomicAdd(&g_t4_phase[i], ph[i]);
@@ -636,7 +690,7 @@ inline T4Geo t4_geometry(int64_t n_rows, int64_t n_cols, int64_t nnz) {
   if (q.G < 1) q.G = 1;
   // tile width: the block's pairs of a tile fill ~88 % of the staging buffer, and a row has ~m entries in a tile
   // (tune tpack4_m, default 16: measured on the bench matrix - whose rows are burstier than Poisson - 14 / 16 / 18
-  //  entries per row and tile retry 0.1 / 3 / 50 % of the tiles)
+  //  entries per row and tile retried 0.1 / 3 / 50 % of the tiles with ONE overflow slot per wave)
   const double per_col = (double)nnz / (double)q.G / (double)(n_cols > 0 ? n_cols : 1);
   double Cc = per_col > 0 ? 0.88 * kCap / per_col : (double)kMaxC;
   const int m = mu_tune_get("tpack4_m") > 0 ? mu_tune_get("tpack4_m") : 16;
@@ -697,7 +751,7 @@ int t4_fill_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_i
 #define MU_T4_LAUNCH(PAIRS_, DBG_, CSR_, RD_, S0_, S1_)                                                                \
   hipLaunchKernelGGL((k_t4_fill<PAIRS_, DBG_, CSR_>), dim3(grid), dim3(kT), 0, st, n_rows, n_cols, q.C, q.rw,           \
                      xcd ? q.G : -q.G, d_indptr, RD_, (const void*)(S0_), (const void*)(S1_), w.cdst, w.cnt, w.coltot,  \
-                     out, w.err, mu_tune_get("tpack4_abl"))
+                     out, w.err, mu_tune_get("tpack4_abl") | (mu_tune_get("tpack4_late") == 1 ? 8 : 0))
   const bool csr_out = out.idx != nullptr;
   const int64_t* no_rd = nullptr;
   if (d_x_ent && dbg && !csr_out) MU_T4_LAUNCH(true, true, false, d_row_dst, d_x_ent, nullptr);

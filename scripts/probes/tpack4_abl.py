@@ -35,7 +35,7 @@ def fill_ms(reps=2):
 
 
 print(f"{cells} x {peaks}: count + layout + fill, stream source", flush=True)
-for c in (256, 480):
+for c in (448, 480, 512):
     be.tune("tpack4_c", c)
     a = fill_ms()
     be.tune("tpack4_abl", 2)
