@@ -289,6 +289,15 @@ int mu_spmm_ell16_f64(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d
                       const void* d_ent, const int32_t* d_perm, const double* d_Q, double* d_Y, int accumulate,
                       void* stream);
 
+/* The layout itself: the windows of a canonical f32 CSR from its slab pointers of the operand's width
+ * (mu_csr_slab_ptr_width(slab_cols): d_slab_ptr[row][0 .. S]).  d_perm / d_hdr / d_win_base[group][slab] (first window
+ * of every (group, slab): the exclusive scan of d_hdr) as the product reads them, made by the caller from the slab
+ * pointers (rows by descending length, the longest row of a group per slab).  Writes every slot of every window
+ * (padding included); the eight windows of slack behind them are the caller's to zero. */
+int mu_ell16_fill(int64_t n_groups, int64_t n_cols, int slab_cols, const int32_t* d_indices, const float* d_values,
+                  const int64_t* d_slab_ptr, const int32_t* d_perm, const int32_t* d_hdr, const int64_t* d_win_base,
+                  void* d_ent, void* stream);
+
 /* ---- EXPERIMENTAL (not on any default path; MUON_AMD_LSI_MFMA=1 opts in and logs a warning) -------------------
  * mu_cells_geometry / mu_cells_cut / mu_dense_to_f16 / mu_spmm_cells_f32 and the two mu_probe_* entries below:
  * the r04 matrix-core SpMM experiment.  Faster than mu_spmm_stream_f32 (3.3 vs 4.0 ms at 125k x 200k) and NOT
@@ -432,6 +441,15 @@ int mu_mofa_rowstats(int dtype, int64_t r0, int64_t r1, int K, const void* d_E, 
                      const void* d_wgt, const void* d_aux, int scale_out, void* d_out_pad, int ld, int col0,
                      void* d_out_t, int64_t ld_t, void* d_gram, void* d_s2, void* d_s1, double* d_work,
                      void* stream);
+
+/* Per-feature moments of rows r0 .. r1-1 of a dense row-major view Y[.][D] (f32 / f64 storage, f64 sums) in one pass:
+ * partial[chunk][0][j] = sum y_rj, partial[chunk][1][j] = sum y_rj^2 over the chunk's rows, `chunks`
+ * (mu_dense_col_moments_chunks(rows, D); <= 65535) chunks of consecutive rows, folded by the caller in a fixed order.
+ * The group means mofapy2 centres a view by before training (kept as the intercepts,
+ * /root/reference/muon/_core/tools.py:283-286) and the sum of squares behind the noise update. */
+int mu_dense_col_moments_chunks(int64_t n_rows, int64_t D);
+int mu_dense_col_moments(int dtype, int64_t r0, int64_t r1, int64_t D, const void* d_Y, int chunks,
+                         double* d_partial, void* stream);
 
 /* ---- exhaustive nearest-neighbour search, the filter pass (replaces the n x n distance panels + radix top-k
  * of the tensor formulation behind muon.pp.neighbors, /root/reference/muon/_core/preproc.py:366-373,453-461,

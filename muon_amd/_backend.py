@@ -159,10 +159,12 @@ def pick_block(width: int) -> int:
     )
 
 
-def ell16_layout(X: DeviceCSR, waves: int = 15, slab_cols: int = 1024, slab_ptr_fn=None) -> "DeviceEll":
-    """The sliced-ELL layout of csrc/spmm_ell.hip as tensor operations on X's device (built once per fit; its cost
-    does not matter).  See DeviceEll / include/muon_amd.h for the format.  ``slab_cols`` = 1024 for f32 blocks, 512
-    for f64 blocks (a slab is 64 KiB of Q rows)."""
+def ell16_layout(X: DeviceCSR, waves: int = 15, slab_cols: int = 1024, slab_ptr_fn=None, fill_fn=None) -> "DeviceEll":
+    """The sliced-ELL layout of csrc/spmm_ell.hip (built once per fit).  See DeviceEll / include/muon_amd.h for the
+    format.  ``slab_cols`` = 1024 for f32 blocks, 512 for f64 blocks (a slab is 64 KiB of Q rows).  As tensor
+    operations on X's device - the specification, and what runs without the library - or, with ``slab_ptr_fn`` and
+    ``fill_fn`` (HipBackend.slab_ptr_width / ._ell16_fill), per (row, slab) only: the windows themselves are written by
+    mu_ell16_fill (r04's dozen tensor passes over every entry took 30 ms per operand at 3.1e8 entries)."""
     assert slab_cols in (1024, 512) and X.values.dtype == torch.float32
     n, d = X.shape
     dev = X.indices.device
@@ -177,9 +179,7 @@ def ell16_layout(X: DeviceCSR, waves: int = 15, slab_cols: int = 1024, slab_ptr_
     perm[:n] = order.to(torch.int32)
     inv = torch.empty((n,), dtype=torch.int64, device=dev)
     inv[order] = torch.arange(n, device=dev)
-    rows = torch.repeat_interleave(torch.arange(n, device=dev), lens)
-    pos = inv[rows]
-    sl = (X.indices >> shift).to(torch.int64)
+    sp = None
     if slab_ptr_fn is not None:
         # entries per (row, slab) off the slab pointers (binary searches: mu_csr_slab_ptr_width) - r04 histogrammed
         # every entry (torch.bincount: 20 ms of the 80 ms a fit's set-up took at 3.1e8 entries)
@@ -187,6 +187,9 @@ def ell16_layout(X: DeviceCSR, waves: int = 15, slab_cols: int = 1024, slab_ptr_
         cnt = torch.zeros((n_pos, S), dtype=torch.int64, device=dev)
         cnt[inv] = sp[:, 1:] - sp[:, :-1]
     else:
+        rows = torch.repeat_interleave(torch.arange(n, device=dev), lens)
+        pos = inv[rows]
+        sl = (X.indices >> shift).to(torch.int64)
         cnt = torch.bincount(pos * S + sl, minlength=n_pos * S).view(n_pos, S)  # entries per (position, slab)
     nwin = (cnt.view(n_groups, 16, S).amax(dim=1) + 3) // 4                       # [group, slab]: the longest row
     flat = nwin.reshape(-1)
@@ -196,6 +199,15 @@ def ell16_layout(X: DeviceCSR, waves: int = 15, slab_cols: int = 1024, slab_ptr_
     win_base = wbase[:-1].view(n_groups, S)
     hdr = nwin.to(torch.int32).contiguous()
     wave_base = win_base[:, 0].contiguous()
+    if sp is not None and fill_fn is not None:
+        ent = torch.empty((total + 8, 384), dtype=torch.uint8, device=dev)        # (+ 8: the ring reads ahead)
+        ent[total:].zero_()
+        fill_fn(X, slab_cols, sp, perm, hdr, win_base.contiguous(), ent)
+        return DeviceEll(hdr, wave_base, ent, perm, (n, d), X.nnz, total * 64, int(waves), int(slab_cols))
+    if sp is not None:
+        rows = torch.repeat_interleave(torch.arange(n, device=dev), lens)
+        pos = inv[rows]
+        sl = (X.indices >> shift).to(torch.int64)
     # rank of an entry inside its (row, slab): the rows are sorted by column, so slabs follow each other
     start = torch.cumsum(cnt, dim=1) - cnt                                        # [position, slab] exclusive
     e = torch.arange(X.nnz, device=dev)
@@ -854,15 +866,48 @@ class HipBackend:
         and f64 values -> SplitEll (hi + lo)."""
         waves = int(self.lib.mu_spmm_ell16_waves(X.shape[0]))
         cols = 512 if wide else 1024
+        fill = None if os.environ.get("MUON_AMD_ELL16_TENSOR_LAYOUT", "0") == "1" else self._ell16_fill
         if X.values.dtype == torch.float32:
-            return ell16_layout(X, waves, cols, self.slab_ptr_width)
+            return ell16_layout(X, waves, cols, self.slab_ptr_width, fill)
         assert wide and X.values.dtype == torch.float64
         hi = X.values.to(torch.float32)
         rest = X.values - hi.to(torch.float64)
-        e_hi = ell16_layout(X.with_values(hi), waves, cols, self.slab_ptr_width)
+        e_hi = ell16_layout(X.with_values(hi), waves, cols, self.slab_ptr_width, fill)
         if bool((rest != 0).any().item()):
-            return SplitEll(e_hi, ell16_layout(X.with_values(rest.to(torch.float32)), waves, cols, self.slab_ptr_width))
+            return SplitEll(e_hi, ell16_layout(X.with_values(rest.to(torch.float32)), waves, cols, self.slab_ptr_width, fill))
         return SplitEll(e_hi, None)
+
+    def ell16_pair(self, X: DeviceCSR, wide: bool = False):
+        """(layout of X, layout of X^T) - both operands of a fit.  The transposed CSR comes from the tile-staged
+        transposition (f32 values; an f64-valued matrix is transposed as its hi and lo parts, the second only when
+        some value is not exact in f32) instead of the general kernel behind `transpose`."""
+        if X.values.dtype == torch.float32:
+            return self.ell16(X, wide), self.ell16(self.transpose_csr(X), wide)
+        assert wide and X.values.dtype == torch.float64
+        hi = X.values.to(torch.float32)
+        rest = X.values - hi.to(torch.float64)
+        parts = [hi] + ([rest.to(torch.float32)] if bool((rest != 0).any().item()) else [])
+        del rest
+        fw = [self.ell16(X.with_values(p), True) for p in parts]
+        tr = [self.ell16(self.transpose_csr(X.with_values(p)), True) for p in parts]
+        return SplitEll(fw[0], fw[1] if len(fw) > 1 else None), SplitEll(tr[0], tr[1] if len(tr) > 1 else None)
+
+    def col_moments(self, Y: torch.Tensor, a: int, b: int):
+        """(sum, sum of squares) per column over rows a .. b-1 of a dense row-major f32 / f64 block: f64 sums, one pass."""
+        assert Y.dim() == 2 and Y.is_contiguous() and Y.dtype in (torch.float32, torch.float64)
+        D = int(Y.shape[1])
+        chunks = max(1, int(self.lib.mu_dense_col_moments_chunks(b - a, D)))
+        part = self.empty((chunks, 2, D), torch.float64)
+        with self._dev_ctx():
+            check(self.lib.mu_dense_col_moments(_dt(Y),
+                                                int(a), int(b), D, _p(Y), chunks, _p(part), self._stream()))
+        s = part.sum(dim=0)
+        return s[0], s[1]
+
+    def _ell16_fill(self, X, slab_cols, sp, perm, hdr, win_base, ent):
+        with self._dev_ctx():
+            check(self.lib.mu_ell16_fill(int(perm.numel()) // 16, X.shape[1], int(slab_cols), _p(X.indices), _p(X.values),
+                                         _p(sp), _p(perm), _p(hdr), _p(win_base), _p(ent), self._stream()))
 
     def slab_ptr_width(self, X: DeviceCSR, width: int) -> torch.Tensor:
         """First entry of every row at or behind every multiple of ``width`` columns (+ the row's end)."""

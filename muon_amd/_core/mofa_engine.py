@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import math
 import os
+import time
 import warnings
 from typing import List, Optional
 
@@ -72,6 +73,9 @@ class MofaEngine:
         self.be = backend
         self.comm = default_comm(comm)
         self.T = dtype
+        # MUON_AMD_MOFA_PROFILE=1: wall time of the set-up's stages (synchronising between them) in `setup_profile`
+        self.setup_profile = [] if os.environ.get("MUON_AMD_MOFA_PROFILE", "0") == "1" else None
+        self._t_last = time.perf_counter()
         self.K = int(n_factors)
         if not (1 <= self.K <= 32):
             raise NotImplementedError("1 <= n_factors <= 32")
@@ -79,6 +83,15 @@ class MofaEngine:
                          spikeslab_weights=spikeslab_weights)
         groups = np.asarray(groups, dtype=np.int64)
         self.N = N = len(groups)
+        # the seeded host draw of the factors' initial expectations (8 ns per normal, the GIL released): on a host
+        # thread while the device works through the views
+        import threading
+
+        z0 = {}
+        nt = N if n_total is None else int(n_total)
+        th = threading.Thread(target=lambda: z0.setdefault("z", np.random.default_rng(seed).standard_normal((nt, self.K))))
+        th.start()
+        self._z0 = (th, z0)
         self.G = G = self._global_max(groups) + 1
         # samples sorted by group (stable) so that every group is a contiguous row range
         self.perm = np.argsort(groups, kind="stable")
@@ -88,9 +101,11 @@ class MofaEngine:
         self.grp = backend.to_device(gs.astype(np.int32))
         self.Ng = self._allreduce(torch.tensor([b - a for a, b in self.gslice], dtype=torch.float64))
         self.M = len(views)
+        self._mark("groups")
         self.views = [self._prepare_view(v, center_groups, scale_views, scale_groups) for v in views]
         self.Ds = [v.D for v in self.views]
         self._init_state(seed, row_offset, n_total)
+        self._mark("state")
         self._stats = {}
         self._stat_buf = {}
         self.elbo = []
@@ -104,6 +119,14 @@ class MofaEngine:
         self._eager_steps = 0
 
     # -- helpers -------------------------------------------------------------------------
+    def _mark(self, label):
+        if self.setup_profile is not None:
+            if getattr(self.be, "name", "") == "hip":
+                torch.cuda.synchronize(self.be.device)
+            now = time.perf_counter()
+            self.setup_profile.append((label, (now - self._t_last) * 1e3))
+            self._t_last = now
+
     def _global_max(self, groups):
         m = int(groups.max()) if groups.size else 0
         if self.comm.world_size > 1:
@@ -185,6 +208,9 @@ class MofaEngine:
                 if self._all_ranks(self._f32_storage_ok(scale_views, scale_groups) and v.dtype == torch.float32):
                     V.Y = v.contiguous()  # read-only from here on: no copy (see _f32_storage_ok)
                     V.implicit = True
+                elif v.dtype == T and v.is_contiguous() and not scale_views and not scale_groups:
+                    V.Y = v            # the caller's tensor, read only: the centred copy is written in ONE pass below
+                    V.alias = True     # (r04: copy, then centre in place - two more passes over the view)
                 else:
                     V.Y = v.to(T, copy=True)
         elif issparse(v):
@@ -215,6 +241,7 @@ class MofaEngine:
                 V.implicit = True
             else:
                 V.Y = self._dev(a)
+        self._mark(f"{V.kind}: values")
         V.pres = self._dev(pres.astype(np.float64))
         V.Ngm = self._allreduce(torch.tensor([float(pres[a:b].sum()) for a, b in self.gslice],
                                              dtype=torch.float64))
@@ -222,7 +249,12 @@ class MofaEngine:
         s1 = torch.zeros((G, D), dtype=T, device=V.pres.device)
         s2 = torch.zeros((G, D), dtype=T, device=V.pres.device)
         for g, (a, b) in enumerate(self.gslice):
-            if V.kind == "dense" and getattr(V, "implicit", False):
+            if V.kind == "dense" and hasattr(be, "col_moments") and V.Y.is_contiguous():
+                # one pass, f64 sums (csrc/mofa_stats.hip) - also over the f32-stored block of an f64 fit
+                if b > a:
+                    m1, m2 = be.col_moments(V.Y, a, b)
+                    s1[g], s2[g] = m1.to(T), m2.to(T)
+            elif V.kind == "dense" and getattr(V, "implicit", False):
                 for c0 in range(a, b, 16384):  # (f64 moments of the f32-stored block, a slab of rows at a time)
                     blk = V.Y[c0:min(b, c0 + 16384)].to(T)
                     s1[g] += blk.sum(dim=0)
@@ -247,6 +279,7 @@ class MofaEngine:
                 idx = V.X.indices[lo:hi].long()
                 s1[g].index_add_(0, idx, V.X.values[lo:hi])
                 s2[g].index_add_(0, idx, V.X.values[lo:hi] ** 2)
+        self._mark(f"{V.kind}: moments")
         s1 = self._allreduce(s1)
         s2 = self._allreduce(s2)
         n = V.Ngm.to(s1.device).to(T).clamp(min=1.0)[:, None]
@@ -286,11 +319,25 @@ class MofaEngine:
             yy = yy * scale[:, None] ** 2
         V.yy = yy
         V.mu = mu
+        self._mark(f"{V.kind}: scaling")
+        try:
+            return self._layout_view(V)
+        finally:
+            self._mark(f"{V.kind}: centring / layouts")
+
+    def _layout_view(self, V):
+        be, mu = self.be, V.mu
         if V.kind == "dense" and getattr(V, "implicit", False):
             V.Yt = None  # centred in the products, like the sparse views: Y stays what it was (exact in f32)
         elif V.kind == "dense":
+            # explicit centring of the dense block, one pass: y - pres mu (pres is 0 / 1: the product is exact)
+            src = V.Y
+            if getattr(V, "alias", False):
+                V.Y = torch.empty_like(src)
+                V.alias = False
             for g, (a, b) in enumerate(self.gslice):
-                V.Y[a:b] -= mu[g] * V.pres[a:b, None]  # explicit centring of the dense block
+                if b > a:
+                    torch.addcmul(src[a:b], V.pres[a:b, None], mu[g][None, :], value=-1.0, out=V.Y[a:b])
             V.Yt = None
         elif (self.T == torch.float32 and hasattr(be, "ell16") and _pad_block(self.G * self.K) == 16
               and V.X.shape[0] > 0 and V.X.shape[1] > 0 and _can_ell16(be, V.X, wide=False)):
@@ -308,8 +355,11 @@ class MofaEngine:
               and V.X.shape[0] > 0 and V.X.shape[1] > 0 and _can_ell16(be, V.X, wide=True)):
             # f64 (the reference's default precision), factor blocks of <= 16 columns: the same static layout with
             # f32 stored values - one operand when the data is exact in f32, hi + lo otherwise - against f64 blocks
-            V.Xt = be.ell16(be.transpose(V.X), wide=True)
-            V.Xs = be.ell16(V.X, wide=True)
+            if hasattr(be, "ell16_pair"):
+                V.Xs, V.Xt = be.ell16_pair(V.X, wide=True)
+            else:
+                V.Xt = be.ell16(be.transpose(V.X), wide=True)
+                V.Xs = be.ell16(V.X, wide=True)
         elif (self.T == torch.float64 and hasattr(be, "split_streams") and _pad_block(self.G * self.K) <= 32
               and V.X.shape[0] > 0 and V.X.shape[1] > 0):
             # f64 (the reference's default precision): the same row streams with f32 stored values -
@@ -323,7 +373,10 @@ class MofaEngine:
     def _init_state(self, seed, row_offset, n_total):
         K, G, T = self.K, self.G, self.T
         n_total = self.N if n_total is None else int(n_total)
-        z0 = np.random.default_rng(seed).standard_normal((n_total, K))[row_offset:row_offset + self.N]
+        th, box = self._z0
+        th.join()
+        del self._z0
+        z0 = box["z"][row_offset:row_offset + self.N]
         self.EZ = self._dev(z0[self.perm])
         self.EZ2 = self.EZ ** 2 + 1.0
         self.sig2z = torch.ones_like(self.EZ)

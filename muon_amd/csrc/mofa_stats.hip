@@ -372,3 +372,94 @@ extern "C" int mu_mofa_jaakkola(int dtype, int64_t n, const void* d_zeta, const 
   MU_CHECK_LAUNCH();
   return MU_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// per-feature first and second moments of a dense view's rows r0 .. r1-1 (the per-(group, feature) means and the yy
+// term of a fit's set-up: mofapy2 centres every view per group before training, /root/reference/muon/_core/tools.py:
+// 283-286 keeps those means as the intercepts).  One pass over the block, f64 sums whatever the storage type; a
+// workgroup = 1024 (vector loads) / 256 columns x one chunk of rows, partial[chunk][0 / 1][column] folded by the caller
+// in a fixed order.  r04 took these sums with tensor reductions: three passes and an 8 GB temporary for the squares in
+// f32, 16384-row slabs widened to f64 for the f32-stored view of an f64 fit (18 ms at 100 000 x 20 000).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_col_moments(int64_t r0, int64_t r1, int64_t D, const T* __restrict__ Y,
+                                                     int64_t rows_per_chunk, double* __restrict__ partial) {
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+  if (c >= D) return;
+  const int64_t a = r0 + (int64_t)blockIdx.y * rows_per_chunk;
+  int64_t b = a + rows_per_chunk;
+  if (b > r1) b = r1;
+  double s1[V], s2[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) s1[j] = s2[j] = 0.0;
+  struct alignas(sizeof(T) * V) Vec { T v[V]; };
+  const T* p = Y + a * D + c;
+  int64_t r = a;
+  for (; r + 4 <= b; r += 4, p += 4 * D) {
+    Vec x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const Vec*>(p + u * D);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const double y = (double)x[u].v[j];
+        s1[j] += y;
+        s2[j] = __builtin_fma(y, y, s2[j]);
+      }
+  }
+  for (; r < b; ++r, p += D) {
+    const Vec x = *reinterpret_cast<const Vec*>(p);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const double y = (double)x.v[j];
+      s1[j] += y;
+      s2[j] = __builtin_fma(y, y, s2[j]);
+    }
+  }
+  double* out = partial + (int64_t)blockIdx.y * 2 * D + c;
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    out[j] = s1[j];
+    out[D + j] = s2[j];
+  }
+}
+
+}  // namespace
+
+extern "C" int mu_dense_col_moments_chunks(int64_t n_rows, int64_t D) {
+  if (n_rows <= 0 || D <= 0) return 0;
+  const int64_t ctiles = (D + 1023) / 1024;
+  int64_t chunks = (8 * (int64_t)mu_num_cus() + ctiles - 1) / ctiles;
+  const int64_t most = (n_rows + 31) / 32;  // (at least 32 rows per chunk)
+  if (chunks > most) chunks = most;
+  if (chunks > 4096) chunks = 4096;
+  return (int)(chunks < 1 ? 1 : chunks);
+}
+
+extern "C" int mu_dense_col_moments(int dtype, int64_t r0, int64_t r1, int64_t D, const void* d_Y, int chunks,
+                                    double* d_partial, void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  MU_REQUIRE(r0 >= 0 && r1 >= r0 && D >= 0 && chunks >= 1 && chunks <= 65535, "shape");
+  if (D == 0) return MU_OK;
+  MU_REQUIRE(d_Y && d_partial, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (r1 == r0) {
+    MU_CHECK_HIP(hipMemsetAsync(d_partial, 0, sizeof(double) * 2 * (size_t)chunks * (size_t)D, st));
+    return MU_OK;
+  }
+  const int64_t rpc = (r1 - r0 + chunks - 1) / chunks;
+  const bool vec = dtype == MU_DTYPE_F32 && D % 4 == 0 && (reinterpret_cast<uintptr_t>(d_Y) & 15) == 0;
+  const int64_t per_block = vec ? 1024 : 256;
+  const dim3 grid((unsigned)((D + per_block - 1) / per_block), (unsigned)chunks);
+  if (vec)
+    hipLaunchKernelGGL((k_col_moments<float, 4>), grid, dim3(256), 0, st, r0, r1, D, (const float*)d_Y, rpc, d_partial);
+  else if (dtype == MU_DTYPE_F32)
+    hipLaunchKernelGGL((k_col_moments<float, 1>), grid, dim3(256), 0, st, r0, r1, D, (const float*)d_Y, rpc, d_partial);
+  else
+    hipLaunchKernelGGL((k_col_moments<double, 1>), grid, dim3(256), 0, st, r0, r1, D, (const double*)d_Y, rpc, d_partial);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}

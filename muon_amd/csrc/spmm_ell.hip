@@ -266,6 +266,50 @@ __global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// the layout itself (r05): CSR + its slab pointers -> windows.  A team of 16 lanes = one (group, slab): lane l is the
+// group's l-th position; per window it reads the next four entries of its row inside the slab (or padding) and writes
+// its 16 bytes of values and 8 bytes of offsets - the team's stores are the window's 256 + 128 contiguous bytes, and
+// every slot of every window is written (no memset of the padded operand).  r04 laid the operand out with a dozen
+// tensor passes over every entry (int64 ranks, destinations, two scatters): 30 ms per operand at 3.1e8 entries, the
+// larger part of a fit's set-up.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ell16_fill(int64_t n_groups, int64_t S, int32_t col_mask, int row_shift,
+                                                    const int32_t* __restrict__ indices,
+                                                    const float* __restrict__ values,
+                                                    const int64_t* __restrict__ sp, const int32_t* __restrict__ perm,
+                                                    const int32_t* __restrict__ hdr,
+                                                    const int64_t* __restrict__ win_base,
+                                                    unsigned char* __restrict__ ent) {
+  const int l = threadIdx.x & 15;
+  const int64_t teams = n_groups * S;
+  for (int64_t team = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; team < teams;
+       team += ((int64_t)gridDim.x * blockDim.x) >> 4) {
+    const int64_t g = team / S, sl = team - g * S;
+    const int32_t row = perm[16 * g + l];
+    int64_t lo = 0, hi = 0;
+    if (row >= 0) {
+      lo = sp[(int64_t)row * (S + 1) + sl];
+      hi = sp[(int64_t)row * (S + 1) + sl + 1];
+    }
+    const int32_t nw = hdr[team];
+    unsigned char* out = ent + win_base[team] * 384;
+    for (int32_t w = 0; w < nw; ++w, lo += 4, out += 384) {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      unsigned short o[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (lo + j < hi) {
+          v[j] = values[lo + j];
+          o[j] = (unsigned short)((indices[lo + j] & col_mask) << row_shift);
+        }
+      *reinterpret_cast<float4*>(out + 16 * l) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<uint2*>(out + 256 + 8 * l) =
+          make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -325,6 +369,25 @@ int mu_spmm_ell16_f64(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d
                       const void* d_ent, const int32_t* d_perm, const double* d_Q, double* d_Y, int accumulate,
                       void* stream) {
   return ell16_launch(true, waves, n_pos, n_cols, d_hdr, d_wave_base, d_ent, d_perm, d_Q, d_Y, accumulate, stream);
+}
+
+int mu_ell16_fill(int64_t n_groups, int64_t n_cols, int slab_cols, const int32_t* d_indices, const float* d_values,
+                  const int64_t* d_slab_ptr, const int32_t* d_perm, const int32_t* d_hdr, const int64_t* d_win_base,
+                  void* d_ent, void* stream) {
+  if (slab_cols != 1024 && slab_cols != 512) return MU_ERR_ARG;
+  if (n_groups < 0 || n_cols < 0) return MU_ERR_ARG;
+  const int64_t S = (n_cols + slab_cols - 1) / slab_cols;
+  const int64_t teams = n_groups * S;
+  if (teams == 0) return MU_OK;
+  if (!d_indices || !d_values || !d_slab_ptr || !d_perm || !d_hdr || !d_win_base || !d_ent) return MU_ERR_ARG;
+  int64_t blocks = (teams + 15) / 16;
+  const int64_t cap = (int64_t)mu_num_cus() * 64;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_ell16_fill, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_groups, S,
+                     (int32_t)(slab_cols - 1), slab_cols == 1024 ? 6 : 7, d_indices, d_values, d_slab_ptr, d_perm, d_hdr,
+                     d_win_base, static_cast<unsigned char*>(d_ent));
+  MU_CHECK_LAUNCH();
+  return MU_OK;
 }
 
 }  // extern "C"

@@ -129,3 +129,43 @@ def test_refusals_and_long_rows(be):
     got = be.to_host(be.spmm(ell16_layout(_upload(be, dense)), Q)).astype(np.float64)
     want = dense.toarray().astype(np.float64) @ be.to_host(Q).astype(np.float64)
     assert np.max(np.abs(got - want)) < 1e-5 * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("shape", [(16, 40), (257, 1025), (1000, 5000), (4099, 3000), (3, 2100)])
+@pytest.mark.parametrize("slab", [1024, 512])
+def test_layout_kernel_writes_the_windows_of_the_tensor_layout(be, shape, slab):
+    """mu_ell16_fill (one pass, a team of 16 lanes per (group, slab)) against the layout as tensor operations -
+    the specification tests/test_ell_layout.py holds against a pure-Python restatement: the same bytes."""
+    from muon_amd._backend import ell16_layout
+
+    n, d = shape
+    if n == 3:
+        m = sp.csr_matrix(np.arange(1, n * d + 1, dtype=np.float32).reshape(n, d) / 64)
+    else:
+        m = _ragged(n, d, seed=n + slab)
+    X = _upload(be, m)
+    want = ell16_layout(X, 15, slab)
+    got = ell16_layout(X, 15, slab, be.slab_ptr_width, be._ell16_fill)
+    assert torch.equal(got.hdr, want.hdr) and torch.equal(got.wave_base, want.wave_base)
+    assert torch.equal(got.perm, want.perm) and got.slots == want.slots
+    assert got.ent.shape == want.ent.shape and torch.equal(got.ent, want.ent)
+
+
+def test_layout_pair_of_an_f64_valued_view(be):
+    """ell16_pair: both operands of an f64 fit from the tile-staged transposition of the hi (and lo) parts."""
+    n, d = 3000, 2500
+    m = _ragged(n, d, seed=5).astype(np.float64)
+    for inexact in (False, True):
+        if inexact:
+            m.data = m.data * (1.0 + 2.0 ** -40)
+        X = be.upload_csr(m.indptr, m.indices, m.data, m.shape, values_dtype=np.float64)
+        Xs, Xt = be.ell16_pair(X, wide=True)
+        assert (Xs.lo is not None) == inexact and (Xt.lo is not None) == inexact
+        Q = torch.randn(d, 16, device=be.device, dtype=torch.float64)
+        Z = torch.randn(n, 16, device=be.device, dtype=torch.float64)
+        a = be.to_host(be.spmm(Xs, Q))
+        b = be.to_host(be.spmm(Xt, Z))
+        wa = m @ be.to_host(Q)
+        wb = m.T @ be.to_host(Z)
+        assert np.max(np.abs(a - wa)) < 1e-11 * np.max(np.abs(wa))
+        assert np.max(np.abs(b - wb)) < 1e-11 * np.max(np.abs(wb))

@@ -377,3 +377,41 @@ def test_poisson_passes_without_the_dense_chunk(dt, tol, K):
     # deterministic
     again = be.mofa_poisson_pass(0, Zd, Wd, kd, X)
     assert torch.equal(again, got[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("shape", [(1, 1), (37, 5), (1000, 1024), (4099, 2052), (513, 1027)])
+def test_dense_column_moments_kernel(hip, dtype, shape):
+    """mu_dense_col_moments (the group means / sums of squares of a fit's set-up) against numpy f64 on the same values:
+    row ranges off the chunking, column counts off the vector width, empty ranges."""
+    n, D = shape
+    g = torch.Generator(device="cuda").manual_seed(n + D)
+    Y = (torch.randn((n, D), generator=g, device="cuda", dtype=torch.float64) * 3 + 1).to(dtype)
+    host = hip.to_host(Y).astype(np.float64)
+    for a, b in ((0, n), (n // 3, n - n // 5), (n // 2, n // 2)):
+        s1, s2 = hip.col_moments(Y, a, b)
+        assert s1.dtype == torch.float64 and s1.shape == (D,)
+        w1, w2 = host[a:b].sum(axis=0), (host[a:b] ** 2).sum(axis=0)
+        assert np.max(np.abs(hip.to_host(s1) - w1)) <= 1e-13 * max(1.0, np.max(np.abs(host)) * (b - a))
+        assert np.max(np.abs(hip.to_host(s2) - w2)) <= 1e-13 * max(1.0, np.max(host ** 2) * (b - a))
+    again = hip.col_moments(Y, 0, n)
+    assert torch.equal(again[0], hip.col_moments(Y, 0, n)[0])  # fixed-order fold: bit-reproducible
+
+
+def test_device_resident_dense_view_is_not_modified_and_centred_once(hip):
+    """A device-resident dense view of the fit's own type is read in place (no copy, one centring pass): the caller's
+    tensor keeps its values and the fit equals the fit of a host copy of it."""
+    from muon_amd._core.mofa_engine import MofaEngine
+
+    n, D = 600, 96
+    g = torch.Generator(device="cuda").manual_seed(3)
+    Y = torch.randn((n, D), generator=g, device="cuda", dtype=torch.float64) + 2.0
+    keep = Y.clone()
+    groups = np.zeros(n, dtype=np.int64)
+    a = MofaEngine(hip, [Y], groups, 4, dtype=torch.float64, seed=1)
+    b = MofaEngine(hip, [hip.to_host(keep) * (1.0 + 2.0 ** -30)], groups, 4, dtype=torch.float64, seed=1)  # (not exact in f32)
+    assert torch.equal(Y, keep)
+    for _ in range(3):
+        a.step()
+        b.step()
+    assert abs(a.elbo[-1] - b.elbo[-1]) <= 1e-6 * abs(b.elbo[-1])
