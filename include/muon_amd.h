@@ -294,7 +294,7 @@ int mu_spmm_ell16_f64(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d
  * of every (group, slab): the exclusive scan of d_hdr) as the product reads them, made by the caller from the slab
  * pointers (rows by descending length, the longest row of a group per slab).  Writes every slot of every window
  * (padding included); the eight windows of slack behind them are the caller's to zero. */
-int mu_ell16_fill(int64_t n_groups, int64_t n_cols, int slab_cols, const int32_t* d_indices, const float* d_values,
+int mu_ell16_fill(int64_t n_groups, int64_t n_cols, int64_t nnz, int slab_cols, const int32_t* d_indices, const float* d_values,
                   const int64_t* d_slab_ptr, const int32_t* d_perm, const int32_t* d_hdr, const int64_t* d_win_base,
                   void* d_ent, void* stream);
 

@@ -141,6 +141,69 @@ def _copy_array(a: np.ndarray) -> np.ndarray:
     return out
 
 
+def torch_f32():
+    import torch
+
+    return torch.float32
+
+
+def _refs_seen(obj) -> int:
+    import sys
+
+    return sys.getrefcount(obj)
+
+
+class _Box:
+    pass
+
+
+def _calibrate_refs():
+    """What _refs_seen reports for an object held by ONE container attribute, (a) passed as an attribute lookup and
+    (b) passed from a local variable: the interpreter's own references during the call, measured, not assumed."""
+    b = _Box()
+    b.x = np.empty(1)
+    a = _refs_seen(b.x)
+    loc = b.x
+    return a, _refs_seen(loc) - 1
+
+
+def _dies_with_rebinding(m, held_by_caller: int) -> bool:
+    """True when host CSR ``m`` and its three arrays are referenced by NOTHING but the container attribute the caller is
+    about to rebind (plus ``held_by_caller`` local names of the caller): the result may then take the matrix's index
+    arrays over and be downloaded into its value array - nobody can observe the difference, and a 250 000 x 200 000
+    experiment saves a 6 GB copy, 12 GB of first-touch page faults and the release of the 12 GB it replaces (34 ms per GB
+    on the bench host: 430 of the API path's 1090 ms, profiles/r05_api_profile.txt).  Anything else that holds the
+    matrix or one of its arrays - ``adata.layers["counts"] = adata.X``, a view, a variable of the user's - counts as a
+    reference and turns this off.  The reference rebinds ``adata.X`` to a new matrix (preproc.py:121-127); an owner
+    of the old one must keep seeing the counts."""
+    import os
+
+    if os.environ.get("MUON_AMD_REUSE_HOST", "1") == "0" or type(m) is not csr_matrix:
+        return False
+    attr, local = _calibrate_refs()
+    # (+ 2: this function's own name for the matrix and the caller's stack slot of the call)
+    if _refs_seen(m) != local + held_by_caller + 2:
+        return False
+    for name in ("data", "indices", "indptr"):
+        a = m.__dict__.get(name)
+        if type(a) is not np.ndarray or not a.flags.writeable or not a.flags.c_contiguous or a.ndim != 1:
+            return False
+        if a.base is not None:
+            # scipy's constructors leave `indices[:nnz]`-style views behind: a view of an array that owns its memory
+            # and that nothing but the view refers to is as good as that array
+            b = a.base
+            ok = type(b) is np.ndarray and b.base is None and b.flags.owndata and b.flags.writeable
+            b = None
+            if not ok or _refs_seen(a.base) != attr:
+                return False
+        elif not a.flags.owndata:
+            return False
+        a = None
+        if _refs_seen(getattr(m, name)) != attr:
+            return False
+    return True
+
+
 def _fingerprint(m: csr_matrix):
     """Identity of a host CSR: shape, dtype and a hash of EVERY byte of data, indices and indptr.
     Any in-place edit between two calls - a single entry, a permuted index array - invalidates the
@@ -397,10 +460,33 @@ def tfidf(
     R = tfidf_device(backend, X, n_obs, flags, _effective_scale(scale_factor), comm=comm,
                      emit_stream=keep_on_device and not (match_scipy_order and log_tf and not log_tfidf))
 
-    vals = backend.to_host(R.values)
-    if host is not None and R.indices is X.indices:
+    shares = host is not None and R.indices is X.indices
+    # the matrix this call replaces, when nothing else can see it (or a canonicalised temporary of this call): the
+    # result takes its index arrays and is downloaded into its value array - see _dies_with_rebinding
+    if shares and host is not counts:  # a canonicalised temporary (canonical_csr copies before it sorts / sums / widens)
+        own = not any(np.may_share_memory(getattr(host, k), getattr(counts, k)) for k in ("data", "indices", "indptr")
+                      if isinstance(getattr(counts, k, None), np.ndarray))
+    else:
+        own = (shares and inplace and to_layer is None and from_layer is None and not copy
+               and _dies_with_rebinding(counts, 2))
+    if own:
+        want = np.dtype(np.float32) if R.values.dtype == torch_f32() else np.dtype(np.float64)
+        buf = host.data if host.data.dtype == want else (host.data.view(want) if host.data.dtype.itemsize == want.itemsize
+                                                         else None)
+        vals = backend.to_host(R.values, out=buf) if buf is not None and buf.shape == (int(R.values.numel()),) else \
+            backend.to_host(R.values)
+        res = csr_matrix((vals, host.indices, host.indptr), shape=host.shape, copy=False)
+        if host is counts:
+            # the fingerprint of the device copy attached to the old matrix describes values that are gone
+            try:
+                delattr(counts, DEVICE_ATTR)
+            except Exception:  # noqa: BLE001
+                pass
+    elif shares:
+        vals = backend.to_host(R.values)
         res = csr_matrix((vals, _copy_array(host.indices), host.indptr.copy()), shape=host.shape)
     else:  # explicit zeros were dropped on the device, or the CSR only ever existed there
+        vals = backend.to_host(R.values)
         ip = backend.to_host(R.indptr)
         if host is not None:
             ip = ip.astype(host.indptr.dtype)

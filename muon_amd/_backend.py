@@ -343,21 +343,31 @@ class HipBackend:
         copy_stream.synchronize()  # the staging buffers are reused by the next call
         return out
 
-    def to_host(self, t: torch.Tensor) -> np.ndarray:
+    def to_host(self, t: torch.Tensor, out: Optional[np.ndarray] = None) -> np.ndarray:
         """Device tensor -> host array.  Big 1-d tensors (the TF-IDF values of a whole experiment are GBs) come down
         through the pinned staging buffers of the upload path, chunk by chunk, a few host threads copying one chunk
         out while the next is on the bus: `.cpu()` on pageable memory ran at 11 GB/s in the API benchmark (r04,
         `bench.py --workload c3_api`)."""
         t = t.detach()
+        if out is not None:
+            # into the caller's array (pages that exist already: a fresh 6 GB array costs 225 ms of first-touch faults
+            # on top of its bytes - scripts/probes/host_alloc_probe.py)
+            want = torch.empty((0,), dtype=t.dtype).numpy().dtype
+            if out.dtype != want or out.shape != tuple(t.shape) or not out.flags.c_contiguous or not out.flags.writeable:
+                raise TypeError("to_host(out=): a writeable contiguous array of the tensor's shape and type")
         if t.ndim == 1 and t.is_cuda and t.is_contiguous() and t.numel() * t.element_size() >= self._UPLOAD_PIPELINE_MIN:
-            return self._download_pipelined(t)
+            return self._download_pipelined(t, out)
+        if out is not None:
+            np.copyto(out, t.cpu().numpy())
+            return out
         return t.cpu().numpy()
 
-    def _download_pipelined(self, t: torch.Tensor) -> np.ndarray:
+    def _download_pipelined(self, t: torch.Tensor, out: Optional[np.ndarray] = None) -> np.ndarray:
         from concurrent.futures import ThreadPoolExecutor
 
         n = t.numel()
-        out = np.empty((n,), dtype=torch.empty((0,), dtype=t.dtype).numpy().dtype)
+        if out is None:
+            out = np.empty((n,), dtype=torch.empty((0,), dtype=t.dtype).numpy().dtype)
         item = t.element_size()
         per = max(1, self._UPLOAD_CHUNK // item)
         st = self.__dict__.get("_upload_state")
@@ -906,7 +916,7 @@ class HipBackend:
 
     def _ell16_fill(self, X, slab_cols, sp, perm, hdr, win_base, ent):
         with self._dev_ctx():
-            check(self.lib.mu_ell16_fill(int(perm.numel()) // 16, X.shape[1], int(slab_cols), _p(X.indices), _p(X.values),
+            check(self.lib.mu_ell16_fill(int(perm.numel()) // 16, X.shape[1], X.nnz, int(slab_cols), _p(X.indices), _p(X.values),
                                          _p(sp), _p(perm), _p(hdr), _p(win_base), _p(ent), self._stream()))
 
     def slab_ptr_width(self, X: DeviceCSR, width: int) -> torch.Tensor:

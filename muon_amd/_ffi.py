@@ -90,7 +90,7 @@ SIGNATURES = {
     "mu_spmm_ell16_waves": (C.c_int, [_i64]),
     "mu_dense_col_moments_chunks": (C.c_int, [_i64, _i64]),
     "mu_dense_col_moments": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _i32, _vp, _vp]),
-    "mu_ell16_fill": (C.c_int, [_i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mu_ell16_fill": (C.c_int, [_i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_spmm_ell16_f32": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_spmm_ell16_f64": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "mu_probe_tr16": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),

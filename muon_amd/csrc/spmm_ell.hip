@@ -274,7 +274,10 @@ __global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_
 // tensor passes over every entry (int64 ranks, destinations, two scatters): 30 ms per operand at 3.1e8 entries, the
 // larger part of a fit's set-up.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ell16_fill(int64_t n_groups, int64_t S, int32_t col_mask, int row_shift,
+struct __attribute__((packed, aligned(4))) U4 { int32_t v[4]; };
+struct __attribute__((packed, aligned(4))) F4 { float v[4]; };
+
+__global__ __launch_bounds__(256) void k_ell16_fill(int64_t n_groups, int64_t S, int64_t nnz, int32_t col_mask, int row_shift,
                                                     const int32_t* __restrict__ indices,
                                                     const float* __restrict__ values,
                                                     const int64_t* __restrict__ sp, const int32_t* __restrict__ perm,
@@ -297,12 +300,29 @@ __global__ __launch_bounds__(256) void k_ell16_fill(int64_t n_groups, int64_t S,
     for (int32_t w = 0; w < nw; ++w, lo += 4, out += 384) {
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       unsigned short o[4] = {0, 0, 0, 0};
+      if (lo < hi) {
+        int32_t ci[4];
+        float cv[4];
+        if (lo + 4 <= nnz) {  // four entries in two loads (4-byte aligned: fine for global memory); what lies behind
+          const U4 a = *reinterpret_cast<const U4*>(indices + lo);  // the row's end in them is masked below
+          const F4 b = *reinterpret_cast<const F4*>(values + lo);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (lo + j < hi) {
-          v[j] = values[lo + j];
-          o[j] = (unsigned short)((indices[lo + j] & col_mask) << row_shift);
+          for (int j = 0; j < 4; ++j) ci[j] = a.v[j], cv[j] = b.v[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool in = lo + j < hi;
+            ci[j] = in ? indices[lo + j] : 0;
+            cv[j] = in ? values[lo + j] : 0.f;
+          }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (lo + j < hi) {
+            v[j] = cv[j];
+            o[j] = (unsigned short)((ci[j] & col_mask) << row_shift);
+          }
+      }
       *reinterpret_cast<float4*>(out + 16 * l) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<uint2*>(out + 256 + 8 * l) =
           make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
@@ -371,7 +391,7 @@ int mu_spmm_ell16_f64(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d
   return ell16_launch(true, waves, n_pos, n_cols, d_hdr, d_wave_base, d_ent, d_perm, d_Q, d_Y, accumulate, stream);
 }
 
-int mu_ell16_fill(int64_t n_groups, int64_t n_cols, int slab_cols, const int32_t* d_indices, const float* d_values,
+int mu_ell16_fill(int64_t n_groups, int64_t n_cols, int64_t nnz, int slab_cols, const int32_t* d_indices, const float* d_values,
                   const int64_t* d_slab_ptr, const int32_t* d_perm, const int32_t* d_hdr, const int64_t* d_win_base,
                   void* d_ent, void* stream) {
   if (slab_cols != 1024 && slab_cols != 512) return MU_ERR_ARG;
@@ -383,7 +403,7 @@ int mu_ell16_fill(int64_t n_groups, int64_t n_cols, int slab_cols, const int32_t
   int64_t blocks = (teams + 15) / 16;
   const int64_t cap = (int64_t)mu_num_cus() * 64;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(k_ell16_fill, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_groups, S,
+  hipLaunchKernelGGL(k_ell16_fill, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_groups, S, nnz,
                      (int32_t)(slab_cols - 1), slab_cols == 1024 ? 6 : 7, d_indices, d_values, d_slab_ptr, d_perm, d_hdr,
                      d_win_base, static_cast<unsigned char*>(d_ent));
   MU_CHECK_LAUNCH();

@@ -27,7 +27,10 @@ class CpuTestBackend:
     def to_device(self, arr, dtype=None):
         return torch.as_tensor(np.ascontiguousarray(arr, dtype=dtype)).clone()
 
-    def to_host(self, t):
+    def to_host(self, t, out=None):
+        if out is not None:
+            np.copyto(out, t.detach().numpy())
+            return out
         return t.detach().numpy().copy()
 
     def fetch_async(self, tensors):

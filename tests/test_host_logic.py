@@ -370,3 +370,72 @@ def test_lsi_pipelined_expansions_give_the_same_answer(monkeypatch, n_comps, max
     assert lsi_oracle.max_subspace_angle(a[1], b[1]) < 2e-5
     np.testing.assert_allclose(a[0], b[0], rtol=1e-6)
     assert a[2]["spmm_unused"] <= 1 and b[2]["spmm_unused"] <= 2  # the pipelined loop runs ahead by two products
+
+
+def _big_counts(seed=0):
+    m = sp.random(400, 300, density=0.1, format="csr", dtype=np.float32, random_state=seed)
+    m.data = np.floor(m.data * 8 + 1).astype(np.float32)
+    return m.copy()
+
+
+def test_tfidf_takes_the_replaced_matrix_over_only_when_nothing_else_sees_it(monkeypatch):
+    """`adata.X = tf_idf` (preproc.py:121-127) leaves the old matrix to its other owners.  When there are none, the
+    result reuses its index arrays and value buffer (no 6 GB copy / first touch / release at scale); an owner -
+    `layers["counts"] = adata.X`, a variable, a view of one of the arrays - keeps seeing the counts."""
+    ref = AnnData(_big_counts())
+    monkeypatch.setenv("MUON_AMD_REUSE_HOST", "0")
+    ac.pp.tfidf(ref, backend=BE)
+    monkeypatch.delenv("MUON_AMD_REUSE_HOST")
+
+    ad = AnnData(_big_counts())
+    where = (ad.X.data.ctypes.data, ad.X.indices.ctypes.data, ad.X.indptr.ctypes.data)
+    ac.pp.tfidf(ad, backend=BE)
+    assert (ad.X.data.ctypes.data, ad.X.indices.ctypes.data, ad.X.indptr.ctypes.data) == where  # taken over
+    assert (ad.X != ref.X).nnz == 0 and np.array_equal(ad.X.data, ref.X.data)
+    ac.tl.lsi(ad, n_comps=5, backend=BE)  # the attached device copy describes the new values
+
+    for how in ("layer", "variable", "array", "view", "shared arrays"):
+        ad = AnnData(_big_counts())
+        counts = ad.X.copy()
+        where = ad.X.data.ctypes.data
+        if how == "layer":
+            ad.layers["counts"] = ad.X
+            seen = lambda: ad.layers["counts"]  # noqa: E731
+        elif how == "variable":
+            keep = ad.X
+            seen = lambda: keep  # noqa: E731
+        elif how == "array":
+            arr = ad.X.data
+            seen = lambda: sp.csr_matrix((arr, counts.indices, counts.indptr), shape=counts.shape)  # noqa: E731
+        elif how == "view":
+            v = ad.X.data[:10]
+            seen = lambda: sp.csr_matrix((v.base if v.base is not None and v.base.shape == counts.data.shape else  # noqa: E731
+                                          np.concatenate([v, counts.data[10:]]), counts.indices, counts.indptr), shape=counts.shape)
+        else:
+            other = sp.csr_matrix((ad.X.data, ad.X.indices, ad.X.indptr), shape=ad.X.shape)
+            seen = lambda: other  # noqa: E731
+        ac.pp.tfidf(ad, backend=BE)
+        assert ad.X.data.ctypes.data != where, how
+        assert np.array_equal(ad.X.data, ref.X.data), how
+        assert (seen() != counts).nnz == 0, how  # the other owner still holds the counts
+
+    # not in place / into a layer / from a layer: the counts stay where they are
+    ad = AnnData(_big_counts())
+    counts = ad.X.copy()
+    res = ac.pp.tfidf(ad, inplace=False, backend=BE)
+    assert (ad.X != counts).nnz == 0 and np.array_equal(res.data, ref.X.data)
+    ac.pp.tfidf(ad, to_layer="tfidf", backend=BE)
+    assert (ad.X != counts).nnz == 0 and np.array_equal(ad.layers["tfidf"].data, ref.X.data)
+
+    # unsorted input: the canonicalised temporary of the call is the result's (and the caller's matrix is untouched)
+    ad = AnnData(_big_counts())
+    perm = np.arange(ad.X.nnz)
+    for r in range(ad.X.shape[0]):
+        lo, hi = ad.X.indptr[r], ad.X.indptr[r + 1]
+        perm[lo:hi] = perm[lo:hi][::-1]
+    shuffled = sp.csr_matrix((ad.X.data[perm], ad.X.indices[perm], ad.X.indptr.copy()), shape=ad.X.shape)
+    keep = shuffled.copy()
+    ad2 = AnnData(shuffled)
+    ac.pp.tfidf(ad2, backend=BE)
+    assert np.array_equal(ad2.X.data, ref.X.data) and np.array_equal(ad2.X.indices, ref.X.indices)
+    assert np.array_equal(shuffled.data, keep.data) and np.array_equal(shuffled.indices, keep.indices)
