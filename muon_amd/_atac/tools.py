@@ -313,16 +313,18 @@ def _lsi_device(
     if (start is None and warm_spec != "0" and pack and not mfma and n_iter is None and hasattr(Xcsr, "indptr")
             and hasattr(backend, "stream_both")):
         frac, qsteps = (int(v) for v in (warm_spec.split(":") + ["2"])[:2])
-        # this rank's slice: 1 / frac of its cells, at least 16 384 (a shard of a few 1e5 cells still gets a slice whose
-        # top subspace means something), at most a quarter, whole 512-row blocks
-        n_s = min(max(n_local // max(frac, 1), 16384), n_local // 4)
+        # this rank's slice: 1 / frac of its cells; the slices of ALL ranks together at least 16 384 cells (an experiment
+        # of a few 1e5 cells still gets a slice whose top subspace means something - but eight ranks with 125 000 cells
+        # each need 2 048 apiece for that, not 16 384), at most a quarter, whole 512-row blocks
+        floor_rows = -(-16384 * n_local // max(int(n_obs), 1))
+        n_s = min(max(n_local // max(frac, 1), floor_rows), n_local // 4)
         n_s = (n_s // 512) * 512
         if comm.agree(qsteps >= 1 and comm.sum_scalar(n_s) >= 8192):  # (all ranks take part in the collectives or none does)
             Ss = St = None
             if n_s > 0:
                 # the slice = 16 row ranges spread evenly over this rank's cells (files list cells sample by sample:
                 # the FIRST n_s cells may be one batch; a start from an odd slice costs an expansion, never the answer)
-                chunks = 16 if n_s >= 16 * 512 else 1
+                chunks = 16 if n_s >= 2048 else 1  # (n_s is a multiple of 512: ranges of >= 128 rows)
                 per = n_s // chunks
                 starts = [c * (n_local // chunks) for c in range(chunks)]
                 ip = Xcsr.indptr
