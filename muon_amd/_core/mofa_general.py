@@ -112,6 +112,20 @@ class GeneralMofaEngine:
         self.alpha_z = torch.ones((G, K), dtype=torch.float64, device=self.dev)
         self.lalpha_z = torch.zeros((G, K), dtype=torch.float64, device=self.dev)
         self.elbo = []
+        self._Ng_dev = self.Ng.to(self.dev)  # (resident: an iteration has no host -> device copies)
+        # One iteration is ~400 short launches (chunk passes of the masked / bernoulli views, the K x K algebra of the
+        # tau / alpha / theta / ELBO terms).  Every expectation is updated in place (r04 rebound alpha / theta), so the
+        # iteration CAN be captured into a HIP graph and replayed - MUON_AMD_MOFA_NG_GRAPH=1, bit-identical to eager
+        # launches (tests/test_gpu_mofa.py) - but it is off by default: measured at 20 000 x 22 000 the replay takes
+        # 5.29 ms against 5.33 ms eager (scripts/probes/mofa_ng_graph_probe.py) and the capture costs 16 ms once.  The
+        # 3 ms next to the poisson passes' 2 ms are not host launches: ~400 kernels of 2-20 us with the device's own
+        # dispatch gap between them, replayed or not.  Fewer kernels (the masked gaussian view's chunk passes and the
+        # tau / alpha / theta algebra fused as in MofaEngine) is what would move it.
+        self._graph = None
+        self._graph_elbo = None
+        self._graph_ok = (getattr(backend, "name", "") == "hip" and self.comm.world_size == 1
+                          and os.environ.get("MUON_AMD_MOFA_NG_GRAPH", "0") == "1")
+        self._eager_steps = 0
 
     # -- collectives ------------------------------------------------------------------------------
     def _on_comm_device(self, t):
@@ -444,23 +458,25 @@ class GeneralMofaEngine:
             if o["ard_weights"]:
                 a = torch.full((K,), A0 + 0.5 * V.D, dtype=f64, device=self.dev)
                 b = B0 + 0.5 * EWh2.sum(dim=0)
-                Wm.alpha, Wm.lalpha = a / b, torch.digamma(a) - torch.log(b)
+                Wm.alpha.copy_(a / b)  # (in place, like every expectation: the iteration replays as a HIP graph)
+                Wm.lalpha.copy_(torch.digamma(a) - torch.log(b))
             if o["spikeslab_weights"]:
                 sg = gam.sum(dim=0)
                 a, b = TH_A0 + sg, TH_B0 + V.D - sg
-                Wm.lth = torch.digamma(a) - torch.digamma(a + b)
-                Wm.l1mth = torch.digamma(b) - torch.digamma(a + b)
+                Wm.lth.copy_(torch.digamma(a) - torch.digamma(a + b))
+                Wm.l1mth.copy_(torch.digamma(b) - torch.digamma(a + b))
         # factors: per-group sums over this rank's samples, added up over the ranks
         zs = torch.zeros((G, 2, K), dtype=f64, device=self.dev)
         for g, (a0, b0) in enumerate(self.gslice):
             zs[g, 0] = self.EZ2[a0:b0].to(f64).sum(dim=0)
             zs[g, 1] = torch.log(self.sig2z[a0:b0].to(f64)).sum(dim=0)
         zs = self._allreduce(zs)
-        Ng = self.Ng.to(self.dev)
+        Ng = self._Ng_dev
         if o["ard_factors"]:
             a = (A0 + 0.5 * Ng)[:, None].expand(G, K)
             b = B0 + 0.5 * zs[:, 0]
-            self.alpha_z, self.lalpha_z = a / b, torch.digamma(a) - torch.log(b)
+            self.alpha_z.copy_(a / b)
+            self.lalpha_z.copy_(torch.digamma(a) - torch.log(b))
         # ---- prior / entropy terms (the same expressions as oracle run()) ----------------------------------
         elbo = lik
         for m, (V, Wm) in enumerate(zip(self.views, self.W)):
@@ -491,13 +507,38 @@ class GeneralMofaEngine:
         return elbo
 
     # -- driver ----------------------------------------------------------------------------------------
-    def step(self):
-        # (no HIP graph here: the updates REBIND the expectation tensors - a replay would read the buffers of the
-        #  captured iteration's inputs again; MofaEngine updates in place and is captured.  Tried in r04, reverted.)
+    def _iteration(self) -> torch.Tensor:
         for m in range(self.M):
             self._update_w(m)
         self._update_z()
-        e = float(self._update_rest_and_elbo().item())
+        return self._update_rest_and_elbo()
+
+    def _capture(self):
+        torch.cuda.synchronize(self.be.device)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g):
+                out = self._iteration()
+        except Exception as e:  # capture refused (a path that asks the device a question): stay eager
+            import warnings
+
+            warnings.warn(f"MOFA iteration not captured into a HIP graph ({e}); running eagerly")
+            self._graph_ok = False
+            torch.cuda.synchronize(self.be.device)
+            return
+        self._graph, self._graph_elbo = g, out
+
+    def step(self):
+        # (two eager iterations first: they answer the once-per-fit questions - which chunks hold every sample - and
+        #  warm the allocator)
+        if self._graph is None and self._graph_ok and self._eager_steps >= 2:
+            self._capture()
+        if self._graph is not None:
+            self._graph.replay()
+            e = float(self._graph_elbo.item())
+        else:
+            e = float(self._iteration().item())
+            self._eager_steps += 1
         self.elbo.append(e)
         return e
 

@@ -415,3 +415,27 @@ def test_device_resident_dense_view_is_not_modified_and_centred_once(hip):
         a.step()
         b.step()
     assert abs(a.elbo[-1] - b.elbo[-1]) <= 1e-6 * abs(b.elbo[-1])
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_general_engine_replayed_iteration_equals_eager(hip, dt, monkeypatch):
+    """The general engine's iteration as a HIP graph (MUON_AMD_MOFA_NG_GRAPH=1: every expectation updated in place;
+    captured after two eager iterations) against the same fit run eagerly: the same numbers, iteration by iteration - gaussian view with NaN,
+    fused sparse poisson view, bernoulli view, two groups."""
+    from muon_amd._core.mofa_general import GeneralMofaEngine
+    from tests.test_mofa_host import _mixed_views
+
+    _, y1, y2, y3 = _mixed_views(n=500, seed=4)
+    groups = np.random.default_rng(2).integers(0, 2, 500)
+    liks = ["gaussian", "poisson", "bernoulli"]
+    runs = []
+    for graph in ("0", "1"):
+        monkeypatch.setenv("MUON_AMD_MOFA_NG_GRAPH", graph)
+        eng = GeneralMofaEngine(hip, [y1, sp.csr_matrix(y2), y3], liks, groups, 5, seed=1, dtype=dt)
+        for _ in range(7):
+            eng.step()
+        assert (eng._graph is not None) == (graph == "1")
+        runs.append((list(eng.elbo), eng.results(sort_factors=False)))
+    (e0, r0), (e1, r1) = runs
+    assert e0 == e1
+    assert np.array_equal(r0["Z"], r1["Z"]) and all(np.array_equal(a, b) for a, b in zip(r0["W"], r1["W"]))
