@@ -94,6 +94,11 @@ class GeneralMofaEngine:
         self.EZ2 = self.EZ ** 2 + 1.0
         self.sig2z = torch.ones_like(self.EZ)
         c = float(torch.digamma(torch.tensor(1.0, dtype=torch.float64)) - torch.digamma(torch.tensor(2.0, dtype=torch.float64)))
+        # the alpha / theta / factor-ARD nodes and their ELBO terms: the fused kernels of MofaEngine (csrc/mofa_elbo.hip -
+        # the same equations; ~170 tensor launches per iteration otherwise) keep these nodes in the fit's type
+        self._fused_small = (hasattr(backend, "mofa_w_elbo") and hasattr(backend, "mofa_z_elbo") and K <= 32
+                             and os.environ.get("MUON_AMD_MOFA_NG_FUSED_SMALL", "1") != "0")
+        ST = dtype if self._fused_small else torch.float64
         self.W = []
         for D in self.Ds:
             w = _GView()
@@ -104,13 +109,16 @@ class GeneralMofaEngine:
             w.sig2 = torch.ones((D, K), dtype=dtype, device=self.dev)
             w.tau = torch.ones((G, D), dtype=dtype, device=self.dev)
             w.ltau = torch.zeros((G, D), dtype=dtype, device=self.dev)
-            w.alpha = torch.ones((K,), dtype=torch.float64, device=self.dev)
-            w.lalpha = torch.zeros((K,), dtype=torch.float64, device=self.dev)
-            w.lth = torch.full((K,), c, dtype=torch.float64, device=self.dev)
-            w.l1mth = torch.full((K,), c, dtype=torch.float64, device=self.dev)
+            w.alpha = torch.ones((K,), dtype=ST, device=self.dev)
+            w.lalpha = torch.zeros((K,), dtype=ST, device=self.dev)
+            w.lth = torch.full((K,), c, dtype=ST, device=self.dev)
+            w.l1mth = torch.full((K,), c, dtype=ST, device=self.dev)
             self.W.append(w)
-        self.alpha_z = torch.ones((G, K), dtype=torch.float64, device=self.dev)
-        self.lalpha_z = torch.zeros((G, K), dtype=torch.float64, device=self.dev)
+        self.alpha_z = torch.ones((G, K), dtype=ST, device=self.dev)
+        self.lalpha_z = torch.zeros((G, K), dtype=ST, device=self.dev)
+        if self._fused_small:
+            self._elbo_work = backend.mofa_elbo_work(K)
+            self._zs = torch.zeros((G, 2, K), dtype=torch.float64, device=self.dev)
         self.elbo = []
         self._Ng_dev = self.Ng.to(self.dev)  # (resident: an iteration has no host -> device copies)
         # One iteration is ~400 short launches (chunk passes of the masked / bernoulli views, the K x K algebra of the
@@ -126,6 +134,8 @@ class GeneralMofaEngine:
         self._graph_ok = (getattr(backend, "name", "") == "hip" and self.comm.world_size == 1
                           and os.environ.get("MUON_AMD_MOFA_NG_GRAPH", "0") == "1")
         self._eager_steps = 0
+        self._zver = 0      # state counter of the factors (the cached statistics of _gauss_stats belong to one state)
+        self._gstats = {}
 
     # -- collectives ------------------------------------------------------------------------------
     def _on_comm_device(self, t):
@@ -233,6 +243,31 @@ class GeneralMofaEngine:
                        and os.environ.get("MUON_AMD_MOFA_FUSED_POISSON", "1") != "0")
         if V.fused:
             V.Xt = be.transpose(V.X)
+        V.centred = False
+        V.stats = False
+        if lik == "gaussian" and V.kind == "dense":
+            # the centred / scaled / masked values are a constant of the fit: made once, in place (r04 recomputed them in
+            # every chunk pass - three tensor passes over the view, six times per iteration).  Same operations in the
+            # same order as _chunks: the same values.
+            for g, (a0, b0) in enumerate(self.gslice):
+                if b0 > a0:
+                    blk = V.Y[a0:b0]
+                    blk.sub_(V.mu[g][None, :]).mul_(V.scale[g])
+                    if V.mask is not None:
+                        blk.mul_(V.mask[a0:b0])
+            V.centred = True
+            # ... and with them the view needs nothing of size N x D per pass: Omega_nd = tau_gd M_nd, so
+            #   T_d = tau_gd (M^T P)_d,  b = tau_gd (Y^T <Z>)_d,  S_n = M_n (tau o <w w^T>),  a_n = Y_n (tau o <W>),
+            #   sum_n M_nd <(y - z w)^2> = sum_n y^2 - 2 <w_d> . (Y^T <Z>)_d + <w_d w_d^T> : (M^T P)_d
+            # (P_n = <z_n z_n^T>): products of the two constant matrices Y (centred, masked) and M with K- and
+            # K^2-column blocks - the sufficient statistics of MofaEngine with the mask inside (r05; r04 made Omega, R,
+            # the prediction and the residuals as N x D tensors in every pass: ~25 kernels per iteration).
+            V.stats = os.environ.get("MUON_AMD_MOFA_NG_STATS", "1") != "0"
+            if V.stats:
+                V.yyM = torch.stack([(V.Y[a0:b0].double() ** 2).sum(dim=0) for a0, b0 in self.gslice])
+                V.Ngd = (torch.stack([V.mask[a0:b0].double().sum(dim=0) for a0, b0 in self.gslice]) if V.mask is not None
+                         else torch.tensor([[float(b0 - a0)] for a0, b0 in self.gslice], dtype=torch.float64,
+                                           device=V.dev).expand(G, D).contiguous())
         return V
 
     def _chunks(self, V, a, b, raw=False):
@@ -263,7 +298,7 @@ class GeneralMofaEngine:
                 if (lo, hi) not in full:
                     full[(lo, hi)] = bool((rm == 1).all())
                 M = None if full[(lo, hi)] else rm[:, None].expand(hi - lo, V.D)
-            if not raw and V.lik == "gaussian":
+            if not raw and V.lik == "gaussian" and not V.centred:
                 g = self._group_of(lo)
                 Y = (Y - V.mu[g][None, :]) * V.scale[g]
                 if M is not None:
@@ -281,13 +316,13 @@ class GeneralMofaEngine:
         Where the precision does not depend on the sample (gaussian / poisson without missing entries) Omega is
         None and ``omega_vec`` [D] says it all: the K x K statistics then factorise (sum_n Omega_nd <z z^T> =
         omega_d sum_n <z z^T>) and nothing of size N x D x K^2 is multiplied."""
-        zeta = Zc @ Wm.EW.T
-        if V.lik == "gaussian":
+        if V.lik == "gaussian":  # (no caller needs the prediction of a gaussian chunk: its N x D x K product is not made)
             if M is None:
                 tau = Wm.tau[g]
-                return None, tau[None, :] * Y, zeta, tau
+                return None, tau[None, :] * Y, None, tau
             Om = Wm.tau[g][None, :] * M
-            return Om, Om * Y, zeta, None
+            return Om, Om * Y, None, None
+        zeta = Zc @ Wm.EW.T
         if V.lik == "poisson":
             if hasattr(self.be, "mofa_poisson_pseudo") and Y.is_contiguous():
                 R = self.be.mofa_poisson_pseudo(zeta, Y, V.kappa.contiguous(), 0)  # one pass, in place of zeta
@@ -317,6 +352,30 @@ class GeneralMofaEngine:
         P[:, idx, idx] = E2
         return P.reshape(n, K * K)
 
+    def _gauss_stats(self, m):
+        """(B, Q) of a dense gaussian view for the CURRENT factors: B[g] = Y_g^T <Z_g> [D, K], Q[g] = M_g^T P_g [D, K^2]
+        (P = <z z^T> rows; without a mask every row of Q[g] is sum_n P_n).  Made once per state of the factors: the
+        tau / ELBO pass of an iteration and the W update of the next read the same ones."""
+        V = self.views[m]
+        hit = self._gstats.get(m)
+        if hit is None:  # (fixed buffers, written in place: a captured iteration finds the previous replay's statistics)
+            Kk = self.K * self.K
+            hit = self._gstats[m] = [-1, [torch.empty((V.D, self.K), dtype=self.T, device=self.dev) for _ in self.gslice],
+                                     [torch.empty((V.D if V.mask is not None else 1, Kk), dtype=self.T, device=self.dev)
+                                      for _ in self.gslice]]
+        if hit[0] == self._zver:
+            return hit[1], hit[2]
+        for g, (a0, b0) in enumerate(self.gslice):
+            Zg = self.EZ[a0:b0]
+            P = self._outer_moments(Zg, self.EZ2[a0:b0])
+            torch.matmul(V.Y[a0:b0].T, Zg, out=hit[1][g])
+            if V.mask is not None:
+                torch.matmul(V.mask[a0:b0].T, P, out=hit[2][g])
+            else:
+                hit[2][g].copy_(P.sum(dim=0)[None, :])
+        hit[0] = self._zver
+        return hit[1], hit[2]
+
     # -- one coordinate-ascent sweep -------------------------------------------------------------------
     def _update_w(self, m):
         V, Wm, K = self.views[m], self.W[m], self.K
@@ -326,6 +385,12 @@ class GeneralMofaEngine:
             # Omega does not depend on the sample: T_d = kappa_d sum_n <z_n z_n^T>; b = R^T <Z> without R
             Tm += V.kappa[:, None] * self._outer_moments(self.EZ, self.EZ2).sum(dim=0)[None, :]
             b += self.be.mofa_poisson_pass(1, Wm.EW.contiguous(), self.EZ.contiguous(), V.kappa.contiguous(), V.Xt)
+        elif V.stats:
+            Bs, Qs = self._gauss_stats(m)
+            for g in range(self.G):
+                tau = Wm.tau[g][:, None]
+                Tm += tau * Qs[g]
+                b += tau * Bs[g]
         else:
             for g, (a0, b0) in enumerate(self.gslice):
                 for lo, hi, Y, M in self._chunks(V, a0, b0):
@@ -369,7 +434,10 @@ class GeneralMofaEngine:
         K = self.K
         WW = [self._outer_moments(w.EW, w.EW2) for w in self.W]
         az = (self.alpha_z if self.opts["ard_factors"] else torch.ones_like(self.alpha_z)).to(self.T)
-        step = min(self._rows_per_chunk(v.D) for v in self.views)
+        # (chunks of samples sized by the views that are walked in dense chunks: a fused poisson view needs none, and
+        #  the [rows, K^2] statistics themselves bound the rest)
+        step = min([self._rows_per_chunk(v.D) for v in self.views if not getattr(v, "fused", False)]
+                   + [self._rows_per_chunk(K * K)])
         # fused poisson views: a = R <W> for ALL samples at once (a sample's row depends on its own <z_n> only, which
         # changes in its own chunk, after use) and the sample-independent S
         fused = {m: (self.be.mofa_poisson_pass(0, self.EZ.contiguous(), self.W[m].EW.contiguous(), V.kappa.contiguous(), V.X),
@@ -385,6 +453,14 @@ class GeneralMofaEngine:
                     if m in fused:
                         S += fused[m][1][None, :]
                         a += fused[m][0][lo:hi]
+                        continue
+                    if V.stats:
+                        tau = self.W[m].tau[g][:, None]
+                        if V.mask is not None:
+                            S += V.mask[lo:hi] @ (tau * WW[m])
+                        else:
+                            S += (tau * WW[m]).sum(dim=0)[None, :]
+                        a += V.Y[lo:hi] @ (tau * self.W[m].EW)
                         continue
                     for l2, h2, Y, M in self._chunks_range(V, lo, hi):
                         Om, R, _, om_vec = self._omega_r(V, self.W[m], g, Y, M, self.EZ[l2:h2], self.EZ2[l2:h2])
@@ -406,6 +482,9 @@ class GeneralMofaEngine:
                     self.sig2z[lo:hi, k] = 1.0 / prec
                     Z2c[:, k] = Zc[:, k] ** 2 + 1.0 / prec
 
+    def _bump_z(self):
+        self._zver += 1
+
     def _chunks_range(self, V, lo, hi):
         """_chunks restricted to [lo, hi) (a Z-update chunk may span several chunks of a wide view)."""
         return self._chunks(V, lo, hi)
@@ -421,7 +500,13 @@ class GeneralMofaEngine:
             W2, Wsq = Wm.EW2, Wm.EW ** 2
             if getattr(V, "fused", False):
                 part += self.be.mofa_poisson_pass(2, self.EZ.contiguous(), Wm.EW.contiguous(), None, V.X).sum(dtype=f64)
-            for g, (a0, b0) in enumerate(self.gslice if not getattr(V, "fused", False) else []):
+            if V.stats:
+                Bs, Qs = self._gauss_stats(m)
+                WWm = self._outer_moments(Wm.EW, Wm.EW2)
+                for g in range(G):
+                    S[g] = V.yyM[g] - 2.0 * (Wm.EW * Bs[g]).sum(dim=1).to(f64) + (Qs[g] * WWm).sum(dim=1).to(f64)
+                Ngd = V.Ngd.clone()
+            for g, (a0, b0) in enumerate(self.gslice if not (getattr(V, "fused", False) or V.stats) else []):
                 for lo, hi, Y, M in self._chunks(V, a0, b0):
                     Zc, Z2c = self.EZ[lo:hi], self.EZ2[lo:hi]
                     zeta = Zc @ Wm.EW.T
@@ -454,6 +539,8 @@ class GeneralMofaEngine:
                 lik = lik + _gamma_kl(A0, B0, a, b, tau, ltau).sum()
             else:
                 lik = lik + self._allreduce(part)
+            if self._fused_small:
+                continue  # (alpha, theta and their ELBO terms: one kernel per view below)
             EWh2, gam = Wm.EWh2.to(f64), Wm.gamma.to(f64)
             if o["ard_weights"]:
                 a = torch.full((K,), A0 + 0.5 * V.D, dtype=f64, device=self.dev)
@@ -465,6 +552,18 @@ class GeneralMofaEngine:
                 a, b = TH_A0 + sg, TH_B0 + V.D - sg
                 Wm.lth.copy_(torch.digamma(a) - torch.digamma(a + b))
                 Wm.l1mth.copy_(torch.digamma(b) - torch.digamma(a + b))
+        if self._fused_small:
+            be, work = self.be, self._elbo_work
+            elbo = torch.zeros((), dtype=f64, device=self.dev)
+            for V, Wm in zip(self.views, self.W):
+                be.mofa_w_elbo(Wm.EWh2, Wm.gamma, Wm.sig2, o["ard_weights"], o["spikeslab_weights"], A0 + 0.5 * V.D, A0, B0,
+                               TH_A0, TH_B0, Wm.alpha, Wm.lalpha, Wm.lth, Wm.l1mth, elbo, work)
+            zs = self._zs
+            for g, (a0, b0) in enumerate(self.gslice):
+                be.mofa_z_sums(self.EZ2, self.sig2z, a0, b0, zs[g], work)
+            self._allreduce(zs)
+            be.mofa_z_elbo(zs, self._Ng_dev, o["ard_factors"], A0, B0, self.alpha_z, self.lalpha_z, elbo)
+            return elbo + lik
         # factors: per-group sums over this rank's samples, added up over the ranks
         zs = torch.zeros((G, 2, K), dtype=f64, device=self.dev)
         for g, (a0, b0) in enumerate(self.gslice):
@@ -511,6 +610,7 @@ class GeneralMofaEngine:
         for m in range(self.M):
             self._update_w(m)
         self._update_z()
+        self._bump_z()
         return self._update_rest_and_elbo()
 
     def _capture(self):
