@@ -141,12 +141,6 @@ def _copy_array(a: np.ndarray) -> np.ndarray:
     return out
 
 
-def torch_f32():
-    import torch
-
-    return torch.float32
-
-
 def _refs_seen(obj) -> int:
     import sys
 
@@ -470,7 +464,7 @@ def tfidf(
         own = (shares and inplace and to_layer is None and from_layer is None and not copy
                and _dies_with_rebinding(counts, 2))
     if own:
-        want = np.dtype(np.float32) if R.values.dtype == torch_f32() else np.dtype(np.float64)
+        want = np.dtype(np.float32) if R.values.element_size() == 4 else np.dtype(np.float64)
         buf = host.data if host.data.dtype == want else (host.data.view(want) if host.data.dtype.itemsize == want.itemsize
                                                          else None)
         vals = backend.to_host(R.values, out=buf) if buf is not None and buf.shape == (int(R.values.numel()),) else \

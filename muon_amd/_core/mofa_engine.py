@@ -89,7 +89,8 @@ class MofaEngine:
 
         z0 = {}
         nt = N if n_total is None else int(n_total)
-        th = threading.Thread(target=lambda: z0.setdefault("z", np.random.default_rng(seed).standard_normal((nt, self.K))))
+        th = threading.Thread(target=lambda: z0.setdefault("z", np.random.default_rng(seed).standard_normal((nt, self.K))),
+                              daemon=True)
         th.start()
         self._z0 = (th, z0)
         self.G = G = self._global_max(groups) + 1
