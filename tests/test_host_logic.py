@@ -439,3 +439,23 @@ def test_tfidf_takes_the_replaced_matrix_over_only_when_nothing_else_sees_it(mon
     ac.pp.tfidf(ad2, backend=BE)
     assert np.array_equal(ad2.X.data, ref.X.data) and np.array_equal(ad2.X.indices, ref.X.indices)
     assert np.array_equal(shuffled.data, keep.data) and np.array_equal(shuffled.indices, keep.indices)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.int32, np.int64])
+def test_tfidf_takeover_with_other_count_types(dtype):
+    """f64 counts are taken over like f32 ones (the result is f64); integer counts are promoted to f64 by a canonicalised
+    temporary of the call (preproc.py:92: 1.0 / n_peaks is float64), which the result owns - the caller's matrix stays."""
+    m = _big_counts(3)
+    m = sp.csr_matrix((m.data.astype(dtype), m.indices.copy(), m.indptr.copy()), shape=m.shape)
+    ref = AnnData(m.astype(np.float64))
+    ac.pp.tfidf(ref, backend=BE, keep_on_device=False)
+    ad = AnnData(m.copy())
+    before = ad.X.copy()
+    keep = ad.X if dtype != np.float64 else None  # (integer input is never written to, owner or not)
+    where = ad.X.data.ctypes.data
+    ac.pp.tfidf(ad, backend=BE)
+    assert ad.X.dtype == np.float64 and np.array_equal(ad.X.data, ref.X.data) and np.array_equal(ad.X.indices, ref.X.indices)
+    if dtype == np.float64:
+        assert ad.X.data.ctypes.data == where
+    else:
+        assert (keep != before).nnz == 0 and keep.dtype == dtype
