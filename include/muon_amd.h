@@ -519,7 +519,9 @@ int mu_mofa_poisson_pseudo(int dtype, int64_t n_rows, int64_t D, int mode, const
  * depends on (z_n, w_d) only, so a pass = a dense sweep over all (n, d) that reads just the two K-column blocks, plus a
  * correction over the stored entries.  mode 0: own = samples, other = features, out[n][k] = sum_d R[n, d] w_dk (the Z
  * update's a = R <W>);  mode 1: own = features, other = samples, out[d][k] = sum_n R[n, d] z_nk (the W update's b = R^T
- * <Z>), kappa indexed by own;  mode 2: out[n] = sum_d y ln(rate) - rate (the likelihood term).  R, rate as in
+ * <Z>), kappa indexed by own;  mode 2: out[n] = sum_d y ln(rate) - rate (the likelihood term);  mode 3 (r05): mode 1 and
+ * the likelihood term in one sweep, rows of K + 1 values: out[d][0 .. K-1] as mode 1, out[d][K] = sum_n y ln(rate) - rate
+ * (d_part [..][n_own][K + 1]) - the ELBO pass of an iteration and the W update of the next read the same factors.  R, rate as in
  * mu_mofa_poisson_pseudo.  E_own [n_own x KP], E_other [n_other x KP] row-major with the K <= 32 columns PADDED with zeros
  * to KP = 4 / 8 / 12 / 16 / 32 (the smallest of these >= K; 16-byte aligned rows); outputs have K columns.
  * mu_mofa_poisson_dense writes PARTIAL results for column blocks of `other_block` rows of the other block

@@ -1327,10 +1327,13 @@ class HipBackend:
                                                   _p(zeta), self._stream()))
         return zeta
 
+    mofa_poisson_lik_with_b = True  # (mode 3 of mofa_poisson_pass)
+
     def mofa_poisson_pass(self, mode: int, E_own, E_other, kappa, X: DeviceCSR):
         """One pass of a poisson view without anything N x D (csrc/mofa_poisson.hip, include/muon_amd.h): mode 0 ->
         a = R <W> [N, K] (E_own = <Z>, E_other = <W>, X = the view), mode 1 -> b = R^T <Z> [D, K] (E_own = <W>, E_other =
-        <Z>, X = the view's transpose), mode 2 -> per-sample likelihood terms [N]."""
+        <Z>, X = the view's transpose), mode 2 -> per-sample likelihood terms [N], mode 3 -> mode 1 with the per-feature
+        likelihood terms as column K: [D, K + 1]."""
         n_own, K = E_own.shape
         n_other = E_other.shape[0]
         assert E_other.shape[1] == K and E_own.dtype == E_other.dtype and 1 <= K <= 32
@@ -1347,7 +1350,7 @@ class HipBackend:
         E_own, E_other = pad(E_own), pad(E_other)
         blk = int(self.lib.mu_mofa_poisson_blocks(n_own, n_other))
         nb = -(-n_other // blk)
-        part = self.empty((nb, n_own) if mode == 2 else (nb, n_own, K), E_own.dtype)
+        part = self.empty((nb, n_own) if mode == 2 else (nb, n_own, K + 1 if mode == 3 else K), E_own.dtype)
         with self._dev_ctx():
             check(self.lib.mu_mofa_poisson_dense(_dt(E_own), int(mode), n_own, n_other, K, blk, _p(E_own), _p(E_other),
                                                  _p(kappa), _p(part), self._stream()))

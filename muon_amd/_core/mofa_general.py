@@ -136,6 +136,8 @@ class GeneralMofaEngine:
         self._eager_steps = 0
         self._zver = 0      # state counter of the factors (the cached statistics of _gauss_stats belong to one state)
         self._gstats = {}
+        self._wver = [0] * self.M  # ... and of every view's weights: b = R^T <Z> of a fused poisson view made by the ELBO
+        self._bnext = {}           # pass (mode 3 of mofa_poisson_pass) serves the next W update if neither has changed
 
     # -- collectives ------------------------------------------------------------------------------
     def _on_comm_device(self, t):
@@ -384,7 +386,11 @@ class GeneralMofaEngine:
         if getattr(V, "fused", False):
             # Omega does not depend on the sample: T_d = kappa_d sum_n <z_n z_n^T>; b = R^T <Z> without R
             Tm += V.kappa[:, None] * self._outer_moments(self.EZ, self.EZ2).sum(dim=0)[None, :]
-            b += self.be.mofa_poisson_pass(1, Wm.EW.contiguous(), self.EZ.contiguous(), V.kappa.contiguous(), V.Xt)
+            hit = self._bnext.get(m)
+            if hit is not None and hit[0] == (self._zver, self._wver[m]):
+                b += hit[1]  # (made by the tau / ELBO pass of the iteration before, in the same sweep as its likelihood term)
+            else:
+                b += self.be.mofa_poisson_pass(1, Wm.EW.contiguous(), self.EZ.contiguous(), V.kappa.contiguous(), V.Xt)
         elif V.stats:
             Bs, Qs = self._gauss_stats(m)
             for g in range(self.G):
@@ -498,7 +504,16 @@ class GeneralMofaEngine:
             Ngd = torch.zeros((G, V.D), dtype=f64, device=self.dev)
             part = torch.zeros((), dtype=f64, device=self.dev)
             W2, Wsq = Wm.EW2, Wm.EW ** 2
-            if getattr(V, "fused", False):
+            if getattr(V, "fused", False) and getattr(self.be, "mofa_poisson_lik_with_b", False):
+                # the likelihood term and the NEXT W update's b = R^T <Z> read the same predictions: one sweep (r05)
+                out = self.be.mofa_poisson_pass(3, Wm.EW.contiguous(), self.EZ.contiguous(), V.kappa.contiguous(), V.Xt)
+                hit = self._bnext.get(m)
+                if hit is None:  # (a fixed buffer, written in place: a captured iteration finds the previous replay's b)
+                    hit = self._bnext[m] = [None, torch.empty((V.D, K), dtype=self.T, device=self.dev)]
+                hit[1].copy_(out[:, :K])
+                hit[0] = (self._zver, self._wver[m])
+                part += out[:, K].sum(dtype=f64)
+            elif getattr(V, "fused", False):
                 part += self.be.mofa_poisson_pass(2, self.EZ.contiguous(), Wm.EW.contiguous(), None, V.X).sum(dtype=f64)
             if V.stats:
                 Bs, Qs = self._gauss_stats(m)
@@ -609,6 +624,7 @@ class GeneralMofaEngine:
     def _iteration(self) -> torch.Tensor:
         for m in range(self.M):
             self._update_w(m)
+            self._wver[m] += 1
         self._update_z()
         self._bump_z()
         return self._update_rest_and_elbo()

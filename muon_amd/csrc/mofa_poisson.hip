@@ -72,6 +72,9 @@ constexpr int kPzThreads = 256;
 // MODE 0: own = samples, other = features, kappa per OTHER row:  out[own][k] = sum_d (kappa_d zeta - sigmoid zeta) w_dk
 // MODE 1: own = features, other = samples, kappa per OWN row:    out[own][k] = sum_n (kappa_own zeta - sigmoid zeta) z_nk
 // MODE 2: own = samples, other = features:                       out[own]    = sum_d -softplus(zeta)
+// MODE 3 (r05): MODE 1 and the likelihood term in ONE sweep - the tau / ELBO pass of an iteration and the W update of the
+//         next one evaluate the same predictions (same factors, same weights): out[own][0 .. K-1] as MODE 1,
+//         out[own][K] = sum_n -softplus(zeta); rows of K + 1 values
 template <typename T, int KP, int MODE>
 __global__ __launch_bounds__(kPzThreads) void k_pois_dense(int64_t n_own, int64_t n_other, int K, int64_t other_block,
                                                            const T* __restrict__ E_own, const T* __restrict__ E_other,
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_dense(int64_t n_own, int64_
 #pragma unroll
   for (int k = 0; k < KP; ++k) e[k] = acc[k] = (T)0;
   if (own < n_own) pz_load_row<T, KP>(E_own + own * KP, e);  // (padding columns are zero)
-  const T kown = (MODE == 1 && own < n_own) ? kappa[own] : (T)0;
+  const T kown = ((MODE == 1 || MODE == 3) && own < n_own) ? kappa[own] : (T)0;
   T lsum = (T)0;
   for (int64_t t0 = o0; t0 < o1; t0 += kPzTile) {
     const int rows = (int)(o1 - t0 < kPzTile ? o1 - t0 : kPzTile);
@@ -104,9 +107,8 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_dense(int64_t n_own, int64_
       T zeta = (T)0;
 #pragma unroll
       for (int k = 0; k < KP; ++k) zeta += e[k] * o[k];
-      if (MODE == 2) {
-        lsum -= pz_softplus_sum(zeta);
-      } else {
+      if (MODE == 2 || MODE == 3) lsum -= pz_softplus_sum(zeta);
+      if (MODE != 2) {
         const T r0 = (MODE == 0 ? kap[j] : kown) * zeta - pz_sigmoid(zeta);
 #pragma unroll
         for (int k = 0; k < KP; ++k) acc[k] += r0 * o[k];
@@ -117,8 +119,10 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_dense(int64_t n_own, int64_
   if (MODE == 2) {
     part[(int64_t)blockIdx.y * n_own + own] = lsum;
   } else {
-    T* out = part + ((int64_t)blockIdx.y * n_own + own) * K;
+    const int ostride = MODE == 3 ? K + 1 : K;
+    T* out = part + ((int64_t)blockIdx.y * n_own + own) * ostride;
     for (int k = 0; k < K; ++k) out[k] = acc[k];
+    if (MODE == 3) out[K] = lsum;
   }
 }
 
@@ -147,9 +151,8 @@ __global__ __launch_bounds__(256) void k_pois_sparse(int64_t n_own, int K, const
 #pragma unroll
     for (int k = 0; k < KP; ++k) zeta += e[k] * o[k];
     const T rate = pz_softplus(zeta);
-    if (MODE == 2) {
-      lsum += y * pz_log(rate);
-    } else {
+    if (MODE == 2 || MODE == 3) lsum += y * pz_log(rate);
+    if (MODE != 2) {
       const T c = pz_sigmoid(zeta) * y / rate;
 #pragma unroll
       for (int k = 0; k < KP; ++k) acc[k] += c * o[k];
@@ -159,12 +162,17 @@ __global__ __launch_bounds__(256) void k_pois_sparse(int64_t n_own, int K, const
     lsum = wave_sum(lsum);
     if (lane == 0) out[own] += lsum;
   } else {
+    const int ostride = MODE == 3 ? K + 1 : K;
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
       if (k < K) {  // (K is wave-uniform)
         const T s = wave_sum(acc[k]);
-        if (lane == 0) out[own * K + k] += s;
+        if (lane == 0) out[own * ostride + k] += s;
       }
+    }
+    if (MODE == 3) {
+      lsum = wave_sum(lsum);
+      if (lane == 0) out[own * ostride + K] += lsum;
     }
   }
 }
@@ -178,7 +186,8 @@ int pois_dense_launch(int mode, int64_t n_own, int64_t n_other, int K, int64_t o
                      (const T*)E_own, (const T*)E_other, (const T*)kappa, (T*)part)
   if (mode == 0) MU_GO(0);
   else if (mode == 1) MU_GO(1);
-  else MU_GO(2);
+  else if (mode == 2) MU_GO(2);
+  else MU_GO(3);
 #undef MU_GO
   MU_CHECK_LAUNCH();
   return MU_OK;
@@ -193,7 +202,8 @@ int pois_sparse_launch(int mode, int64_t n_own, int K, const int64_t* indptr, co
                      (const T*)values, (const T*)E_own, (const T*)E_other, (T*)out)
   if (mode == 0) MU_GO(0);
   else if (mode == 1) MU_GO(1);
-  else MU_GO(2);
+  else if (mode == 2) MU_GO(2);
+  else MU_GO(3);
 #undef MU_GO
   MU_CHECK_LAUNCH();
   return MU_OK;
@@ -217,7 +227,7 @@ int64_t mu_mofa_poisson_blocks(int64_t n_own, int64_t n_other) {
 int mu_mofa_poisson_dense(int dtype, int mode, int64_t n_own, int64_t n_other, int K, int64_t other_block,
                           const void* d_E_own, const void* d_E_other, const void* d_kappa, void* d_part, void* stream) {
   MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
-  MU_REQUIRE(mode >= 0 && mode <= 2 && K >= 1 && K <= 32, "mode 0..2, 1 <= K <= 32");
+  MU_REQUIRE(mode >= 0 && mode <= 3 && K >= 1 && K <= 32, "mode 0..3, 1 <= K <= 32");
   MU_REQUIRE(n_own >= 0 && n_other >= 0 && other_block >= 1, "shape");
   if (n_own == 0 || n_other == 0) return MU_OK;
   MU_REQUIRE(d_E_own && d_E_other && d_part && (mode == 2 || d_kappa), "null pointer");
@@ -235,7 +245,7 @@ int mu_mofa_poisson_dense(int dtype, int mode, int64_t n_own, int64_t n_other, i
 int mu_mofa_poisson_sparse(int dtype, int mode, int64_t n_own, int K, const int64_t* d_indptr, const int32_t* d_indices,
                            const void* d_values, const void* d_E_own, const void* d_E_other, void* d_out, void* stream) {
   MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
-  MU_REQUIRE(mode >= 0 && mode <= 2 && K >= 1 && K <= 32, "mode 0..2, 1 <= K <= 32");
+  MU_REQUIRE(mode >= 0 && mode <= 3 && K >= 1 && K <= 32, "mode 0..3, 1 <= K <= 32");
   if (n_own <= 0) return MU_OK;
   MU_REQUIRE(d_indptr && d_E_own && d_E_other && d_out, "null pointer");
   hipStream_t st = (hipStream_t)stream;

@@ -377,6 +377,11 @@ def test_poisson_passes_without_the_dense_chunk(dt, tol, K):
     # deterministic
     again = be.mofa_poisson_pass(0, Zd, Wd, kd, X)
     assert torch.equal(again, got[0])
+    # mode 3: b and the likelihood term in one sweep over the same predictions
+    both = be.mofa_poisson_pass(3, Wd, Zd, kd, Xt)
+    assert both.shape == (D, K + 1) and torch.equal(both[:, :K].contiguous(), got[1])
+    lik = float(both[:, K].sum(dtype=torch.float64))
+    assert abs(lik - want[2].sum()) <= tol * abs(want[2].sum())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
