@@ -34,7 +34,7 @@ int mu_num_cus() {
 static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "spmm_waves", "spmm_pipe",
                                         "tpack_abl", "tpack_c", "gram_wg", "tpack_v2", "pack_wg",
                                         "tpack_dbg", "tpack_rows", "tpack_narrow", "spmm_narrow_off",
-                                        "mfma_mode", "ell_mode", "tfidf_wide", "tfidf_pipe", "nn_interleave", "tfidf_abl", "tfidf_sum_m", "tn_pipe", "nn_fast_off", "tpack_asm", "tpack_split", "stream_pipe", "tcount_pipe", "tpack4_m", "tpack4_c", "tpack_v3", "scale_stream_off", "tpack4_plain", "tpack4_abl", "tpack4_late"};
+                                        "mfma_mode", "ell_mode", "tfidf_wide", "tfidf_pipe", "nn_interleave", "tfidf_abl", "tfidf_sum_m", "tn_pipe", "nn_fast_off", "tpack_asm", "tpack_split", "stream_pipe", "tcount_pipe", "tpack4_m", "tpack4_c", "tpack_v3", "scale_stream_off", "tpack4_plain", "tpack4_abl", "tpack4_late", "tpack4_circ"};
 constexpr int kTuneN = sizeof(kTuneKeys) / sizeof(kTuneKeys[0]);
 static int g_tune[kTuneN] = {};
 

@@ -235,6 +235,50 @@ __device__ __forceinline__ void t4_issue_csr(uint64_t i0, uint64_t v0, uint64_t 
         [C] "i"(kW0 + 2 * J), [V] "i"(kW0 + 2 * J + 1)
       : MU_T4_CLOB, "memory");
 }
+// CIRCULAR windows (r05, PAIRS only; tune tpack4_circ): pair number p of the stream lives in lane p % 32 of its row's
+// half, so a window keeps the pairs a tile did not consume where they are and only the lanes whose pairs were consumed
+// are loaded again - the next pairs of the row, which land in exactly those lanes.  b = address of the 256-byte block the
+// first new pair lies in, s = its lane, m = the 32 lanes to load (a run of the new pairs' number starting at s, wrapped);
+// a lane before s belongs to the NEXT 256-byte block.  The plain windows request 32 pairs = three lines per row and
+// tile to consume ~15 (162 GB of requests for 50 GB of pairs, profiles/r05_tpack4_ablations.txt).
+template <int J>
+__device__ __forceinline__ void t4_issue_circ(uint64_t b0, uint64_t b1, unsigned s0, unsigned s1, unsigned m0, unsigned m1,
+                                              unsigned sub, unsigned sub8, unsigned sub8w) {
+  unsigned long long save;
+  unsigned t0, t1;
+  asm volatile(
+      "s_mov_b64 %[save], exec\n\t"
+      "v_cmp_gt_u32 vcc, %[s0], %[sub]\n\t"
+      "v_cndmask_b32 %[t0], %[sub8], %[sub8w], vcc\n\t"
+      "v_cmp_gt_u32 vcc, %[s1], %[sub]\n\t"
+      "v_cndmask_b32 %[t1], %[sub8], %[sub8w], vcc\n\t"
+      "s_mov_b32 exec_lo, %[m0]\n\t"
+      "s_mov_b32 exec_hi, 0\n\t"
+      "global_load_dwordx2 v[%c[C]:%c[V]], %[t0], %[b0]\n\t"
+      "s_mov_b32 exec_lo, 0\n\t"
+      "s_mov_b32 exec_hi, %[m1]\n\t"
+      "global_load_dwordx2 v[%c[C]:%c[V]], %[t1], %[b1]\n\t"
+      "s_mov_b64 exec, %[save]"
+      : [save] "=&s"(save), [t0] "=&v"(t0), [t1] "=&v"(t1)
+      : [sub] "v"(sub), [sub8] "v"(sub8), [sub8w] "v"(sub8w), [b0] "s"(b0), [b1] "s"(b1), [s0] "s"(s0), [s1] "s"(s1),
+        [m0] "s"(m0), [m1] "s"(m1), [C] "i"(kW0 + 2 * J), [V] "i"(kW0 + 2 * J + 1)
+      : MU_T4_CLOB, "vcc", "memory");
+}
+// every lane of slot J holds the padding column (before the first circular request)
+template <int J>
+__device__ __forceinline__ void t4_pad_slot() {
+  asm volatile("v_mov_b32 v%c0, 0x7fffffff" ::"i"(kW0 + 2 * J) : MU_T4_CLOB);
+}
+// the pairs of slot J that the tile took (column < cend) become padding: their lanes are loaded again only if the row
+// has pairs left for them
+template <int J>
+__device__ __forceinline__ void t4_retire_slot(int cend, int pad) {  // (pad = 0x7fffffff in a register: vcc takes the constant bus)
+  asm volatile(
+      "v_cmp_le_i32 vcc, %0, v%c1\n\t"
+      "v_cndmask_b32 v%c1, %2, v%c1, vcc" ::"s"(cend),
+      "i"(kW0 + 2 * J), "v"(pad)
+      : MU_T4_CLOB, "vcc");
+}
 __device__ __forceinline__ void t4_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: MU_T4_CLOB, "memory"); }
 template <int J>
 __device__ __forceinline__ int t4_col() {
@@ -284,7 +328,7 @@ __device__ unsigned long long g_t4_phase[8];  // tune tpack_dbg: cycles of heade
 
 // PAIRS: the source is the row stream of X (src0 = ent, row_dst[row] = pair index of the row's first pair);
 // otherwise the CSR arrays (src0 = indices, src1 = values).  rw = rows of a wave (<= 32), rpb = 16 rw rows per block.
-template <bool PAIRS, bool DBG = false, bool OUT_CSR = false>
+template <bool PAIRS, bool DBG = false, bool OUT_CSR = false, bool CIRC = false>
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(44))) void k_t4_fill(
     int64_t n_rows, int64_t n_cols, int C, int rw, int G, const int64_t* __restrict__ indptr,
     const int64_t* __restrict__ row_dst, const void* __restrict__ src0, const void* __restrict__ src1,
@@ -338,10 +382,28 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(44))) void k_t4_
       A2 = (uint64_t)src1 + 4ull * (uint64_t)p0;
     }
   }
+  static_assert(!CIRC || PAIRS, "circular windows read the row stream");
   const unsigned subo = (unsigned)sub * (PAIRS ? 8u : 4u);
   int pa = -1, pb = -1;  // rows (of this wave) whose continuation window the next issue prefetches into slot kSlotP
+  int ld = 0;            // CIRC, lane l < 32: pairs of row l behind its cursor that sit in its window already
+  if constexpr (CIRC) t4_for<16>([&](auto jc) { t4_pad_slot<decltype(jc)::value>(); });
   auto issue_all = [&]() {
     const int remc = rem < 32 ? rem : 32;  // (rem >= 0 always)
+    if constexpr (CIRC) {
+      const int nn = remc - ld;                                  // new pairs of the row (>= 0) ...
+      const uint64_t st = A + 8ull * (uint64_t)(unsigned)ld;     // ... from this address on
+      const unsigned s5 = (unsigned)(st >> 3) & 31u;
+      const unsigned rot = __builtin_rotateleft32((unsigned)((1ull << nn) - 1ull), s5);
+      const uint64_t b256 = st & ~255ull;
+      ld = remc;
+      t4_for<16>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        t4_issue_circ<J>(readlane_u64(b256, 2 * J), readlane_u64(b256, 2 * J + 1),
+                         (unsigned)__builtin_amdgcn_readlane((int)s5, 2 * J), (unsigned)__builtin_amdgcn_readlane((int)s5, 2 * J + 1),
+                         (unsigned)__builtin_amdgcn_readlane((int)rot, 2 * J), (unsigned)__builtin_amdgcn_readlane((int)rot, 2 * J + 1),
+                         (unsigned)sub, subo, subo + 256u);
+      });
+    } else {
     t4_for<16>([&](auto jc) {
       constexpr int J = decltype(jc)::value;
       const int n0 = __builtin_amdgcn_readlane(remc, 2 * J), n1 = __builtin_amdgcn_readlane(remc, 2 * J + 1);
@@ -351,6 +413,7 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(44))) void k_t4_
         t4_issue_csr<J>(readlane_u64(A, 2 * J), readlane_u64(A2, 2 * J), readlane_u64(A, 2 * J + 1),
                         readlane_u64(A2, 2 * J + 1), n0, n1, subo);
     });
+    }
     if (pa >= 0) {
       // the continuation windows (entries 32 .. 63 behind the cursor) of the rows that overflowed in the tile before: a
       // row inside a dense stretch of columns overflows tile after tile, and a continuation requested only when phase 1
@@ -643,10 +706,16 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_num_vgpr(44))) void k_t4_
       if (o2) pb = __builtin_ctz(o2);
     }
     // this wave's cursors move on; its bitmap row is cleared for the next tile; the next windows are requested
+    if constexpr (CIRC) {
+      int padv = 0x7fffffff;
+      asm volatile("" : "+v"(padv));
+      t4_for<16>([&](auto jc) { t4_retire_slot<decltype(jc)::value>(cend, padv); });
+    }
     if (half == 0) {
       A += (uint64_t)(unsigned)cntv * (PAIRS ? 8u : 4u);
       if (!PAIRS) A2 += (uint64_t)(unsigned)cntv * 4u;
       rem -= cntv;
+      if (CIRC) ld = ld > cntv ? ld - cntv : 0;  // (a row that went into its continuation has nothing left in the window)
     }
     for (int t = lane; t < Ct; t += 64) bmw[t].x = 0u;
     issue_all();
@@ -748,19 +817,25 @@ int t4_fill_impl(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_i
   const bool dbg = mu_tune_get("tpack_dbg") > 0;
   const bool xcd = mu_tune_get("tpack4_plain") != 1;  // (tune tpack4_plain = 1: workgroup = row block, for comparison)
   const unsigned grid = xcd ? (unsigned)(8 * ((q.G + 7) / 8)) : (unsigned)q.G;
-#define MU_T4_LAUNCH(PAIRS_, DBG_, CSR_, RD_, S0_, S1_)                                                                \
-  hipLaunchKernelGGL((k_t4_fill<PAIRS_, DBG_, CSR_>), dim3(grid), dim3(kT), 0, st, n_rows, n_cols, q.C, q.rw,           \
+#define MU_T4_LAUNCH(PAIRS_, DBG_, CSR_, RD_, S0_, S1_) MU_T4_LAUNCH4(PAIRS_, DBG_, CSR_, false, RD_, S0_, S1_)
+#define MU_T4_LAUNCH4(PAIRS_, DBG_, CSR_, CIRC_, RD_, S0_, S1_)                                                        \
+  hipLaunchKernelGGL((k_t4_fill<PAIRS_, DBG_, CSR_, CIRC_>), dim3(grid), dim3(kT), 0, st, n_rows, n_cols, q.C, q.rw,    \
                      xcd ? q.G : -q.G, d_indptr, RD_, (const void*)(S0_), (const void*)(S1_), w.cdst, w.cnt, w.coltot,  \
                      out, w.err, mu_tune_get("tpack4_abl") | (mu_tune_get("tpack4_late") == 1 ? 8 : 0))
   const bool csr_out = out.idx != nullptr;
   const int64_t* no_rd = nullptr;
+  // (circular windows: the row stream as source, 256-byte aligned - the lane of a pair is its number mod 32
+  //  - the default; tune tpack4_circ = 2: plain windows, for comparison)
+  const bool circ = mu_tune_get("tpack4_circ") != 2 && (reinterpret_cast<uintptr_t>(d_x_ent) & 255) == 0;
   if (d_x_ent && dbg && !csr_out) MU_T4_LAUNCH(true, true, false, d_row_dst, d_x_ent, nullptr);
+  else if (d_x_ent && !csr_out && circ) MU_T4_LAUNCH4(true, false, false, true, d_row_dst, d_x_ent, nullptr);
   else if (d_x_ent && !csr_out) MU_T4_LAUNCH(true, false, false, d_row_dst, d_x_ent, nullptr);
   else if (d_x_ent) MU_T4_LAUNCH(true, false, true, d_row_dst, d_x_ent, nullptr);
   else if (dbg && !csr_out) MU_T4_LAUNCH(false, true, false, no_rd, d_indices, d_values);
   else if (!csr_out) MU_T4_LAUNCH(false, false, false, no_rd, d_indices, d_values);
   else MU_T4_LAUNCH(false, false, true, no_rd, d_indices, d_values);
 #undef MU_T4_LAUNCH
+#undef MU_T4_LAUNCH4
   MU_CHECK_LAUNCH();
   return MU_OK;
 }

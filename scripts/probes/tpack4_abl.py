@@ -34,7 +34,9 @@ def fill_ms(reps=2):
     return s.elapsed_time(e) / reps
 
 
-print(f"{cells} x {peaks}: count + layout + fill, stream source", flush=True)
+circ = int(os.environ.get("TPACK4_CIRC", "0"))  # (0: default = circular windows, 2: plain)
+be.tune("tpack4_circ", circ)
+print(f"{cells} x {peaks}: count + layout + fill, stream source" + (", plain windows" if circ == 2 else ", circular windows"), flush=True)
 for c in (448, 480, 512):
     be.tune("tpack4_c", c)
     a = fill_ms()

@@ -12,10 +12,12 @@ from tests.test_gpu_kernels import _check_stream, _heavy_rows_csr, _stream_ref, 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _keep_work(hip):
+@pytest.fixture(autouse=True, params=[2, 0], ids=["plain windows", "circular windows"])
+def _keep_work(hip, request):
     hip.keep_tpack4_work = True  # the tests read the fill's error word
+    hip.tune("tpack4_circ", request.param)  # (the stream-source fill with and without its circular windows)
     yield
+    hip.tune("tpack4_circ", 0)
     hip.keep_tpack4_work = False
     hip._tpack4_work = None
 

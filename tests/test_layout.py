@@ -128,7 +128,7 @@ def test_tpack4_isa_keeps_out_of_the_asm_owned_registers(tmp_path):
                            "-o", str(out), src])
     text = out.read_text()
     kernels = re.findall(r"^(_ZN[^\n:]*k_t4_fill[^\n:]*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, flags=re.S | re.M)
-    assert len(kernels) == 6  # (row stream | CSR arrays) x (stream target, CSR target, stream target with phase accounting)
+    assert len(kernels) == 7  # (row stream | CSR arrays) x (stream target, CSR target, stream target with phase accounting) + the row stream through circular windows
     reg = re.compile(r"\bv(\d+)\b|v\[(\d+):(\d+)\]")
     for name, body in kernels:
         production = re.search(r"k_t4_fillILb[01]ELb0ELb[01]E", name) is not None
