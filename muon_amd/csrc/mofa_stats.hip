@@ -18,7 +18,9 @@
 namespace {
 
 constexpr int kST = 256;          // threads per block
-constexpr int kSBlocksMax = 96;   // partial blocks (the fold walks them serially: keep it short)
+constexpr int kSBlocksMax = 512;  // partial blocks.  r05: 96 -> 512 - a thread of the 96-block launch walked 65 row groups one
+                                  // dependent load batch after the other (86 us for 4 MB of factors, three times per MOFA
+                                  // iteration = 6 % of c4); the fold below takes the blocks in 32 chunks instead of 8
 
 // thread t: column j = t % KP of rows t / KP, t / KP + kST / KP, ...
 template <typename T, int KP>
@@ -76,9 +78,9 @@ __global__ __launch_bounds__(kST) void k_rowstats(int64_t r0, int64_t r1, int K,
   }
 }
 
-// out = sum over the partial blocks in a fixed order: eight chunks of blocks in parallel (the serial
+// out = sum over the partial blocks in a fixed order: kFoldChunks chunks of blocks in parallel (the serial
 // walk over all blocks took 94 us at 512 blocks: a third of what the fusion had saved), then the chunks
-constexpr int kFoldChunks = 8, kFoldT = 1024;
+constexpr int kFoldChunks = 32, kFoldT = 1024;
 template <typename T>
 __global__ __launch_bounds__(kFoldT) void k_rowstats_fold(int nb, int K, const double* __restrict__ partial,
                                                           T* __restrict__ gram, T* __restrict__ s2,
@@ -113,7 +115,7 @@ int run(int64_t r0, int64_t r1, int K, const void* E, const void* E2, const void
         void* s1, double* work, hipStream_t st) {
   const int KP = K <= 16 ? 16 : 32;
   const int64_t rows = r1 - r0, per = kST / KP;
-  int nb = (int)((rows + per * 32 - 1) / (per * 32));  // >= 32 rows per thread group
+  int nb = (int)((rows + per * 8 - 1) / (per * 8));  // >= 8 rows per thread group
   if (nb < 1) nb = 1;
   if (nb > kSBlocksMax) nb = kSBlocksMax;
 #define ARGS r0, r1, K, (const T*)E, (const T*)E2, (const T*)wgt, (const T*)aux, scale_out, (T*)out_pad, ld, \
