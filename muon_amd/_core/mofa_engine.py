@@ -442,6 +442,39 @@ class MofaEngine:
                 if V.ld and (V.ld, V.kind == "sparse") not in self._zpad:
                     self._zpad[(V.ld, V.kind == "sparse")] = torch.zeros((self.N, V.ld), dtype=T, device=dev)
             self._zmom = {}
+        # r05: the views' shares of an iteration are independent between the joins W updates | products A | Z update |
+        # statistics, tau, alpha / theta per view | factor node - each view's share runs on its own stream (fork / join by
+        # events; captured into the HIP graph as parallel branches), so the ~25 small kernels of one view hide under the
+        # other view's product and the HBM-bound dense product overlaps the sliced-ELL one.  Same kernels, same operands:
+        # the same numbers; the ELBO adds the views' terms at the end (per-view scalars: the kernels add to a scalar in
+        # place).  One process, fused path only; MUON_AMD_MOFA_VIEW_STREAMS=0: one stream.
+        self._par = (self._fused and self.M > 1 and self.comm.world_size == 1 and getattr(self.be, "name", "") == "hip"
+                     and os.environ.get("MUON_AMD_MOFA_VIEW_STREAMS", "1") != "0")
+        self._side = [torch.cuda.Stream(self.be.device) for _ in range(self.M - 1)] if self._par else []
+        if self._fused:
+            self._rs_work_v = [self._rs_work] + [self.be.mofa_rowstats_work(K) for _ in range(self.M - 1)]
+        self._elbo_work_v = [self._elbo_work] + [self.be.mofa_elbo_work(K) for _ in range(self.M - 1)]
+
+    # -- the views' streams -------------------------------------------------------------------
+    def _fork(self):
+        if self._par:
+            main = torch.cuda.current_stream(self.be.device)
+            for s in self._side:
+                s.wait_stream(main)
+
+    def _on(self, m):
+        """Context in which view m's share of a phase is issued (view 0: the current stream)."""
+        import contextlib
+
+        if self._par and m > 0:
+            return torch.cuda.stream(self._side[m - 1])
+        return contextlib.nullcontext()
+
+    def _join(self):
+        if self._par:
+            main = torch.cuda.current_stream(self.be.device)
+            for s in self._side:
+                main.wait_stream(s)
 
     # -- sufficient statistics --------------------------------------------------------------
     def _zstats(self, m):
@@ -479,7 +512,7 @@ class MofaEngine:
             pads = list(self._zpad.items()) if not self._zmom else []
             for g, (a, b) in enumerate(self.gslice):
                 (ld0, st0), pad0 = pads[0] if pads else ((0, False), None)
-                self.be.mofa_rowstats(self.EZ, self.EZ2, a, b, self._rs_work, wgt=None if V.full else V.pres,
+                self.be.mofa_rowstats(self.EZ, self.EZ2, a, b, self._rs_work_v[m], wgt=None if V.full else V.pres,
                                       out_pad=pad0, col0=g * K if st0 else 0, gram=Gz[g], s2=Z2[g], s1=Zs[g])
                 for (ld, st), pad in pads[1:]:
                     c0 = g * K if st else 0
@@ -549,37 +582,47 @@ class MofaEngine:
                               Wm.lth, Wm.l1mth, self.opts["spikeslab_weights"], Wm.EW, Wm.EW2,
                               Wm.gamma, Wm.EWh2, Wm.sig2)
 
+    def _view_product_a(self, m):
+        """View m's share of the Z update: tau o W with its K x K statistics (one pass over the weight block per group)
+        and A[m] = Y_m (tau o W_m)."""
+        K, G, be, A = self.K, self.G, self.be, self._A
+        V, Wm, rs_work = self.views[m], self.W[m], self._rs_work_v[m]
+        for g, (a, b) in enumerate(self.gslice):
+            kw = dict(wgt=Wm.tau[g], scale_out=True, gram=self._Gw[m, g], s2=self._dw2[m, g])
+            if V.kind == "sparse":
+                be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, rs_work, aux=V.mu[g], out_pad=V.TWs, col0=g * K,
+                                 s1=self._corr[m, g], **kw)
+            elif hasattr(V, "T16") and getattr(V, "implicit", False):
+                be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, rs_work, aux=V.mu[g], out_pad=V.T16[g],
+                                 s1=self._corr[m, g], **kw)  # (the centring term goes into the sweep: corr)
+                A[m, a:b] = be.skinny_nn(V.Y[a:b], V.T16[g])[:, :K]
+            elif hasattr(V, "T16"):
+                be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, rs_work, out_pad=V.T16[g], **kw)
+                A[m, a:b] = be.skinny_nn(V.Y[a:b], V.T16[g])[:, :K]
+            else:
+                # (f32: hipBLASLt streams Y at 5.1 TB/s when the K x D operand is the transposed one,
+                #  scripts/probes/skinny_nn_probe.py: the kernel writes tau o W as K x D)
+                be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, rs_work, out_t=V.TWt[g], **kw)
+                torch.matmul(V.Y[a:b], V.TWt[g].T, out=A[m, a:b])
+        if V.kind == "sparse":
+            out = be.spmm(V.Xs, V.TWs)  # N x (G K); the centring term goes into the sweep (corr)
+            if G == 1:
+                A[m].copy_(out[:, :K])
+            else:
+                for g, (a, b) in enumerate(self.gslice):
+                    A[m, a:b] = out[a:b, g * K:(g + 1) * K]
+
     def _update_z_fused(self):
         """W-side statistics in one pass per (view, group) over the weight block (mu_mofa_rowstats: tau o W
         as the dense operand, Gw, dw2 and the centring correction), the products A = Y (tau o W), the
         sample sweep."""
         K, G, M = self.K, self.G, self.M
         be, A = self.be, self._A
-        for m, (V, Wm) in enumerate(zip(self.views, self.W)):
-            for g, (a, b) in enumerate(self.gslice):
-                kw = dict(wgt=Wm.tau[g], scale_out=True, gram=self._Gw[m, g], s2=self._dw2[m, g])
-                if V.kind == "sparse":
-                    be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, self._rs_work, aux=V.mu[g], out_pad=V.TWs, col0=g * K,
-                                     s1=self._corr[m, g], **kw)
-                elif hasattr(V, "T16") and getattr(V, "implicit", False):
-                    be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, self._rs_work, aux=V.mu[g], out_pad=V.T16[g],
-                                     s1=self._corr[m, g], **kw)  # (the centring term goes into the sweep: corr)
-                    A[m, a:b] = be.skinny_nn(V.Y[a:b], V.T16[g])[:, :K]
-                elif hasattr(V, "T16"):
-                    be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, self._rs_work, out_pad=V.T16[g], **kw)
-                    A[m, a:b] = be.skinny_nn(V.Y[a:b], V.T16[g])[:, :K]
-                else:
-                    # (f32: hipBLASLt streams Y at 5.1 TB/s when the K x D operand is the transposed one,
-                    #  scripts/probes/skinny_nn_probe.py: the kernel writes tau o W as K x D)
-                    be.mofa_rowstats(Wm.EW, Wm.EW2, 0, V.D, self._rs_work, out_t=V.TWt[g], **kw)
-                    torch.matmul(V.Y[a:b], V.TWt[g].T, out=A[m, a:b])
-            if V.kind == "sparse":
-                out = be.spmm(V.Xs, V.TWs)  # N x (G K); the centring term goes into the sweep (corr)
-                if G == 1:
-                    A[m].copy_(out[:, :K])
-                else:
-                    for g, (a, b) in enumerate(self.gslice):
-                        A[m, a:b] = out[a:b, g * K:(g + 1) * K]
+        self._fork()
+        for m in range(M):
+            with self._on(m):
+                self._view_product_a(m)
+        self._join()
         az = self.alpha_z if self.opts["ard_factors"] else torch.ones_like(self.alpha_z)
         be.mofa_update_z(A, self._pres, self.grp, self._Gw, self._dw2, az.contiguous(), self.EZ, self.EZ2,
                          self.sig2z, corr=self._corr)
@@ -634,12 +677,26 @@ class MofaEngine:
         o, be = self.opts, self.be
         elbo = torch.zeros((), dtype=torch.float64, device=self.EZ.device)
         work = self._elbo_work
+        if self._par:
+            # the factors' moments are shared between the views that observe every sample (and refresh the padded <Z>
+            # operands of every product): made once, before the views part
+            if getattr(self, "_fused", False):
+                for m in range(self.M):
+                    if self._stats.get(m) is None:
+                        self._z_moments(m)
+            parts = [elbo] + [torch.zeros((), dtype=torch.float64, device=self.EZ.device) for _ in range(self.M - 1)]
+        else:
+            parts = [elbo] * self.M
+        self._fork()
         for m, (V, Wm) in enumerate(zip(self.views, self.W)):
-            Gz, Z2, B = self._zstats(m)
-            be.mofa_tau_elbo(V.yy, V.Ngm_d, Wm.EW, Wm.EW2, B, Gz, Z2, A0, B0, Wm.tau, Wm.ltau, elbo, work)
-            be.mofa_w_elbo(Wm.EWh2, Wm.gamma, Wm.sig2, o["ard_weights"], o["spikeslab_weights"],
-                           A0 + 0.5 * V.D, A0, B0, TH_A0, TH_B0, Wm.alpha, Wm.lalpha, Wm.lth, Wm.l1mth,
-                           elbo, work)
+            with self._on(m):
+                wk = self._elbo_work_v[m] if self._par else work
+                Gz, Z2, B = self._zstats(m)
+                be.mofa_tau_elbo(V.yy, V.Ngm_d, Wm.EW, Wm.EW2, B, Gz, Z2, A0, B0, Wm.tau, Wm.ltau, parts[m], wk)
+                be.mofa_w_elbo(Wm.EWh2, Wm.gamma, Wm.sig2, o["ard_weights"], o["spikeslab_weights"],
+                               A0 + 0.5 * V.D, A0, B0, TH_A0, TH_B0, Wm.alpha, Wm.lalpha, Wm.lth, Wm.l1mth,
+                               parts[m], wk)
+        self._join()
         # factors: per-group column sums of <z^2> and ln sig2 over this rank's samples, added up over
         # the ranks in one collective; the ARD update and the ELBO terms follow from the global sums
         zs = self._zs
@@ -648,14 +705,20 @@ class MofaEngine:
         if self.comm.world_size > 1:
             self.comm.all_reduce_sum(zs)
         be.mofa_z_elbo(zs, self._Ng64, o["ard_factors"], A0, B0, self.alpha_z, self.lalpha_z, elbo)
+        if self._par:
+            for extra in parts[1:]:
+                elbo = elbo + extra  # (the views' terms, in view order)
         return elbo
 
     # -- driver --------------------------------------------------------------------------------
     def _iteration(self) -> torch.Tensor:
         """One coordinate-ascent sweep (W per view, Z, tau / alpha / theta, ELBO); device work only,
         returns the ELBO as a device scalar."""
+        self._fork()
         for m in range(self.M):
-            self._update_w(m)
+            with self._on(m):
+                self._update_w(m)
+        self._join()
         self._update_z()
         return self._update_rest_and_elbo()
 

@@ -95,12 +95,21 @@ __global__ __launch_bounds__(kET) void k_mofa_tau(int64_t D, int K, int G, const
 }
 
 // *elbo += sum of the partials, in order
+// (r05: 64 lanes take contiguous runs of the partials and the runs are added in lane order - one thread walking up to
+//  512 partials was 27 us behind a 15 us pass)
 __global__ __launch_bounds__(64) void k_mofa_add_partials(int nb, const double* __restrict__ partial,
                                                           double* __restrict__ elbo) {
+  __shared__ double run[64];
+  const int per = (nb + 63) / 64;
+  const int b0 = threadIdx.x * per, b1 = b0 + per < nb ? b0 + per : nb;
+  double s = 0.0;
+  for (int i = b0; i < b1; ++i) s += partial[i];
+  run[threadIdx.x] = s;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < nb; ++i) s += partial[i];
-    *elbo += s;
+    double t = 0.0;
+    for (int i = 0; i < 64; ++i) t += run[i];
+    *elbo += t;
   }
 }
 
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(kET) void k_mofa_w_colsums(int64_t D, int K, const 
 }
 
 // alpha_w / theta updates from the column sums and the ELBO terms of the W, alpha_w and theta nodes
-constexpr int kFinT = 1024, kFinChunks = 8;  // 128 (quantity, factor) values x 8 chunks of partial blocks
+constexpr int kFinT = 1024;  // (quantity, factor) values x chunks of partial blocks: 64 x 16 for K <= 16, 128 x 8 beyond
 template <typename T>
 __global__ __launch_bounds__(kFinT) void k_mofa_w_finish(int64_t D, int K, int nb, int ard, int spikeslab,
                                                          const double* __restrict__ partial, double a_alpha,
@@ -153,7 +162,8 @@ __global__ __launch_bounds__(kFinT) void k_mofa_w_finish(int64_t D, int K, int n
   {
     // the partial blocks are summed in eight chunks side by side, the chunks in order (fixed order; r02
     // walked all of them on one thread per factor: 31 us behind a 15 us pass)
-    constexpr int lanes = kFinT / kFinChunks;  // 128 >= 4 K
+    const int kFinChunks = K <= 16 ? 16 : 8;
+    const int lanes = kFinT / kFinChunks;  // 64 / 128 >= 4 K
     const int c = threadIdx.x / lanes, v = threadIdx.x % lanes;
     const int b0_ = (int)((int64_t)nb * c / kFinChunks), b1_ = (int)((int64_t)nb * (c + 1) / kFinChunks);
     double sacc = 0.0;
@@ -163,7 +173,6 @@ __global__ __launch_bounds__(kFinT) void k_mofa_w_finish(int64_t D, int K, int n
     __syncthreads();
     if (c == 0 && v < 4 * K) {
       double tot = 0.0;
-#pragma unroll
       for (int q = 0; q < kFinChunks; ++q) tot += red[q * lanes + v];
       cs[v / K][v % K] = tot;
     }
