@@ -316,6 +316,47 @@ def run_lsi(args, workload, rank, world, local_rank, comm, steps, warmup, cpu_sa
     return out
 
 
+def flatten_for_driver(out, sec):
+    """The driver's record of the line keeps SCALAR keys of `config` / `roofline` / `cpu_baseline` and a 2 000-character
+    tail of stdout: parity and the figures of the LSI iteration go into `config` as flat scalars, and
+    the LAST key of the line is a compact `summary` (headline, parity, one number per secondary record) so that the tail
+    shows them whatever the length of the sub-records in front."""
+    cfg = out["config"]
+    lsi = cfg.get("lsi") or {}
+    for k in ("spmm_per_step", "converged", "angle_bound", "iterations", "spmm_unused"):
+        if k in lsi:
+            cfg["lsi_" + k] = lsi[k]
+    par = out.get("parity") or {}
+    for k in ("tfidf_pattern_identical", "tfidf_values_max_rel", "lsi_angle_rad", "lsi_stdev_max_rel", "lsi_converged",
+              "lsi_angle_bound"):
+        if k in par:
+            cfg["parity_" + k] = par[k]
+    summ = {"ms_per_step": round(out["ms_per_step"], 2), "cells_per_s": round(out["value"]),
+            "roofline_frac": round(out["roofline"]["frac"], 4), "spmm_ms": round(out["roofline"]["avg_launch_ms"], 3)}
+    for k in ("tfidf_pattern_identical", "tfidf_values_max_rel", "lsi_angle_rad", "lsi_stdev_max_rel"):
+        if k in par:
+            summ["parity_" + k] = par[k]
+    for name, rec in (sec or {}).items():
+        rec = rec or {}
+        if "error" in rec:
+            cfg[name + "_error"] = summ[name + "_error"] = str(rec["error"])[:120]
+            continue
+        # one scalar per sub-record under `config` (the driver drops nested objects), the same in the summary
+        key = name + ("_ms_per_step" if rec.get("unit") == "cells/s" and "ms_per_step" in rec else "_value")
+        val = rec.get("ms_per_step") if key.endswith("_ms_per_step") else rec.get("value")
+        cfg[key] = val
+        summ[key] = val if not isinstance(val, float) else float(f"{val:.5g}")
+        rf = (rec.get("roofline") or {}).get("frac")
+        if rf is not None:
+            cfg[name + "_roofline_frac"] = rf
+            summ[name + "_roofline_frac"] = round(rf, 4)
+        for pk, pv in (rec.get("parity") or {}).items():
+            if isinstance(pv, (bool, int, float)):
+                cfg[f"{name}_parity_{pk}"] = pv
+    out.pop("summary", None)
+    out["summary"] = summ  # (last key: survives the tail)
+
+
 def run_c4(args, steps, warmup, f64=False):
     import importlib.util
 
@@ -455,16 +496,10 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     sec[name] = {"error": repr(e)}
             out["secondary"] = sec
-        if default_line and out is not None:
-            # the two figures the driver's view of the line (known keys + a 4 KB tail) otherwise does not show, mirrored
-            # under `config`: the 10k x 30k record's step time and the c3 sample parity
-            c2 = sec.get("c2") or {}
-            out["config"]["c2_ms_per_step"] = c2.get("ms_per_step")
-            par = out.get("parity") or {}
-            out["config"]["parity_summary"] = {k: par.get(k) for k in ("tfidf_pattern_identical", "tfidf_values_max_rel",
-                                                                         "lsi_angle_rad", "lsi_stdev_max_rel")}
+        if out is not None:
+            flatten_for_driver(out, sec if default_line else None)
     if rank == 0 and out is not None:
-        print(json.dumps(out))
+        print(json.dumps(out, separators=(",", ":")))
     if world > 1 or force_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

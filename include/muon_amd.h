@@ -239,6 +239,9 @@ int mu_tpack4_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_
                        const int64_t* d_t_indptr, int32_t* d_t_indices, float* d_t_values, void* d_work,
                        size_t work_bytes, void* stream);
 int mu_tpack4_status(const void* d_work, int64_t n_rows, int64_t n_cols, int64_t nnz, int* h_err);
+/* byte offset of that error word (an int32) inside d_work, for callers that read it with a fetch of their own instead of
+ * synchronising (lsi reads it with its first Gram fetch and raises if the transposition tripped an invariant) */
+size_t mu_tpack4_err_offset(int64_t n_rows, int64_t n_cols, int64_t nnz);
 int mu_tpack4_phase_cycles(unsigned long long* h_out6, int reset);
 /* diagnostics (scripts/tpack_probe.py): see csrc/tpack.hip */
 int mu_csr_tpack_phase_cycles(unsigned long long* h_out6, int reset);

@@ -151,32 +151,104 @@ class _Box:
     pass
 
 
+def _matrix_refs(m, held_by_caller: int) -> int:
+    """What ``_refs_seen`` reports for ``m`` inside a callee with _dies_with_rebinding's signature (the twin the
+    calibration calls: same arguments, same call path down to sys.getrefcount)."""
+    return _refs_seen(m)
+
+
+def _probe_call(box):
+    # the production call site's shape (tfidf below): the matrix comes out of a container attribute into the local
+    # `counts`, `host` is a second local name for it, the callee gets the local and the literal 2
+    counts = box.X
+    host = counts
+    return _matrix_refs(counts, 2), host is counts
+
+
+_CALIBRATION = None
+
+
 def _calibrate_refs():
-    """What _refs_seen reports for an object held by ONE container attribute, (a) passed as an attribute lookup and
-    (b) passed from a local variable: the interpreter's own references during the call, measured, not assumed."""
+    """The interpreter's own references, MEASURED on this interpreter instead of assumed (CPython 3.11+
+    moves call arguments into the callee's frame without a second reference, 3.14 borrows locals - a hard-coded
+    "+ 2" is one version's truth): (a) an array held by ONE container attribute, passed as an attribute lookup;
+    (b) a matrix held by one container attribute and two locals of the caller, seen from a callee with
+    _dies_with_rebinding's signature through the same call path.  Then the SELF-TEST of the whole decision on throw-away
+    matrices: a sole owner must be taken over, a matrix with one more owner (a layer entry, a variable, a second
+    matrix on the same arrays) must not.  ``ok`` False = the counts cannot be trusted here: never take over."""
+    global _CALIBRATION
+    if _CALIBRATION is not None:
+        return _CALIBRATION
     b = _Box()
     b.x = np.empty(1)
-    a = _refs_seen(b.x)
-    loc = b.x
-    return a, _refs_seen(loc) - 1
+    attr = _refs_seen(b.x)
+    b.X = csr_matrix(np.eye(3, dtype=np.float32))
+    matrix2, _ = _probe_call(b)
+    _CALIBRATION = {"attr": attr, "matrix2": matrix2, "ok": True}  # (provisional: the self-test runs through it)
+
+    def fresh():
+        bx = _Box()
+        m = csr_matrix(np.eye(4, dtype=np.float32))
+        # (scipy leaves views of the constructor's arrays behind; own them like a matrix read from a file does)
+        m.data, m.indices, m.indptr = m.data.copy(), m.indices.copy(), m.indptr.copy()
+        bx.X = m
+        m = None
+        return bx
+
+    def decide(bx):
+        counts = bx.X
+        host = counts
+        return _dies_with_rebinding(counts, 2), host is counts
+
+    ok = decide(fresh())[0] is True
+    bx = fresh()
+    bx.layers = {"counts": bx.X}            # one more owner: a layer
+    ok = ok and decide(bx)[0] is False
+    bx = fresh()
+    keep = bx.X                              # ... a variable
+    ok = ok and decide(bx)[0] is False
+    keep = None
+    bx = fresh()
+    arr = bx.X.data                          # ... one of its arrays
+    ok = ok and decide(bx)[0] is False
+    arr = None
+    bx = fresh()
+    other = csr_matrix((bx.X.data, bx.X.indices, bx.X.indptr), shape=bx.X.shape)  # ... a second matrix on the arrays
+    ok = ok and decide(bx)[0] is False
+    other = None
+    _CALIBRATION["ok"] = bool(ok)
+    return _CALIBRATION
+
+
+def _reuse_host_enabled(reuse_host) -> bool:
+    """The takeover is OPT-IN (r06; it was on by default in r05): ``tfidf(..., reuse_host=True)`` or
+    ``MUON_AMD_REUSE_HOST=1``.  A holder of a raw pointer into the old matrix (ctypes, a C extension, an
+    ``__array_interface__`` consumer) is invisible to reference counts, and the reference never mutates the matrix it
+    replaces (preproc.py:121-127): the default must not either."""
+    import os
+
+    if reuse_host is None:
+        return os.environ.get("MUON_AMD_REUSE_HOST", "0") == "1"
+    return bool(reuse_host)
 
 
 def _dies_with_rebinding(m, held_by_caller: int) -> bool:
     """True when host CSR ``m`` and its three arrays are referenced by NOTHING but the container attribute the caller is
     about to rebind (plus ``held_by_caller`` local names of the caller): the result may then take the matrix's index
-    arrays over and be downloaded into its value array - nobody can observe the difference, and a 250 000 x 200 000
-    experiment saves a 6 GB copy, 12 GB of first-touch page faults and the release of the 12 GB it replaces (34 ms per GB
-    on the bench host: 430 of the API path's 1090 ms, profiles/r05_api_profile.txt).  Anything else that holds the
-    matrix or one of its arrays - ``adata.layers["counts"] = adata.X``, a view, a variable of the user's - counts as a
-    reference and turns this off.  The reference rebinds ``adata.X`` to a new matrix (preproc.py:121-127); an owner
-    of the old one must keep seeing the counts."""
-    import os
-
-    if os.environ.get("MUON_AMD_REUSE_HOST", "1") == "0" or type(m) is not csr_matrix:
+    arrays over and be downloaded into its value array - nobody holding a Python reference can observe the difference,
+    and a 250 000 x 200 000 experiment saves a 6 GB copy, 12 GB of first-touch page faults and the release of the 12 GB
+    it replaces (34 ms per GB on the bench host: 430 of the API path's 1090 ms, profiles/r05_api_profile.txt).
+    Anything else that holds the matrix or one of its arrays - ``adata.layers["counts"] = adata.X``, a view, a variable
+    of the user's - counts as a reference and turns this off.  The reference rebinds ``adata.X`` to a new matrix
+    (preproc.py:121-127); an owner of the old one must keep seeing the counts.  Only reached when the caller opted in
+    (_reuse_host_enabled); the expected counts are measured on this interpreter and self-tested (_calibrate_refs)."""
+    if type(m) is not csr_matrix:
         return False
-    attr, local = _calibrate_refs()
-    # (+ 2: this function's own name for the matrix and the caller's stack slot of the call)
-    if _refs_seen(m) != local + held_by_caller + 2:
+    cal = _calibrate_refs()
+    if not cal["ok"]:
+        return False
+    attr = cal["attr"]
+    if _refs_seen(m) != cal["matrix2"] + (held_by_caller - 2):
         return False
     for name in ("data", "indices", "indptr"):
         a = m.__dict__.get(name)
@@ -374,6 +446,7 @@ def tfidf(
     n_obs: Optional[int] = None,
     match_scipy_order: bool = False,
     keep_on_device: bool = True,
+    reuse_host: Optional[bool] = None,
     backend=None,
 ):
     """
@@ -395,6 +468,11 @@ def tfidf(
             canonical sorted CSR.
     keep_on_device
             Keep the device copy attached to the result so that ``lsi`` skips the upload.
+    reuse_host
+            Opt-in (default off; ``None`` reads ``MUON_AMD_REUSE_HOST=1``): when ``adata.X`` is rebound and NOTHING else
+            holds a Python reference to the matrix it replaces or to its arrays, the result adopts that matrix's index
+            arrays and value buffer instead of allocating 12 bytes per stored entry.  The reference never touches the
+            old matrix (preproc.py:121-127) and a raw-pointer holder is invisible to reference counts: hence opt-in.
     """
     if is_anndata(data):
         adata = data
@@ -462,7 +540,7 @@ def tfidf(
                       if isinstance(getattr(counts, k, None), np.ndarray))
     else:
         own = (shares and inplace and to_layer is None and from_layer is None and not copy
-               and _dies_with_rebinding(counts, 2))
+               and _reuse_host_enabled(reuse_host) and _dies_with_rebinding(counts, 2))
     if own:
         want = np.dtype(np.float32) if R.values.element_size() == 4 else np.dtype(np.float64)
         buf = host.data if host.data.dtype == want else (host.data.view(want) if host.data.dtype.itemsize == want.itemsize

@@ -251,6 +251,7 @@ def _lsi_device(
     mfma = (pack and hasattr(backend, "can_cells") and os.environ.get("MUON_AMD_LSI_MFMA", "0") == "1"
             and backend.can_cells(X, B))
     Xcsr = X  # (the CSR as it came: the warm start below cuts a row range out of it)
+    t4_err = take = None
     if mfma:
         logger.warning("MUON_AMD_LSI_MFMA=1: X Q_j runs on the matrix cores with the Krylov basis rounded to f16 - an "
                        "experiment (DESIGN.md 4.3) that leaves the top-k subspace about 1e-4 rad from the f32 path's, "
@@ -259,6 +260,8 @@ def _lsi_device(
         X = backend.cells(X)
     elif pack:
         X, Xt = backend.stream_both(X)
+        take = getattr(backend, "take_tpack4_err", None)
+        t4_err = take() if take is not None else None  # (read with the first Gram fetch: no synchronisation of its own)
     elif Xt is None:
         Xt = backend.transpose(X)
 
@@ -310,15 +313,18 @@ def _lsi_device(
     # "0": cold start).
     warm_spec = os.environ.get("MUON_AMD_LSI_WARM", "32:2" if nnz_rank > 500_000_000 else "0")
     warm_used = None
-    if (start is None and warm_spec != "0" and pack and not mfma and n_iter is None and hasattr(Xcsr, "indptr")
-            and hasattr(backend, "stream_both")):
+    # (the block below holds collectives, so entering it must be ONE decision of all ranks.  `pack` is per
+    #  rank - a rank whose shard has no rows has no row stream - and such a rank still takes part: with an empty slice it
+    #  contributes zeros to the sums.  `warm_spec`, `start`, `n_iter` are the same on every rank by construction.)
+    can_slice = bool(pack and not mfma and hasattr(Xcsr, "indptr") and hasattr(backend, "stream_both"))
+    if start is None and warm_spec != "0" and n_iter is None:
         frac, qsteps = (int(v) for v in (warm_spec.split(":") + ["2"])[:2])
         # this rank's slice: 1 / frac of its cells; the slices of ALL ranks together at least 16 384 cells (an experiment
         # of a few 1e5 cells still gets a slice whose top subspace means something - but eight ranks with 125 000 cells
         # each need 2 048 apiece for that, not 16 384), at most a quarter, whole 512-row blocks
         floor_rows = -(-16384 * n_local // max(int(n_obs), 1))
         n_s = min(max(n_local // max(frac, 1), floor_rows), n_local // 4)
-        n_s = (n_s // 512) * 512
+        n_s = (n_s // 512) * 512 if can_slice else 0
         if comm.agree(qsteps >= 1 and comm.sum_scalar(n_s) >= 8192):  # (all ranks take part in the collectives or none does)
             Ss = St = None
             if n_s > 0:
@@ -339,6 +345,9 @@ def _lsi_device(
                     cat = (lambda a: torch.cat([a[l:h] for l, h in zip(los, his)])) if chunks > 1 else (lambda a: a[los[0]:his[0]])
                     Xsub = type(Xcsr)(sub_ip.contiguous(), cat(Xcsr.indices), cat(Xcsr.values), (per * chunks, d))
                     Ss, St = backend.stream_both(Xsub)
+                    e2 = take() if take is not None else None  # (the slice's transposition is checked with the shard's)
+                    if e2 is not None:
+                        t4_err = e2 if t4_err is None else (t4_err | e2)
                     n_s = per * chunks
             for _ in range(qsteps):
                 Zs = backend.spmm(St, backend.spmm(Ss, Q0)) if Ss is not None else torch.zeros_like(Q0)
@@ -367,7 +376,10 @@ def _lsi_device(
         comm.all_reduce_sum(Gj, cs, *cross)
         mq = [backend.gram(Qnew)[0]] + [backend.gram_cross(Qi, Qnew) for Qi in Qolds]
         extra = [pending_g1, qr_flag] if (device_qr and pending_g1 is not None) else []
-        return backend.fetch_async([Gj, cs] + cross + mq + extra), bool(extra), len(Yolds)
+        nonlocal t4_err
+        chk = [t4_err] if t4_err is not None else []  # the transposition's error word rides on the first fetch
+        t4_err = None
+        return backend.fetch_async([Gj, cs] + cross + mq + extra + chk), bool(extra), len(Yolds), bool(chk)
 
     def launch_block_grams(j):
         return launch_grams(Ys[j], Ys[:j], Qs[j], Qs[:j])
@@ -377,8 +389,11 @@ def _lsi_device(
         matrix): the launch was made against the m_old blocks of BEFORE a thick restart - the cross blocks against
         the j kept blocks K Cw are Cw^T applied to the stacked old ones."""
         nonlocal beta_hat, pending_g1
-        handle, has_extra, n_old = handle_extra
+        handle, has_extra, n_old, has_chk = handle_extra
         got = handle.wait()
+        if has_chk:
+            backend.raise_tpack4(int(got[-1].reshape(-1)[0]))
+            got = got[:-1]
         if has_extra:
             if int(got[-1].reshape(-1)[0]) != 0:
                 raise _RedoOnHost()

@@ -676,6 +676,7 @@ class HipBackend:
                 check(self.lib.mu_tpack4_fill_csr(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values), None, None,
                                                   _p(t_indptr), _p(t_indices), _p(t_values), _p(work), wb, st))
             self._note_tpack4(work, n, d, X.nnz)
+            self.raise_tpack4(self.take_tpack4_err().item())  # (set-up / ingest paths: a synchronisation is affordable)
             return DeviceCSR(t_indptr, t_indices, t_values, (d, n))
         wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
         work = self.empty((wb,), torch.uint8)
@@ -735,6 +736,21 @@ class HipBackend:
         # (never by default: a work buffer kept across calls is a second 1.8 GB block at 1e6 x 200k - the next call's
         #  allocation then misses the caching allocator's pool: a hipMalloc inside every step, measured at 300 ms)
         self._tpack4_work = (work, (n, d, nnz)) if self.keep_tpack4_work else None
+        # the fill's error word (1: bitmap and count pass disagree, 2: a tile could not be narrowed - a
+        # silently wrong X^T) was read by tests only.  A 4-byte copy of it, queued behind the fill, is picked up by the
+        # consumer at its next synchronisation (lsi: with the first Gram fetch; transpose_csr: right away).
+        off = int(self.lib.mu_tpack4_err_offset(n, d, nnz))
+        self._tpack4_err = work[off:off + 4].view(torch.int32).clone()
+
+    def take_tpack4_err(self):
+        """Device int32[1] error word of the last fourth-generation fill (once; None if there was none)."""
+        return self.__dict__.pop("_tpack4_err", None)
+
+    @staticmethod
+    def raise_tpack4(err: int) -> None:
+        if int(err) != 0:
+            raise _ffi.MuonAmdError(f"mu_tpack4_fill: the transposition tripped an internal invariant (error word {int(err)}: "
+                                    "1 = bitmap and count pass disagree, 2 = a tile could not be narrowed); X^T would be wrong")
 
     def tpack4_status(self) -> int:
         """Error word of the last fourth-generation fill (0 = fine; synchronises: tests and probes)."""

@@ -137,14 +137,19 @@ def _sort_rows(backend, X):
     key = key[order]
     vals = X.values[order]
     if bool((key[1:] == key[:-1]).any()):
-        # duplicate (row, column) pairs: one entry each, values summed as a segmented reduction - differences of the
-        # f64 running sum at the segment ends (a scan: the same result run to run; index_add_ is atomics in arbitrary
-        # order - ADVICE r04), exact for counts
+        # duplicate (row, column) pairs: one entry each.  Entries without a duplicate pass through UNCHANGED (bit for
+        # bit); the duplicated groups are summed group by group in f64, in stored order (torch.segment_reduce: one
+        # sequential sum per segment - the same result run to run; index_add_ is atomics in arbitrary order, ADVICE
+        # r04).  r05 took differences of ONE f64 running sum over all entries: exact for counts, but for general values
+        # its error grew with the running total of the whole matrix and a single NaN / Inf poisoned every later entry
+        #  - a group's sum now sees that group's values only.
         ukey, seg = torch.unique_consecutive(key, return_counts=True)
-        run = torch.cumsum(vals.to(torch.float64), 0)
         ends = torch.cumsum(seg, 0) - 1
-        tot = run[ends]
-        uvals = (tot - torch.cat([tot.new_zeros(1), tot[:-1]])).to(vals.dtype)
+        uvals = vals[ends].clone()  # (singletons: their own value; duplicated groups: overwritten below)
+        dup = seg > 1
+        in_dup = torch.repeat_interleave(dup, seg)
+        sums = torch.segment_reduce(vals[in_dup].to(torch.float64), "sum", lengths=seg[dup])
+        uvals[dup] = sums.to(vals.dtype)
         cnt = torch.bincount(torch.div(ukey, int(d), rounding_mode="floor"), minlength=n)
         indptr = torch.zeros(n + 1, dtype=torch.int64, device=key.device)
         torch.cumsum(cnt, 0, out=indptr[1:])

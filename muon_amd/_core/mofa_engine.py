@@ -714,6 +714,14 @@ class MofaEngine:
     def _iteration(self) -> torch.Tensor:
         """One coordinate-ascent sweep (W per view, Z, tau / alpha / theta, ELBO); device work only,
         returns the ELBO as a device scalar."""
+        if self._par and getattr(self, "_fused", False):
+            # (ADVICE r05) the factors' moments and the padded <Z> operands are SHARED by the views: when no statistics
+            # are cached (first eager iteration, the one after a refused capture) view 0's W update would compute them
+            # on the main stream after the fork while view 1's reads them on its side stream - made here, before the
+            # views part, exactly as _update_rest_and_elbo does
+            for m in range(self.M):
+                if self._stats.get(m) is None:
+                    self._z_moments(m)
         self._fork()
         for m in range(self.M):
             with self._on(m):

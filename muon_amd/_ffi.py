@@ -75,6 +75,7 @@ SIGNATURES = {
     "mu_tpack4_fill_stream": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_tpack4_fill_csr": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_tpack4_status": (C.c_int, [_vp, _i64, _i64, _i64, C.POINTER(C.c_int)]),
+    "mu_tpack4_err_offset": (_sz, [_i64, _i64, _i64]),
     "mu_tpack4_phase_cycles": (C.c_int, [_vp, _i32]),
     "mu_csr_tpack_phase_cycles": (C.c_int, [_vp, _i32]),
     "mu_csr_stream_len": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),

@@ -171,15 +171,19 @@ int mu_host_hash64(const void* h_ptr, size_t n_bytes, int n_threads, uint64_t se
   };
   int T = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
   if ((size_t)T > n_chunks) T = (int)n_chunks;
-  if (T <= 1) {
-    work();
-  } else {
-    std::vector<std::thread> th;
-    th.reserve(T - 1);
-    for (int t = 1; t < T; ++t) th.emplace_back(work);
-    work();
-    for (auto& x : th) x.join();
+  // extern "C": nothing may throw past this frame.  std::thread's constructor throws std::system_error when the
+  // process cannot start another thread (a cgroup pid limit, RLIMIT_NPROC) and std::vector may throw bad_alloc:
+  // whatever threads did start share the chunk counter with the calling thread, which finishes the rest alone.
+  std::vector<std::thread> th;
+  try {
+    if (T > 1) {
+      th.reserve(T - 1);
+      for (int t = 1; t < T; ++t) th.emplace_back(work);
+    }
+  } catch (...) {
   }
+  work();
+  for (auto& x : th) x.join();
   uint64_t h = seed ^ kP5 ^ (uint64_t)n_bytes;
   for (size_t c = 0; c < n_chunks; ++c) h = mu_rotl64(h ^ mu_round64(0, dig[c]), 27) * kP1 + kP4;
   *h_out = mu_avalanche64(h);

@@ -917,6 +917,14 @@ int mu_tpack4_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_
                       out, d_work, (hipStream_t)stream);
 }
 
+/* byte offset of the fill's error word inside d_work: callers that must not synchronise copy the word to the host with
+ * their next fetch (muon_amd/_backend.py: tpack4 fills are checked at lsi's first Gram fetch) */
+size_t mu_tpack4_err_offset(int64_t n_rows, int64_t n_cols, int64_t nnz) {
+  char* base = nullptr;
+  const T4Work w = t4_carve(base, n_rows, n_cols, nnz);
+  return (size_t)((char*)w.err - base);
+}
+
 /* the fill's error word (0 = fine; 1: bitmap and count pass disagreed, 2: a tile could not be narrowed) - synchronises */
 int mu_tpack4_status(const void* d_work, int64_t n_rows, int64_t n_cols, int64_t nnz, int* h_err) {
   MU_REQUIRE(d_work && h_err, "null pointer");

@@ -250,13 +250,13 @@ def run_c3_api(be, n_cells=250_000, n_feat=200_000, density=0.03, seed=0):
             spans[k] = 0.0
         ad = AnnData(m.copy())
         where = ad.X.data.ctypes.data
-        if it == 2:
-            ad.layers["counts"] = ad.X  # the tutorial's workflow: the counts stay visible, the result gets its own arrays
+        # it == 2: the opt-in takeover of the replaced matrix's host arrays (r06: off by default - the reference never
+        # writes into the matrix it replaces and a raw-pointer holder is invisible to reference counts)
         saved = [(be, "upload_csr", timed(be, "upload_csr", "upload")), (be, "to_host", timed(be, "to_host", "download")),
                  (P, "_fingerprint", timed(P, "_fingerprint", "fingerprint"))]
         _sync()
         t0 = time.perf_counter()
-        ac.pp.tfidf(ad, backend=be)
+        ac.pp.tfidf(ad, backend=be, reuse_host=(it == 2))
         _sync()
         t1 = time.perf_counter()
         ac.tl.lsi(ad, backend=be)
@@ -265,10 +265,10 @@ def run_c3_api(be, n_cells=250_000, n_feat=200_000, density=0.03, seed=0):
         for obj, name, f in saved:
             setattr(obj, name, f)
         if it == 2:
-            assert ad.X.data.ctypes.data != where and ad.layers["counts"].data.ctypes.data == where
+            taken = ad.X.data.ctypes.data == where
             kept = (t1 - t0, t2 - t1)
         else:
-            taken = ad.X.data.ctypes.data == where
+            assert ad.X.data.ctypes.data != where  # the default never writes into the replaced matrix
             best = (t1 - t0, t2 - t1, dict(spans))
         del ad
     t_tfidf, t_lsi, sp_ = best
@@ -279,12 +279,13 @@ def run_c3_api(be, n_cells=250_000, n_feat=200_000, density=0.03, seed=0):
             "split_ms": {"tfidf_call": t_tfidf * 1e3, "lsi_call": t_lsi * 1e3, "upload_pcie": sp_["upload"] * 1e3,
                          "download_pcie": sp_["download"] * 1e3, "fingerprints_xxh3": sp_["fingerprint"] * 1e3,
                          "kernels_and_host_logic": (total - sum(sp_.values())) * 1e3},
-            "host_arrays": ("the replaced matrix was referenced by nothing else: the result took its index arrays over and was "
-                            "downloaded into its value array (preproc._dies_with_rebinding)" if taken else
-                            "fresh arrays for the result, the replaced matrix released inside the call"),
-            "counts_kept_in_a_layer_ms": {"tfidf_call": kept[0] * 1e3, "lsi_call": kept[1] * 1e3, "total": (kept[0] + kept[1]) * 1e3,
-                                          "note": "adata.layers['counts'] = adata.X before the call: the result gets fresh arrays "
-                                                  "(a 6 GB index copy and 12 GB of first-touch page faults), nothing is released"},
+            "host_arrays": "default: fresh arrays for the result (a 6 GB index copy, 12 GB of first-touch page faults), the "
+                           "replaced matrix released inside the call - the reference's behaviour (preproc.py:121-127)",
+            "reuse_host_opt_in_ms": {"tfidf_call": kept[0] * 1e3, "lsi_call": kept[1] * 1e3, "total": (kept[0] + kept[1]) * 1e3,
+                                     "taken_over": bool(taken),
+                                     "note": "tfidf(..., reuse_host=True): nothing else referenced the replaced matrix, the result "
+                                             "took its index arrays over and was downloaded into its value array "
+                                             "(preproc._dies_with_rebinding; opt-in since r06)"},
             "config": {"workload": f"c3_api: {n_cells} cells x {n_feat} peaks ({nnz} stored entries, a quarter of configs[2]) as a host "
                                    f"scipy CSR in an AnnData; tfidf writes adata.X back, lsi finds the device copy "
                                    f"(fingerprint check) and writes obsm / varm / uns"},

@@ -382,14 +382,22 @@ def test_tfidf_takes_the_replaced_matrix_over_only_when_nothing_else_sees_it(mon
     """`adata.X = tf_idf` (preproc.py:121-127) leaves the old matrix to its other owners.  When there are none, the
     result reuses its index arrays and value buffer (no 6 GB copy / first touch / release at scale); an owner -
     `layers["counts"] = adata.X`, a variable, a view of one of the arrays - keeps seeing the counts."""
+    from muon_amd._atac import preproc
+
+    monkeypatch.delenv("MUON_AMD_REUSE_HOST", raising=False)
     ref = AnnData(_big_counts())
-    monkeypatch.setenv("MUON_AMD_REUSE_HOST", "0")
-    ac.pp.tfidf(ref, backend=BE)
-    monkeypatch.delenv("MUON_AMD_REUSE_HOST")
+    old = ref.X
+    where = ref.X.data.ctypes.data
+    del old
+    ac.pp.tfidf(ref, backend=BE)          # r06: OFF by default - the reference never writes into the matrix it replaces
+    assert ref.X.data.ctypes.data != where
+    # the counts it compares with are measured on this interpreter and the whole decision is self-tested at first use
+    cal = preproc._calibrate_refs()
+    assert cal["ok"] and cal["matrix2"] >= 3 and cal["attr"] >= 2
 
     ad = AnnData(_big_counts())
     where = (ad.X.data.ctypes.data, ad.X.indices.ctypes.data, ad.X.indptr.ctypes.data)
-    ac.pp.tfidf(ad, backend=BE)
+    ac.pp.tfidf(ad, backend=BE, reuse_host=True)
     assert (ad.X.data.ctypes.data, ad.X.indices.ctypes.data, ad.X.indptr.ctypes.data) == where  # taken over
     assert (ad.X != ref.X).nnz == 0 and np.array_equal(ad.X.data, ref.X.data)
     ac.tl.lsi(ad, n_comps=5, backend=BE)  # the attached device copy describes the new values
@@ -414,10 +422,21 @@ def test_tfidf_takes_the_replaced_matrix_over_only_when_nothing_else_sees_it(mon
         else:
             other = sp.csr_matrix((ad.X.data, ad.X.indices, ad.X.indptr), shape=ad.X.shape)
             seen = lambda: other  # noqa: E731
-        ac.pp.tfidf(ad, backend=BE)
+        ac.pp.tfidf(ad, backend=BE, reuse_host=True)
         assert ad.X.data.ctypes.data != where, how
         assert np.array_equal(ad.X.data, ref.X.data), how
         assert (seen() != counts).nnz == 0, how  # the other owner still holds the counts
+    # the environment switch opts in as well; a failed self-test switches the takeover off whatever the caller asks
+    monkeypatch.setenv("MUON_AMD_REUSE_HOST", "1")
+    ad = AnnData(_big_counts())
+    where = ad.X.data.ctypes.data
+    ac.pp.tfidf(ad, backend=BE)
+    assert ad.X.data.ctypes.data == where
+    monkeypatch.setitem(preproc._CALIBRATION, "ok", False)
+    ad = AnnData(_big_counts())
+    where = ad.X.data.ctypes.data
+    ac.pp.tfidf(ad, backend=BE)
+    assert ad.X.data.ctypes.data != where and np.array_equal(ad.X.data, ref.X.data)
 
     # not in place / into a layer / from a layer: the counts stay where they are
     ad = AnnData(_big_counts())
@@ -453,7 +472,7 @@ def test_tfidf_takeover_with_other_count_types(dtype):
     before = ad.X.copy()
     keep = ad.X if dtype != np.float64 else None  # (integer input is never written to, owner or not)
     where = ad.X.data.ctypes.data
-    ac.pp.tfidf(ad, backend=BE)
+    ac.pp.tfidf(ad, backend=BE, reuse_host=True)  # (opt-in since r06)
     assert ad.X.dtype == np.float64 and np.array_equal(ad.X.data, ref.X.data) and np.array_equal(ad.X.indices, ref.X.indices)
     if dtype == np.float64:
         assert ad.X.data.ctypes.data == where

@@ -119,3 +119,44 @@ def test_read_10x_arrays_feeds_tfidf_without_another_upload():
     assert not uploads  # the device copy made by the ingest was used
     ref = tfidf_oracle.canonical(tfidf_oracle.tfidf(m[:, peaks].astype(np.float32)))
     assert np.array_equal(ad.X.indices, ref.indices) and np.allclose(ad.X.data, ref.data, rtol=1e-5)
+
+
+def test_duplicate_sums_see_their_own_group_only():
+    """the duplicate summation took differences of one f64 running sum over ALL entries - a NaN anywhere
+    poisoned every later entry and non-integer values picked up the rounding of the whole matrix' running total.  Now:
+    entries without a duplicate pass through bit for bit, a group's sum sees that group's values."""
+    import torch
+
+    from muon_amd._backend import DeviceCSR
+
+    rng = np.random.default_rng(3)
+    n, d = 40, 30
+    m = sp.random(n, d, density=0.3, format="csr", random_state=rng, dtype=np.float64)
+    m.data = (rng.standard_normal(m.nnz) * 1e6 + rng.random(m.nnz)).astype(np.float64)
+    # rows reversed (unsorted) + one duplicated entry in row 5 + a NaN in row 1
+    ptr, idx, dat = m.indptr.copy(), m.indices.copy(), m.data.copy()
+    dat[ptr[1]] = np.nan
+    for r in range(n):
+        a, b = ptr[r], ptr[r + 1]
+        idx[a:b], dat[a:b] = idx[a:b][::-1].copy(), dat[a:b][::-1].copy()
+    a5 = ptr[5]
+    idx = np.insert(idx, a5, idx[a5])
+    dat = np.insert(dat, a5, 0.25)
+    ptr[6:] += 1
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a).astype(dt))  # noqa: E731
+    X = DeviceCSR(t(ptr, np.int64), t(idx, np.int32), t(dat, np.float64), (n, d))
+    Y = mio.canonicalize(BE, X)
+    assert not Y.canonical_as_given
+    got = sp.csr_matrix((Y.values.numpy(), Y.indices.numpy(), Y.indptr.numpy()), shape=(n, d))
+    want = m.copy()
+    want.data[m.indptr[1]] = np.nan
+    dup_col = idx[a5]
+    assert got.nnz == m.nnz and np.array_equal(got.indices, m.indices)
+    k = m.indptr[5] + int(np.nonzero(m.indices[m.indptr[5]:m.indptr[6]] == dup_col)[0][0])
+    exp = want.data.copy()
+    exp[k] = 0.25 + exp[k]
+    assert np.isnan(got.data[m.indptr[1]]) and np.isnan(got.data).sum() == 1      # the NaN stays where it is
+    keep = ~np.isnan(exp)
+    keep[k] = False
+    assert np.array_equal(got.data[keep], exp[keep])                              # bit for bit: never part of a sum
+    assert got.data[k] == exp[k]
