@@ -242,6 +242,10 @@ int mu_tpack4_status(const void* d_work, int64_t n_rows, int64_t n_cols, int64_t
 /* byte offset of that error word (an int32) inside d_work, for callers that read it with a fetch of their own instead of
  * synchronising (lsi reads it with its first Gram fetch and raises if the transposition tripped an invariant) */
 size_t mu_tpack4_err_offset(int64_t n_rows, int64_t n_cols, int64_t nnz);
+/* byte offset inside d_work of the count pass' prefix table uint32 cnt[n_blocks + 1][n_cols] (cnt[g][c] = entries of column
+ * c in the row blocks before g; mu_tpack4_geometry gives the rows per block): where the cells of a row-block range begin
+ * inside every row of X^T - the table of mu_spmm_stream_ranges_f32 for the warm start's X_S^T Y_S */
+size_t mu_tpack4_cnt_offset(int64_t n_rows, int64_t n_cols, int64_t nnz);
 int mu_tpack4_phase_cycles(unsigned long long* h_out6, int reset);
 /* diagnostics (scripts/tpack_probe.py): see csrc/tpack.hip */
 int mu_csr_tpack_phase_cycles(unsigned long long* h_out6, int reset);
@@ -266,6 +270,27 @@ int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
  * B = 16 / 32: mofapy2's default precision (tools.py:308 use_float32=False).  accumulate != 0 adds to
  * d_Y - an f64-valued matrix is the sum of two f32-valued ones (v = fl32(v) + fl32(v - fl32(v)), exact
  * to 2^-48), i.e. two streams and two launches; data that is exact in f32 (counts) needs one. */
+/* r06 - the products of lsi's SUBSAMPLED WARM START (muon_amd/_atac/tools.py; the reference has no counterpart: its
+ * ARPACK run, /root/reference/muon/_atac/tools.py:53, starts from a random vector) without operands of their own:
+ * mu_spmm_stream_ranges_f32 is mu_spmm_stream_f32 (B = 64) restricted to a list of <= 32 column ranges.  h_ranges5 holds
+ * {col0, col1, q_off, ta, tb} per range: the entries of position p's row in columns [col0, col1)
+ * are pairs d_sptr[p] + d_tbl[ta * tbl_stride + row] .. d_sptr[p] + d_tbl[tb * tbl_stride + row] (row = d_perm[p], or p),
+ * column c multiplies row c - col0 + q_off of d_Q (q_rows x 64).  Workgroup (x, y) walks ranges [y per_wg, (y + 1) per_wg)
+ * and writes its partial product to d_Y + y * y_stride (elements): the caller sums the ceil(n_ranges / per_wg) partials in
+ * fixed order.  X_S^T Y_S: the row stream of X^T as it is, d_tbl = the transposition's count prefixes
+ * (mu_tpack4_cnt_offset), one range per run of row blocks, per_wg = n_ranges.  X_S Q: mu_csr_slice_stream's compact
+ * stream of the slice's rows, ranges = 8192-column super-slabs, per_wg = 1 .. (the column slabs split over the chip).
+ * mu_csr_slice_stream: the (column, value) pairs of <= 32 ranges of consecutive rows of a CSR, range after range, rows in
+ * their own order (h_row0 / h_rows: the ranges; h_lo / h_hi: d_indptr at their ends, known to the host), d_sptr
+ * int64[n_s + 1], d_rel uint32[(ceil(n_cols / 8192) + 1) * n_s] from the CSR's slab pointers (mu_csr_slab_ptr). */
+int mu_csr_slice_stream(int n_ranges, const int64_t* h_row0, const int64_t* h_rows, const int64_t* h_lo,
+                        const int64_t* h_hi, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
+                        const float* d_values, const int64_t* d_slab_ptr, int64_t* d_sptr, void* d_ent, uint32_t* d_rel,
+                        void* stream);
+int mu_spmm_stream_ranges_f32(int64_t n_pos, const int64_t* d_sptr, const void* d_ent, const int32_t* d_perm,
+                              int k_layout, const float* d_Q, int64_t q_rows, float* d_Y, int64_t y_stride,
+                              const uint32_t* d_tbl, int64_t tbl_stride, int n_ranges, const int32_t* h_ranges5,
+                              int per_wg, void* stream);
 int mu_spmm_stream_f64(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, const void* d_ent,
                        const int32_t* d_perm, int k_layout, const double* d_Q, int B, double* d_Y,
                        int accumulate, void* stream);

@@ -325,9 +325,22 @@ def _lsi_device(
         floor_rows = -(-16384 * n_local // max(int(n_obs), 1))
         n_s = min(max(n_local // max(frac, 1), floor_rows), n_local // 4)
         n_s = (n_s // 512) * 512 if can_slice else 0
+        # r06: the slice as <= 16 ranges of whole row blocks of the transposition - X_S^T Y_S then runs on the row stream
+        # of X^T as it is (the slice's cells are a contiguous piece of every row, found through the count pass' prefix
+        # table) and X_S Q on a compact copy of the slice's rows with the column slabs split over the chip: no
+        # transposition of the slice, no sorted layout, no device -> host read after the first call (the plan is cached
+        # with the index arrays).  At a 125 000-cell shard the slice's operands and four products took 8.3 ms of r05's 50.
+        wplan = None
+        if n_s > 0 and getattr(Xt, "t4", None) is not None and hasattr(backend, "slice_plan") \
+                and os.environ.get("MUON_AMD_LSI_WARM_SLICE", "ranges") == "ranges":
+            wplan = backend.slice_plan(Xcsr, n_s)
+            if wplan is not None:
+                n_s = wplan["n_s"]
         if comm.agree(qsteps >= 1 and comm.sum_scalar(n_s) >= 8192):  # (all ranks take part in the collectives or none does)
             Ss = St = None
-            if n_s > 0:
+            if wplan is not None:
+                Ss = backend.slice_stream(Xcsr, wplan)
+            elif n_s > 0:
                 # the slice = 16 row ranges spread evenly over this rank's cells (files list cells sample by sample:
                 # the FIRST n_s cells may be one batch; a start from an odd slice costs an expansion, never the answer)
                 chunks = 16 if n_s >= 2048 else 1  # (n_s is a multiple of 512: ranges of >= 128 rows)
@@ -350,13 +363,16 @@ def _lsi_device(
                         t4_err = e2 if t4_err is None else (t4_err | e2)
                     n_s = per * chunks
             for _ in range(qsteps):
-                Zs = backend.spmm(St, backend.spmm(Ss, Q0)) if Ss is not None else torch.zeros_like(Q0)
+                if wplan is not None:
+                    Zs = backend.spmm_slice_t(Xt, wplan, backend.spmm_slice(Ss, Q0))
+                else:
+                    Zs = backend.spmm(St, backend.spmm(Ss, Q0)) if Ss is not None else torch.zeros_like(Q0)
                 comm.all_reduce_sum(Zs)
                 if w < B:
                     Zs[:, w:] = 0
                 Q0, _ = _orthonormalize(backend, Zs, w, passes=2, flag=qr_flag)
             del Ss, St
-            warm_used = {"cells": n_s, "power_steps": qsteps}
+            warm_used = {"cells": n_s, "power_steps": qsteps, "slice": "ranges" if wplan is not None else "operands"}
     Qs, Ys, css = [Q0], [], []
     Tb, Mb = {}, {}  # (i, j), i <= j  ->  w x w f64 host blocks
 

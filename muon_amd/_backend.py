@@ -41,7 +41,7 @@ class DeviceCSR:
 
     def with_values(self, values: torch.Tensor) -> "DeviceCSR":
         out = DeviceCSR(self.indptr, self.indices, values, self.shape)
-        for name in ("slab_ptr", "xplan", "tplan"):  # (they describe the index arrays, which the new object shares)
+        for name in ("slab_ptr", "xplan", "tplan", "wplan"):  # (they describe the index arrays, which the new object shares)
             got = getattr(self, name, None)
             if got is not None:
                 setattr(out, name, got)
@@ -61,6 +61,9 @@ class DeviceStream:
     nnz: int
     perm: Optional[torch.Tensor] = None
     k: int = 0
+    # fourth-generation transposition only: the count pass' prefix table (uint32 [(blocks + 1), rows of this stream]: entries
+    # of a row in the source's row blocks before g) and the rows per block - what a ranged product on this stream reads
+    t4: Optional[dict] = None
 
     @property
     def n_pos(self) -> int:
@@ -784,7 +787,7 @@ class HipBackend:
                                                      _p(xs_dst), _p(xs_ent), _p(plan["sptr"]), _p(plan["inv"]), _p(ent),
                                                      _p(plan["work"]), plan["wb"], self._stream()))
             self._note_tpack4(plan["work"], n, d, X.nnz)
-            return DeviceStream(plan["sptr"], ent, (d, n), X.nnz, plan["perm"], plan["K"])
+            return DeviceStream(plan["sptr"], ent, (d, n), X.nnz, plan["perm"], plan["K"], self._t4_prefix(plan["work"], n, d, X.nnz))
         if self._use_tpack4(X):
             wb = int(self.lib.mu_tpack4_worksize(n, d, X.nnz))
             work = self.empty((wb,), torch.uint8)
@@ -810,7 +813,7 @@ class HipBackend:
                 check(self.lib.mu_tpack4_fill_stream(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
                                                      _p(xs_dst), _p(xs_ent), _p(sptr), _p(inv), _p(ent), _p(work), wb, st))
             self._note_tpack4(work, n, d, X.nnz)
-            return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K)
+            return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K, self._t4_prefix(work, n, d, X.nnz))
         wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
         work = self.empty((wb,), torch.uint8)
         with self._dev_ctx():
@@ -834,6 +837,117 @@ class HipBackend:
             check(self.lib.mu_csr_tpack_fill_stream(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
                                                     _p(sptr), _p(inv), _p(ent), _p(work), wb, st))
         return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K)
+
+    def _t4_geometry(self, n, d, nnz):
+        import ctypes as C
+
+        rpb, G, Ct = C.c_int64(0), C.c_int(0), C.c_int(0)
+        check(self.lib.mu_tpack4_geometry(n, d, nnz, C.byref(rpb), C.byref(G), C.byref(Ct)))
+        return int(rpb.value), int(G.value)
+
+    def _t4_prefix(self, work, n, d, nnz):
+        rpb, G = self._t4_geometry(n, d, nnz)
+        off = int(self.lib.mu_tpack4_cnt_offset(n, d, nnz))
+        # (a view: the work buffer lives as long as the stream that carries it)
+        cnt = work[off:off + 4 * (G + 1) * d].view(torch.int32)
+        return dict(cnt=cnt, rpb=rpb, blocks=G, stride=d)
+
+    # -- the cell slice of lsi's warm start (r06: no operands of its own) --------------------------------
+    def slice_plan(self, X: DeviceCSR, n_s: int, max_ranges: int = 16):
+        """Which cells the warm start's slice holds: <= 16 ranges of whole ROW BLOCKS of the transposition (so that the
+        slice's cells are a contiguous piece of every row of X^T, found through the count pass' prefix table), spread
+        evenly over this shard's cells (files list cells sample by sample: the first cells may be one batch), about
+        ``n_s`` cells together.  Host integers only - the ranges and where they lie in the CSR (one read of <= 32 row
+        pointers) - cached with the index arrays they describe, like the other plans: a second call reads nothing from
+        the device.  None when the shape does not take the ranged products (no fourth-generation transposition, no slab
+        pointers)."""
+        n, d = X.shape
+        if n_s <= 0 or X.values.dtype != torch.float32 or not self._use_tpack4(X) or self._slab_ptr_of(X) is None:
+            return None
+        key = (X.indptr.data_ptr(), X.indices.data_ptr(), n, d, X.nnz, int(n_s), int(max_ranges))
+        got = getattr(X, "wplan", None)
+        if got is not None and got[1] == key:
+            return got[0]
+        rpb, G = self._t4_geometry(n, d, X.nnz)
+        if G < 1:
+            return None
+        blocks = max(1, min(G, int(round(n_s / rpb))))
+        R = max(1, min(int(max_ranges), blocks))
+        per = max(1, min(int(round(blocks / R)), G // R))  # (blocks per range; ranges G // R blocks apart: no overlap)
+        g0s = [(r * G) // R for r in range(R)]
+        rows = [(g0 * rpb, min((g0 + per) * rpb, n)) for g0 in g0s]
+        edges = X.indptr[torch.tensor([v for ab in rows for v in ab], device=X.indptr.device)].tolist()
+        plan = dict(rpb=rpb, ranges=[dict(g0=g0, g1=g0 + per, row0=a, row1=b, lo=int(edges[2 * i]), hi=int(edges[2 * i + 1]))
+                                     for i, (g0, (a, b)) in enumerate(zip(g0s, rows))])
+        plan["n_s"] = sum(r["row1"] - r["row0"] for r in plan["ranges"])
+        plan["nnz_s"] = sum(r["hi"] - r["lo"] for r in plan["ranges"])
+        X.wplan = (plan, key)
+        return plan
+
+    def slice_stream(self, X: DeviceCSR, plan) -> dict:
+        """Compact row stream of the slice's rows (mu_csr_slice_stream: range after range, rows in their own order) with
+        the table of its 8192-column super-slab boundaries - the operand of X_S Q (spmm_slice)."""
+        import ctypes as C
+
+        n, d = X.shape
+        rg = plan["ranges"]
+        n_s, nnz_s = plan["n_s"], plan["nnz_s"]
+        S1 = -(-d // 8192) + 1
+        sptr = self.empty((n_s + 1,), torch.int64)
+        ent = self.empty((max(nnz_s, 1),), torch.int64)
+        rel = self.empty((S1 * max(n_s, 1),), torch.int32)
+        arr = lambda key, f=None: (C.c_int64 * len(rg))(*[(f(r) if f else r[key]) for r in rg])  # noqa: E731
+        with self._dev_ctx():
+            check(self.lib.mu_csr_slice_stream(len(rg), arr("row0"), arr(None, lambda r: r["row1"] - r["row0"]), arr("lo"),
+                                               arr("hi"), d, _p(X.indptr), _p(X.indices), _p(X.values),
+                                               _p(self._slab_ptr_of(X)), _p(sptr), _p(ent), _p(rel), self._stream()))
+        # K and the split of the column super-slabs over blockIdx.y: enough workgroups for two rounds of the chip
+        n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        K = 8
+        while K > 1 and -(-n_s // (64 * K)) * (S1 - 1) < 2 * n_cus:
+            K //= 2
+        wgs = -(-n_s // (64 * K))
+        ny = max(1, min(S1 - 1, 16, -(-2 * n_cus // max(wgs, 1))))  # (<= 16 column groups: the launch takes 32 ranges)
+        group = -(-(S1 - 1) // ny)  # consecutive super-slabs of one blockIdx.y: one contiguous column range
+        return dict(sptr=sptr, ent=ent, rel=rel, n_s=n_s, nnz_s=nnz_s, K=K, group=group, d=d, S=S1 - 1)
+
+    def spmm_slice(self, S: dict, Q: torch.Tensor) -> torch.Tensor:
+        """Y_S = X_S Q [n_s x 64] on the compact slice stream, column super-slabs split over the chip, partial products
+        summed in fixed order."""
+        import ctypes as C
+
+        d, n_s = S["d"], S["n_s"]
+        assert Q.shape == (d, 64) and Q.dtype == torch.float32 and Q.is_contiguous()
+        ns, g = S["S"], S["group"]
+        ny = -(-ns // g)
+        part = self.empty((ny, n_s, 64), torch.float32)
+        h = (C.c_int32 * (5 * ny))()
+        for r in range(ny):  # (the super-slabs r g .. (r + 1) g - 1 are contiguous in the columns and in every row)
+            h[5 * r:5 * r + 5] = [r * g * 8192, min((r + 1) * g * 8192, d), r * g * 8192, r * g, min((r + 1) * g, ns)]
+        with self._dev_ctx():
+            check(self.lib.mu_spmm_stream_ranges_f32(n_s, _p(S["sptr"]), _p(S["ent"]), None, S["K"], _p(Q), d, _p(part),
+                                                     n_s * 64, _p(S["rel"]), n_s, ny, h, 1, self._stream()))
+        return part[0] if ny == 1 else part.sum(dim=0)
+
+    def spmm_slice_t(self, Xt: DeviceStream, plan, Ys: torch.Tensor) -> torch.Tensor:
+        """Z = X_S^T Y_S [d x 64] on the row stream of X^T as it is: the slice's cells are <= 16 contiguous pieces of
+        every row, found through the transposition's count prefixes (Xt.t4)."""
+        import ctypes as C
+
+        d, n = Xt.shape
+        t4, rg = Xt.t4, plan["ranges"]
+        assert t4 is not None and t4["rpb"] == plan["rpb"] and Ys.shape == (plan["n_s"], 64) and Ys.is_contiguous()
+        Z = self.empty((d, 64), torch.float32)
+        h = (C.c_int32 * (5 * len(rg)))()
+        q_off = 0
+        for i, r in enumerate(rg):
+            h[5 * i:5 * i + 5] = [r["row0"], r["row1"], q_off, r["g0"], r["g1"]]
+            q_off += r["row1"] - r["row0"]
+        with self._dev_ctx():
+            check(self.lib.mu_spmm_stream_ranges_f32(Xt.n_pos, _p(Xt.sptr), _p(Xt.ent), _p(Xt.perm), Xt.k, _p(Ys),
+                                                     plan["n_s"], _p(Z), 0, _p(t4["cnt"]), t4["stride"], len(rg), h,
+                                                     len(rg), self._stream()))
+        return Z
 
     def split_streams(self, X: DeviceCSR):
         """(row streams of X, row streams of X^T) for an f64-valued CSR: see SplitStream."""

@@ -83,6 +83,9 @@ SIGNATURES = {
     "mu_csr_tpack_fill_stream": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_stream_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "mu_spmm_stream_f64": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
+    "mu_csr_slice_stream": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mu_spmm_stream_ranges_f32": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp]),
+    "mu_tpack4_cnt_offset": (_sz, [_i64, _i64, _i64]),
     "mu_cells_geometry": (C.c_int, [_i32] + [C.POINTER(C.c_int)] * 5),
     "mu_cells_cut": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_dense_f16_worksize": (_sz, [_i64]),

@@ -198,6 +198,34 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
+// r06 - RANGED launches (the warm start's products on a cell slice): a workgroup walks a LIST of column
+// ranges instead of all columns, and where a row's entries of a range begin and end comes from a table of 32-bit
+// offsets relative to the row's first pair, indexed by the matrix row:
+//     lo = sptr[p] + tbl[ta * stride + row],   hi = sptr[p] + tbl[tb * stride + row],   row = perm[p]
+// Two users (muon_amd/_backend.py):
+//   * X_S^T Y_S on the row stream of X^T AS IT IS: the cells of a row block range [g0, g1) of the transposition are a
+//     contiguous piece of every row of X^T (cells ascend), and where it begins is the count pass' prefix table
+//     (csrc/tpack4.hip: cnt[g][peak] = entries of that peak in row blocks before g) - no operand of the slice is built;
+//     the dense operand is the compact Y_S, range r's cells at rows q_off ..;
+//   * X_S Q on a compact stream of the slice's rows with the COLUMN SLABS SPLIT over blockIdx.y (a slice of a few
+//     thousand rows is a handful of workgroups: each would sweep all 782 slabs on 1/20 of the chip): 8192-column
+//     super-slabs from the slab pointers, partial products per blockIdx.y, summed in fixed order by the caller.
+// A range may start at any column: its slabs are the 256 columns from there on (LDS row = (column - start) mod 256).
+constexpr int kMaxRanges = 32;
+struct WinRange {
+  int col0, col1;  // columns [col0, col1) of the operand's index space
+  int q_off;       // row of the dense operand that holds column col0
+  int ta, tb;      // table rows of the begin / end offsets
+};
+struct WinRanges {
+  const uint32_t* tbl;
+  int64_t stride;    // table row length
+  int64_t q_rows;    // rows of the dense operand (the slab copies clamp there)
+  int64_t y_stride;  // elements between the partial products of consecutive blockIdx.y
+  int n, per_wg;     // ranges in total; workgroup (x, y) walks ranges [y per_wg, (y + 1) per_wg)
+  WinRange r[kMaxRanges];
+};
+
 struct Win {      // what stage A of a pass hands to stage B
   int a;          // lane e of a group: LDS byte offset (inside the slab) of window entry e
   float vv;       // lane e: value of window entry e, 0 if the entry is not of this slab
@@ -208,13 +236,13 @@ struct Win {      // what stage A of a pass hands to stage B
 // (results are then wrong on purpose): 1 no LDS gathers / FMAs, 8 no window requests (and no
 // overflow passes), 32 window slots 0-7 as two batches of four LDS reads (r01), 64 per-wave cycle
 // accounting instead of the product.
-template <int K, int MODE, int NB, typename DT>
+template <int K, int MODE, int NB, typename DT, bool RNG = false>
 __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
                                               const int64_t* __restrict__ sptr,
                                               const unsigned long long* __restrict__ ent,
                                               const int32_t* __restrict__ perm,
                                               const DT* __restrict__ Q, DT* __restrict__ Y,
-                                              int accumulate) {
+                                              int accumulate, const WinRanges* rgp = nullptr) {
   static_assert(K >= 1 && K <= kKMax, "K out of range");
   static_assert(sizeof(DT) == 4 || MODE == 0, "the timing ablations exist for f32 only");
   constexpr int W = kWaves;
@@ -266,8 +294,7 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
   const int64_t rb0 = (int64_t)blockIdx.x * (4 * W * K);
   const int64_t rb1 = (rb0 + 4 * W * K) < n_pos ? (rb0 + 4 * W * K) : n_pos;
   const float4* __restrict__ Q4 = reinterpret_cast<const float4*>(Q);
-  const int64_t q4_total = n_cols * (kRowBytes / 16);
-  const int ncols32 = (int)n_cols;
+  const int64_t q4_total = (RNG ? rgp->q_rows : n_cols) * (kRowBytes / 16);
   const unsigned qs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&qs[0][0]);
   // the rows of this workgroup are contiguous in the stream: cursors are byte offsets from here
   const int64_t wg0 = uniform64(sptr[rb0]);
@@ -276,16 +303,49 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
   acc_t acc[K];
   unsigned off[K];  // byte offset of pair (cursor + sub) of (row-set k, this lane's group)
   unsigned endv;    // lane 16 g + k: byte offset of the end of the row of (row-set k, group g)
+  static_for<K>([&](auto kc) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c) acc[decltype(kc)::value][c] = (DT)0;
+  });
+  const unsigned q4_last = (unsigned)(q4_total - 1);
+  // MODE & 64: per-wave cycle accounting (s_memtime) of the places a pass can spend time in;
+  // the passes run unpipelined (A(k) then B(k)) and the sums replace the product in Y.
+  unsigned t_wait = 0, t_a = 0, t_b = 0, t_bar = 0, t_dma = 0;
+  auto now = [&]() -> unsigned { return (unsigned)__builtin_amdgcn_s_memtime(); };
+
+  // RNG: the ranges of this workgroup one after the other - cursors, windows and the first slab are set up again per
+  // range (one exposed round trip each), the accumulators run through.  Otherwise: one "range" = all columns.
+  const int r_first = RNG ? (int)blockIdx.y * rgp->per_wg : 0;
+  const int r_last = RNG ? ((r_first + rgp->per_wg) < rgp->n ? (r_first + rgp->per_wg) : rgp->n) : 1;
+  for (int ri = r_first; ri < r_last; ++ri) {
+  const int col0 = RNG ? rgp->r[ri].col0 : 0;
+  const int ncols32 = RNG ? rgp->r[ri].col1 : (int)n_cols;
+  const int q_shift = RNG ? (rgp->r[ri].q_off - col0) : 0;  // dense operand row of column c: c + q_shift
   {
     // lane 16 g + k looks the row of (row-set k, group g) up; the others idle
-    const int64_t p = rb0 + ((int64_t)wave * K + sub) * 4 + g;
-    const bool ok = (sub < K) && (p < rb1);
-    const unsigned lo = ok ? (unsigned)((sptr[p] - wg0) << 3) : 0u;
-    endv = ok ? (unsigned)((sptr[p + 1] - wg0) << 3) : 0u;
+    // (RNG: this block runs once per range - its per-lane values are made from an opaque copy of the lane id so that
+    //  the compiler recomputes them per range instead of keeping them alive across the slab loop, where the K = 7 / 8
+    //  instances have no register to spare: a spill is a VMEM instruction and would break the counted waits)
+    int lane_o = lane;
+    if constexpr (RNG) asm volatile("" : "+v"(lane_o));
+    const int sub_o = RNG ? (lane_o & 15) : sub, g_o = RNG ? (lane_o >> 4) : g;
+    const int64_t p = rb0 + ((int64_t)wave * K + sub_o) * 4 + g_o;
+    bool ok = (sub_o < K) && (p < rb1);
+    unsigned lo;
+    if constexpr (RNG) {
+      const int64_t row = ok ? (perm ? (int64_t)perm[p] : p) : -1;
+      ok = ok && row >= 0;
+      const int64_t b = ok ? (sptr[p] - wg0) : 0;
+      const uint32_t t0 = ok ? rgp->tbl[(int64_t)rgp->r[ri].ta * rgp->stride + row] : 0u;
+      const uint32_t t1 = ok ? rgp->tbl[(int64_t)rgp->r[ri].tb * rgp->stride + row] : 0u;
+      lo = (unsigned)((b + (int64_t)t0) << 3);
+      endv = (unsigned)((b + (int64_t)t1) << 3);
+    } else {
+      lo = ok ? (unsigned)((sptr[p] - wg0) << 3) : 0u;
+      endv = ok ? (unsigned)((sptr[p + 1] - wg0) << 3) : 0u;
+    }
     static_for<K>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
-#pragma unroll
-      for (int c = 0; c < NB; ++c) acc[k][c] = (DT)0;
       off[k] = (unsigned)bcast_i<k>((int)lo) + (unsigned)sub * 8u;
       const bool in = off[k] < (unsigned)bcast_i<k>((int)endv);
       const unsigned long long e = in ? *reinterpret_cast<const unsigned long long*>(entb + off[k]) : 0ull;
@@ -293,26 +353,20 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
     });
   }
 
-  const unsigned q4_last = (unsigned)(q4_total - 1);
   auto dma_one = [&](int64_t s0, int buf, int u) {           // 1 KiB piece u of this wave
     const int piece = wave + u * W;
-    unsigned i = (unsigned)s0 * (unsigned)(kRowBytes / 16) + (unsigned)(piece * 64 + lane);  // float4 index into Q
+    unsigned i = (unsigned)((int)s0 + q_shift) * (unsigned)(kRowBytes / 16) + (unsigned)(piece * 64 + lane);  // float4 index into Q
     i = i < q4_last ? i : q4_last;                           // tail / past the end: clamp (never consumed)
     dma_piece(Q4, i << 4, qs_lds + (unsigned)buf * (unsigned)kSlabBytes + (unsigned)piece * 1024u);
   };
 #pragma unroll
-  for (int u = 0; u < kMyPieces; ++u) dma_one(0, 0, u);
+  for (int u = 0; u < kMyPieces; ++u) dma_one(col0, 0, u);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // MODE & 64: per-wave cycle accounting (s_memtime) of the places a pass can spend time in;
-  // the passes run unpipelined (A(k) then B(k)) and the sums replace the product in Y.
-  unsigned t_wait = 0, t_a = 0, t_b = 0, t_bar = 0, t_dma = 0;
-  auto now = [&]() -> unsigned { return (unsigned)__builtin_amdgcn_s_memtime(); };
-
   int buf = 0;
   unsigned ovf_prev = 0;  // row-sets whose window in flight was requested by a revisit of the previous slab
-  for (int64_t s0 = 0; s0 < n_cols; s0 += kSlabCols, buf ^= 1) {
+  for (int64_t s0 = col0; s0 < ncols32; s0 += kSlabCols, buf ^= 1) {
     // piece u of the next slab, issued right before pass u: the 64 KiB do not hit the texture
     // path as one burst behind which every wave's window requests would queue
     auto next_piece = [&](int u) {
@@ -372,7 +426,7 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
       //  time, scripts/probes/spmm_power_probe.py -, and a third of the window slots a pass gathers are
       //  padding: they all read row 0 of the slab instead of whatever row their stale column names, so
       //  the padded gathers return the same bytes again and again)
-      w.a = valid ? ((col & (kSlabCols - 1)) << kRowShift) : 0;
+      w.a = valid ? (((col - col0) & (kSlabCols - 1)) << kRowShift) : 0;  // (col0 = 0 unless ranged: a range may start anywhere)
       w.vv = valid ? __builtin_bit_cast(float, valbits) : 0.f;
       if constexpr (!(MODE & 8)) {
         // entries consumed by this lane's group: the bits of its 16 lanes in the ballot, counted on
@@ -597,6 +651,7 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
     if constexpr (MODE & 64) t_bar += now() - tb0;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // requests still in flight target v[kNX ..]
+  }  // (ranges)
   if constexpr (MODE & 64) {
     float dep = 0.f;  // (keeps the FMAs of stage B alive)
     static_for<K>([&](auto kc) {
@@ -616,7 +671,7 @@ __device__ __forceinline__ void spmm_win_body(int64_t n_pos, int64_t n_cols,
     if (p < rb1) {
       const int64_t out = perm ? (int64_t)perm[p] : p;  // position -> row of the product (-1: none)
       if (out >= 0) {
-        acc_t* y = reinterpret_cast<acc_t*>(Y + out * (16 * NB) + sub * NB);
+        acc_t* y = reinterpret_cast<acc_t*>(Y + (RNG ? (int64_t)blockIdx.y * rgp->y_stride : 0) + out * (16 * NB) + sub * NB);
         *y = accumulate ? (*y + acc[k]) : acc[k];
       }
     }
@@ -629,6 +684,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(55))) void k_s
     const unsigned long long* __restrict__ ent, const int32_t* __restrict__ perm,
     const DT* __restrict__ Q, DT* __restrict__ Y, int accumulate) {
   spmm_win_body<K, MODE, NB, DT>(n_pos, n_cols, sptr, ent, perm, Q, Y, accumulate);
+}
+
+// the ranged instance (B = 64, f32): the descriptors travel as a by-value kernel argument (scalar loads)
+template <int K>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(55))) void k_spmm_win_rng(
+    int64_t n_pos, const int64_t* __restrict__ sptr, const unsigned long long* __restrict__ ent,
+    const int32_t* __restrict__ perm, const float* __restrict__ Q, float* __restrict__ Y, const WinRanges rg) {
+  spmm_win_body<K, 0, 4, float, true>(n_pos, 0, sptr, ent, perm, Q, Y, 0, &rg);
 }
 
 // ---- the row stream ------------------------------------------------------------------------
@@ -755,6 +818,48 @@ __global__ __launch_bounds__(256) void k_stream_fill_pipe(int64_t n_pos, const i
     sf_wait<0>(ca, va);  // what is still in flight targets these registers
     sf_wait<0>(cb, vb_);
   }
+}
+
+// ---- compact row stream of a cell slice (r06: the operand of the warm start's X_S Q) ---------------------------------
+// R ranges of consecutive rows of a CSR, one after the other, rows in their own order (no sort, no deal: the slice is
+// 1/32 of the cells and multiplied four times), plus what a ranged launch needs: sptr and, per 8192-column super-slab
+// boundary t, the offset of the row's first entry at or behind it relative to the row's first entry (from the CSR's
+// slab pointers, mu_csr_slab_ptr) - rel[t * n_s + i].
+struct SliceRanges {
+  int n;
+  int64_t row0[kMaxRanges], lo[kMaxRanges];                // first row of range r, its first entry in the CSR
+  int64_t dst_row[kMaxRanges + 1], dst_ent[kMaxRanges + 1];  // where the range begins in the slice (rows, pairs)
+};
+__global__ __launch_bounds__(256) void k_slice_pairs(const SliceRanges sr, const int32_t* __restrict__ indices,
+                                                     const float* __restrict__ values,
+                                                     unsigned long long* __restrict__ ent) {
+  const int64_t total = sr.dst_ent[sr.n];
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int r = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxRanges; ++i) r += (i < sr.n && e >= sr.dst_ent[i]) ? 1 : 0;
+    const int64_t src = sr.lo[r] + (e - sr.dst_ent[r]);
+    ent[e] = (unsigned long long)(unsigned)indices[src] |
+             ((unsigned long long)__builtin_bit_cast(unsigned, values[src]) << 32);
+  }
+}
+__global__ __launch_bounds__(256) void k_slice_rows(const SliceRanges sr, int64_t S1, const int64_t* __restrict__ indptr,
+                                                    const int64_t* __restrict__ slab_ptr, int64_t* __restrict__ sptr,
+                                                    uint32_t* __restrict__ rel) {
+  const int64_t n_s = sr.dst_row[sr.n];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_s) return;
+  if (i == n_s) {
+    sptr[i] = sr.dst_ent[sr.n];
+    return;
+  }
+  int r = 0;
+#pragma unroll
+  for (int j = 1; j < kMaxRanges; ++j) r += (j < sr.n && i >= sr.dst_row[j]) ? 1 : 0;
+  const int64_t row = sr.row0[r] + (i - sr.dst_row[r]);
+  const int64_t first = indptr[row];
+  sptr[i] = first - sr.lo[r] + sr.dst_ent[r];
+  for (int64_t t = 0; t < S1; ++t) rel[t * n_s + i] = (uint32_t)(slab_ptr[row * S1 + t] - first);
 }
 
 // K row-sets per wave: the smallest number of full-chip rounds R whose 64*K-row blocks fit the
@@ -890,6 +995,89 @@ int mu_spmm_stream_f32(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, con
     default: return launch<8, 0>(MU_ARGS);
   }
 #undef MU_ARGS
+}
+
+int mu_csr_slice_stream(int n_ranges, const int64_t* h_row0, const int64_t* h_rows, const int64_t* h_lo,
+                        const int64_t* h_hi, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
+                        const float* d_values, const int64_t* d_slab_ptr, int64_t* d_sptr, void* d_ent, uint32_t* d_rel,
+                        void* stream) {
+  MU_REQUIRE(n_ranges >= 1 && n_ranges <= kMaxRanges && n_cols > 0, "1 .. 32 ranges");
+  MU_REQUIRE(h_row0 && h_rows && h_lo && h_hi && d_indptr && d_indices && d_values && d_slab_ptr && d_sptr && d_ent && d_rel,
+             "null pointer");
+  SliceRanges sr;
+  sr.n = n_ranges;
+  sr.dst_row[0] = sr.dst_ent[0] = 0;
+  for (int i = 0; i < n_ranges; ++i) {
+    MU_REQUIRE(h_rows[i] >= 0 && h_hi[i] >= h_lo[i] && h_hi[i] - h_lo[i] < ((int64_t)1 << 32), "range out of bounds");
+    sr.row0[i] = h_row0[i];
+    sr.lo[i] = h_lo[i];
+    sr.dst_row[i + 1] = sr.dst_row[i] + h_rows[i];
+    sr.dst_ent[i + 1] = sr.dst_ent[i] + (h_hi[i] - h_lo[i]);
+  }
+  for (int i = n_ranges; i < kMaxRanges; ++i) {
+    sr.row0[i] = sr.lo[i] = 0;
+    sr.dst_row[i + 1] = sr.dst_row[n_ranges];
+    sr.dst_ent[i + 1] = sr.dst_ent[n_ranges];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n_s = sr.dst_row[n_ranges], nnz_s = sr.dst_ent[n_ranges];
+  const int64_t S1 = (n_cols + 8191) / 8192 + 1;
+  if (nnz_s > 0) {
+    int64_t blocks = (nnz_s + 1023) / 1024;
+    const int64_t cap = (int64_t)mu_num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_slice_pairs, dim3((unsigned)blocks), dim3(256), 0, st, sr, d_indices, d_values,
+                       (unsigned long long*)d_ent);
+    MU_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_slice_rows, dim3((unsigned)((n_s + 1 + 255) / 256)), dim3(256), 0, st, sr, S1, d_indptr, d_slab_ptr,
+                     d_sptr, d_rel);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_spmm_stream_ranges_f32(int64_t n_pos, const int64_t* d_sptr, const void* d_ent, const int32_t* d_perm,
+                              int k_layout, const float* d_Q, int64_t q_rows, float* d_Y, int64_t y_stride,
+                              const uint32_t* d_tbl, int64_t tbl_stride, int n_ranges, const int32_t* h_ranges5,
+                              int per_wg, void* stream) {
+  MU_REQUIRE(n_pos >= 0 && q_rows > 0 && n_ranges >= 1 && n_ranges <= kMaxRanges && per_wg >= 1, "shape out of range");
+  MU_REQUIRE(k_layout >= 1 && k_layout <= kKMax, "the layout's K is needed");
+  MU_REQUIRE((q_rows + 512) * (int64_t)64 * 4 < ((int64_t)1 << 32), "dense operand of 4 GiB or more");
+  if (n_pos == 0) return MU_OK;
+  MU_REQUIRE(d_sptr && d_ent && d_Q && d_Y && d_tbl && h_ranges5, "null pointer");
+  WinRanges rg;
+  rg.tbl = d_tbl;
+  rg.stride = tbl_stride;
+  rg.q_rows = q_rows;
+  rg.y_stride = y_stride;
+  rg.n = n_ranges;
+  rg.per_wg = per_wg;
+  for (int i = 0; i < n_ranges; ++i) {
+    const int32_t* h = h_ranges5 + 5 * i;
+    MU_REQUIRE(h[0] >= 0 && h[1] >= h[0] && h[2] >= 0 && h[3] >= 0 && h[4] >= 0, "range out of bounds");
+    rg.r[i] = WinRange{h[0], h[1], h[2], h[3], h[4]};
+  }
+  for (int i = n_ranges; i < kMaxRanges; ++i) rg.r[i] = WinRange{0, 0, 0, 0, 0};
+  const int K = k_layout;
+  const unsigned wgs = (unsigned)((n_pos + 64 * K - 1) / (64 * K));
+  const unsigned ny = (unsigned)((n_ranges + per_wg - 1) / per_wg);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned long long* ent = (const unsigned long long*)d_ent;
+#define MU_RNG(K_)                                                                                                   \
+  hipLaunchKernelGGL((k_spmm_win_rng<K_>), dim3(wgs, ny), dim3(1024), 0, st, n_pos, d_sptr, ent, d_perm, d_Q, d_Y, rg)
+  switch (K) {
+    case 1: MU_RNG(1); break;
+    case 2: MU_RNG(2); break;
+    case 3: MU_RNG(3); break;
+    case 4: MU_RNG(4); break;
+    case 5: MU_RNG(5); break;
+    case 6: MU_RNG(6); break;
+    case 7: MU_RNG(7); break;
+    default: MU_RNG(8); break;
+  }
+#undef MU_RNG
+  MU_CHECK_LAUNCH();
+  return MU_OK;
 }
 
 int mu_spmm_stream_f64(int64_t n_pos, int64_t n_cols, const int64_t* d_sptr, const void* d_ent,

@@ -925,6 +925,15 @@ size_t mu_tpack4_err_offset(int64_t n_rows, int64_t n_cols, int64_t nnz) {
   return (size_t)((char*)w.err - base);
 }
 
+/* byte offset inside d_work of the count pass' prefix table: uint32 cnt[(n_blocks + 1)][n_cols], cnt[g][c] = entries of
+ * column c in the row blocks before g (row n_blocks: the column totals).  The fill only reads it: the cells of a row-block
+ * range are a contiguous piece of every row of X^T and this table says where it begins (mu_spmm_stream_ranges_f32) */
+size_t mu_tpack4_cnt_offset(int64_t n_rows, int64_t n_cols, int64_t nnz) {
+  char* base = nullptr;
+  const T4Work w = t4_carve(base, n_rows, n_cols, nnz);
+  return (size_t)((char*)w.cnt - base);
+}
+
 /* the fill's error word (0 = fine; 1: bitmap and count pass disagreed, 2: a tile could not be narrowed) - synchronises */
 int mu_tpack4_status(const void* d_work, int64_t n_rows, int64_t n_cols, int64_t nnz, int* h_err) {
   MU_REQUIRE(d_work && h_err, "null pointer");

@@ -321,9 +321,69 @@ def test_warm_start_saves_an_expansion_and_gives_the_same_subspace(hip, monkeypa
     Uc, sdc, Vc, ic = lsi_device(hip, T, n_comps=20, n_obs=X.shape[0], return_info=True)
     monkeypatch.setenv("MUON_AMD_LSI_WARM", "8:2")
     Uw, sdw, Vw, iw = lsi_device(hip, T, n_comps=20, n_obs=X.shape[0], return_info=True)
-    assert ic["warm_start"] is None and iw["warm_start"] == {"cells": 9728, "power_steps": 2}
+    assert ic["warm_start"] is None and iw["warm_start"]["power_steps"] == 2 and 4000 < iw["warm_start"]["cells"] < 12000
     assert iw["converged"] and ic["converged"] and iw["iterations"] < ic["iterations"], (ic["bounds"], iw["bounds"])
     ref = lsi_oracle.lsi(tfidf_oracle.canonical(tfidf_oracle.tfidf(X)), n_comps=20)
     for V, sd in ((Vc, sdc), (Vw, sdw)):
         assert lsi_oracle.max_subspace_angle(hip.to_host(V), ref["LSI"]) < 1e-4
         assert np.max(np.abs(sd - ref["stdev"]) / ref["stdev"]) < 1e-5
+
+
+@pytest.mark.parametrize("n,d,n_s,dens", [(40000, 12000, 5000, 0.03), (6000, 30000, 1500, 0.02), (3000, 700, 640, 0.1),
+                                          (70000, 9000, 2200, 0.01)])
+def test_slice_products_without_operands_of_their_own(hip, n, d, n_s, dens):
+    """r06: the warm start's products on a cell slice.  X_S Q on the compact slice stream with the column super-slabs
+    split over blockIdx.y (mu_csr_slice_stream, mu_spmm_stream_ranges_f32), X_S^T Y_S on the row stream of X^T as it
+    is, the slice's cells found through the transposition's count prefixes - against scipy on the same rows."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(n + d)
+    m = sp.random(n, d, density=dens, format="csr", random_state=rng, dtype=np.float32)
+    m.data = (0.5 + rng.random(m.nnz)).astype(np.float32)
+    m.sort_indices()
+    if n == 3000:  # rows with hundreds of entries in one 256-column slab, and empty rows
+        m = m.tolil(); m[5, :300] = 1.5; m[7, :] = 0; m = m.tocsr(); m.sort_indices(); m.eliminate_zeros()
+    X = hip.upload_csr(m.indptr, m.indices, m.data, m.shape)
+    Xs, Xt = hip.stream_both(X)
+    assert Xt.t4 is not None
+    plan = hip.slice_plan(X, n_s)
+    assert plan is not None and hip.slice_plan(X, n_s) is plan  # (cached with the index arrays)
+    rows = np.concatenate([np.arange(r["row0"], r["row1"]) for r in plan["ranges"]])
+    assert len(rows) == plan["n_s"] and len(set(rows)) == len(rows) and abs(len(rows) - n_s) <= max(plan["rpb"], n_s // 2)
+    ms = m[rows].astype(np.float64)
+    assert plan["nnz_s"] == ms.nnz
+    S = hip.slice_stream(X, plan)
+    Q = rng.standard_normal((d, 64)).astype(np.float32)
+    Ys = hip.spmm_slice(S, hip.to_device(Q))
+    want = ms @ Q.astype(np.float64)
+    got = hip.to_host(Ys)
+    assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want))
+    Z = hip.to_host(hip.spmm_slice_t(Xt, plan, Ys))
+    wantz = ms.T @ got.astype(np.float64)
+    assert np.max(np.abs(Z - wantz)) <= 2e-5 * np.max(np.abs(wantz))
+    # the same bytes run to run (fixed-order sums)
+    assert np.array_equal(hip.to_host(hip.spmm_slice(S, hip.to_device(Q))), got)
+
+
+def test_warm_start_on_ranges_matches_the_slice_operands(hip, monkeypatch):
+    """The r06 slice (ranges of row blocks, no operands) and the r05 slice (copy + transposition of the slice) start
+    the same iteration: same number of expansions, both inside the parity bar of the f64 oracle."""
+    from muon_amd._atac.preproc import tfidf_device
+    from muon_amd._atac.tools import lsi_device
+    from oracle import lsi_oracle, tfidf_oracle
+    from tests.synth import planted_topics_csr
+
+    X = planted_topics_csr(40000, 12000, n_topics=20, density=0.03, seed=4, dtype=np.float32)
+    Xd = hip.upload_csr(X.indptr, X.indices, X.data, X.shape)
+    T = tfidf_device(hip, Xd, X.shape[0], 3, 1e4)
+    ref = lsi_oracle.lsi(tfidf_oracle.canonical(tfidf_oracle.tfidf(X)), n_comps=20)
+    monkeypatch.setenv("MUON_AMD_LSI_WARM", "8:2")
+    out = {}
+    for how in ("ranges", "operands"):
+        monkeypatch.setenv("MUON_AMD_LSI_WARM_SLICE", how)
+        U, sd, V, info = lsi_device(hip, T, n_comps=20, n_obs=X.shape[0], return_info=True)
+        assert info["warm_start"]["slice"] == how and info["converged"]
+        assert lsi_oracle.max_subspace_angle(hip.to_host(V), ref["LSI"]) < 1e-4
+        assert np.max(np.abs(sd - ref["stdev"]) / ref["stdev"]) < 1e-5
+        out[how] = info
+    assert out["ranges"]["iterations"] == out["operands"]["iterations"]

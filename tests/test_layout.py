@@ -87,8 +87,10 @@ def test_stream_spmm_isa_keeps_out_of_the_asm_owned_registers(tmp_path):
                          flags=re.S | re.M)
     # production instances only (MODE = 0, the second template argument); the timing ablations never
     # feed results to anybody
-    kernels = [(n, b) for n, b in kernels if re.search(r"k_spmm_winILi\d+ELi0ELi", n)]
-    assert len(kernels) == 40  # K = 1..8 x (f32: B = 64 / 32 / 16; f64 blocks: B = 32 / 16)
+    kernels = [(n, b) for n, b in kernels if re.search(r"k_spmm_winILi\d+ELi0ELi|k_spmm_win_rngILi\d+E", n)]
+    # K = 1..8 x (f32: B = 64 / 32 / 16; f64 blocks: B = 32 / 16) + the ranged B = 64 instances of r06 (K = 1..8), whose
+    # per-range set-up must not keep anything alive across the slab loop (K = 7 / 8 spilled before it was made opaque)
+    assert len(kernels) == 48
     reg = re.compile(r"\bv(\d+)\b|v\[(\d+):(\d+)\]")
     for name, body in kernels:
         assert "scratch_" not in body, name
