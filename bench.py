@@ -76,6 +76,7 @@ WORKLOADS = {  # cells = TOTAL cells for strong scaling, cells PER GPU for weak 
     "c4": None,  # BASELINE.json configs[3]/[4]: mu.tl.mofa, 100 ELBO iterations (scripts/bench_mofa.py)
     "ingest": None, "mofa_ng": None, "wnn": None,  # SURVEY 8f.2 - 8f.4 (scripts/bench_widened.py)
     "c3_api": None,  # tfidf + lsi through the public API from a host scipy CSR (upload, fingerprints, write-back)
+    "c3_rank8": None, "c5_rank8": None,  # one rank of eight, emulated on one GPU (scripts/bench_rank8.py)
 }
 
 
@@ -353,6 +354,11 @@ def flatten_for_driver(out, sec):
         for pk, pv in (rec.get("parity") or {}).items():
             if isinstance(pv, (bool, int, float)):
                 cfg[f"{name}_parity_{pk}"] = pv
+    r8 = ((sec or {}).get("c3_rank8") or {}).get("ms_per_step")
+    if r8:
+        # one rank of eight against the whole matrix on one GPU: the 8-GPU speed-up BEFORE communication (an emulation
+        # on one GPU - scripts/bench_rank8.py - not a measured curve)
+        cfg["speedup_8gpu_before_comm_emulated"] = summ["speedup_8gpu_before_comm_emulated"] = round(out["ms_per_step"] / r8, 3)
     out.pop("summary", None)
     out["summary"] = summ  # (last key: survives the tail)
 
@@ -374,12 +380,13 @@ def run_c4(args, steps, warmup, f64=False):
 
 
 def run_widened(name):
-    """Sub-records of the widened rows: scripts/bench_widened.py."""
+    """Sub-records of the widened rows: scripts/bench_widened.py; of one rank of eight: scripts/bench_rank8.py."""
     import importlib.util
 
     from muon_amd._backend import get_backend
 
-    spec = importlib.util.spec_from_file_location("bench_widened", os.path.join(ROOT, "scripts", "bench_widened.py"))
+    script = "bench_rank8" if name.endswith("_rank8") else "bench_widened"
+    spec = importlib.util.spec_from_file_location(script, os.path.join(ROOT, "scripts", script + ".py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod.RUNNERS[name](get_backend())
@@ -462,7 +469,7 @@ def main():
 
     if args.workload == "c4":
         out = run_c4(args, args.steps or 100, args.warmup)
-    elif args.workload in ("ingest", "mofa_ng", "wnn", "c3_api"):
+    elif args.workload in ("ingest", "mofa_ng", "wnn", "c3_api", "c3_rank8", "c5_rank8"):
         out = run_widened(args.workload) if rank == 0 else None
     else:
         default_line = (args.workload == "c3" and world == 1 and not (args.cells or args.peaks or args.no_pack
@@ -489,7 +496,8 @@ def main():
                 sec["c4_f64"] = run_c4(args, 100, 3, f64=True)
             except Exception as e:  # noqa: BLE001
                 sec["c4_f64"] = {"error": repr(e)}
-            for name in ("ingest", "mofa_ng", "wnn", "c3_api"):  # the widened rows and the API path, seconds each
+            # the widened rows, the API path and one rank of eight (configs[2] / [4] shards), seconds each
+            for name in ("ingest", "mofa_ng", "wnn", "c3_api", "c3_rank8", "c5_rank8"):
                 try:
                     torch.cuda.empty_cache()
                     sec[name] = run_widened(name)

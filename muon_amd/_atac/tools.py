@@ -311,7 +311,10 @@ def _lsi_device(
     # runs 1.0e-5 rad apart (two f32 runs through different Krylov spaces: the level at which f32 ARPACK repeats
     # itself), singular values 5e-9.  MUON_AMD_LSI_WARM = "frac:q" (default "32:2" above 5e8 stored entries per rank;
     # "0": cold start).
-    warm_spec = os.environ.get("MUON_AMD_LSI_WARM", "32:2" if nnz_rank > 500_000_000 else "0")
+    # (several ranks: 1 / 16 of each rank's cells - since r06 the slice's products cost next to nothing (ranged products,
+    #  below), and a rank's 3 500 cells were what made the emulated rank-of-8 call need a sixth product)
+    warm_spec = os.environ.get("MUON_AMD_LSI_WARM", ("32:2" if getattr(comm, "world_size", 1) == 1 else "16:2")
+                               if nnz_rank > 500_000_000 else "0")
     warm_used = None
     # (the block below holds collectives, so entering it must be ONE decision of all ranks.  `pack` is per
     #  rank - a rank whose shard has no rows has no row stream - and such a rank still takes part: with an empty slice it
@@ -464,6 +467,7 @@ def _lsi_device(
         return full[:, :ncol]
 
     it = 0          # Krylov expansions done
+    grow_left = 0 if os.environ.get("MUON_AMD_LSI_GROW", "1") == "0" else 1  # (see `grow` in the loop)
     beta_hat = 0.0
     big_products = nnz_rank > 500_000_000
     restarts = 0
@@ -550,6 +554,23 @@ def _lsi_device(
             m = j + 1
             Tm, Mm = assemble(Tb, m), assemble(Mb, m)
             lam_all, C_all = _ritz(Tm, Mm, keep + 1)  # top-k pairs, the restart's `keep`, the first unwanted value
+            # r06 - k INSIDE A CLUSTER of singular values (planted rank 80, n_comps = 50: a 1.3 % gap; real spectra decay
+            # smoothly): a thick restart that keeps ONE block (64 vectors) cuts through the cluster every time and the
+            # iteration crawls - 47 products on the 3000 x 2500 test matrix where keeping two blocks needs 25.  The Ritz
+            # values say so before the first restart: when the gap behind sigma_k is under 3 % and the restart is due
+            # while the bound is still far from the target, the restarts keep one block more from here on (and the space
+            # one more before it restarts); the host's Ritz problems grow to (4 w)^2.  One decision of all ranks.
+            grow = False
+            if (n_iter is None and grow_left > 0 and m * w > k and len(Qs) >= max_blocks - (1 if early_cap is None else 0)
+                    and lam_all[k - 1] > 0 and (lam_all[k - 1] - lam_all[k]) < 0.03 * lam_all[k - 1]):
+                grow = True
+            if comm.agree(grow) if n_iter is None and getattr(comm, "world_size", 1) > 1 else grow:
+                grow_left -= 1
+                keep_blocks += 1
+                keep = keep_blocks * w
+                max_blocks += 2
+                early_cap = None
+                lam_all, C_all = _ritz(Tm, Mm, keep + 1)
             lam, C, rest = lam_all[:k], C_all[:, :k], lam_all[k:]
             history.append(np.sqrt(lam))
             enough = m * w > k  # (n_comps > block width: the first Ritz steps cannot deliver k vectors yet)

@@ -865,7 +865,10 @@ class HipBackend:
         if n_s <= 0 or X.values.dtype != torch.float32 or not self._use_tpack4(X) or self._slab_ptr_of(X) is None:
             return None
         key = (X.indptr.data_ptr(), X.indices.data_ptr(), n, d, X.nnz, int(n_s), int(max_ranges))
-        got = getattr(X, "wplan", None)
+        # (kept in the transposition plan's dict when there is one: `with_values` hands that dict - by reference - from
+        #  the counts to every TF-IDF result, so the plan made in the first call serves the later ones)
+        shared = self._plan_of(X, "tplan")
+        got = shared.get("wplan") if shared is not None else getattr(X, "wplan", None)
         if got is not None and got[1] == key:
             return got[0]
         rpb, G = self._t4_geometry(n, d, X.nnz)
@@ -881,7 +884,10 @@ class HipBackend:
                                      for i, (g0, (a, b)) in enumerate(zip(g0s, rows))])
         plan["n_s"] = sum(r["row1"] - r["row0"] for r in plan["ranges"])
         plan["nnz_s"] = sum(r["hi"] - r["lo"] for r in plan["ranges"])
-        X.wplan = (plan, key)
+        if shared is not None:
+            shared["wplan"] = (plan, key)
+        else:
+            X.wplan = (plan, key)
         return plan
 
     def slice_stream(self, X: DeviceCSR, plan) -> dict:
