@@ -77,6 +77,7 @@ WORKLOADS = {  # cells = TOTAL cells for strong scaling, cells PER GPU for weak 
     "ingest": None, "mofa_ng": None, "wnn": None,  # SURVEY 8f.2 - 8f.4 (scripts/bench_widened.py)
     "c3_api": None,  # tfidf + lsi through the public API from a host scipy CSR (upload, fingerprints, write-back)
     "c3_rank8": None, "c5_rank8": None,  # one rank of eight, emulated on one GPU (scripts/bench_rank8.py)
+    "unstructured": None, "hard": None,  # configs[2]'s shape on other spectra (scripts/bench_spectra.py)
 }
 
 
@@ -385,7 +386,7 @@ def run_widened(name):
 
     from muon_amd._backend import get_backend
 
-    script = "bench_rank8" if name.endswith("_rank8") else "bench_widened"
+    script = "bench_rank8" if name.endswith("_rank8") else ("bench_spectra" if name in ("unstructured", "hard") else "bench_widened")
     spec = importlib.util.spec_from_file_location(script, os.path.join(ROOT, "scripts", script + ".py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
@@ -469,7 +470,7 @@ def main():
 
     if args.workload == "c4":
         out = run_c4(args, args.steps or 100, args.warmup)
-    elif args.workload in ("ingest", "mofa_ng", "wnn", "c3_api", "c3_rank8", "c5_rank8"):
+    elif args.workload in ("ingest", "mofa_ng", "wnn", "c3_api", "c3_rank8", "c5_rank8", "unstructured", "hard"):
         out = run_widened(args.workload) if rank == 0 else None
     else:
         default_line = (args.workload == "c3" and world == 1 and not (args.cells or args.peaks or args.no_pack
@@ -497,7 +498,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 sec["c4_f64"] = {"error": repr(e)}
             # the widened rows, the API path and one rank of eight (configs[2] / [4] shards), seconds each
-            for name in ("ingest", "mofa_ng", "wnn", "c3_api", "c3_rank8", "c5_rank8"):
+            for name in ("ingest", "mofa_ng", "wnn", "c3_api", "c3_rank8", "c5_rank8", "unstructured", "hard"):
                 try:
                     torch.cuda.empty_cache()
                     sec[name] = run_widened(name)

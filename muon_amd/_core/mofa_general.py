@@ -63,14 +63,18 @@ class GeneralMofaEngine:
     def __init__(self, backend, views: List, likelihoods: List[str], groups: np.ndarray, n_factors: int, *,
                  dtype=torch.float64, center_groups=True, scale_views=False, scale_groups=False,
                  ard_weights=True, ard_factors=True, spikeslab_weights=True, seed=1, comm=None,
-                 row_offset: int = 0, n_total: Optional[int] = None, chunk_elems: int = 1 << 27):
+                 row_offset: int = 0, n_total: Optional[int] = None, chunk_elems: int = 1 << 27,
+                 spikeslab_factors: bool = False):
         assert len(likelihoods) == len(views) and set(likelihoods).issubset(LIKELIHOODS)
         self.be = backend
         self.comm = default_comm(comm)
         self.T = dtype
         self.K = K = int(n_factors)
         self.lik = list(likelihoods)
-        self.opts = dict(ard_weights=ard_weights, ard_factors=ard_factors, spikeslab_weights=spikeslab_weights)
+        # spikeslab_factors (/root/reference/muon/_core/tools.py:305,486): the W node's spike-and-slab update with samples in
+        # the place of features, one (alpha, theta) pair per (group, factor) - oracle/mofa_oracle.py run_general
+        self.opts = dict(ard_weights=ard_weights, ard_factors=ard_factors, spikeslab_weights=spikeslab_weights,
+                         spikeslab_factors=bool(spikeslab_factors))
         groups = np.asarray(groups, dtype=np.int64)
         self.N = N = len(groups)
         gmax = int(groups.max()) if groups.size else 0
@@ -96,7 +100,9 @@ class GeneralMofaEngine:
         c = float(torch.digamma(torch.tensor(1.0, dtype=torch.float64)) - torch.digamma(torch.tensor(2.0, dtype=torch.float64)))
         # the alpha / theta / factor-ARD nodes and their ELBO terms: the fused kernels of MofaEngine (csrc/mofa_elbo.hip -
         # the same equations; ~170 tensor launches per iteration otherwise) keep these nodes in the fit's type
+        # (the fused factor nodes have no spike: with spikeslab_factors the small nodes run as tensor operations)
         self._fused_small = (hasattr(backend, "mofa_w_elbo") and hasattr(backend, "mofa_z_elbo") and K <= 32
+                             and not spikeslab_factors
                              and os.environ.get("MUON_AMD_MOFA_NG_FUSED_SMALL", "1") != "0")
         ST = dtype if self._fused_small else torch.float64
         self.W = []
@@ -116,6 +122,10 @@ class GeneralMofaEngine:
             self.W.append(w)
         self.alpha_z = torch.ones((G, K), dtype=ST, device=self.dev)
         self.lalpha_z = torch.zeros((G, K), dtype=ST, device=self.dev)
+        self.gamma_z = torch.ones_like(self.EZ)
+        self.EZh2 = self.EZ2.clone()
+        self.lthz = torch.full((G, K), c, dtype=torch.float64, device=self.dev)
+        self.l1mthz = torch.full((G, K), c, dtype=torch.float64, device=self.dev)
         if self._fused_small:
             self._elbo_work = backend.mofa_elbo_work(K)
             self._zs = torch.zeros((G, 2, K), dtype=torch.float64, device=self.dev)
@@ -476,17 +486,34 @@ class GeneralMofaEngine:
                             S[l2 - lo:h2 - lo] += Om @ WW[m]
                         a[l2 - lo:h2 - lo] += R @ self.W[m].EW
                 S = S.reshape(hi - lo, K, K)
+                ssf = self.opts["spikeslab_factors"]
                 if hasattr(self.be, "mofa_gs_update") and K <= 32:
                     # (row slices of contiguous [N, K] tensors are contiguous: updated in place)
-                    self.be.mofa_gs_update(S.contiguous(), a.contiguous(), az[g].to(torch.float64).contiguous(), None,
-                                           None, False, Zc, Z2c, None, None, self.sig2z[lo:hi])
+                    if ssf:  # the W form of the sweep: (alpha, ln theta, ln(1 - theta)) of this group
+                        self.be.mofa_gs_update(S.contiguous(), a.contiguous(), az[g].to(torch.float64).contiguous(),
+                                               self.lthz[g].contiguous(), self.l1mthz[g].contiguous(), True, Zc, Z2c,
+                                               self.gamma_z[lo:hi], self.EZh2[lo:hi], self.sig2z[lo:hi])
+                    else:
+                        self.be.mofa_gs_update(S.contiguous(), a.contiguous(), az[g].to(torch.float64).contiguous(), None,
+                                               None, False, Zc, Z2c, None, None, self.sig2z[lo:hi])
                     continue
                 for k in range(K):
                     num = a[:, k] - (Zc * S[:, k, :]).sum(dim=1) + Zc[:, k] * S[:, k, k]
                     prec = az[g, k] + S[:, k, k]
-                    Zc[:, k] = num / prec
-                    self.sig2z[lo:hi, k] = 1.0 / prec
-                    Z2c[:, k] = Zc[:, k] ** 2 + 1.0 / prec
+                    s2 = 1.0 / prec
+                    mu = num * s2
+                    if ssf:
+                        lam = ((self.lthz[g, k] - self.l1mthz[g, k]).to(self.T) + 0.5 * torch.log(az[g, k]) - 0.5 * torch.log(prec)
+                               + 0.5 * num * num * s2)
+                        gz = torch.sigmoid(lam)
+                        Zc[:, k] = gz * mu
+                        Z2c[:, k] = gz * (mu * mu + s2)
+                        self.gamma_z[lo:hi, k] = gz
+                        self.EZh2[lo:hi, k] = gz * (mu * mu + s2) + (1.0 - gz) / az[g, k]
+                    else:
+                        Zc[:, k] = mu
+                        Z2c[:, k] = mu * mu + s2
+                    self.sig2z[lo:hi, k] = s2
 
     def _bump_z(self):
         self._zver += 1
@@ -580,10 +607,19 @@ class GeneralMofaEngine:
             be.mofa_z_elbo(zs, self._Ng_dev, o["ard_factors"], A0, B0, self.alpha_z, self.lalpha_z, elbo)
             return elbo + lik
         # factors: per-group sums over this rank's samples, added up over the ranks
-        zs = torch.zeros((G, 2, K), dtype=f64, device=self.dev)
+        ssf = o["spikeslab_factors"]
+        zs = torch.zeros((G, 5 if ssf else 2, K), dtype=f64, device=self.dev)
         for g, (a0, b0) in enumerate(self.gslice):
-            zs[g, 0] = self.EZ2[a0:b0].to(f64).sum(dim=0)
-            zs[g, 1] = torch.log(self.sig2z[a0:b0].to(f64)).sum(dim=0)
+            ls = torch.log(self.sig2z[a0:b0].to(f64))
+            if ssf:  # sums of <zhat^2>, gamma ln sig2, gamma, the entropy of the switches (per group, over the ranks)
+                gz = self.gamma_z[a0:b0].to(f64)
+                zs[g, 0] = self.EZh2[a0:b0].to(f64).sum(dim=0)
+                zs[g, 1] = (gz * ls).sum(dim=0)
+                zs[g, 2] = gz.sum(dim=0)
+                zs[g, 3] = torch.nan_to_num(-(torch.xlogy(gz, gz) + torch.xlogy(1 - gz, 1 - gz))).sum(dim=0)
+            else:
+                zs[g, 0] = self.EZ2[a0:b0].to(f64).sum(dim=0)
+                zs[g, 1] = ls.sum(dim=0)
         zs = self._allreduce(zs)
         Ng = self._Ng_dev
         if o["ard_factors"]:
@@ -591,6 +627,10 @@ class GeneralMofaEngine:
             b = B0 + 0.5 * zs[:, 0]
             self.alpha_z.copy_(a / b)
             self.lalpha_z.copy_(torch.digamma(a) - torch.log(b))
+        if ssf:
+            a, b = TH_A0 + zs[:, 2], TH_B0 + Ng[:, None] - zs[:, 2]
+            self.lthz.copy_(torch.digamma(a) - torch.digamma(a + b))
+            self.l1mthz.copy_(torch.digamma(b) - torch.digamma(a + b))
         # ---- prior / entropy terms (the same expressions as oracle run()) ----------------------------------
         elbo = lik
         for m, (V, Wm) in enumerate(zip(self.views, self.W)):
@@ -614,6 +654,12 @@ class GeneralMofaEngine:
         laz = self.lalpha_z if o["ard_factors"] else torch.zeros((G, K), dtype=f64, device=self.dev)
         for g in range(G):
             elbo = elbo + (0.5 * laz[g] * Ng[g] - 0.5 * az[g] * zs[g, 0] + 0.5 * zs[g, 1] + 0.5 * Ng[g]).sum()
+            if ssf:
+                sg = zs[g, 2]
+                elbo = elbo + ((Ng[g] - sg) * 0.5 * torch.log(1.0 / az[g])).sum()
+                elbo = elbo + (sg * self.lthz[g] + (Ng[g] - sg) * self.l1mthz[g]).sum() + zs[g, 3].sum()
+                a, b = TH_A0 + sg, TH_B0 + Ng[g] - sg
+                elbo = elbo + _beta_kl(TH_A0, TH_B0, a, b, self.lthz[g], self.l1mthz[g]).sum()
             if o["ard_factors"]:
                 a = (A0 + 0.5 * Ng[g]).expand(K)
                 b = B0 + 0.5 * zs[g, 0]

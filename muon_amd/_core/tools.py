@@ -218,8 +218,6 @@ def mofa(
         raise NotImplementedError("stochastic variational inference (svi_mode) is not implemented")
     if smooth_covariate is not None or smooth_warping or smooth_kwargs:
         raise NotImplementedError("MEFISTO (smooth_covariate / smooth_warping) is not implemented")
-    if spikeslab_factors:
-        raise NotImplementedError("spikeslab_factors=True is not implemented")
     if convergence_mode not in ("fast", "medium", "slow"):
         raise ValueError("convergence_mode must be 'fast', 'medium' or 'slow'")
 
@@ -243,12 +241,17 @@ def mofa(
               center_groups=center_groups, scale_views=scale_views, scale_groups=scale_groups,
               ard_weights=ard_weights, ard_factors=ard_factors, spikeslab_weights=spikeslab_weights,
               seed=seed, comm=comm)
-    if any(l != "gaussian" for l in lik) or any(_has_elementwise_nan(v) for v in views):
+    n_groups = int(np.max(groups)) + 1 if len(groups) else 1
+    wide = int(n_factors) > 32 or (n_groups * int(n_factors) > 64 and any(issparse(v) for v in views))
+    if any(l != "gaussian" for l in lik) or any(_has_elementwise_nan(v) for v in views) or spikeslab_factors or wide:
         # pseudo-data likelihoods / element-wise missing values: element-wise precisions, walked in
-        # row chunks (the sparse modalities stay CSR on the device)
+        # row chunks (the sparse modalities stay CSR on the device).  r06: also the model options the two-pass engine's
+        # kernels are not instantiated for - more than 32 factors (tools.py:298 takes any int), more than 64 stacked
+        # (group, factor) columns against a sparse view, spikeslab_factors=True (tools.py:305,486) - the same model on
+        # the general engine's chunk passes (slower: those are rare settings; n_factors defaults to 10)
         from .mofa_general import GeneralMofaEngine
 
-        eng = GeneralMofaEngine(backend, views, list(lik), groups, n_factors, **kw)
+        eng = GeneralMofaEngine(backend, views, list(lik), groups, n_factors, spikeslab_factors=bool(spikeslab_factors), **kw)
     else:
         eng = MofaEngine(backend, views, groups, n_factors, **kw)
     logger.info("Running the model...")

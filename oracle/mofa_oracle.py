@@ -329,9 +329,14 @@ def _omega_r(lik, Y, Mk, EZ, EZ2, EW, EW2, tau_rows, kappa):
 
 def run_general(views, likelihoods, groups=None, n_factors=10, n_iterations=1000, convergence_mode="fast",
                 seed=1, ard_weights=True, ard_factors=True, spikeslab_weights=True, center_groups=True,
-                scale_views=False, scale_groups=False, min_iterations=2):
+                scale_views=False, scale_groups=False, min_iterations=2, spikeslab_factors=False):
     """Coordinate-ascent VI with per-view likelihoods in {'gaussian', 'poisson', 'bernoulli'} and
-    element-wise missing values (NaN).  Dense numpy, loops over factors."""
+    element-wise missing values (NaN).  Dense numpy, loops over factors.
+
+    ``spikeslab_factors`` (/root/reference/muon/_core/tools.py:305,486 -> mofapy2 set_model_options): the factors get
+    the spike-and-slab prior the weights have - z_nk = s_nk zhat_nk, s_nk ~ Bernoulli(theta_gk), zhat_nk ~ N(0, 1 /
+    alpha_gk), theta_gk ~ Beta - i.e. the W node's update with samples in the place of features and one (alpha, theta)
+    pair per (group, factor).  Restated from the MOFA+ publication like the rest of this file: parity unpinned."""
     M, N = len(views), views[0].shape[0]
     groups = np.zeros(N, dtype=np.int64) if groups is None else np.asarray(groups, dtype=np.int64)
     G, K = int(groups.max()) + 1, int(n_factors)
@@ -359,6 +364,10 @@ def run_general(views, likelihoods, groups=None, n_factors=10, n_iterations=1000
     EWh2 = [np.ones((D, K)) for D in Ds]
     sig2w = [np.ones((D, K)) for D in Ds]
     sig2z = np.ones((N, K))
+    gamma_z = np.ones((N, K))
+    EZh2 = EZ2.copy()
+    c0 = digamma(1.0) - digamma(2.0)
+    lthz, l1mthz = np.full((G, K), c0), np.full((G, K), c0)
     pres = [(Mk.sum(axis=1) > 0).astype(np.float64) for Mk in masks]  # sample has any entry in view m
     elbos = []
 
@@ -407,9 +416,19 @@ def run_general(views, likelihoods, groups=None, n_factors=10, n_iterations=1000
                         a -= EZ[:, j] * (Om @ (EW[:, k] * EW[:, j]))
                 num += a
                 prec += Om @ EW2[:, k]
-            EZ[:, k] = num / prec
-            sig2z[:, k] = 1.0 / prec
-            EZ2[:, k] = EZ[:, k] ** 2 + 1.0 / prec
+            s2 = 1.0 / prec
+            mu = num * s2
+            if spikeslab_factors:
+                lam = (lthz[groups, k] - l1mthz[groups, k] + 0.5 * np.log(az[:, k]) - 0.5 * np.log(prec)
+                       + 0.5 * num * num * s2)
+                gz = 1.0 / (1.0 + np.exp(-lam))
+            else:
+                gz = np.ones(N)
+            EZ[:, k] = gz * mu
+            sig2z[:, k] = s2
+            EZ2[:, k] = gz * (mu * mu + s2)
+            gamma_z[:, k] = gz
+            EZh2[:, k] = gz * (mu * mu + s2) + (1.0 - gz) / az[:, k]
         # ---- tau (gaussian views) and the data terms of the ELBO ----------------------------------------
         lik_sum = 0.0
         for m in range(M):
@@ -448,9 +467,16 @@ def run_general(views, likelihoods, groups=None, n_factors=10, n_iterations=1000
         if ard_factors:
             for g in range(G):
                 a = A0 + 0.5 * Ng[g]
-                b = B0 + 0.5 * EZ2[gidx[g]].sum(axis=0)
+                b = B0 + 0.5 * EZh2[gidx[g]].sum(axis=0)  # (= <z^2> without the spike: gamma = 1)
                 st["alpha_z"][g] = a / b
                 st["lalpha_z"][g] = digamma(a) - np.log(b)
+        if spikeslab_factors:
+            for g in range(G):
+                sg = gamma_z[gidx[g]].sum(axis=0)
+                a = TH_A0 + sg
+                b = TH_B0 + Ng[g] - sg
+                lthz[g] = digamma(a) - digamma(a + b)
+                l1mthz[g] = digamma(b) - digamma(a + b)
         # ---- prior / entropy terms of the ELBO (same as run()) -------------------------------------------
         elbo = lik_sum
         for m in range(M):
@@ -474,9 +500,19 @@ def run_general(views, likelihoods, groups=None, n_factors=10, n_iterations=1000
         laz = st["lalpha_z"] if ard_factors else np.zeros((G, K))
         for g in range(G):
             i = gidx[g]
-            elbo += np.sum(0.5 * laz[g] - 0.5 * azg[g] * EZ2[i] + 0.5 * np.log(sig2z[i]) + 0.5)
+            gz = gamma_z[i]
+            elbo += np.sum(0.5 * laz[g] - 0.5 * azg[g] * EZh2[i])
+            elbo += np.sum(gz * 0.5 * np.log(sig2z[i]) + (1 - gz) * 0.5 * np.log(1.0 / azg[g]) + 0.5)
+            if spikeslab_factors:
+                elbo += np.sum(gz * lthz[g] + (1 - gz) * l1mthz[g])
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    ent = -(gz * np.log(gz) + (1 - gz) * np.log1p(-gz))
+                elbo += np.sum(np.nan_to_num(ent))
+                sg = gz.sum(axis=0)
+                a = TH_A0 + sg; b = TH_B0 + Ng[g] - sg
+                elbo += np.sum(_beta_kl(TH_A0, TH_B0, a, b, lthz[g], l1mthz[g]))
             if ard_factors:
-                a = A0 + 0.5 * Ng[g]; b = B0 + 0.5 * EZ2[i].sum(axis=0)
+                a = A0 + 0.5 * Ng[g]; b = B0 + 0.5 * EZh2[i].sum(axis=0)
                 elbo += np.sum(_gamma_kl(A0, B0, a, b, azg[g], laz[g]))
         elbos.append(float(elbo))
         if it >= min_iterations and len(elbos) >= 2:

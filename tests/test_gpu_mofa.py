@@ -444,3 +444,51 @@ def test_general_engine_replayed_iteration_equals_eager(hip, dt, monkeypatch):
     (e0, r0), (e1, r1) = runs
     assert e0 == e1
     assert np.array_equal(r0["Z"], r1["Z"]) and all(np.array_equal(a, b) for a, b in zip(r0["W"], r1["W"]))
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-9), (torch.float32, 5e-3)])
+def test_spikeslab_factors_on_the_gpu_match_the_oracle(hip, dt, tol):
+    """r06: spikeslab_factors=True on the device - the factor sweep is the W form of
+    mu_mofa_gs_update with one (alpha, theta) pair per (group, factor) - against oracle.run_general, mixed likelihoods,
+    two groups."""
+    from muon_amd._core.mofa_general import GeneralMofaEngine
+    from tests.test_mofa_host import _mixed_views
+
+    _, y1, y2, y3 = _mixed_views(n=400, seed=2)
+    groups = np.random.default_rng(1).integers(0, 2, 400)
+    liks = ["gaussian", "poisson", "bernoulli"]
+    ref = mofa_oracle.run_general([y1, y2, y3], liks, groups=groups, n_factors=5, n_iterations=8,
+                                  convergence_mode="slow", min_iterations=100, spikeslab_factors=True)
+    eng = GeneralMofaEngine(hip, [y1, sp.csr_matrix(y2), y3], liks, groups, 5, seed=1, dtype=dt, chunk_elems=6000,
+                            spikeslab_factors=True)
+    eng.run(8, "slow", min_iterations=100)
+    res = eng.results(sort_factors=False)
+    np.testing.assert_allclose(res["elbo"], ref["elbo"], rtol=tol)
+    np.testing.assert_allclose(res["Z"], ref["Z"], atol=max(tol * 10, 1e-8))
+
+
+def test_wrapper_fits_48_factors_and_90_stacked_columns_on_the_gpu():
+    """n_factors = 48 (tools.py:298 takes any int; the two-pass engine's kernels stop at 32) and 9 groups x 10 factors
+    against a sparse modality (its stacked products stop at 64 columns): the general engine, against the gaussian
+    oracle iteration by iteration."""
+    import pandas as pd
+
+    rng = np.random.default_rng(5)
+    n = 600
+    Z = rng.standard_normal((n, 4))
+    y1 = Z @ rng.standard_normal((4, 300)) + 0.5 * rng.standard_normal((n, 300))
+    y2 = Z @ rng.standard_normal((4, 500)) + 0.5 * rng.standard_normal((n, 500))
+    ref = mofa_oracle.run([y1, y2], n_factors=48, n_iterations=4, convergence_mode="slow", min_iterations=100)
+    md = MuData({"a": AnnData(y1), "b": AnnData(y2)})
+    mu.tl.mofa(md, n_factors=48, n_iterations=4, convergence_mode="slow", quiet=True)
+    assert md.obsm["X_mofa"].shape == (n, 48)
+    np.testing.assert_allclose(md.uns["mofa"]["elbo"][:4], ref["elbo"][:4], rtol=1e-9)
+    y2s = np.where(rng.random(y2.shape) < 0.2, y2, 0.0)
+    grp = np.array([i % 9 for i in range(n)])
+    ref = mofa_oracle.run([y1, y2s], groups=grp, n_factors=10, n_iterations=4, convergence_mode="slow", min_iterations=100)
+    md = MuData({"a": AnnData(y1), "s": AnnData(sp.csr_matrix(y2s))})
+    md.obs["grp"] = pd.Categorical([f"g{i}" for i in grp])
+    for m in md.mod.values():
+        m.obs["grp"] = md.obs["grp"].values
+    mu.tl.mofa(md, n_factors=10, groups_label="grp", n_iterations=4, convergence_mode="slow", quiet=True)
+    np.testing.assert_allclose(md.uns["mofa"]["elbo"][:4], ref["elbo"][:4], rtol=1e-8)
