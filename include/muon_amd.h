@@ -142,28 +142,15 @@ int mu_spmm_f32(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const i
                 const float* d_values, const float* d_Q, int B, float* d_Y, int accumulate,
                 void* stream);
 
-/* X^T straight from the CSR of X (csrc/tpack.hip), cell ids ascending inside every output row -
- * what Z = X^T Y of the iteration streams; no intermediate copy.
- *   1. mu_csr_tpack_count: col_nnz[c] = stored entries of column c (and keeps its per-row-block
- *      column offsets in d_work)
+/* X^T straight from X, cell ids ascending inside every output row - what Z = X^T Y of the iteration streams; no
+ * intermediate copy: mu_tpack4_* below (csrc/tpack4.hip; r06 removed the third generation, mu_csr_tpack_*):
+ *   1. mu_tpack4_count: col_nnz[c] = stored entries of column c (and keeps its per-row-block column prefixes in d_work)
  *   2. caller lays the output rows out and scans their lengths into row pointers
- *   3. mu_csr_tpack_fill_stream (row stream, below) or mu_csr_tpack_fill_csr with the SAME d_work
+ *   3. mu_tpack4_fill_stream (row stream) or mu_tpack4_fill_csr with the SAME d_work
  * nnz = stored entries of X (it sizes the row blocks and tiles; pass the same value everywhere).
- * d_slab_ptr (may be NULL): the slab pointers of the SAME index arrays if a caller still holds them - the first
- * n_rows x (ceil(n_cols / 8192) + 1) int64 of the work buffer of mu_csr_row_col_sums (TF-IDF searches the same
- * 8192-column slabs one call earlier: r04, the search is not repeated).
- * Stable and free of global atomics => bit-reproducible. */
-size_t mu_csr_tpack_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz);
-int mu_csr_tpack_count(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
-                       const int32_t* d_indices, int64_t* d_col_nnz, void* d_work,
-                       size_t work_bytes, const int64_t* d_slab_ptr, void* stream);
-/* The same transposition written as a plain CSR of X^T (t_indptr int64[n_cols + 1] = exclusive scan
- * of col_nnz, t_indices int32[nnz] = cell ids ascending inside every row, t_values f32[nnz]): step 3
- * of the sequence above with the CSR arrays as the target (the fast stable transpose). */
-int mu_csr_tpack_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
-                          const int32_t* d_indices, const float* d_values, const int64_t* d_t_indptr,
-                          int32_t* d_t_indices, float* d_t_values, void* d_work, size_t work_bytes,
-                          void* stream);
+ * d_slab_ptr (may be NULL): the slab pointers of the SAME index arrays (mu_csr_slab_ptr) if the caller holds them.
+ * Stable and free of global atomics => bit-reproducible.  Shapes mu_tpack4_supported refuses (2^31 rows, a row block
+ * of 2^29 entries) take mu_csr_transpose + mu_csr_stream_fill (stable as well, slower). */
 
 /* ---- the SpMM of the LSI iteration and its operand, the ROW STREAM (r02) --------------------------
  * Y[perm[p]][0..B-1] = row perm[p] of X times Q for every position p < n_pos (B = 16, 32 or 64): the
@@ -179,8 +166,8 @@ int mu_csr_tpack_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int
  * one workgroup must span less than 4 GiB of the stream (cursors are 32-bit byte offsets).
  *   1. mu_csr_stream_len: len[p] = stored entries of row perm[p] (0 for an empty position)
  *   2. caller scans len into sptr (mu_exclusive_scan_i64) and allocates ent: 8 bytes x sptr[n_pos]
- *   3. mu_csr_stream_fill (a streaming copy), or - for X^T straight from the CSR of X -
- *      mu_csr_tpack_count, the layout of the output rows from col_nnz, and mu_csr_tpack_fill_stream
+ *   3. mu_csr_stream_fill (a streaming copy), or - for X^T straight from X -
+ *      mu_tpack4_count, the layout of the output rows from col_nnz, and mu_tpack4_fill_stream
  *      (inv int32[n_cols]: output row -> position) with the SAME d_work
  * Requires canonical CSR (sorted column indices, no duplicates).  The entries of a row are
  * accumulated in column order with one fmaf chain per dense column, whatever the layout =>
@@ -194,11 +181,11 @@ int mu_spmm_stream_k(int64_t n_rows);
  * the streaming copy mu_csr_stream_fill is not needed (replaces, with the values array it still writes,
  * /root/reference/muon/_atac/preproc.py:96-117; the stream is the matvec operand of scipy svds, _svds.py:441-466).
  *
- * mu_tpack4_*: X^T as a row stream (or CSR) straight from X, fourth generation (csrc/tpack4.hip) - same output bytes
- * as mu_csr_tpack_fill_stream / _csr.  Source: the row stream of X when d_x_ent != NULL (d_x_row_dst[r] = pair index of
+ * mu_tpack4_*: X^T as a row stream (or CSR) straight from X, fourth generation (csrc/tpack4.hip) - the bytes of
+ * scipy's csr.T.tocsr() with sorted indices.  Source: the row stream of X when d_x_ent != NULL (d_x_row_dst[r] = pair index of
  * row r's first pair; d_indptr gives the row lengths) - rows are read as contiguous pairs - else the CSR arrays.
  * Row blocks are fixed row ranges (mu_tpack4_geometry: 16 waves x <= 32 rows), d_work is shared by _count and _fill,
- * d_slab_ptr as in mu_csr_tpack_count.  mu_tpack4_supported: 0 for shapes that need mu_csr_tpack_* (2^31 rows, a
+ * d_slab_ptr: see above.  mu_tpack4_supported: 0 for shapes that take the general transposition (2^31 rows, a
  * row block of 2^29 entries).  mu_tpack4_status reads the fill's error word (0 = fine; synchronises: tests). */
 int mu_tfidf_scale_sweep_stream(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
                                 const float* d_values, const double* d_rowsum, const float* d_idf, double scale,
@@ -209,7 +196,7 @@ int mu_tfidf_scale_sweep_stream(int64_t n_rows, int64_t n_cols, const int64_t* d
  * (ceil(n_cols / 8192) + 1)]) depend on the index arrays alone, which do not change between ingest, binarize, tfidf
  * and lsi: built ONCE where the device CSR is made (upload, 10x ingest) instead of searched by every tfidf call (26
  * binary searches per row at 200 000 columns: 3.0 ms of a 1e6-cell step).  The _sp entries take the table
- * (mu_tfidf_scale_sweep_stream and mu_csr_tpack_count / mu_tpack4_count have a d_slab_ptr argument of their own);
+ * (mu_tfidf_scale_sweep_stream and mu_tpack4_count have a d_slab_ptr argument of their own);
  * NULL = search as before.  Replaces nothing in the reference by itself: bookkeeping of preproc.py:92-117's kernels. */
 int mu_csr_slab_ptr(int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices, int64_t* d_sp,
                     void* stream);
@@ -247,17 +234,11 @@ size_t mu_tpack4_err_offset(int64_t n_rows, int64_t n_cols, int64_t nnz);
  * inside every row of X^T - the table of mu_spmm_stream_ranges_f32 for the warm start's X_S^T Y_S */
 size_t mu_tpack4_cnt_offset(int64_t n_rows, int64_t n_cols, int64_t nnz);
 int mu_tpack4_phase_cycles(unsigned long long* h_out6, int reset);
-/* diagnostics (scripts/tpack_probe.py): see csrc/tpack.hip */
-int mu_csr_tpack_phase_cycles(unsigned long long* h_out6, int reset);
 int mu_csr_stream_len(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr, int64_t* d_len,
                       void* stream);
 int mu_csr_stream_fill(int64_t n_pos, const int32_t* d_perm, const int64_t* d_indptr,
                        const int32_t* d_indices, const float* d_values, const int64_t* d_sptr,
                        void* d_ent, void* stream);
-int mu_csr_tpack_fill_stream(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t* d_indptr,
-                             const int32_t* d_indices, const float* d_values, const int64_t* d_sptr,
-                             const int32_t* d_inv, void* d_ent, void* d_work, size_t work_bytes,
-                             void* stream);
 /* B = 64 / 32: k_spmm_win (csrc/spmm_win.hip).  B = 16: k_spmm_narrow (csrc/spmm_narrow.hip: 16 stored entries x 4
  * columns per wave step) - the DEFAULT kernel of every 16-column product on a row stream: lsi with n_comps <= 2, the
  * neighbourhood means of mu.pp.neighbors on embeddings of <= 16 dimensions, MOFA f32 views whose operand is not laid
@@ -326,47 +307,6 @@ int mu_ell16_fill(int64_t n_groups, int64_t n_cols, int64_t nnz, int slab_cols, 
                   const int64_t* d_slab_ptr, const int32_t* d_perm, const int32_t* d_hdr, const int64_t* d_win_base,
                   void* d_ent, void* stream);
 
-/* ---- EXPERIMENTAL (not on any default path; MUON_AMD_LSI_MFMA=1 opts in and logs a warning) -------------------
- * mu_cells_geometry / mu_cells_cut / mu_dense_to_f16 / mu_spmm_cells_f32 and the two mu_probe_* entries below:
- * the r04 matrix-core SpMM experiment.  Faster than mu_spmm_stream_f32 (3.3 vs 4.0 ms at 125k x 200k) and NOT
- * accurate enough for the LSI parity bar (the Krylov basis is rounded to f16: ~1e-4 rad).  Kept
- * tested (tests/test_gpu_mfma.py) as the record of that experiment; the entry points may change or go.
- * ---- matrix-core SpMM of the LSI iteration (r04; csrc/spmm_mfma.hip) --------------------------------------
- * Replaces, like mu_spmm_stream_f32, the csr_matvec / csr_matvecs calls of ARPACK's reverse-communication loop
- * behind scipy.sparse.linalg.svds (/root/reference/muon/_atac/tools.py:53, scipy _svds.py:441-466,516), for
- * 64-column blocks: rows of the dense operand are gathered from LDS with ds_read_b64_tr_b16 and summed per
- * matrix row by v_mfma_f32_16x16x32_f16 (A = the stored values placed in the row they belong to).
- *
- * Operand ("cells"): rows in tiles of 8, 4 tiles = a band of 32 rows, operand rows in slabs of slab_rows.  The
- * entries of (tile, slab) form a cell = steps of 32 k-slots; a step is step_bytes = 224 bytes:
- *   hi[32] f16 | lo[32] f16   value / value_scale = hi + lo
- *   off[32] u16               in gather order: index 8 kb + 2 j + t holds slot 8 kb + 4 t + j; bits 0-13 = row of
- *                             the dense operand inside the slab * (stride / 8), bits 14-15 of off[0] = tile of the band
- *   mask[4][8] u8             bit i of mask[kb][r]: slot 8 kb + i belongs to tile row r (no bit: padding slot)
- * A band's steps are contiguous from step d_band_base[band], ordered (slab, tile, step); d_hdr[band][slab] is the
- * number of steps of the band in that slab.  d_band_base[band + 1] - d_band_base[band] >= the steps of the band
- * (mu_cells_cut reports a violated bound through *d_err); d_cells needs `ring` steps of slack behind the last band. */
-int mu_cells_geometry(int nset, int* slab_rows, int* stride, int* step_bytes, int* band_rows, int* ring);
-/* Cut a canonical (sorted) f32 CSR into cells.  *d_value_inv_scale: 1 / value_scale, a power of two (device). */
-int mu_cells_cut(int nset, int64_t n_rows, int64_t n_cols, const int64_t* d_indptr, const int32_t* d_indices,
-                 const float* d_values, const float* d_value_inv_scale, const int64_t* d_band_base, void* d_cells,
-                 int32_t* d_hdr, int* d_err, void* stream);
-/* f32 block [rows, 64] -> padded f16 operand [rows_padded, stride bytes] (nset 1: 64 f16; 2: hi 64 | lo 64) with one
- * power-of-two scale per column (d_scale, its inverse d_inv; the largest entry of a column lands in [2^13, 2^14)).
- * rewrite != 0: d_Q is replaced by the rounded block (float(hi) * scale) - the caller keeps THAT as its basis. */
-size_t mu_dense_f16_worksize(int64_t rows);
-int mu_dense_to_f16(int nset, int64_t rows, int64_t rows_padded, float* d_Q, int rewrite, void* d_out,
-                    float* d_scale, float* d_inv, void* d_work, size_t work_bytes, void* stream);
-/* Y[n_rows, 64] = (cells) x (f16 operand), f32 accumulation, Y[:, c] multiplied by d_outscale[c]
- * (= column scale x value scale).  nset 1 / 2: the operand of mu_dense_to_f16(nset). */
-int mu_spmm_cells_f32(int nset, int64_t n_rows, int64_t n_operand_rows, const int32_t* d_hdr,
-                      const int64_t* d_band_base, const void* d_cells, const void* d_B16,
-                      const float* d_outscale, float* d_Y, void* stream);
-/* hardware semantics the kernel rests on (tests/test_gpu_mfma.py): one wave reads d_image (LDS copy, <= 64 KiB)
- * with ds_read_b64_tr_b16 at the per-lane byte addresses d_addr[64] -> d_out[64][2] dwords; one
- * v_mfma_f32_16x16x32_f16 on per-lane fragments d_a[64][4], d_b[64][4] dwords -> d_d[64][4] floats. */
-int mu_probe_tr16(const void* d_image, int n_dwords, const void* d_addr, void* d_out, void* stream);
-int mu_probe_mfma16(const void* d_a, const void* d_b, float* d_d, void* stream);
 
 /* Tuning / ablation knobs (tests and bench only; all default to 0 = what ships):
  *   "spmm_k"     row-sets per wave of the packed SpMM (0 = automatic)

@@ -409,7 +409,7 @@ def tfidf_device(backend, X, n_obs, flags: int, scale: float, comm=None, out=Non
         res = backend.compact_nonzero(res)
     else:
         # the result shares X's index arrays: the slab pointers the sweeps searched go with it, lsi's transposition
-        # cuts the same 8192-column slabs (csrc/tpack.hip) and does not search them again
+        # cuts the same 8192-column slabs (csrc/tpack4.hip) and does not search them again
         if sp is not None and getattr(res, "slab_ptr", None) is None:  # (else: X came with its table, `with_values` kept it)
             res.slab_ptr = (sp, (res.indptr.data_ptr(), res.indices.data_ptr(), res.shape[0], res.shape[1]))
         if emit is not None:  # (keyed by the arrays it mirrors: a result whose zeros were compacted has no stream)
@@ -519,7 +519,7 @@ def tfidf(
         # single-threaded scipy tocsr() on the host
         n_r, n_c = counts.shape
         Xc = backend.upload_csr(counts.indptr, counts.indices, counts.data, (n_c, n_r))
-        # f32: the tile-staged transposition of csrc/tpack.hip (3x the rate of the general kernel)
+        # f32: the tile-staged transposition of csrc/tpack4.hip (3x the rate of the general kernel)
         fast = counts.dtype == np.float32 and hasattr(backend, "transpose_csr") and counts.nnz > 0
         X = backend.transpose_csr(Xc) if fast else backend.transpose(Xc)
         host = None

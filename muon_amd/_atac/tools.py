@@ -242,23 +242,9 @@ def _lsi_device(
     # straight from the CSR of X, no CSR of X^T in between.  (`pack=False`: plain CSR kernels.)
     if pack is None:
         pack = Xt is None and hasattr(backend, "can_stream") and backend.can_stream(X, B)
-    # r04 experiment, OFF unless MUON_AMD_LSI_MFMA=1: X Q_j on the matrix cores (csrc/spmm_mfma.hip).
-    # The operand is cut into cells and the product rounds Q_j IN PLACE to f16 (a power-of-two scale per column)
-    # before it is used anywhere else, so Y_j = X Q_j is exact for the block that is kept as the basis.  Measured:
-    # 3.3 against 4.0 ms per product at 125 000 x 200 000 and - rounding the basis blocks perturbs the Krylov
-    # space - 7e-5 .. 1e-4 rad where the f32 products reach 1e-6 (scripts/probes/f16_operand_precision.py, mode
-    # "basis"): not the default.  X^T Y_j keeps the f32 row-stream kernel either way.
-    mfma = (pack and hasattr(backend, "can_cells") and os.environ.get("MUON_AMD_LSI_MFMA", "0") == "1"
-            and backend.can_cells(X, B))
     Xcsr = X  # (the CSR as it came: the warm start below cuts a row range out of it)
     t4_err = take = None
-    if mfma:
-        logger.warning("MUON_AMD_LSI_MFMA=1: X Q_j runs on the matrix cores with the Krylov basis rounded to f16 - an "
-                       "experiment (DESIGN.md 4.3) that leaves the top-k subspace about 1e-4 rad from the f32 path's, "
-                       "at the edge of the parity bar")
-        Xt = backend.transpose_stream(X)
-        X = backend.cells(X)
-    elif pack:
+    if pack:
         X, Xt = backend.stream_both(X)
         take = getattr(backend, "take_tpack4_err", None)
         t4_err = take() if take is not None else None  # (read with the first Gram fetch: no synchronisation of its own)
@@ -319,7 +305,7 @@ def _lsi_device(
     # (the block below holds collectives, so entering it must be ONE decision of all ranks.  `pack` is per
     #  rank - a rank whose shard has no rows has no row stream - and such a rank still takes part: with an empty slice it
     #  contributes zeros to the sums.  `warm_spec`, `start`, `n_iter` are the same on every rank by construction.)
-    can_slice = bool(pack and not mfma and hasattr(Xcsr, "indptr") and hasattr(backend, "stream_both"))
+    can_slice = bool(pack and hasattr(Xcsr, "indptr") and hasattr(backend, "stream_both"))
     if start is None and warm_spec != "0" and n_iter is None:
         frac, qsteps = (int(v) for v in (warm_spec.split(":") + ["2"])[:2])
         # this rank's slice: 1 / frac of its cells; the slices of ALL ranks together at least 16 384 cells (an experiment
@@ -479,21 +465,7 @@ def _lsi_device(
     wasted = 0
     host = {"wait_ms": 0.0, "ritz_ms": 0.0}
 
-    # Measurement knob ("measure 16-bit Q on the GPU for the last expansion only"), not an API:
-    # MUON_AMD_LSI_Q16 = "<f16|bf16>:<p0>" rounds the dense operand of every product from product number p0 on
-    # (0-based: X Q_0 is 0, X^T Y_0 is 1, ...) to that type - the arithmetic stays f32, so this isolates what a
-    # 16-bit Q slab in LDS would do to the angle (scripts/probes/lsi_q16_probe.py).
-    q16 = os.environ.get("MUON_AMD_LSI_Q16")
-    q16_dtype, q16_from = None, 1 << 30
-    if q16:
-        q16_dtype = {"f16": torch.float16, "bf16": torch.bfloat16}[q16.split(":")[0]]
-        q16_from = int(q16.split(":")[1])
-    n_products = [0]
-
     def product(A, Qd):
-        if n_products[0] >= q16_from:
-            Qd = Qd.to(q16_dtype).to(Qd.dtype)
-        n_products[0] += 1
         return backend.spmm(A, Qd)
 
     def expand_product(j):

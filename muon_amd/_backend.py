@@ -85,28 +85,6 @@ class SplitStream:
 
 
 @dataclass
-class DeviceCells:
-    """A sparse operand cut into cells for the matrix-core SpMM (csrc/spmm_mfma.hip, include/muon_amd.h):
-    rows in tiles of 8 / bands of 32, columns in slabs of ``slab_rows`` operand rows; ``hdr[band, slab]`` =
-    steps (32 k-slots, 224 bytes) of the band in that slab, ``band_base[band]`` = first step of the band's
-    stream inside ``cells``; the stored values were divided by ``vscale`` (a power of two) and split into
-    two f16.  ``nset`` = 1: the dense operand is a basis block that the product ROUNDS IN PLACE to f16
-    (one power-of-two scale per column) - X Q~ is then exact; 2: the dense operand is read as hi + lo.
-    SpMM-only."""
-
-    hdr: torch.Tensor
-    band_base: torch.Tensor
-    cells: torch.Tensor
-    shape: Tuple[int, int]
-    nnz: int
-    nset: int
-    vscale: torch.Tensor
-    slab_rows: int
-    stride: int
-    cache: dict = None
-
-
-@dataclass
 class DeviceEll:
     """Sliced-ELL operand of the narrow-block SpMM (csrc/spmm_ell.hip, include/muon_amd.h): rows in launch order
     (``perm``: position -> row, -1 none), groups of 16 positions (one wave each), columns in slabs of 1024;
@@ -442,10 +420,9 @@ class HipBackend:
         `xplan` - where the rows go in the row stream of X (launch_layout of the row lengths, scanned; what the TF-IDF
         scale sweep needs to write that stream) - and `tplan` - the transposition's count phase (entries per (row block,
         column), their prefixes, the column totals) and the layout of X^T's stream.  Keyed by the arrays they describe;
-        a result whose zeros were compacted has other arrays and none of this.  MUON_AMD_PLANS=0: off."""
+        a result whose zeros were compacted has other arrays and none of this."""
         n, d = X.shape
-        if (n == 0 or d == 0 or X.nnz == 0 or os.environ.get("MUON_AMD_PLANS", "1") == "0"
-                or not (X.shape[0] > 0 and X.shape[1] > 0)):
+        if n == 0 or d == 0 or X.nnz == 0:
             return X
         if getattr(X, "xplan", None) is None:
             lens = X.indptr[1:] - X.indptr[:-1]
@@ -459,8 +436,7 @@ class HipBackend:
                     return X
             X.xplan = (dict(perm=perm, inv=inv, K=K, sptr=sptr, row_dst=sptr[inv.long()].contiguous()),
                        (X.indptr.data_ptr(), n, d))
-        if getattr(X, "tplan", None) is None and bool(self.lib.mu_tpack4_supported(n, d, X.nnz)) \
-                and self.lib.mu_tune_get(b"tpack_v3") != 1:
+        if getattr(X, "tplan", None) is None and self._use_tpack4(X):
             col_nnz = self.empty((d,), torch.int64)
             wb = int(self.lib.mu_tpack4_worksize(n, d, X.nnz))
             work = self.empty((wb,), torch.uint8)
@@ -516,7 +492,7 @@ class HipBackend:
     def can_emit_stream(self, X: DeviceCSR) -> bool:
         """The TF-IDF scale sweep can write the row stream of its result (f32, a shape the stream SpMM takes)."""
         return (X.values.dtype == torch.float32 and X.nnz > 0 and self.can_stream(X, 64)
-                and os.environ.get("MUON_AMD_TFIDF_STREAM", "1") != "0" and self.lib.mu_tune_get(b"scale_stream_off") != 1)
+                and self.lib.mu_tune_get(b"scale_stream_off") != 1)
 
     def stream_layout(self, X: DeviceCSR, K: Optional[int] = None):
         """Where the rows of X go in its row stream (launch_layout: needs the row LENGTHS only, so it can be made before
@@ -661,7 +637,7 @@ class HipBackend:
 
     def transpose_csr(self, X: DeviceCSR) -> DeviceCSR:
         """CSR of X^T straight from the CSR of X (f32; stable: cells ascending inside every row =>
-        canonical rows), through the tile-staged transposition of csrc/tpack.hip."""
+        canonical rows), through the tile-staged transposition of csrc/tpack4.hip."""
         n, d = X.shape
         assert X.values.dtype == torch.float32
         col_nnz = self.empty((max(d, 1),), torch.int64)
@@ -681,16 +657,8 @@ class HipBackend:
             self._note_tpack4(work, n, d, X.nnz)
             self.raise_tpack4(self.take_tpack4_err().item())  # (set-up / ingest paths: a synchronisation is affordable)
             return DeviceCSR(t_indptr, t_indices, t_values, (d, n))
-        wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
-        work = self.empty((wb,), torch.uint8)
-        with self._dev_ctx():
-            st = self._stream()
-            check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
-                                              _p(work), wb, _p(self._slab_ptr_of(X)), st))
-            check(self.lib.mu_exclusive_scan_i64(d, _p(col_nnz), _p(t_indptr), st))
-            check(self.lib.mu_csr_tpack_fill_csr(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
-                                                 _p(t_indptr), _p(t_indices), _p(t_values), _p(work), wb, st))
-        return DeviceCSR(t_indptr, t_indices, t_values, (d, n))
+        # (2^31 rows, a row block of 2^29 entries: the general stable transposition, csrc/transpose.hip)
+        return self.transpose(X)
 
     def can_stream(self, X: DeviceCSR, B: int) -> bool:
         """The row-stream SpMM exists for f32 values and B in (16, 32, 64)."""
@@ -728,10 +696,10 @@ class HipBackend:
         return DeviceStream(sptr, ent, (n, d), X.nnz, perm, K)
 
     def _use_tpack4(self, X: DeviceCSR) -> bool:
-        """The fourth-generation transposition (csrc/tpack4.hip) unless the shape needs the third (or tune tpack_v3 = 1)."""
+        """The tile-staged transposition (csrc/tpack4.hip) unless the shape needs the general one (2^31 rows, a row block
+        of 2^29 entries; tune tpack4_off = 1 forces it: tests)."""
         n, d = X.shape
-        return (self.lib.mu_tune_get(b"tpack_v3") != 1 and os.environ.get("MUON_AMD_TPACK_V3", "0") != "1"
-                and bool(self.lib.mu_tpack4_supported(n, d, X.nnz)))
+        return self.lib.mu_tune_get(b"tpack4_off") != 1 and bool(self.lib.mu_tpack4_supported(n, d, X.nnz))
 
     keep_tpack4_work = False  # tests / probes: keep the last fill's work buffer so that tpack4_status() can read its error word
 
@@ -814,29 +782,10 @@ class HipBackend:
                                                      _p(xs_dst), _p(xs_ent), _p(sptr), _p(inv), _p(ent), _p(work), wb, st))
             self._note_tpack4(work, n, d, X.nnz)
             return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K, self._t4_prefix(work, n, d, X.nnz))
-        wb = int(self.lib.mu_csr_tpack_worksize(n, d, X.nnz))
-        work = self.empty((wb,), torch.uint8)
-        with self._dev_ctx():
-            st = self._stream()
-            check(self.lib.mu_csr_tpack_count(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(col_nnz),
-                                              _p(work), wb, _p(self._slab_ptr_of(X)), st))
-            want_k = K
-            perm, inv, K, n_pos = None, None, max(1, int(want_k or self.lib.mu_spmm_stream_k(d))), d
-            lens = col_nnz[:d]
-            if sort_rows and d > 0:
-                perm, inv, K = self.launch_layout(lens, want_k)
-                n_pos = int(perm.numel())
-                plens = torch.zeros((n_pos,), dtype=torch.int64, device=self.device)
-                plens[inv.long()] = lens
-            else:
-                plens = lens.contiguous()
-            sptr = self._stream_sptr(plens, K)
-            ent = self.empty((max(X.nnz, 1),), torch.int64)
-            if before_fill is not None:
-                before_fill()
-            check(self.lib.mu_csr_tpack_fill_stream(n, d, X.nnz, _p(X.indptr), _p(X.indices), _p(X.values),
-                                                    _p(sptr), _p(inv), _p(ent), _p(work), wb, st))
-        return DeviceStream(sptr, ent, (d, n), X.nnz, perm, K)
+        # (shapes the tile-staged transposition refuses: the CSR of X^T from the general kernel, then a streaming copy)
+        if before_fill is not None:
+            before_fill()
+        return self.stream(self.transpose(X), sort_rows=sort_rows, K=K)
 
     def _t4_geometry(self, n, d, nnz):
         import ctypes as C
@@ -986,8 +935,7 @@ class HipBackend:
         n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         if n_wg > n_cus and not self.__dict__.get("_no_round_fill"):
             n_wg = -(-n_wg // n_cus) * n_cus
-        elif (5 * n_wg >= 4 * n_cus and not self.__dict__.get("_no_round_fill")
-              and os.environ.get("MUON_AMD_SPREAD_WGS", "1") != "0"):
+        elif 5 * n_wg >= 4 * n_cus and not self.__dict__.get("_no_round_fill"):
             # a little less than one round: every CU takes a workgroup (100 000 rows at K = 7: 224 -> 256
             # workgroups of 391 rows; empty row slots are cheap).  A/B on one box: MOFA c4 -1 %, c3shard -0.3 %;
             # at 157 of 256 workgroups (10k x 30k) it cost 1 %: hence the 4 / 5 threshold.
@@ -1012,7 +960,7 @@ class HipBackend:
         and f64 values -> SplitEll (hi + lo)."""
         waves = int(self.lib.mu_spmm_ell16_waves(X.shape[0]))
         cols = 512 if wide else 1024
-        fill = None if os.environ.get("MUON_AMD_ELL16_TENSOR_LAYOUT", "0") == "1" else self._ell16_fill
+        fill = self._ell16_fill
         if X.values.dtype == torch.float32:
             return ell16_layout(X, waves, cols, self.slab_ptr_width, fill)
         assert wide and X.values.dtype == torch.float64
@@ -1085,93 +1033,6 @@ class HipBackend:
                                                  _p(E.ent), _p(E.perm), _p(Q), _p(out), self._stream()))
         return out
 
-    # -- matrix-core SpMM operand (csrc/spmm_mfma.hip) ------------------------------------------
-    def cells_geometry(self, nset: int):
-        import ctypes as C
-
-        v = [C.c_int(0) for _ in range(5)]
-        check(self.lib.mu_cells_geometry(nset, *[C.byref(x) for x in v]))
-        return dict(slab_rows=v[0].value, stride=v[1].value, step_bytes=v[2].value, band_rows=v[3].value,
-                    ring=v[4].value)
-
-    def can_cells(self, X: DeviceCSR, B: int, nset: int = 1) -> bool:
-        """The matrix-core SpMM exists for f32 values and 64-column blocks; its cell stream is sized by a
-        bound (stored entries / 32 + 4 steps per band and slab) that must stay near the entries themselves."""
-        if not (X.values.dtype == torch.float32 and B == 64 and X.shape[0] > 0 and X.shape[1] > 0 and X.nnz > 0):
-            return False
-        g = self.cells_geometry(nset)
-        n_bands = -(-X.shape[0] // g["band_rows"])
-        n_slabs = -(-X.shape[1] // g["slab_rows"])
-        if n_slabs * g["slab_rows"] * g["stride"] >= (1 << 32):
-            return False
-        return 5 * n_slabs * n_bands <= 2 * (X.nnz // 32) + 4096
-
-    def cells(self, X: DeviceCSR, nset: int = 1) -> DeviceCells:
-        """Cut a canonical f32 CSR into cells (one pass over the matrix, once per lsi call)."""
-        n, d = X.shape
-        assert X.values.dtype == torch.float32
-        g = self.cells_geometry(nset)
-        br, sr, sb = g["band_rows"], g["slab_rows"], g["step_bytes"]
-        n_bands, n_slabs = -(-n // br), -(-d // sr)
-        # steps of a band: sum over its cells of ceil(entries / 32) <= entries / 32 + cells
-        edge = X.indptr[::br]
-        if edge.numel() < n_bands + 1:
-            edge = torch.cat([edge, X.indptr[-1:]])
-        ub = (edge[1:] - edge[:-1]) // 32 + 5 * n_slabs  # (+ an all-zero step where a band's count in a slab is odd)
-        band_base = torch.zeros((n_bands + 1,), dtype=torch.int64, device=self.device)
-        torch.cumsum(ub, 0, out=band_base[1:])
-        total = int(band_base[-1].item()) + g["ring"] + 1  # (the step ring reads ahead of the last step)
-        cells = self.empty((total * sb,), torch.uint8)
-        hdr = self.empty((n_bands, n_slabs), torch.int32)
-        err = self.zeros((1,), torch.int32)
-        # stored values are divided by a power of two that puts the largest one into [2^13, 2^14)
-        vmax = X.values.abs().max()
-        e = torch.where(vmax > 0, torch.floor(torch.log2(vmax)) - 13.0, torch.zeros_like(vmax))
-        vscale = torch.exp2(e).to(torch.float32).reshape(1)
-        vinv = torch.exp2(-e).to(torch.float32).reshape(1)
-        with self._dev_ctx():
-            check(self.lib.mu_cells_cut(nset, n, d, _p(X.indptr), _p(X.indices), _p(X.values), _p(vinv),
-                                        _p(band_base), _p(cells), _p(hdr), _p(err), self._stream()))
-        out = DeviceCells(hdr, band_base, cells, (n, d), X.nnz, nset, vscale, sr, g["stride"], {})
-        out.cache["err"] = err
-        return out
-
-    def _cells_check(self, Xc: DeviceCells) -> None:
-        err = Xc.cache.pop("err", None)
-        if err is not None and int(err.item()) != 0:
-            raise _ffi.MuonAmdError("mu_cells_cut: a band needed more steps than the caller's bound")
-
-    def dense16(self, Xc: DeviceCells, Q: torch.Tensor, rewrite: bool):
-        """f32 block [d, 64] -> the padded f16 operand of the matrix-core SpMM (+ per-column scales);
-        ``rewrite``: Q is replaced by its rounded self (the block IS what the f16 operand holds)."""
-        d = Xc.shape[1]
-        rows_padded = -(-d // Xc.slab_rows) * Xc.slab_rows
-        c = Xc.cache
-        if "b16" not in c:
-            c["b16"] = self.zeros((rows_padded * Xc.stride,), torch.uint8)  # (the pad bytes stay zero)
-            c["scale"] = self.empty((64,), torch.float32)
-            c["inv"] = self.empty((64,), torch.float32)
-            c["work"] = self.empty((int(self.lib.mu_dense_f16_worksize(d)),), torch.uint8)
-        with self._dev_ctx():
-            check(self.lib.mu_dense_to_f16(Xc.nset, d, rows_padded, _p(Q), int(bool(rewrite)), _p(c["b16"]),
-                                           _p(c["scale"]), _p(c["inv"]), _p(c["work"]), c["work"].numel(),
-                                           self._stream()))
-        return c["b16"], c["scale"]
-
-    def spmm_cells(self, Xc: DeviceCells, Q: torch.Tensor, out=None) -> torch.Tensor:
-        n, d = Xc.shape
-        if Q.shape != (d, 64) or Q.dtype != torch.float32 or not Q.is_contiguous():
-            raise TypeError("the matrix-core SpMM needs a contiguous f32 block of 64 columns")
-        self._cells_check(Xc)
-        b16, scale = self.dense16(Xc, Q, rewrite=(Xc.nset == 1))
-        outscale = scale * Xc.vscale
-        if out is None:
-            out = self.empty((n, 64), torch.float32)
-        with self._dev_ctx():
-            check(self.lib.mu_spmm_cells_f32(Xc.nset, n, d, _p(Xc.hdr), _p(Xc.band_base), _p(Xc.cells), _p(b16),
-                                             _p(outscale), _p(out), self._stream()))
-        return out
-
     def stream_both(self, X: DeviceCSR):
         """(row stream of X, row stream of X^T).  The two builders are independent; the streaming
         copy of X (HBM bound) runs on a second stream under the transposition, whose fill is
@@ -1191,7 +1052,7 @@ class HipBackend:
             # right before the fill: the count phase of the transposition (binary searches and a
             # histogram, latency bound) slowed down 4x next to the streaming copy, the fill does not
             side.wait_stream(cur)
-            wg = int(os.environ.get("MUON_AMD_PACK_WG", "2"))  # (A/B on one box, c3: 32 -> 451, 4 -> 449, 2 -> 441 ms per step)
+            wg = 2  # (A/B on one box, c3: 32 -> 451, 4 -> 449, 2 -> 441 ms per step)
             with torch.cuda.stream(side):
                 self.tune("pack_wg", wg)  # few workgroups per CU: the fill's 1024-thread groups must fit next to them
                 # ... and the unpipelined loop: the pipelined copy is faster alone (22.5 -> 20-21.6 ms at 1e6 x 200k) and
@@ -1241,9 +1102,6 @@ class HipBackend:
             if X.lo is not None:
                 self.spmm(X.lo, Q, out=out, accumulate=True)
             return out
-        if isinstance(X, DeviceCells):
-            assert not accumulate
-            return self.spmm_cells(X, Q, out=out)
         if isinstance(X, SplitEll):
             out = self.spmm_ell(X.hi, Q, out=out, accumulate=accumulate)
             if X.lo is not None:

@@ -15,7 +15,7 @@ device CSR of this rank's cells directly:
   * ``atac_only``: the peak columns are selected ON THE DEVICE (a column map + the compaction kernel
     that tfidf already owns), cells keep their stored entries in order;
   * coordinate triplets (Matrix Market / snap): key sort + run-length row pointers on the device;
-  * feature-major CSC (features compressed): transposed on the device (csrc/tpack.hip).
+  * feature-major CSC (features compressed): transposed on the device (csrc/tpack4.hip).
 
 ``read_10x_arrays`` wraps the single-process case in an AnnData whose ``X`` shares the caller's arrays
 when no column is dropped and carries the device copy, so ``tfidf`` / ``lsi`` start without another

@@ -430,8 +430,8 @@ class MofaEngine:
                     V.ld = 16
                     # f32: the library GEMM for A = Y (tau o W) had been 3 % ahead of mu_skinny_nn; with the branch-free,
                     # asm-prefetching build of r04 (views of whole 128-byte tiles) the kernel is 2 % ahead of it
-                    # (c4: 0.465 against 0.475 s; MUON_AMD_MOFA_F32_NN=blas brings the library back)
-                    own_f32 = V.D % 32 == 0 and os.environ.get("MUON_AMD_MOFA_F32_NN", "") != "blas"
+                    # (c4: 0.465 against 0.475 s with the library GEMM)
+                    own_f32 = V.D % 32 == 0
                     if (T == torch.float64 or own_f32) and hasattr(self.be, "skinny_nn"):
                         V.T16 = [torch.zeros((V.D, 16), dtype=T, device=dev) for _ in range(G)]
                     else:
@@ -447,9 +447,8 @@ class MofaEngine:
         # events; captured into the HIP graph as parallel branches), so the ~25 small kernels of one view hide under the
         # other view's product and the HBM-bound dense product overlaps the sliced-ELL one.  Same kernels, same operands:
         # the same numbers; the ELBO adds the views' terms at the end (per-view scalars: the kernels add to a scalar in
-        # place).  One process, fused path only; MUON_AMD_MOFA_VIEW_STREAMS=0: one stream.
-        self._par = (self._fused and self.M > 1 and self.comm.world_size == 1 and getattr(self.be, "name", "") == "hip"
-                     and os.environ.get("MUON_AMD_MOFA_VIEW_STREAMS", "1") != "0")
+        # place).  One process, fused path only.
+        self._par = (self._fused and self.M > 1 and self.comm.world_size == 1 and getattr(self.be, "name", "") == "hip")
         self._side = [torch.cuda.Stream(self.be.device) for _ in range(self.M - 1)] if self._par else []
         if self._fused:
             self._rs_work_v = [self._rs_work] + [self.be.mofa_rowstats_work(K) for _ in range(self.M - 1)]

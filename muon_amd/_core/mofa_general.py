@@ -102,8 +102,7 @@ class GeneralMofaEngine:
         # the same equations; ~170 tensor launches per iteration otherwise) keep these nodes in the fit's type
         # (the fused factor nodes have no spike: with spikeslab_factors the small nodes run as tensor operations)
         self._fused_small = (hasattr(backend, "mofa_w_elbo") and hasattr(backend, "mofa_z_elbo") and K <= 32
-                             and not spikeslab_factors
-                             and os.environ.get("MUON_AMD_MOFA_NG_FUSED_SMALL", "1") != "0")
+                             and not spikeslab_factors)
         ST = dtype if self._fused_small else torch.float64
         self.W = []
         for D in self.Ds:
@@ -251,8 +250,7 @@ class GeneralMofaEngine:
         # depend on (z_n, w_d) only - dense sweeps over the two factor blocks + corrections over the stored entries
         # (csrc/mofa_poisson.hip, r04)
         V.fused = bool(lik == "poisson" and V.kind == "sparse" and hasattr(be, "mofa_poisson_pass") and self.K <= 32
-                       and V.X.values.dtype == T and pres.all()
-                       and os.environ.get("MUON_AMD_MOFA_FUSED_POISSON", "1") != "0")
+                       and V.X.values.dtype == T and pres.all())
         if V.fused:
             V.Xt = be.transpose(V.X)
         V.centred = False
@@ -274,7 +272,7 @@ class GeneralMofaEngine:
             # (P_n = <z_n z_n^T>): products of the two constant matrices Y (centred, masked) and M with K- and
             # K^2-column blocks - the sufficient statistics of MofaEngine with the mask inside (r05; r04 made Omega, R,
             # the prediction and the residuals as N x D tensors in every pass: ~25 kernels per iteration).
-            V.stats = os.environ.get("MUON_AMD_MOFA_NG_STATS", "1") != "0"
+            V.stats = True
             if V.stats:
                 V.yyM = torch.stack([(V.Y[a0:b0].double() ** 2).sum(dim=0) for a0, b0 in self.gslice])
                 V.Ngd = (torch.stack([V.mask[a0:b0].double().sum(dim=0) for a0, b0 in self.gslice]) if V.mask is not None

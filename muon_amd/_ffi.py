@@ -58,9 +58,6 @@ SIGNATURES = {
     "mu_csr_transpose_worksize": (_sz, [_i64, _i64, _i64]),
     "mu_csr_transpose": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
-    "mu_csr_tpack_worksize": (_sz, [_i64, _i64, _i64]),
-    "mu_csr_tpack_count": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "mu_csr_tpack_fill_csr": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_stream_k": (C.c_int, [_i64]),
     "mu_tfidf_scale_sweep_stream": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _dbl, _i32, _vp, _vp, _vp, _sz, _i32,
                                               _vp, _vp, _vp, _vp]),
@@ -77,28 +74,19 @@ SIGNATURES = {
     "mu_tpack4_status": (C.c_int, [_vp, _i64, _i64, _i64, C.POINTER(C.c_int)]),
     "mu_tpack4_err_offset": (_sz, [_i64, _i64, _i64]),
     "mu_tpack4_phase_cycles": (C.c_int, [_vp, _i32]),
-    "mu_csr_tpack_phase_cycles": (C.c_int, [_vp, _i32]),
     "mu_csr_stream_len": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "mu_csr_stream_fill": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mu_csr_tpack_fill_stream": (C.c_int, [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mu_spmm_stream_f32": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "mu_spmm_stream_f64": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp]),
     "mu_csr_slice_stream": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_spmm_stream_ranges_f32": (C.c_int, [_i64, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _vp]),
     "mu_tpack4_cnt_offset": (_sz, [_i64, _i64, _i64]),
-    "mu_cells_geometry": (C.c_int, [_i32] + [C.POINTER(C.c_int)] * 5),
-    "mu_cells_cut": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mu_dense_f16_worksize": (_sz, [_i64]),
-    "mu_dense_to_f16": (C.c_int, [_i32, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "mu_spmm_cells_f32": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_spmm_ell16_waves": (C.c_int, [_i64]),
     "mu_dense_col_moments_chunks": (C.c_int, [_i64, _i64]),
     "mu_dense_col_moments": (C.c_int, [_i32, _i64, _i64, _i64, _vp, _i32, _vp, _vp]),
     "mu_ell16_fill": (C.c_int, [_i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_spmm_ell16_f32": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_spmm_ell16_f64": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
-    "mu_probe_tr16": (C.c_int, [_vp, _i32, _vp, _vp, _vp]),
-    "mu_probe_mfma16": (C.c_int, [_vp, _vp, _vp, _vp]),
     "mu_tune_set": (C.c_int, [C.c_char_p, _i32]),
     "mu_tune_get": (C.c_int, [C.c_char_p]),
     "mu_spmm_f64": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),

@@ -3,9 +3,9 @@
 // This is the kernel the block Lanczos iteration of muon_amd.atac.tl.lsi spends its time in; it
 // stands where ARPACK's reverse-communication loop calls csr_matvec / csr_matvecs through
 // scipy.sparse.linalg.svds (/root/reference/muon/_atac/tools.py:53, scipy _svds.py:441-466,516).
-// The transposed product runs through the same kernel on the row stream of X^T (tpack.hip).
+// The transposed product runs through the same kernel on the row stream of X^T (tpack4.hip).
 //
-// Operand ("row stream", built once per lsi() call by mu_csr_stream_fill / mu_csr_tpack_fill_stream):
+// Operand ("row stream", built once per lsi() call by mu_csr_stream_fill / mu_tpack4_fill_stream):
 // the (column, value) pairs of the matrix, 8 bytes each, row after row in LAUNCH ORDER - position p
 // of the launch holds row perm[p] at ent[sptr[p] .. sptr[p+1]) - without any padding.  The rows of
 // one workgroup are contiguous, so a cursor is a 32-bit byte offset from the workgroup's base.

@@ -1,6 +1,6 @@
 // X^T as a row stream (or CSR) from X - fourth generation of the transposition's fill (r05).
 //
-// Same job, same output bytes as csrc/tpack.hip (the rmatvec operand of scipy svds, _svds.py:441-466, reached from
+// Same job, same output bytes as its predecessor (archived: scripts/probes/tpack_v3.hip; the rmatvec operand of scipy svds, _svds.py:441-466, reached from
 // /root/reference/muon/_atac/tools.py:53): a workgroup stages a (row block x column tile) in LDS sorted by (column, cell)
 // and writes every column's run with consecutive lanes; stable, no global atomics.  What changed is how a tile is
 // sorted, because of what bounded the third generation: its row visits fetched 64 (column, value)
@@ -37,7 +37,7 @@ constexpr int kH0 = 88;              // asm-owned v[88..91]: the next tile's hea
 constexpr int kW0 = 92;              // asm-owned registers v[kW0 ..]: slot j = (v[kW0 + 2j] column, v[kW0 + 2j + 1] value bits)
 constexpr int kSlotP = 16;           // overflow slot of the rows PREDICTED to overflow (they did in the tile before): prefetched
 constexpr int kSlotX = 17;           // overflow slot of the rows that overflow unannounced: loaded on the spot
-constexpr int kCountSlab = 8192;     // = sweep.hpp kSlab = tpack.hip kTSlab: the slab pointers are shared
+constexpr int kCountSlab = 8192;     // = sweep.hpp kSlab: the slab pointers are shared
 
 #define MU_T4_CLOB                                                                                                  \
   "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",  \
@@ -76,7 +76,7 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
 }
 
 // ---- count: entries per (row block, column), row blocks of `rpb` consecutive rows ------------------------------------
-// (csrc/tpack.hip k_t_count_pipe with fixed row blocks: the pieces of a wave's strip of rows as one flat sequence of
+// (the r04 pipelined count sweep with fixed row blocks: the pieces of a wave's strip of rows as one flat sequence of
 //  iterations, unconditional clamped loads from asm, two iterations in flight, bins of M x 8192 columns)
 struct T4Walk {
   int l, pb, hi, nrow, step;

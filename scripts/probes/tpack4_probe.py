@@ -71,24 +71,24 @@ ms0, T0 = timed(lambda: tfidf_device(be, X, cells, 3, 1e4, out=out, emit_stream=
 print(f"tfidf_device without the stream (sums + idf + scale):          {ms0:.2f} ms", flush=True)
 nnz = T0.nnz
 
-# r04's operand building: streaming copy next to the third-generation fill
-be.tune("tpack_v3", 1)
+# the reference: streaming copy + the general transposition (r06: the third generation is archived in scripts/probes/tpack_v3.hip)
+be.tune("tpack4_off", 1)
 ms3, (Xs3, Xt3) = timed(lambda: be.stream_both(T0))
-print(f"v3: stream_both (copy of X on a second stream + count + layout + fill): {ms3:.2f} ms", flush=True)
+print(f"general: stream_both (copy of X on a second stream + count + layout + fill): {ms3:.2f} ms", flush=True)
 ref_t, ref_x = checksum(Xt3.ent, nnz), checksum(Xs3.ent, nnz)
 ref_sptr, ref_perm = Xt3.sptr.clone(), Xt3.perm.clone()
 del Xs3, Xt3
 torch.cuda.empty_cache()
 ms3a, _r = timed(lambda: be.transpose_stream(T0))
 del _r
-print(f"v3: transposition alone:                                                {ms3a:.2f} ms", flush=True)
-be.tune("tpack_v3", 0)
+print(f"general: transposition alone:                                                {ms3a:.2f} ms", flush=True)
+be.tune("tpack4_off", 0)
 torch.cuda.empty_cache()
 
 ms4c, Xt4 = timed(lambda: be.transpose_stream(T0))
 print(f"v4: transposition from the CSR arrays:    {ms4c:.2f} ms  (error word {be.tpack4_status()})", flush=True)
 same = checksum(Xt4.ent, nnz) == ref_t and torch.equal(Xt4.sptr, ref_sptr) and torch.equal(Xt4.perm, ref_perm)
-print(f"    same bytes as v3: {same}", flush=True)
+print(f"    same bytes as general: {same}", flush=True)
 del Xt4, T0
 torch.cuda.empty_cache()
 
@@ -98,7 +98,7 @@ assert be._xstream_of(T) is not None
 ms4s, (Xs4, Xt4) = timed(lambda: be.stream_both(T))
 print(f"v4: stream_both with the sweep's stream:   {ms4s:.2f} ms  (error word {be.tpack4_status()})", flush=True)
 same = checksum(Xt4.ent, nnz) == ref_t and torch.equal(Xt4.sptr, ref_sptr) and torch.equal(Xt4.perm, ref_perm)
-print(f"    X^T stream same bytes as v3: {same};  X stream same bytes as the copy: {checksum(Xs4.ent, nnz) == ref_x}", flush=True)
+print(f"    X^T stream same bytes as general: {same};  X stream same bytes as the copy: {checksum(Xs4.ent, nnz) == ref_x}", flush=True)
 del Xt4, Xs4
 torch.cuda.empty_cache()
 # count phase alone

@@ -329,8 +329,8 @@ def test_transpose_stream_empty_matrix(hip):
 
 
 def test_transpose_stream_tile_overflow_falls_back(hip):
-    """A (row block x column slab) tile larger than the staging buffer takes the direct-store path;
-    the staged kernels (v3, v2) and the fallback give the bytes of the numpy stream."""
+    """A (row block x column tile) denser than the staging buffer is retried at half the width until it fits; the
+    tile-staged transposition and the general one (tune tpack4_off) give the bytes of the numpy stream."""
     rng = np.random.default_rng(21)
     n, d = 60000, 200
     dense = sp.random(n, 100, density=0.95, format="csr", random_state=rng, dtype=np.float32)
@@ -340,88 +340,16 @@ def test_transpose_stream_tile_overflow_falls_back(hip):
     mt = m.T.tocsr()
     mt.sort_indices()
     sptr, ent = _stream_ref(mt)
-    for v2 in (0, 1, 2):  # third generation, second generation, fourth (the default)
+    for off in (0, 1):
         try:
-            hip.tune("tpack_v3", 0 if v2 == 2 else 1)
-            hip.tune("tpack_v2", 1 if v2 == 1 else 0)
+            hip.tune("tpack4_off", off)
             P = hip.transpose_stream(X, sort_rows=False)
             Ps = hip.transpose_stream(X)
         finally:
-            hip.tune("tpack_v2", 0)
-            hip.tune("tpack_v3", 0)
+            hip.tune("tpack4_off", 0)
         assert np.array_equal(hip.to_host(P.sptr), sptr)
         assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
         _check_stream(hip, Ps, mt)
-
-
-@pytest.mark.parametrize("build", [1, 2])
-def test_transpose_stream_both_cursor_widths(hip, build):
-    """The fill exists with packed 16-bit cursors (inputs of more than one round of row blocks) and
-    with 32-bit ones; small inputs only reach the second by themselves.  Both builds, forced: ragged
-    rows with bursts, narrow tiles, and a tile that overflows the staging buffer (direct stores with
-    the 32-bit cursors kept in the staging memory in the packed build)."""
-    rng = np.random.default_rng(5 + build)
-    cases = [(_heavy_rows_csr(2000, 20000, 0.004, rng, bursts=True), 0),
-             (_heavy_rows_csr(5000, 700, 0.03, rng, bursts=True), 64),
-             (_heavy_rows_csr(300, 9000, 0.01, rng, bursts=True), 32)]
-    dense = sp.random(60000, 100, density=0.95, format="csr", random_state=rng, dtype=np.float32)
-    big = sp.hstack([dense, sp.csr_matrix((60000, 100), dtype=np.float32)], format="csr")
-    big.sort_indices()
-    cases.append((big, 0))
-    for m, C in cases:
-        mt = m.T.tocsr()
-        mt.sort_indices()
-        sptr, ent = _stream_ref(mt)
-        try:
-            hip.tune("tpack_v3", 1)
-            hip.tune("tpack_narrow", build)
-            hip.tune("tpack_c", C)
-            P = hip.transpose_stream(_up(hip, m), sort_rows=False)
-            Ps = hip.transpose_stream(_up(hip, m))
-        finally:
-            hip.tune("tpack_narrow", 0)
-            hip.tune("tpack_c", 0)
-            hip.tune("tpack_v3", 0)
-        assert np.array_equal(hip.to_host(P.sptr), sptr)
-        assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
-        _check_stream(hip, Ps, mt)
-
-
-@pytest.mark.parametrize("C", [32, 64, 0])
-def test_transpose_stream_count_rides_on_previous_tile(hip, C):
-    """Third-generation fill: the place walk of a tile counts the next tile's entries.  Narrow tiles
-    against rows with long dense bursts (more than 64 entries inside one / two tiles), empty column
-    ranges (the tile after an empty one counts for itself) and ragged rows; the bytes equal the
-    numpy stream and the ones of the two-walk kernel."""
-    rng = np.random.default_rng(77 + C)
-    n, d = 3000, 2600
-    m = sp.random(n, d, density=0.02, format="lil", random_state=rng, dtype=np.float32)
-    for r in rng.choice(n, 60, replace=False):      # dense bursts of 70..400 consecutive columns
-        c0 = int(rng.integers(0, d - 450))
-        L = int(rng.integers(70, 400))
-        m[r, c0:c0 + L] = rng.random(L).astype(np.float32) + 0.5
-    m = m.tocsr()
-    m[:, 900:1400] = 0                              # empty column ranges
-    m[:, 2000:2100] = 0
-    m.eliminate_zeros()
-    m.sort_indices()
-    X = _up(hip, m)
-    mt = m.T.tocsr()
-    mt.sort_indices()
-    sptr, ent = _stream_ref(mt)
-    try:
-        hip.tune("tpack_v3", 1)
-        hip.tune("tpack_c", C)
-        P = hip.transpose_stream(X, sort_rows=False)
-        hip.tune("tpack_v2", 1)
-        P2 = hip.transpose_stream(X, sort_rows=False)
-    finally:
-        hip.tune("tpack_c", 0)
-        hip.tune("tpack_v2", 0)
-        hip.tune("tpack_v3", 0)
-    assert np.array_equal(hip.to_host(P.sptr), sptr)
-    assert np.array_equal(hip.to_host(P.ent).view(np.uint64)[: ent.size], ent)
-    assert torch.equal(P2.ent[: ent.size], P.ent[: ent.size])
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])

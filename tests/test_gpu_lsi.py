@@ -273,7 +273,7 @@ def test_widened_bench_records_run_small_and_hold_parity(hip):
 
 def test_transposition_takes_the_slab_pointers_tfidf_searched(hip):
     """tfidf_device leaves the 8192-column slab pointers with its result; the transposition of that matrix reads them
-    instead of searching again (csrc/tpack.hip mu_csr_tpack_count d_slab_ptr) - same output, and a wrapper of the
+    instead of searching again (csrc/tpack4.hip mu_tpack4_count d_slab_ptr) - same output, and a wrapper of the
     backend (bench.py's TimedBackend) must not lose them"""
     import torch
 

@@ -478,3 +478,31 @@ def test_tfidf_takeover_with_other_count_types(dtype):
         assert ad.X.data.ctypes.data == where
     else:
         assert (keep != before).nnz == 0 and keep.dtype == dtype
+
+
+def test_restarts_keep_more_when_k_sits_inside_a_cluster(monkeypatch):
+    """r06: 80 planted topics, n_comps = 50 - sigma_50 and sigma_51 lie inside one cluster (a ~1 % gap).  A thick restart
+    that keeps one 64-vector block cuts through the cluster every time; when the Ritz values show the small gap at the
+    first restart, the restarts keep one block more (MUON_AMD_LSI_GROW=0: the fixed rule).  Same subspace, within the
+    parity bar of f64 ARPACK, in about half the products."""
+    from muon_amd._atac.tools import lsi_device
+
+    X = planted_topics_csr(3000, 2500, n_topics=80, density=0.03, seed=3, dtype=np.float32)
+    T, Xd = _device_tfidf(X)
+    ref = lsi_oracle.lsi(T, n_comps=50)
+    out = {}
+    for grow in ("0", "1"):
+        monkeypatch.setenv("MUON_AMD_LSI_GROW", grow)
+        _, sd, V, info = lsi_device(BE, Xd, n_comps=50, return_info=True)
+        assert info["converged"] and lsi_oracle.max_subspace_angle(V.numpy(), ref["LSI"]) < 1e-4
+        np.testing.assert_allclose(sd, ref["stdev"], rtol=1e-5)
+        out[grow] = info["spmm"]
+    assert out["1"] <= 0.7 * out["0"], out
+    # a gapped spectrum (planted rank = n_comps) never triggers it: same products either way
+    X = planted_topics_csr(1500, 1200, n_topics=20, density=0.05, seed=2, dtype=np.float32)
+    T, Xd = _device_tfidf(X)
+    cnt = []
+    for grow in ("0", "1"):
+        monkeypatch.setenv("MUON_AMD_LSI_GROW", grow)
+        cnt.append(lsi_device(BE, Xd, n_comps=20, return_info=True)[3]["spmm"])
+    assert cnt[0] == cnt[1]
