@@ -118,6 +118,14 @@ class MofaEngine:
         self._graph_ok = (getattr(backend, "name", "") == "hip" and self.comm.world_size == 1
                           and os.environ.get("MUON_AMD_MOFA_GRAPH", "1") != "0")
         self._eager_steps = 0
+        # several ranks: the iteration as two captured segments around one packed all-reduce (see _seg_a); on operator
+        # sets without graphs (CPU tests) the segments run eagerly - same schedule, one collective per iteration
+        self._loc = {}
+        self._seg_graphs = None
+        self._seg = bool(self.comm.world_size > 1 and getattr(self, "_fused", False)
+                         and os.environ.get("MUON_AMD_MOFA_SEGMENTS", "1") != "0")
+        self._seg_ok = (self._seg and getattr(backend, "name", "") == "hip"
+                        and os.environ.get("MUON_AMD_MOFA_GRAPH", "1") != "0")
 
     # -- helpers -------------------------------------------------------------------------
     def _mark(self, label):
@@ -448,8 +456,11 @@ class MofaEngine:
         # other view's product and the HBM-bound dense product overlaps the sliced-ELL one.  Same kernels, same operands:
         # the same numbers; the ELBO adds the views' terms at the end (per-view scalars: the kernels add to a scalar in
         # place).  One process, fused path only.
-        self._par = (self._fused and self.M > 1 and self.comm.world_size == 1 and getattr(self.be, "name", "") == "hip")
-        self._side = [torch.cuda.Stream(self.be.device) for _ in range(self.M - 1)] if self._par else []
+        # (several ranks: the first, eager iteration has collectives inside the views' shares and stays on one stream;
+        #  the segmented iterations that follow - _seg_a / _seg_b, no collective inside - take the views' streams too)
+        self._par_ok = bool(self._fused and self.M > 1 and getattr(self.be, "name", "") == "hip")
+        self._par = self._par_ok and self.comm.world_size == 1
+        self._side = [torch.cuda.Stream(self.be.device) for _ in range(self.M - 1)] if self._par_ok else []
         if self._fused:
             self._rs_work_v = [self._rs_work] + [self.be.mofa_rowstats_work(K) for _ in range(self.M - 1)]
         self._elbo_work_v = [self._elbo_work] + [self.be.mofa_elbo_work(K) for _ in range(self.M - 1)]
@@ -519,7 +530,9 @@ class MofaEngine:
             got = self._zmom[key] = (Gz, Z2, Zs)
         return got
 
-    def _zstats_fused(self, m):
+    def _stats_local(self, m):
+        """This rank's share of view m's statistics - (Gz, Z2, Zs) of its presence mask and B_g = Y_g^T <Z_g> - before any
+        sum over the ranks and before the implicit centring (which needs the summed Zs)."""
         V, K, G = self.views[m], self.K, self.G
         Gz, Z2, Zs = self._z_moments(m)
         if V.kind == "sparse":
@@ -530,6 +543,11 @@ class MofaEngine:
             B = torch.stack([self.be.skinny_tn(V.Y[a:b], Z16[a:b])[:, :K] for a, b in self.gslice])
         else:
             B = torch.stack([V.Y[a:b].T @ self.EZ[a:b] for a, b in self.gslice])
+        return Gz, Z2, Zs, B
+
+    def _zstats_fused(self, m):
+        V = self.views[m]
+        Gz, Z2, Zs, B = self._stats_local(m)
         if self.comm.world_size > 1:
             B = B.contiguous()
             Gz, Z2, Zs = Gz.clone(), Z2.clone(), Zs.clone()  # (shared between views: reduce copies)
@@ -709,6 +727,97 @@ class MofaEngine:
                 elbo = elbo + extra  # (the views' terms, in view order)
         return elbo
 
+    # -- several ranks: an iteration as TWO captured segments around ONE packed all-reduce (r06) -------------------------
+    # With collectives inside, r02 - r05 launched a multi-rank iteration eagerly (~150 launches: 1.1 ms at the 12 500-cell
+    # shard of configs[4], host-bound, against 4.2 ms / 8 = 0.5 ms of device work) and spent three collectives per
+    # iteration (one per view's statistics, one for the factors' sums).  The iteration splits where the sums over the
+    # ranks are needed: segment A = W updates | Z update | every view's LOCAL statistics | the factors' local sums, one
+    # all-reduce of all of them (fixed buffers, packed into one message per dtype by the communicator), segment B = the
+    # implicit centring | tau, alpha, theta per view | the factor node | the ELBO.  Each segment is a HIP graph; the host
+    # replays A, issues the collective, replays B, reads the ELBO.  Same kernels on the same operands as the eager
+    # iteration: the same numbers (tests/test_distributed_gloo.py runs the segments eagerly on CPU with two ranks,
+    # tests/test_gpu_mofa.py the captured ones against the eager trace).
+    def _seg_a(self):
+        self._fork()
+        for m in range(self.M):
+            with self._on(m):
+                self._update_w(m)
+        self._join()
+        self._update_z()
+        if self._par:  # the factors' moments and the padded <Z> operands are shared by the views: before they part
+            for m in range(self.M):
+                self._z_moments(m)
+        self._fork()
+        for m in range(self.M):
+            with self._on(m):
+                st = self._stats_local(m)
+                buf = self._loc.get(m)
+                if buf is None:
+                    self._loc[m] = [t.contiguous().clone() for t in st]
+                else:
+                    for dst, src in zip(buf, st):
+                        dst.copy_(src)
+        self._join()
+        for g, (a_, b_) in enumerate(self.gslice):
+            self.be.mofa_z_sums(self.EZ2, self.sig2z, a_, b_, self._zs[g], self._elbo_work)
+
+    def _seg_reduce(self):
+        self.comm.all_reduce_sum(*[t for m in range(self.M) for t in self._loc[m]], self._zs)
+
+    def _seg_b(self) -> torch.Tensor:
+        o, be = self.opts, self.be
+        elbo = torch.zeros((), dtype=torch.float64, device=self.EZ.device)
+        parts = [elbo] + ([torch.zeros((), dtype=torch.float64, device=self.EZ.device) for _ in range(self.M - 1)]
+                          if self._par else [elbo] * (self.M - 1))
+        self._fork()
+        for m, (V, Wm) in enumerate(zip(self.views, self.W)):
+            with self._on(m):
+                wk = self._elbo_work_v[m] if self._par else self._elbo_work
+                Gz, Z2, Zs, B = self._loc[m]
+                if V.kind == "sparse" or getattr(V, "implicit", False):
+                    B = B - V.mu[:, :, None] * Zs[:, None, :]  # implicit centring, with the sums over all ranks
+                buf = self._stat_buf.get(m)
+                if buf is None:
+                    self._stat_buf[m] = buf = (Gz.clone(), Z2.clone(), B.contiguous().clone())
+                else:
+                    for dst, src in zip(buf, (Gz, Z2, B)):
+                        dst.copy_(src)
+                self._stats[m] = buf
+                be.mofa_tau_elbo(V.yy, V.Ngm_d, Wm.EW, Wm.EW2, buf[2], buf[0], buf[1], A0, B0, Wm.tau, Wm.ltau, parts[m], wk)
+                be.mofa_w_elbo(Wm.EWh2, Wm.gamma, Wm.sig2, o["ard_weights"], o["spikeslab_weights"], A0 + 0.5 * V.D, A0,
+                               B0, TH_A0, TH_B0, Wm.alpha, Wm.lalpha, Wm.lth, Wm.l1mth, parts[m], wk)
+        self._join()
+        be.mofa_z_elbo(self._zs, self._Ng64, o["ard_factors"], A0, B0, self.alpha_z, self.lalpha_z, elbo)
+        if self._par:
+            for extra in parts[1:]:
+                elbo = elbo + extra  # (the views' terms, in view order)
+        return elbo
+
+    def _iteration_segments(self) -> torch.Tensor:
+        self._seg_a()
+        self._seg_reduce()
+        return self._seg_b()
+
+    def _capture_segments(self):
+        dev = self.be.device
+        torch.cuda.synchronize(dev)
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(ga):
+                self._seg_a()
+            ga.replay()  # (capturing records, it does not run: this replay IS the iteration's first half)
+            self._seg_reduce()
+            with torch.cuda.graph(gb):
+                out = self._seg_b()
+            gb.replay()
+        except Exception as e:  # capture refused: stay eager (the state may be half an iteration ahead: finish it)
+            warnings.warn(f"MOFA iteration not captured into HIP graph segments ({e}); running eagerly")
+            self._seg_ok = False
+            self._stats = {}
+            return None
+        self._seg_graphs, self._graph_elbo = (ga, gb), out
+        return out
+
     # -- driver --------------------------------------------------------------------------------
     def _iteration(self) -> torch.Tensor:
         """One coordinate-ascent sweep (W per view, Z, tau / alpha / theta, ELBO); device work only,
@@ -751,6 +860,20 @@ class MofaEngine:
         if self._graph is not None:
             self._graph.replay()
             e = float(self._graph_elbo.item())
+        elif self._seg_graphs is not None:
+            self._seg_graphs[0].replay()
+            self._seg_reduce()
+            self._seg_graphs[1].replay()
+            e = float(self._graph_elbo.item())
+        elif self._seg and self._eager_steps >= 1:
+            self._par = self._par_ok  # (no collective inside a segment: the views' shares on their own streams)
+            out = None
+            if self._seg_ok and self._eager_steps >= 3:
+                out = self._capture_segments()  # (runs the iteration it captures)
+            if out is None:
+                out = self._iteration_segments()
+            e = float(out.item())
+            self._eager_steps += 1
         else:
             e = float(self._iteration().item())
             self._eager_steps += 1

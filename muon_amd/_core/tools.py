@@ -276,7 +276,12 @@ def mofa(
         # mask in data.obs order, :617-621 - the same thing only when the names happen to be sorted; otherwise each
         # common cell receives another cell's factors: not reproduced.)
         xm = np.full((data.n_obs, z.shape[1]), np.nan)
-        xm[data.obs.index.get_indexer(pd.Index(obs_used))] = z
+        if os.environ.get("MUON_AMD_MOFA_INTERSECTION_MASK", "0") == "1":
+            # the reference's statement, bit for bit (:615-621): the model's rows - in sorted-name order - land in the
+            # True positions of the mask in data.obs order.  Identical to the default when the names are sorted.
+            xm[data.obs.index.isin(pd.Index(obs_used))] = z
+        else:
+            xm[data.obs.index.get_indexer(pd.Index(obs_used))] = z
         data.obsm["X_mofa"] = xm
     else:
         data.obsm["X_mofa"] = z

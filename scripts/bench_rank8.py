@@ -119,6 +119,7 @@ def run_c5_rank8(be, iters=100, warmup=3, f64=False):
     return {"metric": "ms per MOFA ELBO iteration of ONE rank of eight (emulated on one GPU, no communication)",
             "value": ms, "unit": "ms", "higher_is_better": False, "n_gpus": 1, "dtype": "f64" if f64 else "f32",
             "data": "synthetic", "ms_per_iteration": ms, "graph": bool(eng._graph is not None),
+            "segments": bool(getattr(eng, "_seg_graphs", None) is not None),
             "elbo_monotone": bool(np.all(np.diff(e) > -1e-6 * abs(e[0]))),
             "config": {"workload": f"c5_rank8: the {n_local}-cell shard of configs[4] (rna {n_local} x 20000 dense + atac "
                                    f"{n_local} x 100000 sparse, {atac.nnz} stored entries), K = 10, a stand-in communicator of "

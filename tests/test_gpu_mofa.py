@@ -492,3 +492,39 @@ def test_wrapper_fits_48_factors_and_90_stacked_columns_on_the_gpu():
         m.obs["grp"] = md.obs["grp"].values
     mu.tl.mofa(md, n_factors=10, groups_label="grp", n_iterations=4, convergence_mode="slow", quiet=True)
     np.testing.assert_allclose(md.uns["mofa"]["elbo"][:4], ref["elbo"][:4], rtol=1e-8)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-12), (torch.float32, 1e-5)])
+def test_multi_rank_iteration_as_two_graph_segments(hip, dt, tol):
+    """r06: with several ranks an iteration is two captured segments around ONE packed all-reduce (mofa_engine._seg_a /
+    _seg_b).  A stand-in communicator that claims two ranks and sums nothing (the partner holds no samples) must
+    reproduce the single-process trace: same kernels, same operands; sparse + dense view, two groups."""
+    from muon_amd._comm import LocalComm
+
+    class LonelyPair(LocalComm):
+        world_size = 2
+        calls = 0
+
+        def all_reduce_sum(self, *tensors):
+            LonelyPair.calls += 1
+            return tensors[0] if len(tensors) == 1 else tensors
+
+    rng = np.random.default_rng(4)
+    n = 3000
+    Z = rng.standard_normal((n, 4))
+    y1 = (Z @ rng.standard_normal((4, 320)) + 0.5 * rng.standard_normal((n, 320))).astype(np.float32)
+    y2 = sp.random(n, 900, density=0.05, format="csr", random_state=rng, dtype=np.float32)
+    groups = rng.integers(0, 2, n)
+    ref = MofaEngine(hip, [y1, y2], groups, 6, dtype=dt, seed=1)
+    seg = MofaEngine(hip, [y1, y2], groups, 6, dtype=dt, seed=1, comm=LonelyPair())
+    for _ in range(10):
+        ref.step()
+        seg.step()
+    assert seg._seg_graphs is not None and seg._graph is None
+    before = LonelyPair.calls
+    seg.step()
+    ref.step()
+    assert LonelyPair.calls == before + 1  # one collective per iteration
+    np.testing.assert_allclose(seg.elbo, ref.elbo, rtol=tol)
+    a, b = seg.results(sort_factors=False), ref.results(sort_factors=False)
+    np.testing.assert_allclose(a["Z"], b["Z"], atol=1e-9 if dt == torch.float64 else 1e-3)

@@ -569,3 +569,31 @@ def test_wrapper_takes_every_plain_mofa_option():
     assert md.uns["mofa"]["params"]["model"]["spikeslab_factors"] is True or md.uns["mofa"]["params"]["model"]["spikeslab_factors"] == 1
     e = md.uns["mofa"]["elbo"]
     assert np.all(np.diff(e) > -1e-7 * abs(e[0]))
+
+
+def test_intersection_write_back_by_name_or_by_the_reference_mask(monkeypatch):
+    """use_obs="intersection" with cell names that are NOT in sorted order.  Default: every common cell gets its own
+    factors back, by name.  MUON_AMD_MOFA_INTERSECTION_MASK=1: the reference's statement bit for
+    bit - the model's rows, in sorted-name order, assigned through the boolean mask in data.obs order
+    (/root/reference/muon/_core/tools.py:615-621) - i.e. the same rows in another place when the names are unsorted."""
+    rng = np.random.default_rng(8)
+    n = 40
+    names = [f"c{v:02d}" for v in rng.permutation(n)]
+    z = rng.standard_normal((n, 3))
+    y1 = z @ rng.standard_normal((3, 25)) + 0.3 * rng.standard_normal((n, 25))
+    y2 = z @ rng.standard_normal((3, 30)) + 0.3 * rng.standard_normal((n, 30))
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MUON_AMD_MOFA_INTERSECTION_MASK", flag)
+        a = AnnData(y1[:-6], obs=pd.DataFrame(index=names[:-6]))
+        b = AnnData(y2[6:], obs=pd.DataFrame(index=names[6:]))
+        md = MuData({"a": a, "b": b})
+        mu.tl.mofa(md, use_obs="intersection", n_factors=3, n_iterations=15, quiet=True, backend=BE)
+        out[flag] = (md.obsm["X_mofa"].copy(), list(md.obs.index))
+    (x0, idx), (x1, _) = out["0"], out["1"]
+    common = sorted(set(names[:-6]) & set(names[6:]))
+    rows = {c: x0[idx.index(c)] for c in common}                       # by name (default)
+    mask = np.isin(np.asarray(idx), common)
+    assert np.array_equal(np.isnan(x0).all(axis=1), ~mask) and np.array_equal(np.isnan(x1).all(axis=1), ~mask)
+    np.testing.assert_allclose(x1[mask], np.stack([rows[c] for c in common]), atol=1e-12)  # sorted-order rows through the mask
+    assert not np.allclose(x0[mask], x1[mask])                          # ... which is another placement here
