@@ -387,20 +387,24 @@ def tfidf_device(backend, X, n_obs, flags: int, scale: float, comm=None, out=Non
 
     Pipeline: one reduction sweep (row sums, LDS-staged column sums), an all-reduce of the
     d column sums when rows are sharded, the idf vector, one fused scale pass."""
+    from .._trace import phase
+
     comm = default_comm(comm)
-    rowsum, colsum = backend.row_col_sums(X)
-    comm.all_reduce_sum(colsum)
-    idf = backend.idf(colsum, float(n_obs), flags, X.values.dtype)
+    with phase("tfidf/sums"):
+        rowsum, colsum = backend.row_col_sums(X)
+        comm.all_reduce_sum(colsum)
+        idf = backend.idf(colsum, float(n_obs), flags, X.values.dtype)
     # r05: the scale sweep also writes the ROW STREAM of the result - the operand layout of lsi's products - while it has
     # every entry in registers (the layout needs the row lengths only); lsi then skips its streaming copy of X and
     # transposes from the stream.  Operator sets without the kernel (CPU tests) simply do not offer it.
     emit = None
     can = getattr(backend, "can_emit_stream", None)
-    if emit_stream and can is not None and can(X):
-        emit = backend.stream_layout(X)
-        vals, zero_count = backend.tfidf_scale(X, rowsum, idf, scale, flags, out=out, emit=emit)
-    else:
-        vals, zero_count = backend.tfidf_scale(X, rowsum, idf, scale, flags, out=out)
+    with phase("tfidf/scale"):
+        if emit_stream and can is not None and can(X):
+            emit = backend.stream_layout(X)
+            vals, zero_count = backend.tfidf_scale(X, rowsum, idf, scale, flags, out=out, emit=emit)
+        else:
+            vals, zero_count = backend.tfidf_scale(X, rowsum, idf, scale, flags, out=out)
     res = X.with_values(vals)
     take = getattr(backend, "take_slab_ptr", None)  # (a method: wrappers of the backend forward it)
     sp = take() if take is not None else None

@@ -242,8 +242,11 @@ def _lsi_device(
     # straight from the CSR of X, no CSR of X^T in between.  (`pack=False`: plain CSR kernels.)
     if pack is None:
         pack = Xt is None and hasattr(backend, "can_stream") and backend.can_stream(X, B)
+    from .._trace import mark
+
     Xcsr = X  # (the CSR as it came: the warm start below cuts a row range out of it)
     t4_err = take = None
+    mark("lsi/operands")
     if pack:
         X, Xt = backend.stream_both(X)
         take = getattr(backend, "take_tpack4_err", None)
@@ -302,6 +305,7 @@ def _lsi_device(
     warm_spec = os.environ.get("MUON_AMD_LSI_WARM", ("32:2" if getattr(comm, "world_size", 1) == 1 else "16:2")
                                if nnz_rank > 500_000_000 else "0")
     warm_used = None
+    mark("lsi/warm_start")
     # (the block below holds collectives, so entering it must be ONE decision of all ranks.  `pack` is per
     #  rank - a rank whose shard has no rows has no row stream - and such a rank still takes part: with an empty slice it
     #  contributes zeros to the sums.  `warm_spec`, `start`, `n_iter` are the same on every rank by construction.)
@@ -362,6 +366,7 @@ def _lsi_device(
                 Q0, _ = _orthonormalize(backend, Zs, w, passes=2, flag=qr_flag)
             del Ss, St
             warm_used = {"cells": n_s, "power_steps": qsteps, "slice": "ranges" if wplan is not None else "operands"}
+    mark("lsi/krylov")
     Qs, Ys, css = [Q0], [], []
     Tb, Mb = {}, {}  # (i, j), i <= j  ->  w x w f64 host blocks
 
@@ -677,6 +682,7 @@ def _lsi_device(
         Qs.append(Z)
         it += 1
 
+    mark("lsi/ritz_vectors")
     s = np.sqrt(lam)
     # deterministic signs: largest-magnitude coefficient of each Ritz vector positive
     sg = np.sign(C[np.argmax(np.abs(C), axis=0), np.arange(k)])
@@ -700,6 +706,7 @@ def _lsi_device(
     U = first_columns(combine(Ys, CS, bias=bias), k)
 
     stdev = s / np.sqrt(n_obs - 1)  # tools.py:65
+    mark("")
     if return_info:
         basis = None
         if return_basis:  # the top-w Ritz vectors (one full block): what a warm start of another run begins with

@@ -789,20 +789,28 @@ inline size_t t4_worksize(int64_t n_rows, int64_t n_cols, int64_t nnz) {
   return al((size_t)(n_rows * (S + 1)) * sizeof(int64_t)) + al((size_t)(q.G + 1) * (size_t)n_cols * sizeof(uint32_t)) +
          2 * al((size_t)n_cols * sizeof(int64_t)) + 256 + 256;
 }
-inline T4Work t4_carve(void* work, int64_t n_rows, int64_t n_cols, int64_t nnz) {
+struct T4Off {  // byte offsets of the pieces inside the work buffer
+  size_t cnt, coltot, cdst, err;
+};
+inline T4Off t4_offsets(int64_t n_rows, int64_t n_cols, int64_t nnz) {
   const int64_t S = (n_cols + kCountSlab - 1) / kCountSlab;
   const T4Geo q = t4_geometry(n_rows, n_cols, nnz);
+  T4Off o;
+  o.cnt = al((size_t)(n_rows * (S + 1)) * sizeof(int64_t));
+  o.coltot = o.cnt + al((size_t)(q.G + 1) * (size_t)n_cols * sizeof(uint32_t));
+  o.cdst = o.coltot + al((size_t)n_cols * sizeof(int64_t));
+  o.err = o.cdst + al((size_t)n_cols * sizeof(int64_t));
+  return o;
+}
+inline T4Work t4_carve(void* work, int64_t n_rows, int64_t n_cols, int64_t nnz) {
+  const T4Off o = t4_offsets(n_rows, n_cols, nnz);
   char* w = (char*)work;
   T4Work t;
   t.sp = (int64_t*)w;
-  w += al((size_t)(n_rows * (S + 1)) * sizeof(int64_t));
-  t.cnt = (uint32_t*)w;
-  w += al((size_t)(q.G + 1) * (size_t)n_cols * sizeof(uint32_t));
-  t.coltot = (int64_t*)w;
-  w += al((size_t)n_cols * sizeof(int64_t));
-  t.cdst = (int64_t*)w;
-  w += al((size_t)n_cols * sizeof(int64_t));
-  t.err = (int*)w;
+  t.cnt = (uint32_t*)(w + o.cnt);
+  t.coltot = (int64_t*)(w + o.coltot);
+  t.cdst = (int64_t*)(w + o.cdst);
+  t.err = (int*)(w + o.err);
   return t;
 }
 
@@ -919,20 +927,12 @@ int mu_tpack4_fill_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_
 
 /* byte offset of the fill's error word inside d_work: callers that must not synchronise copy the word to the host with
  * their next fetch (muon_amd/_backend.py: tpack4 fills are checked at lsi's first Gram fetch) */
-size_t mu_tpack4_err_offset(int64_t n_rows, int64_t n_cols, int64_t nnz) {
-  char* base = nullptr;
-  const T4Work w = t4_carve(base, n_rows, n_cols, nnz);
-  return (size_t)((char*)w.err - base);
-}
+size_t mu_tpack4_err_offset(int64_t n_rows, int64_t n_cols, int64_t nnz) { return t4_offsets(n_rows, n_cols, nnz).err; }
 
 /* byte offset inside d_work of the count pass' prefix table: uint32 cnt[(n_blocks + 1)][n_cols], cnt[g][c] = entries of
  * column c in the row blocks before g (row n_blocks: the column totals).  The fill only reads it: the cells of a row-block
  * range are a contiguous piece of every row of X^T and this table says where it begins (mu_spmm_stream_ranges_f32) */
-size_t mu_tpack4_cnt_offset(int64_t n_rows, int64_t n_cols, int64_t nnz) {
-  char* base = nullptr;
-  const T4Work w = t4_carve(base, n_rows, n_cols, nnz);
-  return (size_t)((char*)w.cnt - base);
-}
+size_t mu_tpack4_cnt_offset(int64_t n_rows, int64_t n_cols, int64_t nnz) { return t4_offsets(n_rows, n_cols, nnz).cnt; }
 
 /* the fill's error word (0 = fine; 1: bitmap and count pass disagreed, 2: a tile could not be narrowed) - synchronises */
 int mu_tpack4_status(const void* d_work, int64_t n_rows, int64_t n_cols, int64_t nnz, int* h_err) {

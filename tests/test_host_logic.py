@@ -506,3 +506,38 @@ def test_restarts_keep_more_when_k_sits_inside_a_cluster(monkeypatch):
         monkeypatch.setenv("MUON_AMD_LSI_GROW", grow)
         cnt.append(lsi_device(BE, Xd, n_comps=20, return_info=True)[3]["spmm"])
     assert cnt[0] == cnt[1]
+
+
+def test_roctx_ranges_are_balanced_and_off_by_default(monkeypatch):
+    """MUON_AMD_TRACE=1 brackets the phases of tfidf / lsi with roctx ranges (muon_amd/_trace.py).  Off by
+    default; when on, every push has its pop - also when lsi leaves through its redo-on-host path - and the result is
+    the same."""
+    from muon_amd import _trace
+    from muon_amd._atac.tools import lsi_device
+
+    X = planted_topics_csr(600, 400, n_topics=8, density=0.08, seed=11, dtype=np.float32)
+    T, Xd = _device_tfidf(X)
+    monkeypatch.setattr(_trace, "_state", None)
+    monkeypatch.delenv("MUON_AMD_TRACE", raising=False)
+    assert not _trace._enabled()
+    _, sd0, _, _ = lsi_device(BE, Xd, n_comps=8, return_info=True)
+
+    calls = []
+
+    class Fake:
+        def roctxRangePushA(self, b):
+            calls.append(("push", b.decode()))
+            return 0
+
+        def roctxRangePop(self):
+            calls.append(("pop", None))
+            return 0
+
+    monkeypatch.setattr(_trace, "_state", True)
+    monkeypatch.setattr(_trace, "_lib", Fake())
+    monkeypatch.setattr(_trace, "_depth", [0])
+    _, sd1, _, _ = lsi_device(BE, Xd, n_comps=8, return_info=True)
+    names = [n for k, n in calls if k == "push"]
+    assert names == ["lsi/operands", "lsi/warm_start", "lsi/krylov", "lsi/ritz_vectors"]
+    assert sum(k == "push" for k, _ in calls) == sum(k == "pop" for k, _ in calls) and _trace._depth[0] == 0
+    np.testing.assert_array_equal(sd0, sd1)
