@@ -297,6 +297,17 @@ int mu_spmm_ell16_f32(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d
 int mu_spmm_ell16_f64(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr, const int64_t* d_wave_base,
                       const void* d_ent, const int32_t* d_perm, const double* d_Q, double* d_Y, int accumulate,
                       void* stream);
+/* r06: the same two products with the column slabs split into `parts` over blockIdx.y - part y writes its partial product
+ * to d_Y + y * y_stride (elements), the caller sums the partials in order - for operands of a few thousand rows (one rank's
+ * shard of a sharded mu.tl.mofa fit, /root/reference/muon/_core/tools.py:583-585): every workgroup otherwise pulls all of Q
+ * through its LDS.  mu_spmm_ell16_parts: the (waves, parts) to launch with (parts = 1: the plain entries). */
+int mu_spmm_ell16_parts(int64_t n_rows, int64_t n_cols, int wide, int* waves, int* parts);
+int mu_spmm_ell16_parts_f32(int waves, int parts, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr,
+                            const int64_t* d_wave_base, const void* d_ent, const int32_t* d_perm, const float* d_Q,
+                            float* d_Y, int64_t y_stride, void* stream);
+int mu_spmm_ell16_parts_f64(int waves, int parts, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr,
+                            const int64_t* d_wave_base, const void* d_ent, const int32_t* d_perm, const double* d_Q,
+                            double* d_Y, int64_t y_stride, void* stream);
 
 /* The layout itself: the windows of a canonical f32 CSR from its slab pointers of the operand's width
  * (mu_csr_slab_ptr_width(slab_cols): d_slab_ptr[row][0 .. S]).  d_perm / d_hdr / d_win_base[group][slab] (first window

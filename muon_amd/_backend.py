@@ -1023,6 +1023,26 @@ class HipBackend:
         if out is None:
             assert not accumulate
             out = self.empty((n, 16), Q.dtype)
+        # r06: an operand of a few thousand rows (one rank's shard of a sharded fit) is a few dozen workgroups that each
+        # pull all of Q through their LDS - its column slabs are split over blockIdx.y, the partial products summed in
+        # order (mu_spmm_ell16_parts: one part for every shape that fills a round of the chip by its rows)
+        import ctypes as C
+
+        wv, parts = C.c_int(0), C.c_int(1)
+        check(self.lib.mu_spmm_ell16_parts(n, d, int(wide), C.byref(wv), C.byref(parts)))
+        if parts.value > 1:
+            slabs = -(-d // E.slab_cols)
+            ny = -(-slabs // -(-slabs // parts.value))
+            part = self.empty((ny, n, 16), Q.dtype)
+            fn = self.lib.mu_spmm_ell16_parts_f64 if wide else self.lib.mu_spmm_ell16_parts_f32
+            with self._dev_ctx():
+                check(fn(wv.value, parts.value, int(E.perm.numel()), d, _p(E.hdr), _p(E.wave_base), _p(E.ent), _p(E.perm),
+                         _p(Q), _p(part), n * 16, self._stream()))
+            if accumulate:
+                out += part.sum(dim=0)
+            else:
+                torch.sum(part, dim=0, out=out)
+            return out
         with self._dev_ctx():
             if wide:
                 check(self.lib.mu_spmm_ell16_f64(E.waves, int(E.perm.numel()), d, _p(E.hdr), _p(E.wave_base),

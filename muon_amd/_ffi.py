@@ -87,6 +87,9 @@ SIGNATURES = {
     "mu_ell16_fill": (C.c_int, [_i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_spmm_ell16_f32": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_spmm_ell16_f64": (C.c_int, [_i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "mu_spmm_ell16_parts": (C.c_int, [_i64, _i64, _i32, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mu_spmm_ell16_parts_f32": (C.c_int, [_i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "mu_spmm_ell16_parts_f64": (C.c_int, [_i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "mu_tune_set": (C.c_int, [C.c_char_p, _i32]),
     "mu_tune_get": (C.c_int, [C.c_char_p]),
     "mu_spmm_f64": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),

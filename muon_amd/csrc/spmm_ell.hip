@@ -117,8 +117,15 @@ __global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_
                                                                      const unsigned char* __restrict__ ent,
                                                                      const int32_t* __restrict__ perm,
                                                                      const DT* __restrict__ Q, DT* __restrict__ Y,
-                                                                     int accumulate) {
+                                                                     int accumulate, int s_per_part, int64_t y_stride) {
+  // r06 - COLUMN PARTS (blockIdx.y): workgroup (x, y) sweeps slabs [y s_per_part, (y + 1) s_per_part) only and writes its
+  // partial product to Y + y y_stride.  A shard of a few thousand rows is a few dozen workgroups, and every one of them
+  // pulls ALL of Q through its LDS at the producer wave's ~25 GB/s: the 12 500-cell shard of configs[4] took 0.25 ms
+  // for a product whose share of the full-size launch is 0.07.  (One part: the launch of before.)
   constexpr int kRowBytes = 16 * (int)sizeof(DT);
+  const int s_begin = (int)blockIdx.y * s_per_part;
+  const int s_end = (s_begin + s_per_part) < n_slabs ? (s_begin + s_per_part) : n_slabs;
+  Y += (int64_t)blockIdx.y * y_stride;
   __shared__ __attribute__((aligned(1024))) unsigned char slab[2 * kESlabBytes];
   const int lane = threadIdx.x & 63;
   const int wave = uniform32(threadIdx.x >> 6);
@@ -135,11 +142,11 @@ __global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    whole(0, 0);
+    whole(s_begin, 0);
     __syncthreads();
-    for (int s = 0; s + 1 < n_slabs; ++s) {
-      whole(s + 1, (s + 1) & 1);  // (its buffer held slab s - 1: everyone is past the barrier that ended it)
-      __syncthreads();            // the end of slab s for the others
+    for (int s = s_begin; s + 1 < s_end; ++s) {
+      whole(s + 1, (s + 1 - s_begin) & 1);  // (its buffer held slab s - 1: everyone is past the barrier that ended it)
+      __syncthreads();                      // the end of slab s for the others
     }
     return;
   }
@@ -158,7 +165,16 @@ __global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_
   typedef __attribute__((address_space(4))) const int32_t* chdr_p;
   const chdr_p myhdr = (chdr_p)(hdr + (active ? gwave : 0) * (int64_t)n_slabs);
   auto counts_of = [&](int s) -> int { return active ? uniform32(myhdr[s]) : 0; };
-  const unsigned char* wp = ent + uniform64(active ? wave_base[gwave] : 0) * kEWin + kEWin * kEDepth;  // next REQUEST
+  // (a later part starts behind the windows of the slabs before it: a wave-wide sum of its counts)
+  int64_t skip = 0;
+  if (s_begin > 0 && active) {
+    int part = 0;
+    for (int i = lane; i < s_begin; i += 64) part += hdr[gwave * (int64_t)n_slabs + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    skip = (int64_t)uniform32(part);
+  }
+  const unsigned char* wp = ent + (uniform64(active ? wave_base[gwave] : 0) + skip) * kEWin + kEWin * kEDepth;  // next REQUEST
 
   const unsigned lane_c = (unsigned)(lane & 3) * (unsigned)(4 * sizeof(DT));
   unsigned base = lds0 + lane_c;  // this lane's four columns of the current slab buffer
@@ -216,19 +232,19 @@ __global__ __launch_bounds__(64 * (kEMaxWaves + 1)) void k_spmm_ell16(int64_t n_
     e_request0<6>(w0, lane4, lane2);
     e_request0<7>(w0, lane4, lane2);
   }
-  int s = 0;
-  int left = counts_of(0);  // windows of this wave in slab s still to take
-  int next_cnt = n_slabs > 1 ? counts_of(1) : 0;
+  int s = s_begin;
+  int left = s_begin < s_end ? counts_of(s_begin) : 0;  // windows of this wave in slab s still to take
+  int next_cnt = s_begin + 1 < s_end ? counts_of(s_begin + 1) : 0;
   __syncthreads();
   // to the next slab that holds windows of this wave (a barrier per slab boundary); false: no slab is left
   auto advance = [&]() -> bool {
     do {
-      if (s + 1 >= n_slabs) return false;
+      if (s + 1 >= s_end) return false;
       __syncthreads();  // through with slab s; the producer's slab s + 1 has landed
       ++s;
-      base = lds0 + lane_c + (unsigned)(s & 1) * (unsigned)kESlabBytes;
+      base = lds0 + lane_c + (unsigned)((s - s_begin) & 1) * (unsigned)kESlabBytes;
       left = next_cnt;
-      next_cnt = s + 1 < n_slabs ? counts_of(s + 1) : 0;
+      next_cnt = s + 1 < s_end ? counts_of(s + 1) : 0;
     } while (left == 0);
     return true;
   };
@@ -348,7 +364,7 @@ int mu_spmm_ell16_waves(int64_t n_rows) {
 
 static int ell16_launch(bool wide, int waves, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr,
                         const int64_t* d_wave_base, const void* d_ent, const int32_t* d_perm, const void* d_Q, void* d_Y,
-                        int accumulate, void* stream) {
+                        int accumulate, void* stream, int parts = 1, int64_t y_stride = 0) {
   MU_REQUIRE(waves >= 1 && waves <= kEMaxWaves, "row-owning waves per workgroup: 1 .. 15");
   const int64_t row_bytes = wide ? 128 : 64;
   MU_REQUIRE(n_pos >= 0 && n_cols > 0 && n_cols * row_bytes < ((int64_t)1 << 32), "shape out of range");
@@ -360,10 +376,13 @@ static int ell16_launch(bool wide, int waves, int64_t n_pos, int64_t n_cols, con
   const int64_t wgs = (n_waves + waves - 1) / waves;
   const int mode = mu_tune_get("ell_mode") & 3;
   hipStream_t st = (hipStream_t)stream;
-#define MU_GO(MD, DT)                                                                                            \
-  hipLaunchKernelGGL((k_spmm_ell16<MD, DT>), dim3((unsigned)wgs), dim3(64 * (waves + 1)), 0, st, n_pos, n_cols,   \
-                     (int)n_slabs, waves, d_hdr, d_wave_base, (const unsigned char*)d_ent, d_perm, (const DT*)d_Q, \
-                     (DT*)d_Y, accumulate)
+  MU_REQUIRE(parts >= 1 && parts <= n_slabs && (parts == 1 || !accumulate), "column parts: 1 .. slabs, partial products");
+  const int s_per_part = (int)((n_slabs + parts - 1) / parts);
+  const unsigned ny = (unsigned)((n_slabs + s_per_part - 1) / s_per_part);
+#define MU_GO(MD, DT)                                                                                                  \
+  hipLaunchKernelGGL((k_spmm_ell16<MD, DT>), dim3((unsigned)wgs, ny), dim3(64 * (waves + 1)), 0, st, n_pos, n_cols,     \
+                     (int)n_slabs, waves, d_hdr, d_wave_base, (const unsigned char*)d_ent, d_perm, (const DT*)d_Q,       \
+                     (DT*)d_Y, accumulate, s_per_part, y_stride)
   if (wide) {
     if (mode == 1) MU_GO(1, double);
     else if (mode == 2) MU_GO(2, double);
@@ -389,6 +408,41 @@ int mu_spmm_ell16_f64(int waves, int64_t n_pos, int64_t n_cols, const int32_t* d
                       const void* d_ent, const int32_t* d_perm, const double* d_Q, double* d_Y, int accumulate,
                       void* stream) {
   return ell16_launch(true, waves, n_pos, n_cols, d_hdr, d_wave_base, d_ent, d_perm, d_Q, d_Y, accumulate, stream);
+}
+
+/* r06 - the same products with the COLUMN SLABS SPLIT into `parts` (blockIdx.y): part y writes its partial product to
+ * d_Y + y * y_stride (elements); the caller sums the ceil(slabs / ceil(slabs / parts)) partials in order.  For operands
+ * of a few thousand rows (one rank's shard of a sharded fit): see mu_spmm_ell16_parts. */
+int mu_spmm_ell16_parts_f32(int waves, int parts, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr,
+                            const int64_t* d_wave_base, const void* d_ent, const int32_t* d_perm, const float* d_Q,
+                            float* d_Y, int64_t y_stride, void* stream) {
+  return ell16_launch(false, waves, n_pos, n_cols, d_hdr, d_wave_base, d_ent, d_perm, d_Q, d_Y, 0, stream, parts, y_stride);
+}
+int mu_spmm_ell16_parts_f64(int waves, int parts, int64_t n_pos, int64_t n_cols, const int32_t* d_hdr,
+                            const int64_t* d_wave_base, const void* d_ent, const int32_t* d_perm, const double* d_Q,
+                            double* d_Y, int64_t y_stride, void* stream) {
+  return ell16_launch(true, waves, n_pos, n_cols, d_hdr, d_wave_base, d_ent, d_perm, d_Q, d_Y, 0, stream, parts, y_stride);
+}
+/* (waves, parts) for n_rows x n_cols: one part - the launch of mu_spmm_ell16_waves - unless the row groups fill less
+ * than a round of workgroups at full width; then 15 waves per workgroup and enough column parts for two rounds, each
+ * part at least four slabs */
+int mu_spmm_ell16_parts(int64_t n_rows, int64_t n_cols, int wide, int* waves, int* parts) {
+  MU_REQUIRE(waves && parts && n_rows >= 0 && n_cols > 0, "bad arguments");
+  const int64_t cus = mu_num_cus();
+  const int64_t nw = (n_rows + 15) / 16;
+  const int64_t slabs = (n_cols + (wide ? 512 : 1024) - 1) / (wide ? 512 : 1024);
+  *waves = mu_spmm_ell16_waves(n_rows);
+  *parts = 1;
+  const int64_t wgs = (nw + kEMaxWaves - 1) / kEMaxWaves;
+  if (nw > 0 && 2 * wgs <= cus && slabs >= 8) {
+    int64_t p = (2 * cus + wgs - 1) / wgs;
+    if (p > slabs / 4) p = slabs / 4;
+    if (p >= 2) {
+      *waves = kEMaxWaves;
+      *parts = (int)p;
+    }
+  }
+  return MU_OK;
 }
 
 int mu_ell16_fill(int64_t n_groups, int64_t n_cols, int64_t nnz, int slab_cols, const int32_t* d_indices, const float* d_values,

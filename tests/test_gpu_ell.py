@@ -169,3 +169,43 @@ def test_layout_pair_of_an_f64_valued_view(be):
         wb = m.T @ be.to_host(Z)
         assert np.max(np.abs(a - wa)) < 1e-11 * np.max(np.abs(wa))
         assert np.max(np.abs(b - wb)) < 1e-11 * np.max(np.abs(wb))
+
+
+@pytest.mark.parametrize("shape,wide", [((3000, 20000), False), ((700, 100000), False), ((2500, 9000), True), ((40, 30000), False)])
+def test_column_parts_for_operands_of_few_rows(be, shape, wide):
+    """r06: an operand of a few thousand rows (one rank's shard of a sharded fit) is launched with its column slabs split
+    over blockIdx.y (mu_spmm_ell16_parts) and the partial products summed in order: against f64 arithmetic, the same bits
+    run to run, every row written; the heuristic keeps one part for shapes that fill a round by their rows."""
+    import ctypes as C
+
+    n, d = shape
+    m = _ragged(n, d, seed=n + 11)
+    wv, parts = C.c_int(0), C.c_int(0)
+    assert be.lib.mu_spmm_ell16_parts(n, d, int(wide), C.byref(wv), C.byref(parts)) == 0
+    assert parts.value > 1 and wv.value == 15
+    assert be.lib.mu_spmm_ell16_parts(100000, d, int(wide), C.byref(wv), C.byref(parts)) == 0 and parts.value == 1
+    rng = np.random.default_rng(n)
+    if wide:
+        m = m.astype(np.float64)
+        X = be.upload_csr(m.indptr, m.indices, m.data, m.shape, values_dtype=np.float64)
+        E = be.ell16(X, wide=True)
+        Q = rng.standard_normal((d, 16))
+        tol = 1e-13
+    else:
+        X = _upload(be, m)
+        E = be.ell16(X)
+        Q = rng.standard_normal((d, 16)).astype(np.float32)
+        tol = 2e-6
+    Qd = torch.from_numpy(Q).to(be.device)
+    want = m.astype(np.float64) @ Q.astype(np.float64)
+    scale = np.abs(m).astype(np.float64) @ np.abs(Q).astype(np.float64) + 1e-30
+    out = torch.full((n, 16), float("nan"), device=be.device, dtype=Qd.dtype)
+    got = be.spmm(E, Qd, out=out)
+    g = be.to_host(got).astype(np.float64)
+    assert np.isfinite(g).all() and np.max(np.abs(g - want) / scale) < tol
+    assert torch.equal(got, be.spmm(E, Qd))
+    assert np.all(g[np.diff(m.indptr) == 0] == 0)
+    if wide:
+        acc = got.clone()
+        be.spmm(E, Qd, out=acc, accumulate=True)
+        assert np.max(np.abs(be.to_host(acc) - 2 * want) / scale) < 1e-12
