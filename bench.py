@@ -277,10 +277,10 @@ def run_lsi(args, workload, rank, world, local_rank, comm, steps, warmup, cpu_sa
                             f"{n_local} cells on rank 0 ({wl['scaling']} scaling), {nnz_local} nnz on rank 0 "
                             f"({nnz_local / n_local / d:.4f} dense), tfidf + lsi(n_comps={args.n_comps})",
                 "parallelism": (f"cells row-sharded x{world}; Z collective = "
-                                f"{os.environ.get('MUON_AMD_Z_COLLECTIVE', 'allreduce')} (reduce-scatter + all-gather "
-                                "variant: MUON_AMD_Z_COLLECTIVE=rsag); NOTE no 8-GPU node was available to the builder in "
-                                "rounds 1-5: the multi-GPU path is tested with gloo and with 2 ranks on one GPU, its "
-                                "scaling is unmeasured") if world > 1 else "1 GPU",
+                                f"{os.environ.get('MUON_AMD_Z_COLLECTIVE', 'allreduce')} (variants: MUON_AMD_Z_COLLECTIVE=rsag "
+                                "= reduce-scatter + all-gather, rsqr = SURVEY 8e's form with the CholeskyQR on row slices in "
+                                "between); NOTE no 8-GPU node was available to the builder in rounds 1-6: the multi-GPU path "
+                                "is tested with gloo and with 2 ranks on one GPU, its scaling is unmeasured") if world > 1 else "1 GPU",
                 "allocator": alloc,
                 "lsi": {"block": info.get("block"), "iterations": info.get("iterations"),
                         "converged": info.get("converged"), "spmm_per_step": len(ms) // max(steps, 1),

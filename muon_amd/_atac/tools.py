@@ -99,6 +99,56 @@ def _project_out(backend, Z: torch.Tensor, blocks, passes: int = 2) -> torch.Ten
     return Z
 
 
+# ---- SURVEY 8e's form of an expansion: reduce-scatter -> CholeskyQR and projection on row slices -> all-gather (r06) ----
+# MUON_AMD_Z_COLLECTIVE=rsqr.  After the reduce-scatter of Z = X^T Y every rank holds the summed rows [r0, r1) of the d x B
+# block; the projection against the Krylov basis and the CholeskyQR2 run on that slice (the basis blocks are replicated:
+# their slices are views), the B x B cross Grams and Grams of the slices are all-reduced - one packed message per pass -
+# and the finished block is all-gathered.  The replicated d x B passes of the default form become d / W-row passes at
+# the price of four small all-reduces per expansion.  Opt-in: nothing here can time it with more than one RCCL rank;
+# tests/test_distributed_gloo.py checks it against the single-process result (the sums over the ranks are the same
+# numbers added in another grouping: 1e-6 rad, not bits).
+def _slice_or_none(t, rows):
+    r0, r1 = rows
+    return t[r0:r1] if r1 > r0 else None
+
+
+def _project_out_rows(backend, comm, Z, blocks, rows):
+    """One pass of Z <- (I - K K^T) Z on this rank's rows: every block's cross Gram from the same Z (the blocks are
+    mutually orthonormal: the order of the subtractions does not matter beyond rounding), one all-reduce for all."""
+    Zs = _slice_or_none(Z, rows)
+    B = Z.shape[1]
+    Cs = [backend.gram_cross(Qi[rows[0]:rows[1]], Zs) if Zs is not None else backend.zeros((B, B), torch.float64)
+          for Qi in blocks]
+    if Cs:
+        comm.all_reduce_sum(*Cs)
+    if Zs is not None:
+        for Qi, C in zip(blocks, Cs):
+            backend.project_out_block(Qi[rows[0]:rows[1]], C, Zs)
+
+
+def _orthonormalize_rows(backend, comm, Z, w, rows, passes=2, flag=None):
+    """CholeskyQR(passes) with the Gram summed over the ranks' row slices; returns the first Gram like _orthonormalize
+    (a device tensor with ``flag``, a host array without)."""
+    Zs = _slice_or_none(Z, rows)
+    B = Z.shape[1]
+    first = None
+    for _ in range(passes):
+        G = backend.gram(Zs)[0] if Zs is not None else backend.zeros((B, B), torch.float64)
+        comm.all_reduce_sum(G)
+        if flag is not None:
+            if first is None:
+                first = G
+            M = backend.chol_rinv(G, w, flag)
+        else:
+            Gh = G.cpu().numpy()
+            if first is None:
+                first = Gh
+            M = backend.to_device(_chol_inverse(Gh, w).astype(np.float32))
+        if Zs is not None:
+            backend.apply(Zs, M, out=Zs)
+    return first
+
+
 def _ritz(Tm: np.ndarray, Mm: np.ndarray, want: int):
     """Top ``want`` pairs of  T c = theta M c  (T = K^T X^T X K, M = K^T K from f64 Grams of the
     stored f32 blocks), descending.  M is the identity up to f32 rounding unless the Krylov space is
@@ -473,8 +523,16 @@ def _lsi_device(
     def product(A, Qd):
         return backend.spmm(A, Qd)
 
+    # (SURVEY 8e's form, opt-in: see _project_out_rows above)
+    rsqr = (os.environ.get("MUON_AMD_Z_COLLECTIVE", "allreduce") == "rsqr" and getattr(comm, "world_size", 1) > 1
+            and hasattr(comm, "reduce_scatter_rows"))
+    zrows = [None]  # rsqr: the rows of Z this rank owns between the reduce-scatter and the all-gather
+
     def expand_product(j):
         Zn = product(Xt, Ys[j])
+        if rsqr:
+            zrows[0] = comm.reduce_scatter_rows(Zn)
+            return Zn
         big = getattr(comm, "all_reduce_sum_big", None)  # (plain all-reduce, or reduce-scatter + all-gather: _comm.py)
         (big or comm.all_reduce_sum)(Zn)
         return Zn
@@ -485,7 +543,7 @@ def _lsi_device(
     # thick restart in between only re-expresses the kept blocks as K Cw: the new block is orthogonal to their span
     # either way, and its cross Grams are Cw^T applied to the ones computed against the old blocks (collect_block_grams
     # `through`).  A wrong guess ("not the last step") costs the two products it queued.
-    pipeline = device_qr and not big_products and os.environ.get("MUON_AMD_LSI_PIPELINE", "1") != "0"
+    pipeline = device_qr and not big_products and not rsqr and os.environ.get("MUON_AMD_LSI_PIPELINE", "1") != "0"
 
     def speculate(Z):
         nonlocal pending_g1
@@ -630,10 +688,19 @@ def _lsi_device(
         if nxt is None:
             if w < B:
                 Z[:, w:] = 0
-            before = None if device_qr else float(np.trace(backend.gram(Z)[0].cpu().numpy()[:w, :w]))
-            # the next block is the part of A Q_j outside the WHOLE space built so far - also when that
-            # space is about to be compressed: the residuals of all its Ritz vectors lie in this block
-            Z = _project_out(backend, Z, Qs, passes=1)  # (the second pass follows the normalisation below)
+            if rsqr:
+                before = None
+                if not device_qr:
+                    Zs0 = _slice_or_none(Z, zrows[0])
+                    G0 = backend.gram(Zs0)[0] if Zs0 is not None else backend.zeros((B, B), torch.float64)
+                    comm.all_reduce_sum(G0)
+                    before = float(np.trace(G0.cpu().numpy()[:w, :w]))
+                _project_out_rows(backend, comm, Z, Qs, zrows[0])
+            else:
+                before = None if device_qr else float(np.trace(backend.gram(Z)[0].cpu().numpy()[:w, :w]))
+                # the next block is the part of A Q_j outside the WHOLE space built so far - also when that
+                # space is about to be compressed: the residuals of all its Ritz vectors lie in this block
+                Z = _project_out(backend, Z, Qs, passes=1)  # (the second pass follows the normalisation below)
         through = None
         if len(Qs) >= (early_cap if (early_cap is not None and it < 5) else max_blocks):
             # thick restart: the top-w Ritz vectors (and their images X v, linear combinations of
@@ -668,7 +735,10 @@ def _lsi_device(
             cur = (nxt[2], through)
             it += 1
             continue
-        Z, G1 = _orthonormalize(backend, Z, w, passes=2, flag=qr_flag)
+        if rsqr:
+            G1 = _orthonormalize_rows(backend, comm, Z, w, zrows[0], passes=2, flag=qr_flag)
+        else:
+            Z, G1 = _orthonormalize(backend, Z, w, passes=2, flag=qr_flag)
         if device_qr:
             pending_g1 = G1  # read with the Grams of the next step (no host round trip here)
         else:
@@ -678,7 +748,11 @@ def _lsi_device(
                 converged = True  # nothing left outside the Krylov space: the Ritz pairs are exact
                 bound = floor = 0.0
                 break
-        Z = _project_out(backend, Z, Qs, passes=1)  # the normalisation amplified what the f32 projection left
+        if rsqr:
+            _project_out_rows(backend, comm, Z, Qs, zrows[0])  # the normalisation amplified what the f32 projection left
+            comm.all_gather_rows_into(Z, zrows[0])
+        else:
+            Z = _project_out(backend, Z, Qs, passes=1)  # the normalisation amplified what the f32 projection left
         Qs.append(Z)
         it += 1
 

@@ -27,6 +27,12 @@ class LocalComm:
     def all_reduce_sum_big(self, t):
         return t
 
+    def reduce_scatter_rows(self, t):
+        return 0, int(t.shape[0])
+
+    def all_gather_rows_into(self, t, rows):
+        return t
+
     def sum_scalar(self, x):
         return x
 
@@ -80,7 +86,8 @@ class TorchDistComm:
 
     def all_reduce_sum_big(self, t, mode=None):
         """In-place sum of ONE large contiguous tensor - Z = X^T Y of an LSI expansion, 51 MB at 200 000 peaks - either
-        as a plain all-reduce (default) or, with MUON_AMD_Z_COLLECTIVE=rsag (or mode="rsag"), as an explicit
+        as a plain all-reduce (default) or, with MUON_AMD_Z_COLLECTIVE=rsag (or mode="rsag"; an "rsqr" caller that does
+        not work on the slice in between gets the same), as an explicit
         reduce-scatter + all-gather over row chunks: every rank sums 1 / W of the rows, then the chunks are gathered.
         On xGMI's point-to-point links the two halves are what a ring all-reduce does anyway; having them as separate
         calls is what lets the first 8-GPU lease A/B them (and later overlap the reduce-scatter of one column chunk
@@ -90,34 +97,75 @@ class TorchDistComm:
 
         mode = mode or os.environ.get("MUON_AMD_Z_COLLECTIVE", "allreduce")
         W = self.world_size
-        if mode != "rsag" or W == 1 or not t.is_contiguous() or t.numel() < W:
+        if mode not in ("rsag", "rsqr") or W == 1 or not t.is_contiguous() or t.numel() < W:
             return self.all_reduce_sum(t)
+        t2 = t.view(t.shape[0], -1) if t.dim() >= 2 else t.view(-1, 1)
+        rows = self.reduce_scatter_rows(t2)
+        self.all_gather_rows_into(t2, rows)
+        return t
+
+    def _row_chunks(self, t):
+        W = self.world_size
+        d = int(t.shape[0])
+        width = int(t.numel() // max(d, 1)) if d else 0
+        per = -(-d // W) if d else 0
+        r0 = min(self.rank * per, d)
+        return d, width, per, r0, min(r0 + per, d)
+
+    def reduce_scatter_rows(self, t):
+        """SURVEY 8e's first half for a contiguous [rows, width] block: every rank ends up with the SUM over the ranks of
+        its own 1 / W of the rows - in place, t[r0:r1] - and returns (r0, r1); the other rows keep this rank's partial
+        values (the caller works on its slice and calls all_gather_rows_into).  Chunks are ceil(rows / W) rows; the last
+        ranks' chunks may be short or empty."""
         dist = self._dist
+        assert t.is_contiguous()
+        d, width, per, r0, r1 = self._row_chunks(t)
+        W = self.world_size
+        if W == 1 or d == 0:
+            return 0, d
         flat = t.view(-1)
-        n = flat.numel()
-        per = -(-n // W)
-        if per * W != n:
-            buf = torch.zeros((per * W,), dtype=t.dtype, device=t.device)
+        n, chunk = d * width, per * width
+        if chunk * W != n:
+            buf = torch.zeros((chunk * W,), dtype=t.dtype, device=t.device)
             buf[:n] = flat
         else:
             buf = flat
-        mine = torch.empty((per,), dtype=t.dtype, device=t.device)
+        mine = torch.empty((chunk,), dtype=t.dtype, device=t.device)
         if dist.get_backend(self.group) == "nccl":
             dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_gather_into_tensor(buf, mine, group=self.group)
         else:
             # gloo has no reduce-scatter: W reductions, one per owner (the CPU tests exercise the chunking and the gather)
             for r in range(W):
-                chunk = buf[r * per:(r + 1) * per].clone()
+                piece = buf[r * chunk:(r + 1) * chunk].clone()
                 dst = dist.get_global_rank(self.group, r) if self.group is not None else r
-                dist.reduce(chunk, dst=dst, op=dist.ReduceOp.SUM, group=self.group)
+                dist.reduce(piece, dst=dst, op=dist.ReduceOp.SUM, group=self.group)
                 if r == self.rank:
-                    mine.copy_(chunk)
+                    mine.copy_(piece)
+        if r1 > r0:
+            t[r0:r1].reshape(-1).copy_(mine[:(r1 - r0) * width])
+        return r0, r1
+
+    def all_gather_rows_into(self, t, rows):
+        """The second half: every rank's slice t[r0:r1] into every rank's t (in place)."""
+        dist = self._dist
+        d, width, per, r0, r1 = self._row_chunks(t)
+        W = self.world_size
+        if W == 1 or d == 0:
+            return t
+        assert (r0, r1) == tuple(rows)
+        flat = t.view(-1)
+        n, chunk = d * width, per * width
+        mine = torch.zeros((chunk,), dtype=t.dtype, device=t.device)
+        if r1 > r0:
+            mine[:(r1 - r0) * width] = t[r0:r1].reshape(-1)
+        if dist.get_backend(self.group) == "nccl":
+            buf = torch.empty((chunk * W,), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(buf, mine, group=self.group)
+        else:
             parts = [torch.empty_like(mine) for _ in range(W)]
             dist.all_gather(parts, mine, group=self.group)
             buf = torch.cat(parts)
-        if buf.data_ptr() != flat.data_ptr():
-            flat.copy_(buf[:n])
+        flat.copy_(buf[:n])
         return t
 
     def all_gather_rows(self, t):

@@ -37,6 +37,18 @@ assert info2["iterations"] == info["iterations"] and torch.equal(V2, V) and torc
     "reduce-scatter + all-gather changed the result"
 if rank == 0:
     print("rsag == allreduce: bit-identical U, V, stdev")
+# SURVEY 8e's form (r06): reduce-scatter -> projection + CholeskyQR2 on row slices (device Cholesky of the all-reduced Gram)
+# -> all-gather.  The same expansions, the subspace to 1e-6 rad (sums over the ranks grouped differently)
+os.environ["MUON_AMD_Z_COLLECTIVE"] = "rsqr"
+U3, sd3, V3, info3 = lsi_device(be, T, n_comps=k, n_obs=n, comm=comm, return_info=True)
+os.environ.pop("MUON_AMD_Z_COLLECTIVE")
+qa, _ = torch.linalg.qr(V.double())
+qb, _ = torch.linalg.qr(V3.double())
+ang3 = float(torch.linalg.matrix_norm(qb - qa @ (qa.T @ qb), ord=2))
+assert info3["iterations"] == info["iterations"] and info3["converged"] and ang3 < 1e-6 and float(np.max(np.abs(sd3 - sd) / sd)) < 1e-6, \
+    (ang3, info3["bounds"])
+if rank == 0:
+    print(f"rsqr (reduce-scatter, sliced CholeskyQR2, all-gather): angle to the all-reduce run {ang3:.2e}, same expansions")
 # the subsampled power warm start across ranks (each rank's first cells; one all-reduce per power step)
 os.environ["MUON_AMD_LSI_WARM"] = "8:2"
 Uw, sdw, Vw, infow = lsi_device(be, T, n_comps=k, n_obs=n, comm=comm, return_info=True)

@@ -54,6 +54,22 @@ def _worker(rank, world, port, q):
         U2, stdev2, V2, info2 = lsi_device(be, T, n_comps=8, n_obs=n, comm=comm, return_info=True)
         os.environ.pop("MUON_AMD_Z_COLLECTIVE")
         rsag_same = bool(torch.equal(V2, V) and torch.equal(U2, U) and info2["iterations"] == info["iterations"])
+        # SURVEY 8e's form (r06): reduce-scatter -> projection + CholeskyQR on row slices -> all-gather.  The sums over the
+        # ranks are the same numbers in another grouping: the subspace to 1e-6 rad, the same expansions.
+        os.environ["MUON_AMD_Z_COLLECTIVE"] = "rsqr"
+        U3, stdev3, V3, info3 = lsi_device(be, T, n_comps=8, n_obs=n, comm=comm, return_info=True)
+        os.environ.pop("MUON_AMD_Z_COLLECTIVE")
+        from oracle import lsi_oracle as _lo
+
+        rsqr = {"angle": _lo.max_subspace_angle(V3.numpy(), V.numpy()), "iters": info3["iterations"],
+                "stdev": float(np.max(np.abs(stdev3 - stdev) / stdev)), "converged": bool(info3["converged"]),
+                "replicated": bool(torch.equal(comm.all_gather_rows(V3[:3].contiguous())[:3],
+                                               comm.all_gather_rows(V3[:3].contiguous())[3:6]))}
+        rows_probe = torch.arange(14, dtype=torch.float64).reshape(7, 2) * (rank + 1)  # (7 rows, 2 ranks: chunks of 4 and 3)
+        r0, r1 = comm.reduce_scatter_rows(rows_probe)
+        own_ok = bool(torch.equal(rows_probe[r0:r1], 3 * torch.arange(14, dtype=torch.float64).reshape(7, 2)[r0:r1]))
+        comm.all_gather_rows_into(rows_probe, (r0, r1))
+        rsqr["halves"] = own_ok and bool(torch.equal(rows_probe, 3 * torch.arange(14, dtype=torch.float64).reshape(7, 2)))
         probe = torch.arange(10, dtype=torch.float64) + rank  # (a length the world size does not divide)
         comm.all_reduce_sum_big(probe, mode="rsag")
         rsag_same = rsag_same and bool(torch.equal(probe, 2 * torch.arange(10, dtype=torch.float64) + 1))
@@ -94,7 +110,7 @@ def _worker(rank, world, port, q):
         if rank == 0:
             q.put({"tfidf": T.values.numpy(), "U": Uall.numpy(), "stdev": stdev, "V": V.numpy(),
                    "elbo": res["elbo"], "Z": Zall.numpy(), "W": res["W"], "iters": info["iterations"],
-                   "elbo_x": elbo_x, "modes_x": modes, "rsag_same": rsag_same,
+                   "elbo_x": elbo_x, "modes_x": modes, "rsag_same": rsag_same, "rsqr": rsqr,
                    "g_elbo": gres["elbo"], "g_Z": gZ.numpy(), "g_W": gres["W"], "g_r2": gres["r2"]})
     finally:
         dist.destroy_process_group()
@@ -134,6 +150,9 @@ def test_world_size_2_matches_single_process():
     assert lsi_oracle.max_subspace_angle(got["V"], V.numpy()) < 1e-4
     assert got["U"].shape == (600, 8)
     assert got["rsag_same"]
+    r = got["rsqr"]
+    assert r["halves"] and r["replicated"] and r["converged"] and r["iters"] == got["iters"], r
+    assert r["angle"] < 1e-6 and r["stdev"] < 1e-6, r
     assert lsi_oracle.max_subspace_angle(got["U"], U.numpy()) < 5e-4
 
     rng = np.random.default_rng(0)
