@@ -149,3 +149,24 @@ def test_tpack4_isa_keeps_out_of_the_asm_owned_registers(tmp_path):
                 for a, b, c in reg.findall(line.split(";")[0]):
                     hi = int(a) if a else int(c)
                     assert hi < 88, (name, line)
+
+
+def test_every_environment_switch_is_in_the_table_of_integration_md():
+    """ONE table of the switches - every MUON_AMD_* variable the package or
+    bench.py reads must be a row of it, and every row must still be read somewhere."""
+    import re
+
+    read = set()
+    for base, _dirs, files in os.walk(os.path.join(ROOT, "muon_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                read |= set(re.findall(r"MUON_AMD_[A-Z0-9_]+", open(os.path.join(base, f)).read()))
+    read |= set(re.findall(r"MUON_AMD_[A-Z0-9_]+", open(os.path.join(ROOT, "bench.py")).read()))
+    read |= set(re.findall(r"MUON_AMD_BENCH_[A-Z0-9_]+", open(os.path.join(ROOT, "scripts", "bench_mofa.py")).read()))
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = text[text.index("**Switches** (environment"):text.index("Folded in r06 (no longer read)")]
+    rows = set(re.findall(r"MUON_AMD_[A-Z0-9_]+", table))
+    assert read <= rows, sorted(read - rows)
+    assert rows <= read, sorted(rows - read)
+    folded = set(re.findall(r"MUON_AMD_[A-Z0-9_]+", text[text.index("Folded in r06 (no longer read)"):]))
+    assert not (folded & read), sorted(folded & read)
