@@ -516,9 +516,13 @@ class MofaEngine:
         key = "all" if V.full else m
         got = self._zmom.get(key)
         if got is None:
-            Gz = torch.empty((G, K, K), dtype=T, device=dev)
-            Z2 = torch.empty((G, K), dtype=T, device=dev)
-            Zs = torch.empty((G, K), dtype=T, device=dev)
+            fixed = self.__dict__.get("_zmom_out", {}).get(key)  # (segmented iterations: views of one flat block)
+            if fixed is not None:
+                Gz, Z2, Zs = fixed
+            else:
+                Gz = torch.empty((G, K, K), dtype=T, device=dev)
+                Z2 = torch.empty((G, K), dtype=T, device=dev)
+                Zs = torch.empty((G, K), dtype=T, device=dev)
             pads = list(self._zpad.items()) if not self._zmom else []
             for g, (a, b) in enumerate(self.gslice):
                 (ld0, st0), pad0 = pads[0] if pads else ((0, False), None)
@@ -737,7 +741,43 @@ class MofaEngine:
     # replays A, issues the collective, replays B, reads the ELBO.  Same kernels on the same operands as the eager
     # iteration: the same numbers (tests/test_distributed_gloo.py runs the segments eagerly on CPU with two ranks,
     # tests/test_gpu_mofa.py the captured ones against the eager trace).
+    def _seg_alloc(self):
+        """The fixed buffers of the segmented iteration as ONE flat block: the factors' moments (one set per distinct
+        presence mask), every view's B, and - in an f64 fit - the factors' sums.  What a rank contributes to the sums over
+        the ranks is then one contiguous tensor: the collective needs no packing copy and no copy back."""
+        K, G, T, dev = self.K, self.G, self.T, self.EZ.device
+        keys = []
+        for m, V in enumerate(self.views):
+            key = "all" if V.full else m
+            if key not in keys:
+                keys.append(key)
+        n_mom = G * K * K + 2 * G * K
+        n_b = [G * V.D * K for V in self.views]
+        n_zs = G * 2 * K if T == torch.float64 else 0
+        flat = torch.zeros((len(keys) * n_mom + sum(n_b) + n_zs,), dtype=T, device=dev)
+        off = 0
+        self._zmom_out = {}
+        for key in keys:
+            Gz = flat[off:off + G * K * K].view(G, K, K)
+            Z2 = flat[off + G * K * K:off + G * K * K + G * K].view(G, K)
+            Zs = flat[off + G * K * K + G * K:off + n_mom].view(G, K)
+            self._zmom_out[key] = (Gz, Z2, Zs)
+            off += n_mom
+        self._locB = []
+        for V, nb in zip(self.views, n_b):
+            self._locB.append(flat[off:off + nb].view(G, V.D, K))
+            off += nb
+        if n_zs:
+            self._zs = flat[off:off + n_zs].view(G, 2, K)  # (f64 fit: the factors' sums travel in the same message)
+        self._loc_flat = flat
+        # B with the implicit centring applied (sparse / implicitly centred views); the others read their B in place
+        self._statB = [torch.empty((G, V.D, K), dtype=T, device=dev)
+                       if (V.kind == "sparse" or getattr(V, "implicit", False)) else None for V in self.views]
+        self._zmom = {}  # (the next moments are written into the fixed tensors)
+
     def _seg_a(self):
+        if self.__dict__.get("_loc_flat") is None:
+            self._seg_alloc()
         self._fork()
         for m in range(self.M):
             with self._on(m):
@@ -750,19 +790,17 @@ class MofaEngine:
         self._fork()
         for m in range(self.M):
             with self._on(m):
-                st = self._stats_local(m)
-                buf = self._loc.get(m)
-                if buf is None:
-                    self._loc[m] = [t.contiguous().clone() for t in st]
-                else:
-                    for dst, src in zip(buf, st):
-                        dst.copy_(src)
+                self._locB[m].copy_(self._stats_local(m)[3])  # (the moments are in the flat block already)
         self._join()
         for g, (a_, b_) in enumerate(self.gslice):
             self.be.mofa_z_sums(self.EZ2, self.sig2z, a_, b_, self._zs[g], self._elbo_work)
 
     def _seg_reduce(self):
-        self.comm.all_reduce_sum(*[t for m in range(self.M) for t in self._loc[m]], self._zs)
+        if self._zs.dtype == self._loc_flat.dtype:
+            self.comm.all_reduce_sum(self._loc_flat)  # (an f64 fit: one message, the factors' sums inside)
+        else:
+            self.comm.all_reduce_sum(self._loc_flat)
+            self.comm.all_reduce_sum(self._zs)
 
     def _seg_b(self) -> torch.Tensor:
         o, be = self.opts, self.be
@@ -773,17 +811,13 @@ class MofaEngine:
         for m, (V, Wm) in enumerate(zip(self.views, self.W)):
             with self._on(m):
                 wk = self._elbo_work_v[m] if self._par else self._elbo_work
-                Gz, Z2, Zs, B = self._loc[m]
-                if V.kind == "sparse" or getattr(V, "implicit", False):
-                    B = B - V.mu[:, :, None] * Zs[:, None, :]  # implicit centring, with the sums over all ranks
-                buf = self._stat_buf.get(m)
-                if buf is None:
-                    self._stat_buf[m] = buf = (Gz.clone(), Z2.clone(), B.contiguous().clone())
-                else:
-                    for dst, src in zip(buf, (Gz, Z2, B)):
-                        dst.copy_(src)
-                self._stats[m] = buf
-                be.mofa_tau_elbo(V.yy, V.Ngm_d, Wm.EW, Wm.EW2, buf[2], buf[0], buf[1], A0, B0, Wm.tau, Wm.ltau, parts[m], wk)
+                Gz, Z2, Zs = self._zmom_out["all" if V.full else m]
+                B = self._locB[m]
+                if self._statB[m] is not None:
+                    # implicit centring with the sums over all ranks: B - mu (x) Zs in one kernel
+                    B = torch.addcmul(B, V.mu[:, :, None], Zs[:, None, :], value=-1.0, out=self._statB[m])
+                self._stats[m] = (Gz, Z2, B)
+                be.mofa_tau_elbo(V.yy, V.Ngm_d, Wm.EW, Wm.EW2, B, Gz, Z2, A0, B0, Wm.tau, Wm.ltau, parts[m], wk)
                 be.mofa_w_elbo(Wm.EWh2, Wm.gamma, Wm.sig2, o["ard_weights"], o["spikeslab_weights"], A0 + 0.5 * V.D, A0,
                                B0, TH_A0, TH_B0, Wm.alpha, Wm.lalpha, Wm.lth, Wm.l1mth, parts[m], wk)
         self._join()
