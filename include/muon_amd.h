@@ -504,10 +504,13 @@ int mu_mofa_poisson_pseudo(int dtype, int64_t n_rows, int64_t D, int mode, const
  * mu_mofa_poisson_pseudo.  E_own [n_own x KP], E_other [n_other x KP] row-major with the K <= 32 columns PADDED with zeros
  * to KP = 4 / 8 / 12 / 16 / 32 (the smallest of these >= K; 16-byte aligned rows); outputs have K columns.
  * mu_mofa_poisson_dense writes PARTIAL results for column blocks of `other_block` rows of the other block
- * (mu_mofa_poisson_blocks(n_own, n_other) picks it): d_part [ceil(n_other / other_block)][n_own][K] (mode 2: [..][n_own]),
+ * (mu_mofa_poisson_blocks_for(dtype, mode, K, n_own, n_other) picks it - r06: from the occupancy of the kernel those
+ * arguments select, so that the workgroups fill whole rounds; mu_mofa_poisson_blocks is r04's kernel-blind rule, kept
+ * for callers of that release; any multiple of 128 is valid): d_part [ceil(n_other / other_block)][n_own][K] (mode 2: [..][n_own]),
  * to be added in block order; mu_mofa_poisson_sparse ADDS the stored entries' terms to the summed result: (indptr,
  * indices, values) = CSR of the view for modes 0 / 2, of its transpose for mode 1. */
 int64_t mu_mofa_poisson_blocks(int64_t n_own, int64_t n_other);
+int64_t mu_mofa_poisson_blocks_for(int dtype, int mode, int K, int64_t n_own, int64_t n_other);
 int mu_mofa_poisson_dense(int dtype, int mode, int64_t n_own, int64_t n_other, int K, int64_t other_block,
                           const void* d_E_own, const void* d_E_other, const void* d_kappa, void* d_part, void* stream);
 int mu_mofa_poisson_sparse(int dtype, int mode, int64_t n_own, int K, const int64_t* d_indptr, const int32_t* d_indices,

@@ -1362,7 +1362,7 @@ class HipBackend:
             return P
 
         E_own, E_other = pad(E_own), pad(E_other)
-        blk = int(self.lib.mu_mofa_poisson_blocks(n_own, n_other))
+        blk = int(self.lib.mu_mofa_poisson_blocks_for(_dt(E_own), int(mode), K, n_own, n_other))
         nb = -(-n_other // blk)
         part = self.empty((nb, n_own) if mode == 2 else (nb, n_own, K + 1 if mode == 3 else K), E_own.dtype)
         with self._dev_ctx():

@@ -118,6 +118,7 @@ SIGNATURES = {
     "mu_mofa_jaakkola": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_poisson_pseudo": (C.c_int, [_i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_poisson_blocks": (_i64, [_i64, _i64]),
+    "mu_mofa_poisson_blocks_for": (_i64, [_i32, _i32, _i32, _i64, _i64]),
     "mu_mofa_poisson_dense": (C.c_int, [_i32, _i32, _i64, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_poisson_sparse": (C.c_int, [_i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_gs_update": (C.c_int, [_i32, _i64, _i32] + [_vp] * 5 + [_i32] + [_vp] * 6),

@@ -17,7 +17,7 @@ HEADERS = ["common.hpp", "sweep.hpp", os.path.join(ROOT, "include", "muon_amd.h"
 # loops in VGPRs BETWEEN the steps and copied them to AGPRs and back around the MFMAs of every step (k_skinny_tn: 64
 # v_accvgpr_write + 64 v_accvgpr_read per 8 MFMAs); gfx950's MFMAs take either register file.
 _VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-EXTRA = {"skinny.hip": _VGPR_FORM, "dense.hip": _VGPR_FORM, "knn.hip": _VGPR_FORM}
+EXTRA = {"skinny.hip": _VGPR_FORM, "dense.hip": _VGPR_FORM, "knn.hip": _VGPR_FORM, "mofa_poisson.hip": _VGPR_FORM}
 LIB = os.path.join(HERE, "libmuon_amd.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(ROOT, "include"),

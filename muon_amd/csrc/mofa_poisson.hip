@@ -126,6 +126,139 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_dense(int64_t n_own, int64_
   }
 }
 
+// ---- the dense sweep on the matrix cores (r06; f32 models, K <= 16) ------------------------------------------------
+// `k_pois_dense` is bound by its vector ALU: 2 KP multiply-adds and ~10 other instructions per (own, other) pair, 0.50 ms
+// per sweep at 20 000 x 20 000, K = 10 (profiles/r05_mofa_ng_kernel_stats.md).  Both halves of that arithmetic are small
+// matrix products, and v_mfma_f32_16x16x4_f32 is exact f32 at the vector rate on its OWN pipe, next to the transform:
+//   1. zeta^T tile [16 other x 16 own] = E_other[16 x KP] E_own^T[KP x 16]   (KP / 4 instructions; A = other, B = own)
+//      -> lane 16 q + c holds zeta[other = 4 q + r][own = c] in register r = 0..3
+//   2. the transform in those registers (4 pairs per lane, every lane busy)
+//   3. out tile [16 own x 16 k] += R^T[16 own x 16 other] E_other[16 other x 16 k]  (4 instructions; A = R, B = E_other)
+// Step 3's A operand wants lane 16 j + i to hold R[other = pi(s, j)][own = i] at reduction step s - and a reduction index
+// may be walked in any order as long as A and B agree: with pi(s, j) = 4 j + s that value IS register s of the lane
+// that computed it, so the prediction never leaves its registers and no lane exchanges anything (B then reads row
+// 4 j + s of the LDS tile).  The same freedom makes step 1's operands one contiguous run of KP / 4 columns per lane.
+// A wave owns kPmOwn tiles of 16 own rows (their E_own operands and accumulators stay in registers), a workgroup 256 own
+// rows; the other block is staged through the same 128-row LDS tiles as above (row stride padded where the step-3
+// reads of four row groups would meet in the same banks).  Modes and the layout of `part` as k_pois_dense.
+typedef float pm_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPmOwn = 4;
+
+template <int KP, int MODE>
+__global__ __launch_bounds__(kPzThreads) void k_pois_mfma(int64_t n_own, int64_t n_other, int K, int64_t other_block,
+                                                          const float* __restrict__ E_own,
+                                                          const float* __restrict__ E_other,
+                                                          const float* __restrict__ kappa, float* __restrict__ part) {
+  constexpr int KS = KP / 4;                                   // reduction steps of the prediction
+  constexpr int LS = KP == 8 ? 12 : (KP == 16 ? 20 : KP);      // LDS row stride (dwords): 4 LS mod 64 in {16, 48}
+  __shared__ float tile[kPzTile * LS + 16];  // (+16: step 3 reads 16 columns of every row, the last row's run past it)
+  __shared__ float kap[kPzTile];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lj = lane >> 4;
+  const int64_t own0 = (int64_t)blockIdx.x * kPzThreads + wave * (16 * kPmOwn);
+  const int64_t o0 = (int64_t)blockIdx.y * other_block;
+  const int64_t o1 = o0 + other_block < n_other ? o0 + other_block : n_other;
+  float eo[kPmOwn][KS], kown[kPmOwn], lsum[kPmOwn];
+  pm_f32x4 acc[kPmOwn];
+#pragma unroll
+  for (int u = 0; u < kPmOwn; ++u) {
+    const int64_t row = own0 + 16 * u + li;  // (own = the tile's column = lane & 15)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) eo[u][s] = row < n_own ? E_own[row * KP + KS * lj + s] : 0.f;
+    kown[u] = ((MODE == 1 || MODE == 3) && row < n_own) ? kappa[row] : 0.f;
+    lsum[u] = 0.f;
+    acc[u] = (pm_f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  if (threadIdx.x < 16) tile[kPzTile * LS + threadIdx.x] = 0.f;
+  if (LS != KP)
+    for (int i = threadIdx.x; i < kPzTile; i += kPzThreads)
+      for (int k = KP; k < LS; ++k) tile[i * LS + k] = 0.f;  // (the stride padding is read as columns >= KP too)
+  for (int64_t t0 = o0; t0 < o1; t0 += kPzTile) {
+    const int rows = (int)(o1 - t0 < kPzTile ? o1 - t0 : kPzTile);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kPzTile * KP; i += kPzThreads) {
+      const int r = i / KP, k = i - r * KP;
+      tile[r * LS + k] = r < rows ? E_other[(t0 + r) * KP + k] : 0.f;
+    }
+    if (MODE == 0)
+      for (int i = threadIdx.x; i < kPzTile; i += kPzThreads) kap[i] = i < rows ? kappa[t0 + i] : 0.f;
+    __syncthreads();
+    for (int tt = 0; tt < rows; tt += 16) {
+      float a1[KS], b2[4], kp[4];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) a1[s] = tile[(tt + li) * LS + KS * lj + s];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        // (columns >= KP of B are the next row's values: finite, and output columns >= K are never stored)
+        b2[s] = MODE != 2 ? tile[(tt + 4 * lj + s) * LS + li] : 0.f;
+        kp[s] = MODE == 0 ? kap[tt + 4 * lj + s] : 0.f;
+      }
+      // all the first products of the step, then the transform and the second product register by register across the
+      // own tiles: four independent chains instead of one (0.291 -> 0.265 ms in scripts/probes/pois_mfma_bench.hip;
+      // the f32 matrix instructions and the vector ALU do not overlap there - first product alone 0.098 ms, transform
+      // alone 0.112, both products alone 0.206 - so the order only trims dependency stalls).
+      // The transform on the hardware exp2 / rcp / log2 (1 ulp each; libm's __logf alone is 14 instructions, an IEEE
+      // division 10): with a = -zeta log2(e) and d = 1 + 2^a,  sigmoid = 1 / d  and  softplus = ln2 (log2 d - a).
+      // a is clamped so that 2^a stays finite (zeta < -87: sigmoid 1e-38, softplus ln2 (126 - 126) = 0); MODE 1 as
+      // MODE 3, so that the two give the same b bit for bit.  A padding row has zeta = 0: it adds exactly 1 to the
+      // softplus sum (2^0 = 1, log2 2 = 1), taken off after the loop instead of a select per element.
+      pm_f32x4 z[kPmOwn];
+#pragma unroll
+      for (int u = 0; u < kPmOwn; ++u) {
+        z[u] = (pm_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) z[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], eo[u][s], z[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int u = 0; u < kPmOwn; ++u) {
+          float a = z[u][r] * -1.4426950408889634f;
+          if (MODE != 0) a = fminf(a, 126.0f);
+          const float d = 1.0f + __builtin_amdgcn_exp2f(a);
+          if (MODE == 2 || MODE == 3) lsum[u] += __builtin_amdgcn_logf(d) - a;
+          if (MODE != 2) {
+            const float rr = (MODE == 0 ? kp[r] : kown[u]) * z[u][r] - __builtin_amdgcn_rcpf(d);
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(rr, b2[r], acc[u], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  if (MODE == 2 || MODE == 3) {
+    // padding rows: only the last 16-row tile of the block can be partial; this lane holds rows 4 lj .. 4 lj + 3 of it
+    const int rem = (int)((o1 - o0) & 15);
+    int npad = 0;
+    if (o1 > o0 && rem)
+      for (int r = 0; r < 4; ++r) npad += 4 * lj + r >= rem;
+#pragma unroll
+    for (int u = 0; u < kPmOwn; ++u) lsum[u] = -0.6931471805599453f * (lsum[u] - (float)npad);
+  }
+  if (MODE == 2 || MODE == 3) {
+#pragma unroll
+    for (int u = 0; u < kPmOwn; ++u) {  // the four row groups of a tile hold the four quarters of an own row's sum
+      lsum[u] += __shfl_xor(lsum[u], 16);
+      lsum[u] += __shfl_xor(lsum[u], 32);
+    }
+  }
+  const int ostride = MODE == 2 ? 1 : (MODE == 3 ? K + 1 : K);
+  float* out = part + (int64_t)blockIdx.y * n_own * ostride;
+#pragma unroll
+  for (int u = 0; u < kPmOwn; ++u) {
+    if (MODE != 2 && li < K) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // acc register r of lane 16 q + c: out[own = 4 q + r][k = c]
+        const int64_t row = own0 + 16 * u + 4 * lj + r;
+        if (row < n_own) out[row * ostride + li] = acc[u][r];
+      }
+    }
+    if ((MODE == 2 || MODE == 3) && lj == 0) {
+      const int64_t row = own0 + 16 * u + li;
+      if (row < n_own) out[row * ostride + (MODE == 3 ? K : 0)] = lsum[u];
+    }
+  }
+}
+
 // the stored entries: a wave per own row.  MODE as above; (indptr, indices, values) = CSR of the view (MODE 0, 2) or of
 // its transpose (MODE 1); the result is ADDED to out (which holds the dense part).
 template <typename T, int KP, int MODE>
@@ -193,6 +326,22 @@ int pois_dense_launch(int mode, int64_t n_own, int64_t n_other, int K, int64_t o
   return MU_OK;
 }
 
+template <int KP>
+int pois_mfma_launch(int mode, int64_t n_own, int64_t n_other, int K, int64_t other_block, const void* E_own,
+                     const void* E_other, const void* kappa, void* part, hipStream_t st) {
+  const dim3 grid((unsigned)((n_own + kPzThreads - 1) / kPzThreads), (unsigned)((n_other + other_block - 1) / other_block));
+#define MU_GO(MD)                                                                                                 \
+  hipLaunchKernelGGL((k_pois_mfma<KP, MD>), grid, dim3(kPzThreads), 0, st, n_own, n_other, K, other_block,        \
+                     (const float*)E_own, (const float*)E_other, (const float*)kappa, (float*)part)
+  if (mode == 0) MU_GO(0);
+  else if (mode == 1) MU_GO(1);
+  else if (mode == 2) MU_GO(2);
+  else MU_GO(3);
+#undef MU_GO
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
 template <typename T, int KP>
 int pois_sparse_launch(int mode, int64_t n_own, int K, const int64_t* indptr, const int32_t* indices, const void* values,
                        const void* E_own, const void* E_other, void* out, hipStream_t st) {
@@ -209,9 +358,67 @@ int pois_sparse_launch(int mode, int64_t n_own, int K, const int64_t* indptr, co
   return MU_OK;
 }
 
+template <int KP>
+const void* pois_mfma_ptr(int mode) {
+  return mode == 0 ? (const void*)k_pois_mfma<KP, 0> : mode == 1 ? (const void*)k_pois_mfma<KP, 1>
+       : mode == 2 ? (const void*)k_pois_mfma<KP, 2> : (const void*)k_pois_mfma<KP, 3>;
+}
+template <typename T, int KP>
+const void* pois_dense_ptr(int mode) {
+  return mode == 0 ? (const void*)k_pois_dense<T, KP, 0> : mode == 1 ? (const void*)k_pois_dense<T, KP, 1>
+       : mode == 2 ? (const void*)k_pois_dense<T, KP, 2> : (const void*)k_pois_dense<T, KP, 3>;
+}
+bool pois_use_mfma(int dtype, int K) { return dtype == MU_DTYPE_F32 && K <= 16 && mu_tune_get("pois_valu") <= 0; }
+const void* pois_dense_kernel(int dtype, int mode, int K) {
+  if (pois_use_mfma(dtype, K))
+    return K <= 4 ? pois_mfma_ptr<4>(mode) : K <= 8 ? pois_mfma_ptr<8>(mode) : K <= 12 ? pois_mfma_ptr<12>(mode)
+                                                                                       : pois_mfma_ptr<16>(mode);
+#define MU_P(T_)                                                                                                   \
+  (K <= 4 ? pois_dense_ptr<T_, 4>(mode) : K <= 8 ? pois_dense_ptr<T_, 8>(mode) : K <= 12 ? pois_dense_ptr<T_, 12>(mode) \
+   : K <= 16 ? pois_dense_ptr<T_, 16>(mode) : pois_dense_ptr<T_, 32>(mode))
+  return dtype == MU_DTYPE_F32 ? MU_P(float) : MU_P(double);
+#undef MU_P
+}
+
 }  // namespace
 
 extern "C" {
+
+int64_t mu_mofa_poisson_blocks_for(int dtype, int mode, int K, int64_t n_own, int64_t n_other) {
+  // Column blocks of the dense sweep for the kernel that (dtype, mode, K) selects.  Workgroups do equal work, so the
+  // sweep lasts (rounds of resident workgroups) x (tiles per workgroup): r05's "~8 workgroups per CU" put 2054 workgroups
+  // on the 1792 places of a kernel that fits 7 per CU - a second round for 13 % of them, 1.4x the time.  Here the
+  // number of places comes from the kernel's own occupancy and the split with the smallest rounds x tiles wins (ties:
+  // fewer blocks, i.e. less partial-result traffic).
+  if (dtype != MU_DTYPE_F32 && dtype != MU_DTYPE_F64) dtype = MU_DTYPE_F32;
+  if (mode < 0 || mode > 3) mode = 0;
+  if (K < 1) K = 1;
+  if (K > 32) K = 32;
+  const int64_t own_wgs = n_own > 0 ? (n_own + kPzThreads - 1) / kPzThreads : 1;
+  const int64_t tiles = n_other > 0 ? (n_other + kPzTile - 1) / kPzTile : 1;
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pois_dense_kernel(dtype, mode, K), kPzThreads, 0) != hipSuccess ||
+      occ < 1) {
+    (void)hipGetLastError();
+    occ = 4;
+  }
+  const int64_t slots = (int64_t)mu_num_cus() * occ;
+  int64_t best_per = tiles, best_cost = -1, best_nb = 1;
+  for (int r = 1; r <= 3; ++r) {
+    int64_t nb = r * slots / own_wgs;
+    if (nb < 1) nb = 1;
+    if (nb > tiles) nb = tiles;
+    const int64_t per = (tiles + nb - 1) / nb, nb_real = (tiles + per - 1) / per;
+    const int64_t rounds = (own_wgs * nb_real + slots - 1) / slots;
+    const int64_t cost = rounds * per;
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && nb_real < best_nb)) {
+      best_cost = cost;
+      best_per = per;
+      best_nb = nb_real;
+    }
+  }
+  return best_per * kPzTile;
+}
 
 int64_t mu_mofa_poisson_blocks(int64_t n_own, int64_t n_other) {
   // column blocks of the dense sweep: ~8 workgroups per CU in total, blocks of whole LDS tiles
@@ -232,6 +439,11 @@ int mu_mofa_poisson_dense(int dtype, int mode, int64_t n_own, int64_t n_other, i
   if (n_own == 0 || n_other == 0) return MU_OK;
   MU_REQUIRE(d_E_own && d_E_other && d_part && (mode == 2 || d_kappa), "null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (pois_use_mfma(dtype, K)) {  // the matrix-core sweep (k_pois_mfma)
+#define MU_M(KP_) pois_mfma_launch<KP_>(mode, n_own, n_other, K, other_block, d_E_own, d_E_other, d_kappa, d_part, st)
+    return K <= 4 ? MU_M(4) : K <= 8 ? MU_M(8) : K <= 12 ? MU_M(12) : MU_M(16);
+#undef MU_M
+  }
 #define MU_D(T_)                                                                                                   \
   (K <= 4    ? pois_dense_launch<T_, 4>(mode, n_own, n_other, K, other_block, d_E_own, d_E_other, d_kappa, d_part, st)  \
    : K <= 8  ? pois_dense_launch<T_, 8>(mode, n_own, n_other, K, other_block, d_E_own, d_E_other, d_kappa, d_part, st)  \

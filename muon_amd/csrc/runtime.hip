@@ -31,7 +31,7 @@ int mu_num_cus() {
 }
 
 // tuning / ablation knobs (tests and bench only)
-static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "gram_wg", "pack_wg", "tpack_dbg", "spmm_narrow_off", "ell_mode", "tfidf_wide", "tfidf_pipe", "nn_interleave", "tfidf_abl", "tfidf_sum_m", "tn_pipe", "nn_fast_off", "stream_pipe", "tpack4_m", "tpack4_c", "scale_stream_off", "tpack4_plain", "tpack4_abl", "tpack4_late", "tpack4_circ", "tpack4_off"};
+static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "gram_wg", "pack_wg", "tpack_dbg", "spmm_narrow_off", "ell_mode", "tfidf_wide", "tfidf_pipe", "nn_interleave", "tfidf_abl", "tfidf_sum_m", "tn_pipe", "nn_fast_off", "stream_pipe", "tpack4_m", "tpack4_c", "scale_stream_off", "tpack4_plain", "tpack4_abl", "tpack4_late", "tpack4_circ", "tpack4_off", "pois_valu"};
 constexpr int kTuneN = sizeof(kTuneKeys) / sizeof(kTuneKeys[0]);
 static int g_tune[kTuneN] = {};
 

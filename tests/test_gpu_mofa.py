@@ -384,6 +384,113 @@ def test_poisson_passes_without_the_dense_chunk(dt, tol, K):
     assert abs(lik - want[2].sum()) <= tol * abs(want[2].sum())
 
 
+def _pois_dense_sweep(be, mode, Eo, Et, kap, K, blk=None):
+    """mu_mofa_poisson_dense alone (no stored entries): the partial results folded in block order"""
+    from muon_amd._backend import _dt, _p, check
+
+    n_own, n_other = Eo.shape[0], Et.shape[0]
+    if blk is None:
+        blk = int(be.lib.mu_mofa_poisson_blocks_for(_dt(Eo), mode, K, n_own, n_other))
+    assert blk >= 128 and blk % 128 == 0
+    nb = -(-n_other // blk)
+    part = torch.full((nb, n_own) if mode == 2 else (nb, n_own, K + 1 if mode == 3 else K), float("nan"),
+                      dtype=Eo.dtype, device=Eo.device)
+    check(be.lib.mu_mofa_poisson_dense(_dt(Eo), mode, n_own, n_other, K, blk, _p(Eo), _p(Et),
+                                       _p(kap) if kap is not None else None, _p(part), be._stream()))
+    return part.sum(dim=0)
+
+
+def _pois_dense_reference(mode, Eo, Et, kap, K):
+    """the element-wise definition in numpy f64 (include/muon_amd.h): own x other predictions, y = 0 everywhere"""
+    zeta = Eo[:, :K] @ Et[:, :K].T
+    sig = 1.0 / (1.0 + np.exp(-zeta))
+    sp_ = np.logaddexp(0.0, zeta)
+    if mode == 0:
+        return (kap[None, :] * zeta - sig) @ Et[:, :K]
+    if mode == 2:
+        return -sp_.sum(axis=1)
+    b = (kap[:, None] * zeta - sig) @ Et[:, :K]
+    return b if mode == 1 else np.concatenate([b, -sp_.sum(axis=1, keepdims=True)], axis=1)
+
+
+@pytest.mark.parametrize("K", [1, 4, 5, 8, 10, 13, 16])
+@pytest.mark.parametrize("shape", [(1, 1), (17, 15), (255, 16), (257, 17), (700, 127), (64, 129), (300, 1300)])
+def test_poisson_dense_sweep_on_the_matrix_cores(K, shape):
+    """k_pois_mfma (r06: the dense sweep of an f32 model as two small matrix products around the transform, csrc/
+    mofa_poisson.hip) against the element-wise definition in f64 AND against the vector kernel it replaces (tune key
+    pois_valu): every mode, own / other sizes off the 16-row tiles, the 128-row stages and the 256-row workgroups, every
+    padded width (K = 1 .. 16 -> KP = 4, 8, 12, 16), several column blocks (their last one partial: the padding rows'
+    share of the likelihood sum is taken off after the loop)."""
+    from muon_amd._backend import get_backend
+
+    be = get_backend()
+    n_own, n_other = shape
+    rng = np.random.default_rng(1000 * K + n_own + n_other)
+    KP = next(k for k in (4, 8, 12, 16) if k >= K)
+    Eo = np.zeros((n_own, KP)); Eo[:, :K] = rng.standard_normal((n_own, K)) * 0.8
+    Et = np.zeros((n_other, KP)); Et[:, :K] = rng.standard_normal((n_other, K)) * 0.6
+    dev = lambda a: torch.from_numpy(a).to(be.device).to(torch.float32).contiguous()
+    Eod, Etd = dev(Eo), dev(Et)
+    try:
+        for mode in (0, 1, 2, 3):
+            kap = 0.25 + rng.random(n_other if mode == 0 else n_own)
+            kd = None if mode == 2 else dev(kap)
+            want = _pois_dense_reference(mode, Eo, Et, kap, K)
+            scale = max(1.0, float(np.max(np.abs(want))))
+            got = {}
+            for valu in (0, 1):
+                be.lib.mu_tune_set(b"pois_valu", valu)
+                for blk in (None, 128):
+                    g = be.to_host(_pois_dense_sweep(be, mode, Eod, Etd, kd, K, blk)).astype(np.float64)
+                    assert g.shape == want.shape and np.all(np.isfinite(g))
+                    assert np.max(np.abs(g - want)) <= 2e-5 * scale, (mode, valu, blk)
+                    got[valu, blk] = g
+            assert np.max(np.abs(got[0, None] - got[1, None])) <= 1e-5 * scale
+            if mode == 3:  # mode 1 and mode 3 give the same b, bit for bit
+                be.lib.mu_tune_set(b"pois_valu", 0)
+                b1 = _pois_dense_sweep(be, 1, Eod, Etd, kd, K)
+                b3 = _pois_dense_sweep(be, 3, Eod, Etd, kd, K)
+                assert torch.equal(b1, b3[:, :K].contiguous())
+    finally:
+        be.lib.mu_tune_set(b"pois_valu", 0)
+
+
+def test_poisson_dense_sweep_with_extreme_predictions():
+    """predictions far outside anything a fit produces (|zeta| up to ~300): the hardware exp2 / log2 / rcp of the
+    matrix-core sweep must stay finite and right - sigmoid 0 / 1, softplus 0 / zeta"""
+    from muon_amd._backend import get_backend
+
+    be = get_backend()
+    K, KP, n_own, n_other = 3, 4, 40, 50
+    rng = np.random.default_rng(5)
+    Eo = np.zeros((n_own, KP)); Eo[:, :K] = rng.standard_normal((n_own, K)) * 12
+    Et = np.zeros((n_other, KP)); Et[:, :K] = rng.standard_normal((n_other, K)) * 12
+    assert np.max(np.abs(Eo[:, :K] @ Et[:, :K].T)) > 200
+    dev = lambda a: torch.from_numpy(a).to(be.device).to(torch.float32).contiguous()
+    Eo32, Et32 = Eo.astype(np.float32).astype(np.float64), Et.astype(np.float32).astype(np.float64)
+    for mode in (0, 1, 2, 3):
+        kap = 0.25 + rng.random(n_other if mode == 0 else n_own)
+        want = _pois_dense_reference(mode, Eo32, Et32, kap.astype(np.float32).astype(np.float64), K)
+        g = be.to_host(_pois_dense_sweep(be, mode, dev(Eo), dev(Et), None if mode == 2 else dev(kap), K)).astype(np.float64)
+        assert np.all(np.isfinite(g))
+        assert np.max(np.abs(g - want)) <= 1e-5 * np.max(np.abs(want)), mode
+
+
+def test_poisson_block_rule_fills_whole_rounds():
+    """mu_mofa_poisson_blocks_for: a multiple of the 128-row stage, never more column blocks than stages, and the
+    workgroups of the sweep fit the places the kernel's occupancy gives (or come in whole rounds of them)"""
+    from muon_amd._backend import get_backend
+
+    be = get_backend()
+    for dt in (0, 1):
+        for mode in (0, 1, 2, 3):
+            for K in (3, 10, 16, 24):
+                for n_own, n_other in ((20000, 20000), (1, 1), (100, 100000), (100000, 100), (513, 129)):
+                    blk = int(be.lib.mu_mofa_poisson_blocks_for(dt, mode, K, n_own, n_other))
+                    assert blk >= 128 and blk % 128 == 0
+                    assert blk <= 128 * -(-n_other // 128)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("shape", [(1, 1), (37, 5), (1000, 1024), (4099, 2052), (513, 1027)])
 def test_dense_column_moments_kernel(hip, dtype, shape):

@@ -111,6 +111,47 @@ def test_stream_spmm_isa_keeps_out_of_the_asm_owned_registers(tmp_path):
 
 
 
+def test_poisson_matrix_core_sweep_isa(tmp_path):
+    """k_pois_mfma (csrc/mofa_poisson.hip, r06): the sweep costs what its instruction count says - the f32 matrix
+    instructions and the vector ALU do not overlap there - so the generated gfx950 ISA is pinned: accumulators in VGPRs
+    (no v_accvgpr copies around every product: the file is built with -amdgpu-mfma-vgpr-form, csrc/build.py), no spills,
+    no IEEE division sequence and no libm log expansion in the transform (one v_exp_f32 per prediction, one v_rcp_f32
+    where the mode needs the sigmoid, one v_log_f32 where it needs the likelihood), KP / 4 + 4 matrix instructions per
+    16 x 16 tile (KP / 4 in the likelihood-only mode)."""
+    import re
+    import shutil
+    import subprocess
+
+    from muon_amd.csrc import build as csrc_build
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "muon_amd", "csrc", "mofa_poisson.hip")
+    assert "-amdgpu-mfma-vgpr-form" in csrc_build.EXTRA["mofa_poisson.hip"]
+    out = tmp_path / "mofa_poisson.s"
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "muon_amd", "csrc"), *csrc_build.EXTRA["mofa_poisson.hip"], "-S",
+                           "--cuda-device-only", "-w", "-o", str(out), src])
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN[^\n:]*k_pois_mfmaILi(\d+)ELi(\d)E[^\n:]*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
+                         flags=re.S | re.M)
+    assert len(kernels) == 16  # KP = 4, 8, 12, 16 x modes 0..3
+    tiles = 4  # kPmOwn: 16-row own tiles per wave, all in one unrolled step
+    for name, kp, mode, body in kernels:
+        kp, mode = int(kp), int(mode)
+        assert "scratch_" not in body and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body), name
+        assert "accvgpr" not in body, name
+        assert "v_div_" not in body and "v_ldexp" not in body, name
+        count = lambda op: len(re.findall(r"^\s*" + op + r"\b", body, flags=re.M))
+        assert count("v_mfma_f32_16x16x4_f32") == tiles * (kp // 4 + (0 if mode == 2 else 4)), name
+        assert count("v_exp_f32_e32") + count("v_exp_f32_e64") == 4 * tiles, name
+        assert count("v_rcp_f32_e32") + count("v_rcp_f32_e64") == (0 if mode == 2 else 4 * tiles), name
+        assert count("v_log_f32_e32") + count("v_log_f32_e64") == (4 * tiles if mode in (2, 3) else 0), name
+        m = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
+        assert m and int(m.group(1)) <= 128, (name, m and m.group(1))
+
+
 def test_tpack4_isa_keeps_out_of_the_asm_owned_registers(tmp_path):
     """The fourth-generation transposition (csrc/tpack4.hip) keeps the next tile's header in v[88..91] and its 18 window
     slots in v[92..127], written by loads issued from inline asm one tile ahead: hipcc must stay below v88 (a copy or a
