@@ -515,6 +515,16 @@ int mu_mofa_poisson_dense(int dtype, int mode, int64_t n_own, int64_t n_other, i
                           const void* d_E_own, const void* d_E_other, const void* d_kappa, void* d_part, void* stream);
 int mu_mofa_poisson_sparse(int dtype, int mode, int64_t n_own, int K, const int64_t* d_indptr, const int32_t* d_indices,
                            const void* d_values, const void* d_E_own, const void* d_E_other, void* d_out, void* stream);
+/* r06: the same two with an explicit row stride `ld` (in elements) of BOTH factor blocks: a multiple of 4, at least the
+ * padded width above; columns K .. ld - 1 zero.  With 9 <= K <= 16 and ld = 16 (64-byte rows of f32) the stored-entry pass
+ * reads a row with ONE cache-line look-up - four lanes per entry, k_pois_sparse_quad - instead of three (the look-up rate
+ * of the gathers is what bounds it), while the dense sweep still runs its KP = 12 instance for K <= 12. */
+int mu_mofa_poisson_dense_ld(int dtype, int mode, int64_t n_own, int64_t n_other, int K, int ld, int64_t other_block,
+                             const void* d_E_own, const void* d_E_other, const void* d_kappa, void* d_part,
+                             void* stream);
+int mu_mofa_poisson_sparse_ld(int dtype, int mode, int64_t n_own, int K, int ld, const int64_t* d_indptr,
+                              const int32_t* d_indices, const void* d_values, const void* d_E_own, const void* d_E_other,
+                              void* d_out, void* stream);
 
 /* ---- MOFA+ small nodes and the ELBO, fused (tools.py:585 ent.run(): mofapy2's Tau, AlphaW, ThetaW,
  * AlphaZ node updates and calculateELBO()).  Arithmetic in f64 for both storage types; every entry

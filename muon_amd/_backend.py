@@ -1352,12 +1352,14 @@ class HipBackend:
         n_other = E_other.shape[0]
         assert E_other.shape[1] == K and E_own.dtype == E_other.dtype and 1 <= K <= 32
         assert X.shape == (n_own, n_other) and X.values.dtype == E_own.dtype
-        KP = next(k for k in (4, 8, 12, 16, 32) if k >= K)  # rows padded to 16-byte multiples (include/muon_amd.h)
+        # rows padded with zeros to ld columns (include/muon_amd.h): the padded width 4 / 8 / 12 / 16 / 32, and 16 for
+        # 9 <= K <= 12 too - 64-byte rows let the stored-entry pass read a row in one cache-line look-up (r06)
+        ld = 16 if 8 < K <= 16 else next(k for k in (4, 8, 32) if k >= K)
 
         def pad(E):
-            if K == KP and E.is_contiguous():
+            if K == ld and E.is_contiguous():
                 return E
-            P = torch.zeros((E.shape[0], KP), dtype=E.dtype, device=E.device)
+            P = torch.zeros((E.shape[0], ld), dtype=E.dtype, device=E.device)
             P[:, :K] = E
             return P
 
@@ -1366,12 +1368,12 @@ class HipBackend:
         nb = -(-n_other // blk)
         part = self.empty((nb, n_own) if mode == 2 else (nb, n_own, K + 1 if mode == 3 else K), E_own.dtype)
         with self._dev_ctx():
-            check(self.lib.mu_mofa_poisson_dense(_dt(E_own), int(mode), n_own, n_other, K, blk, _p(E_own), _p(E_other),
-                                                 _p(kappa), _p(part), self._stream()))
+            check(self.lib.mu_mofa_poisson_dense_ld(_dt(E_own), int(mode), n_own, n_other, K, ld, blk, _p(E_own),
+                                                    _p(E_other), _p(kappa), _p(part), self._stream()))
             out = part[0] if nb == 1 else part.sum(dim=0)  # (fixed order: deterministic)
             out = out.contiguous()
-            check(self.lib.mu_mofa_poisson_sparse(_dt(E_own), int(mode), n_own, K, _p(X.indptr), _p(X.indices),
-                                                  _p(X.values), _p(E_own), _p(E_other), _p(out), self._stream()))
+            check(self.lib.mu_mofa_poisson_sparse_ld(_dt(E_own), int(mode), n_own, K, ld, _p(X.indptr), _p(X.indices),
+                                                     _p(X.values), _p(E_own), _p(E_other), _p(out), self._stream()))
         return out
 
     def mofa_gs_update(self, Tm, b, prior, lth, l1mth, spikeslab, E, E2, gamma, Eh2, sig2):

@@ -51,6 +51,47 @@ __device__ __forceinline__ double pz_softplus_sum(double z) { return pz_softplus
 template <typename T>
 __device__ __forceinline__ T pz_sigmoid(T z) { return (T)1 / ((T)1 + pz_exp(-z)); }
 
+// The stored entries of an f32 model (k_pois_sparse): rate, sigmoid and ln(rate) of a prediction on the hardware exp2 /
+// log2 / rcp (r06; libm's log1pf + __logf and two IEEE divisions were ~110 of the ~170 vector instructions per 64
+// entries, and the kernel was 57 % VALU-busy).  Unlike the dense sweep, which only SUMS softplus, an entry needs the
+// rate to a RELATIVE accuracy (it divides by it and takes its logarithm), also where the prediction is far below zero
+// and the rate is e^zeta: ln(1 + e) is taken as ln(d) e / (d - 1) with d = fl(1 + e) (Kahan's log1p: the rounding of
+// d cancels in the quotient), e = exp(-|zeta|) <= 1.
+struct PzEntry { float rate, sig, lnrate; };
+__device__ __forceinline__ PzEntry pz_entry(float z) {
+  const float e = __builtin_amdgcn_exp2f(fabsf(z) * -1.4426950408889634f);
+  const float d = 1.0f + e, inv = __builtin_amdgcn_rcpf(d), dm1 = d - 1.0f;
+  const float lnd = 0.6931471805599453f * __builtin_amdgcn_logf(d);
+  const float l1p = dm1 == 0.f ? e : lnd * (e * __builtin_amdgcn_rcpf(dm1));
+  PzEntry r;
+  r.sig = z >= 0.f ? inv : e * inv;
+  r.rate = fmaxf(fmaxf(z, 0.f) + l1p, pz_tiny<float>());
+  r.lnrate = 0.6931471805599453f * __builtin_amdgcn_logf(r.rate);  // (rate >= 1e-30: a normal number)
+  return r;
+}
+struct PzEntryD { double rate, sig, lnrate; };
+__device__ __forceinline__ PzEntryD pz_entry(double z) {
+  PzEntryD r;
+  r.rate = pz_softplus(z);
+  r.sig = pz_sigmoid(z);
+  r.lnrate = pz_log(r.rate);
+  return r;
+}
+// sum over the 64 lanes in six DPP additions, the total in lane 63 (wave_sum's __shfl_down is an LDS permute plus its
+// index arithmetic per step: ~500 instructions for the 12 accumulators of a row)
+__device__ __forceinline__ float pz_wave_sum63(float v) {
+#define MU_DPP(CTRL, RM) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, RM, 0xf, true))
+  v += MU_DPP(0xB1, 0xf);   // quad_perm [1, 0, 3, 2]
+  v += MU_DPP(0x4E, 0xf);   // quad_perm [2, 3, 0, 1]
+  v += MU_DPP(0x141, 0xf);  // row_half_mirror
+  v += MU_DPP(0x140, 0xf);  // row_mirror: every lane of a row of 16 holds the row's sum
+  v += MU_DPP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  v += MU_DPP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef MU_DPP
+  return v;
+}
+__device__ __forceinline__ double pz_wave_sum63(double v) { return wave_sum_all(v); }
+
 // a row of a factor block PADDED to KP columns (16-byte aligned rows: three 16-byte loads for K = 10 instead of ten
 // dword gathers - the sparse corrections are bound by the number of gather instructions)
 template <typename T, int KP>
@@ -76,7 +117,7 @@ constexpr int kPzThreads = 256;
 //         next one evaluate the same predictions (same factors, same weights): out[own][0 .. K-1] as MODE 1,
 //         out[own][K] = sum_n -softplus(zeta); rows of K + 1 values
 template <typename T, int KP, int MODE>
-__global__ __launch_bounds__(kPzThreads) void k_pois_dense(int64_t n_own, int64_t n_other, int K, int64_t other_block,
+__global__ __launch_bounds__(kPzThreads) void k_pois_dense(int64_t n_own, int64_t n_other, int K, int ld, int64_t other_block,
                                                            const T* __restrict__ E_own, const T* __restrict__ E_other,
                                                            const T* __restrict__ kappa, T* __restrict__ part) {
   __shared__ T tile[kPzTile][KP];
@@ -87,7 +128,7 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_dense(int64_t n_own, int64_
   T e[KP], acc[KP];
 #pragma unroll
   for (int k = 0; k < KP; ++k) e[k] = acc[k] = (T)0;
-  if (own < n_own) pz_load_row<T, KP>(E_own + own * KP, e);  // (padding columns are zero)
+  if (own < n_own) pz_load_row<T, KP>(E_own + own * ld, e);  // (padding columns are zero)
   const T kown = ((MODE == 1 || MODE == 3) && own < n_own) ? kappa[own] : (T)0;
   T lsum = (T)0;
   for (int64_t t0 = o0; t0 < o1; t0 += kPzTile) {
@@ -95,7 +136,7 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_dense(int64_t n_own, int64_
     __syncthreads();
     for (int i = threadIdx.x; i < kPzTile * KP; i += kPzThreads) {
       const int r = i / KP, k = i - r * KP;
-      tile[r][k] = r < rows ? E_other[(t0 + r) * KP + k] : (T)0;
+      tile[r][k] = r < rows ? E_other[(t0 + r) * ld + k] : (T)0;
     }
     if (MODE == 0)
       for (int i = threadIdx.x; i < kPzTile; i += kPzThreads) kap[i] = i < rows ? kappa[t0 + i] : (T)0;
@@ -145,7 +186,7 @@ typedef float pm_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kPmOwn = 4;
 
 template <int KP, int MODE>
-__global__ __launch_bounds__(kPzThreads) void k_pois_mfma(int64_t n_own, int64_t n_other, int K, int64_t other_block,
+__global__ __launch_bounds__(kPzThreads) void k_pois_mfma(int64_t n_own, int64_t n_other, int K, int ld, int64_t other_block,
                                                           const float* __restrict__ E_own,
                                                           const float* __restrict__ E_other,
                                                           const float* __restrict__ kappa, float* __restrict__ part) {
@@ -164,7 +205,7 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_mfma(int64_t n_own, int64_t
   for (int u = 0; u < kPmOwn; ++u) {
     const int64_t row = own0 + 16 * u + li;  // (own = the tile's column = lane & 15)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) eo[u][s] = row < n_own ? E_own[row * KP + KS * lj + s] : 0.f;
+    for (int s = 0; s < KS; ++s) eo[u][s] = row < n_own ? E_own[row * ld + KS * lj + s] : 0.f;
     kown[u] = ((MODE == 1 || MODE == 3) && row < n_own) ? kappa[row] : 0.f;
     lsum[u] = 0.f;
     acc[u] = (pm_f32x4){0.f, 0.f, 0.f, 0.f};
@@ -178,7 +219,7 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_mfma(int64_t n_own, int64_t
     __syncthreads();
     for (int i = threadIdx.x; i < kPzTile * KP; i += kPzThreads) {
       const int r = i / KP, k = i - r * KP;
-      tile[r * LS + k] = r < rows ? E_other[(t0 + r) * KP + k] : 0.f;
+      tile[r * LS + k] = r < rows ? E_other[(t0 + r) * ld + k] : 0.f;
     }
     if (MODE == 0)
       for (int i = threadIdx.x; i < kPzTile; i += kPzThreads) kap[i] = i < rows ? kappa[t0 + i] : 0.f;
@@ -259,63 +300,238 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_mfma(int64_t n_own, int64_t
   }
 }
 
-// the stored entries: a wave per own row.  MODE as above; (indptr, indices, values) = CSR of the view (MODE 0, 2) or of
-// its transpose (MODE 1); the result is ADDED to out (which holds the dense part).
+// The stored entries: a wave per own row, a lane per entry.  MODE as above; (indptr, indices, values) = CSR of the view
+// (MODE 0, 2) or of its transpose (MODE 1, 3); the result is ADDED to out (which holds the dense part).
+//
+// r06: the kernel was bound by its own dependency chain, not by anything the machine runs out of.  A step of 64 entries
+// reads (index, value) from the CSR stream (HBM: ~2 us under load), then gathers the other block's rows through the L2
+// (~0.7 us), then computes - and the next step's reads were issued after that, so a row of ~1100 entries was 18 round
+// trips one after the other and the 8 waves a SIMD can hold were all there is to overlap them: 0.22 ms per pass at
+// 22.8 M entries whatever else changed (170 -> 60 vector instructions per step: nothing; a third of the cache-line
+// look-ups per entry with four lanes per entry: nothing; the next step's loads issued one step ahead: -8 %).  The steps
+// of a row do not depend on each other, so they now go in BATCHES of kPsBatch: all the batch's gathers are issued
+// together, the (index, value) pairs of the next batch right behind them, then the batch is computed - a row is
+// ~ceil(18 / 4) round trips to the L2, the HBM latency behind the arithmetic.
+// A lane past the end of the row carries y = 0 and row 0 of the other block: it adds 0 x (finite) everywhere, so no
+// step needs a guard.
+constexpr int kPsBatch = 4;
+
 template <typename T, int KP, int MODE>
-__global__ __launch_bounds__(256) void k_pois_sparse(int64_t n_own, int K, const int64_t* __restrict__ indptr,
+__global__ __launch_bounds__(256) void k_pois_sparse(int64_t n_own, int K, int ld, const int64_t* __restrict__ indptr,
                                                      const int32_t* __restrict__ indices, const T* __restrict__ values,
                                                      const T* __restrict__ E_own, const T* __restrict__ E_other,
                                                      T* __restrict__ out) {
+  constexpr int kRowRegs = KP * (int)sizeof(T) / 4;  // registers of one gathered row
+  constexpr int U = 48 / kRowRegs >= kPsBatch ? kPsBatch : (48 / kRowRegs >= 1 ? 48 / kRowRegs : 1);  // <= 48 registers of rows in flight
   const int lane = threadIdx.x & 63;
   const int64_t own = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (own >= n_own) return;
   T e[KP], acc[KP];
 #pragma unroll
   for (int k = 0; k < KP; ++k) acc[k] = (T)0;
-  pz_load_row<T, KP>(E_own + own * KP, e);
+  pz_load_row<T, KP>(E_own + own * ld, e);
   T lsum = (T)0;
   const int64_t lo = indptr[own], hi = indptr[own + 1];
-  for (int64_t p = lo + lane; p < hi; p += 64) {
-    const int64_t j = indices[p];
-    const T y = values[p];
-    T o[KP];
-    pz_load_row<T, KP>(E_other + j * KP, o);
-    T zeta = (T)0;
+  int32_t jn[U];
+  T yn[U];
 #pragma unroll
-    for (int k = 0; k < KP; ++k) zeta += e[k] * o[k];
-    const T rate = pz_softplus(zeta);
-    if (MODE == 2 || MODE == 3) lsum += y * pz_log(rate);
-    if (MODE != 2) {
-      const T c = pz_sigmoid(zeta) * y / rate;
+  for (int u = 0; u < U; ++u) {
+    const int64_t p = lo + 64 * u + lane;
+    jn[u] = 0;
+    yn[u] = (T)0;
+    if (p < hi) { jn[u] = indices[p]; yn[u] = values[p]; }
+  }
+  for (int64_t base = lo; base < hi; base += 64 * U) {  // (wave-uniform trip count)
+    T o[U][KP], y[U];
 #pragma unroll
-      for (int k = 0; k < KP; ++k) acc[k] += c * o[k];
+    for (int u = 0; u < U; ++u) {
+      y[u] = yn[u];
+      pz_load_row<T, KP>(E_other + (int64_t)jn[u] * ld, o[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t p = base + 64 * (U + u) + lane;
+      jn[u] = 0;
+      yn[u] = (T)0;
+      if (p < hi) { jn[u] = indices[p]; yn[u] = values[p]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      T zeta = (T)0;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) zeta += e[k] * o[u][k];
+      const auto en = pz_entry(zeta);
+      if (MODE == 2 || MODE == 3) lsum += y[u] * en.lnrate;
+      if (MODE != 2) {
+        const T c = sizeof(T) == 4 ? (T)(en.sig * y[u] * (T)__builtin_amdgcn_rcpf((float)en.rate)) : en.sig * y[u] / en.rate;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) acc[k] += c * o[u][k];
+      }
     }
   }
   if (MODE == 2) {
-    lsum = wave_sum(lsum);
-    if (lane == 0) out[own] += lsum;
+    lsum = pz_wave_sum63(lsum);
+    if (lane == 63) out[own] += lsum;
   } else {
     const int ostride = MODE == 3 ? K + 1 : K;
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
       if (k < K) {  // (K is wave-uniform)
-        const T s = wave_sum(acc[k]);
-        if (lane == 0) out[own * ostride + k] += s;
+        const T s = pz_wave_sum63(acc[k]);
+        if (lane == 63) out[own * ostride + k] += s;
       }
     }
     if (MODE == 3) {
-      lsum = wave_sum(lsum);
-      if (lane == 0) out[own * ostride + K] += lsum;
+      lsum = pz_wave_sum63(lsum);
+      if (lane == 63) out[own * ostride + K] += lsum;
     }
   }
 }
 
+// The same pass with FOUR lanes per entry (r06, KP = 12 / 16, i.e. 9 <= K <= 16): what bounds the kernel above once its
+// dependency chain is out of the way is the cache-line look-up rate of the gathers - the texture addresser was 77 % busy
+// (profiles/r06_pois_pmc.txt), one look-up per lane and 16-byte piece, three per entry, and every line it finds
+// is used for 16 of its 64 bytes.  Here the four lanes of an entry read four consecutive 16-byte pieces of the row: with
+// rows padded to ld = 16 columns (64-byte aligned) an entry is ONE look-up, a third of the traffic through the addresser.
+// The price is that a prediction is now spread over four lanes.  Summing it into all four and repeating the transform
+// in each would quadruple the vector work (and was no faster); instead four steps are reduced together - a 4 x 4
+// transpose-reduce inside the quad, two select / DPP-add rounds - which leaves lane q of a quad with the complete
+// prediction of ITS step q, so the transform runs once per entry, on every lane, and the four scale factors go back
+// to the quad by DPP broadcast.  Batches as above: kPqGroups x 4 steps x 16 entries in flight per wave.
+template <typename T>
+__device__ __forceinline__ void pz_load4(const T* __restrict__ p, T (&o)[4]) {
+  constexpr int V = 16 / (int)sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  const vec_t* q = reinterpret_cast<const vec_t*>(p);
+#pragma unroll
+  for (int i = 0; i < 4 / V; ++i) {
+    const vec_t v = q[i];
+#pragma unroll
+    for (int u = 0; u < V; ++u) o[i * V + u] = v[u];
+  }
+}
+template <int CTRL>
+__device__ __forceinline__ float pz_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double pz_dpp(double v) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xf, 0xf, true);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+template <typename T, int KP, int MODE>
+__global__ __launch_bounds__(256) void k_pois_sparse_quad(int64_t n_own, int K, int ld, const int64_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ indices,
+                                                          const T* __restrict__ values, const T* __restrict__ E_own,
+                                                          const T* __restrict__ E_other, T* __restrict__ out) {
+  static_assert(KP == 12 || KP == 16, "four lanes of four columns per entry");
+  constexpr int G = sizeof(T) == 4 ? 2 : 1;  // groups of four steps per batch
+  constexpr int S = 4 * G;                   // steps per batch, 16 entries each
+  const int lane = threadIdx.x & 63, q = lane & 3, slot = lane >> 2;
+  const int64_t own = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (own >= n_own) return;
+  const bool act = 4 * q < KP;  // (KP = 12: the fourth lane of an entry holds no columns; it re-reads the first piece)
+  const int col = act ? 4 * q : 0;
+  const bool odd = q & 1, upper = q & 2;
+  T e[4], acc[4];
+  pz_load4<T>(E_own + own * ld + col, e);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    acc[i] = (T)0;
+    if (!act) e[i] = (T)0;
+  }
+  T lsum = (T)0;
+  const int64_t lo = indptr[own], hi = indptr[own + 1];
+  // the CSR stream is read a lane per entry - one instruction per 64 entries and array, not one per step of 16: the
+  // addresser pays ~16 cycles per memory instruction whatever it fetches (profiles/r06_pois_pmc.txt) - and a
+  // step's 16 (index, value) pairs reach its quads through the LDS crossbar (ds_bpermute)
+  constexpr int C = (S + 3) / 4;  // 64-entry chunks per batch
+  int32_t jn[C];
+  T yn[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int64_t p = lo + 64 * c + lane;
+    jn[c] = 0;
+    yn[c] = (T)0;
+    if (p < hi) { jn[c] = indices[p]; yn[c] = values[p]; }
+  }
+  for (int64_t base = lo; base < hi; base += 16 * S) {  // (wave-uniform trip count)
+    T o[S][4], y[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int src = 16 * (s & 3) + slot;  // the lane that read entry 16 s + slot of the batch
+      const int32_t j = __shfl(jn[s >> 2], src, 64);
+      y[s] = __shfl(yn[s >> 2], src, 64);
+      pz_load4<T>(E_other + (int64_t)j * ld + col, o[s]);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int64_t p = base + 16 * S + 64 * c + lane;
+      jn[c] = 0;
+      yn[c] = (T)0;
+      if (p < hi) { jn[c] = indices[p]; yn[c] = values[p]; }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      T z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        z[u] = e[0] * o[4 * g + u][0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) z[u] += e[i] * o[4 * g + u][i];
+      }
+      // 4 x 4 transpose-reduce: lane q ends up with the sum over the quad of z[q]
+      const T a0 = (odd ? z[1] : z[0]) + pz_dpp<0xB1>(odd ? z[0] : z[1]);   // steps 0 | 1, summed over the lane pair
+      const T a1 = (odd ? z[3] : z[2]) + pz_dpp<0xB1>(odd ? z[2] : z[3]);   // steps 2 | 3
+      const T zeta = (upper ? a1 : a0) + pz_dpp<0x4E>(upper ? a0 : a1);     // step q
+      const T y01 = odd ? y[4 * g + 1] : y[4 * g + 0], y23 = odd ? y[4 * g + 3] : y[4 * g + 2];
+      const T yq = upper ? y23 : y01;
+      const auto en = pz_entry(zeta);
+      if (MODE == 2 || MODE == 3) lsum += yq * en.lnrate;
+      if (MODE != 2) {
+        const T c = sizeof(T) == 4 ? (T)(en.sig * yq * (T)__builtin_amdgcn_rcpf((float)en.rate)) : en.sig * yq / en.rate;
+        const T c0 = pz_dpp<0x00>(c), c1 = pz_dpp<0x55>(c), c2 = pz_dpp<0xAA>(c), c3 = pz_dpp<0xFF>(c);  // quad broadcasts
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[i] += c0 * o[4 * g + 0][i];
+          acc[i] += c1 * o[4 * g + 1][i];
+          acc[i] += c2 * o[4 * g + 2][i];
+          acc[i] += c3 * o[4 * g + 3][i];
+        }
+      }
+    }
+  }
+  const int ostride = MODE == 2 ? 1 : (MODE == 3 ? K + 1 : K);
+  if (MODE != 2) {
+    // the 16 entry slots fold: lanes with the same q hold the same four columns
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[i] += pz_dpp<0x124>(acc[i]);  // row_ror:4
+      acc[i] += pz_dpp<0x128>(acc[i]);  // row_ror:8: every lane holds the sum over the four quads of its row of 16
+      acc[i] += __shfl_xor(acc[i], 16, 64);
+      acc[i] += __shfl_xor(acc[i], 32, 64);
+    }
+    if (slot == 0 && act) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (col + i < K) out[own * ostride + col + i] += acc[i];
+    }
+  }
+  if (MODE == 2 || MODE == 3) {
+    lsum = wave_sum(lsum);
+    if (lane == 0) out[own * ostride + (MODE == 3 ? K : 0)] += lsum;
+  }
+}
+
 template <typename T, int KP>
-int pois_dense_launch(int mode, int64_t n_own, int64_t n_other, int K, int64_t other_block, const void* E_own,
+int pois_dense_launch(int mode, int64_t n_own, int64_t n_other, int K, int ld, int64_t other_block, const void* E_own,
                       const void* E_other, const void* kappa, void* part, hipStream_t st) {
   const dim3 grid((unsigned)((n_own + kPzThreads - 1) / kPzThreads), (unsigned)((n_other + other_block - 1) / other_block));
 #define MU_GO(MD)                                                                                                      \
-  hipLaunchKernelGGL((k_pois_dense<T, KP, MD>), grid, dim3(kPzThreads), 0, st, n_own, n_other, K, other_block,          \
+  hipLaunchKernelGGL((k_pois_dense<T, KP, MD>), grid, dim3(kPzThreads), 0, st, n_own, n_other, K, ld, other_block,      \
                      (const T*)E_own, (const T*)E_other, (const T*)kappa, (T*)part)
   if (mode == 0) MU_GO(0);
   else if (mode == 1) MU_GO(1);
@@ -327,11 +543,11 @@ int pois_dense_launch(int mode, int64_t n_own, int64_t n_other, int K, int64_t o
 }
 
 template <int KP>
-int pois_mfma_launch(int mode, int64_t n_own, int64_t n_other, int K, int64_t other_block, const void* E_own,
+int pois_mfma_launch(int mode, int64_t n_own, int64_t n_other, int K, int ld, int64_t other_block, const void* E_own,
                      const void* E_other, const void* kappa, void* part, hipStream_t st) {
   const dim3 grid((unsigned)((n_own + kPzThreads - 1) / kPzThreads), (unsigned)((n_other + other_block - 1) / other_block));
 #define MU_GO(MD)                                                                                                 \
-  hipLaunchKernelGGL((k_pois_mfma<KP, MD>), grid, dim3(kPzThreads), 0, st, n_own, n_other, K, other_block,        \
+  hipLaunchKernelGGL((k_pois_mfma<KP, MD>), grid, dim3(kPzThreads), 0, st, n_own, n_other, K, ld, other_block,    \
                      (const float*)E_own, (const float*)E_other, (const float*)kappa, (float*)part)
   if (mode == 0) MU_GO(0);
   else if (mode == 1) MU_GO(1);
@@ -343,16 +559,26 @@ int pois_mfma_launch(int mode, int64_t n_own, int64_t n_other, int K, int64_t ot
 }
 
 template <typename T, int KP>
-int pois_sparse_launch(int mode, int64_t n_own, int K, const int64_t* indptr, const int32_t* indices, const void* values,
-                       const void* E_own, const void* E_other, void* out, hipStream_t st) {
+int pois_sparse_launch(int mode, int64_t n_own, int K, int ld, const int64_t* indptr, const int32_t* indices,
+                       const void* values, const void* E_own, const void* E_other, void* out, hipStream_t st) {
   const unsigned blocks = (unsigned)((n_own + 3) / 4);
-#define MU_GO(MD)                                                                                                    \
-  hipLaunchKernelGGL((k_pois_sparse<T, KP, MD>), dim3(blocks), dim3(256), 0, st, n_own, K, indptr, indices,          \
+#define MU_GO(KERNEL, MD)                                                                                            \
+  hipLaunchKernelGGL((KERNEL<T, KP, MD>), dim3(blocks), dim3(256), 0, st, n_own, K, ld, indptr, indices,             \
                      (const T*)values, (const T*)E_own, (const T*)E_other, (T*)out)
-  if (mode == 0) MU_GO(0);
-  else if (mode == 1) MU_GO(1);
-  else if (mode == 2) MU_GO(2);
-  else MU_GO(3);
+  if constexpr (KP == 12 || KP == 16) {
+    if (mu_tune_get("pois_lane") <= 0) {  // four lanes per entry (k_pois_sparse_quad)
+      if (mode == 0) MU_GO(k_pois_sparse_quad, 0);
+      else if (mode == 1) MU_GO(k_pois_sparse_quad, 1);
+      else if (mode == 2) MU_GO(k_pois_sparse_quad, 2);
+      else MU_GO(k_pois_sparse_quad, 3);
+      MU_CHECK_LAUNCH();
+      return MU_OK;
+    }
+  }
+  if (mode == 0) MU_GO(k_pois_sparse, 0);
+  else if (mode == 1) MU_GO(k_pois_sparse, 1);
+  else if (mode == 2) MU_GO(k_pois_sparse, 2);
+  else MU_GO(k_pois_sparse, 3);
 #undef MU_GO
   MU_CHECK_LAUNCH();
   return MU_OK;
@@ -431,44 +657,58 @@ int64_t mu_mofa_poisson_blocks(int64_t n_own, int64_t n_other) {
   return per * kPzTile;                           // rows of the other block per column block
 }
 
-int mu_mofa_poisson_dense(int dtype, int mode, int64_t n_own, int64_t n_other, int K, int64_t other_block,
-                          const void* d_E_own, const void* d_E_other, const void* d_kappa, void* d_part, void* stream) {
+static int pois_padded_width(int K) { return K <= 4 ? 4 : K <= 8 ? 8 : K <= 12 ? 12 : K <= 16 ? 16 : 32; }
+
+int mu_mofa_poisson_dense_ld(int dtype, int mode, int64_t n_own, int64_t n_other, int K, int ld, int64_t other_block,
+                             const void* d_E_own, const void* d_E_other, const void* d_kappa, void* d_part,
+                             void* stream) {
   MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
   MU_REQUIRE(mode >= 0 && mode <= 3 && K >= 1 && K <= 32, "mode 0..3, 1 <= K <= 32");
+  MU_REQUIRE(ld >= pois_padded_width(K) && ld % 4 == 0, "ld: a multiple of 4, at least the padded width of K");
   MU_REQUIRE(n_own >= 0 && n_other >= 0 && other_block >= 1, "shape");
   if (n_own == 0 || n_other == 0) return MU_OK;
   MU_REQUIRE(d_E_own && d_E_other && d_part && (mode == 2 || d_kappa), "null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (pois_use_mfma(dtype, K)) {  // the matrix-core sweep (k_pois_mfma)
-#define MU_M(KP_) pois_mfma_launch<KP_>(mode, n_own, n_other, K, other_block, d_E_own, d_E_other, d_kappa, d_part, st)
+#define MU_M(KP_) pois_mfma_launch<KP_>(mode, n_own, n_other, K, ld, other_block, d_E_own, d_E_other, d_kappa, d_part, st)
     return K <= 4 ? MU_M(4) : K <= 8 ? MU_M(8) : K <= 12 ? MU_M(12) : MU_M(16);
 #undef MU_M
   }
-#define MU_D(T_)                                                                                                   \
-  (K <= 4    ? pois_dense_launch<T_, 4>(mode, n_own, n_other, K, other_block, d_E_own, d_E_other, d_kappa, d_part, st)  \
-   : K <= 8  ? pois_dense_launch<T_, 8>(mode, n_own, n_other, K, other_block, d_E_own, d_E_other, d_kappa, d_part, st)  \
-   : K <= 12 ? pois_dense_launch<T_, 12>(mode, n_own, n_other, K, other_block, d_E_own, d_E_other, d_kappa, d_part, st) \
-   : K <= 16 ? pois_dense_launch<T_, 16>(mode, n_own, n_other, K, other_block, d_E_own, d_E_other, d_kappa, d_part, st) \
-             : pois_dense_launch<T_, 32>(mode, n_own, n_other, K, other_block, d_E_own, d_E_other, d_kappa, d_part, st))
-  return dtype == MU_DTYPE_F32 ? MU_D(float) : MU_D(double);
+#define MU_D(T_, KP_) pois_dense_launch<T_, KP_>(mode, n_own, n_other, K, ld, other_block, d_E_own, d_E_other, d_kappa, d_part, st)
+#define MU_DK(T_) (K <= 4 ? MU_D(T_, 4) : K <= 8 ? MU_D(T_, 8) : K <= 12 ? MU_D(T_, 12) : K <= 16 ? MU_D(T_, 16) : MU_D(T_, 32))
+  return dtype == MU_DTYPE_F32 ? MU_DK(float) : MU_DK(double);
+#undef MU_DK
 #undef MU_D
+}
+
+int mu_mofa_poisson_dense(int dtype, int mode, int64_t n_own, int64_t n_other, int K, int64_t other_block,
+                          const void* d_E_own, const void* d_E_other, const void* d_kappa, void* d_part, void* stream) {
+  MU_REQUIRE(K >= 1 && K <= 32, "1 <= K <= 32");
+  return mu_mofa_poisson_dense_ld(dtype, mode, n_own, n_other, K, pois_padded_width(K), other_block, d_E_own, d_E_other,
+                                  d_kappa, d_part, stream);
+}
+
+int mu_mofa_poisson_sparse_ld(int dtype, int mode, int64_t n_own, int K, int ld, const int64_t* d_indptr,
+                              const int32_t* d_indices, const void* d_values, const void* d_E_own, const void* d_E_other,
+                              void* d_out, void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  MU_REQUIRE(mode >= 0 && mode <= 3 && K >= 1 && K <= 32, "mode 0..3, 1 <= K <= 32");
+  MU_REQUIRE(ld >= pois_padded_width(K) && ld % 4 == 0, "ld: a multiple of 4, at least the padded width of K");
+  if (n_own <= 0) return MU_OK;
+  MU_REQUIRE(d_indptr && d_E_own && d_E_other && d_out, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+#define MU_S(T_, KP_) pois_sparse_launch<T_, KP_>(mode, n_own, K, ld, d_indptr, d_indices, d_values, d_E_own, d_E_other, d_out, st)
+#define MU_SK(T_) (K <= 4 ? MU_S(T_, 4) : K <= 8 ? MU_S(T_, 8) : K <= 12 ? MU_S(T_, 12) : K <= 16 ? MU_S(T_, 16) : MU_S(T_, 32))
+  return dtype == MU_DTYPE_F32 ? MU_SK(float) : MU_SK(double);
+#undef MU_SK
+#undef MU_S
 }
 
 int mu_mofa_poisson_sparse(int dtype, int mode, int64_t n_own, int K, const int64_t* d_indptr, const int32_t* d_indices,
                            const void* d_values, const void* d_E_own, const void* d_E_other, void* d_out, void* stream) {
-  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
-  MU_REQUIRE(mode >= 0 && mode <= 3 && K >= 1 && K <= 32, "mode 0..3, 1 <= K <= 32");
-  if (n_own <= 0) return MU_OK;
-  MU_REQUIRE(d_indptr && d_E_own && d_E_other && d_out, "null pointer");
-  hipStream_t st = (hipStream_t)stream;
-#define MU_S(T_)                                                                                                       \
-  (K <= 4    ? pois_sparse_launch<T_, 4>(mode, n_own, K, d_indptr, d_indices, d_values, d_E_own, d_E_other, d_out, st)  \
-   : K <= 8  ? pois_sparse_launch<T_, 8>(mode, n_own, K, d_indptr, d_indices, d_values, d_E_own, d_E_other, d_out, st)  \
-   : K <= 12 ? pois_sparse_launch<T_, 12>(mode, n_own, K, d_indptr, d_indices, d_values, d_E_own, d_E_other, d_out, st) \
-   : K <= 16 ? pois_sparse_launch<T_, 16>(mode, n_own, K, d_indptr, d_indices, d_values, d_E_own, d_E_other, d_out, st) \
-             : pois_sparse_launch<T_, 32>(mode, n_own, K, d_indptr, d_indices, d_values, d_E_own, d_E_other, d_out, st))
-  return dtype == MU_DTYPE_F32 ? MU_S(float) : MU_S(double);
-#undef MU_S
+  MU_REQUIRE(K >= 1 && K <= 32, "1 <= K <= 32");
+  return mu_mofa_poisson_sparse_ld(dtype, mode, n_own, K, pois_padded_width(K), d_indptr, d_indices, d_values, d_E_own,
+                                   d_E_other, d_out, stream);
 }
 
 }  // extern "C"

@@ -31,13 +31,13 @@ int mu_num_cus() {
 }
 
 // tuning / ablation knobs (tests and bench only)
-static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "gram_wg", "pack_wg", "tpack_dbg", "spmm_narrow_off", "ell_mode", "tfidf_wide", "tfidf_pipe", "nn_interleave", "tfidf_abl", "tfidf_sum_m", "tn_pipe", "nn_fast_off", "stream_pipe", "tpack4_m", "tpack4_c", "scale_stream_off", "tpack4_plain", "tpack4_abl", "tpack4_late", "tpack4_circ", "tpack4_off", "pois_valu"};
+static const char* const kTuneKeys[] = {"spmm_k", "spmm_mode", "gram_wg", "pack_wg", "tpack_dbg", "spmm_narrow_off", "ell_mode", "tfidf_wide", "tfidf_pipe", "nn_interleave", "tfidf_abl", "tfidf_sum_m", "tn_pipe", "nn_fast_off", "stream_pipe", "tpack4_m", "tpack4_c", "scale_stream_off", "tpack4_plain", "tpack4_abl", "tpack4_late", "tpack4_circ", "tpack4_off", "pois_valu", "pois_lane"};
 constexpr int kTuneN = sizeof(kTuneKeys) / sizeof(kTuneKeys[0]);
 static int g_tune[kTuneN] = {};
 
 extern "C" {
 
-int mu_version(void) { return 600; }  // r06: mu_spmm_stream_ranges_f32, mu_csr_slice_stream, mu_tpack4_cnt_offset / _err_offset added; the matrix-core SpMM experiment (mu_cells_*, mu_dense_to_f16, mu_spmm_cells_f32, mu_probe_*) and the third-generation transposition (mu_csr_tpack_*) removed (archived: scripts/probes/spmm_mfma.hip, tpack_v3.hip);  // r05: mu_tfidf_scale_sweep_stream, mu_tpack4_* (the transposition on the row stream);  // r04: matrix-core SpMM (mu_cells_*, mu_dense_to_f16, mu_spmm_cells_f32, probes);  // r03: mu_mofa_rowstats, mu_mofa_gs_update, mu_mofa_poisson_pseudo, mu_mofa_jaakkola, mu_csr_densify_rows, mu_knn_filter_f64, mu_wnn_bandwidth_f64, mu_umap_strengths_f64 added, mu_mofa_update_z takes d_corr, mu_spmm_ws_* removed
+int mu_version(void) { return 601; }  // r06 (601): mu_mofa_poisson_blocks_for, mu_mofa_poisson_dense_ld / _sparse_ld (row stride of the factor blocks);  // r06: mu_spmm_stream_ranges_f32, mu_csr_slice_stream, mu_tpack4_cnt_offset / _err_offset added; the matrix-core SpMM experiment (mu_cells_*, mu_dense_to_f16, mu_spmm_cells_f32, mu_probe_*) and the third-generation transposition (mu_csr_tpack_*) removed (archived: scripts/probes/spmm_mfma.hip, tpack_v3.hip);  // r05: mu_tfidf_scale_sweep_stream, mu_tpack4_* (the transposition on the row stream);  // r04: matrix-core SpMM (mu_cells_*, mu_dense_to_f16, mu_spmm_cells_f32, probes);  // r03: mu_mofa_rowstats, mu_mofa_gs_update, mu_mofa_poisson_pseudo, mu_mofa_jaakkola, mu_csr_densify_rows, mu_knn_filter_f64, mu_wnn_bandwidth_f64, mu_umap_strengths_f64 added, mu_mofa_update_z takes d_corr, mu_spmm_ws_* removed
 
 int mu_tune_set(const char* key, int value) {
   MU_REQUIRE(key, "null key");

@@ -7,7 +7,7 @@ cd /tmp
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU" "SQ_INST_LEVEL_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $grp -d "$OUT/p$i" -o pmc --output-format csv -- python "$ROOT/scripts/probes/pois_mfma_probe.py" "$@" > "$OUT/p$i.log" 2>&1
+  timeout 200 rocprofv3 --pmc $grp -d "$OUT/p$i" -o pmc --output-format csv -- python "$ROOT/${PROBE:-scripts/probes/pois_mfma_probe.py}" "$@" > "$OUT/p$i.log" 2>&1
   echo "pass $i rc=$?"
 done
 cd "$ROOT"

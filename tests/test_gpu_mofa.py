@@ -384,6 +384,67 @@ def test_poisson_passes_without_the_dense_chunk(dt, tol, K):
     assert abs(lik - want[2].sum()) <= tol * abs(want[2].sum())
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-11), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("K,ld", [(3, 4), (7, 8), (10, 12), (10, 16), (13, 16), (16, 16), (16, 20), (20, 32)])
+def test_poisson_stored_entries_ragged_rows(dt, tol, K, ld):
+    """mu_mofa_poisson_sparse_ld alone (the correction over the stored entries, added to a given array) against numpy f64:
+    rows of 0, 1, .. entries around every batch size of the two kernels (16 / 64 entries per step, 128 / 256 per batch),
+    both kernels where both exist (four lanes per entry at 9 <= K <= 16 - tune key pois_lane selects the lane-per-entry
+    one), row strides at and above the padded width, predictions far below zero (the rate needs its RELATIVE accuracy
+    there: ln(1 + e^z) by Kahan's quotient), every mode."""
+    from muon_amd._backend import _dt, _p, check, get_backend
+
+    be = get_backend()
+    rng = np.random.default_rng(K * 100 + ld)
+    lens = [0, 1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 0, 513, 700]
+    n_own, n_other = len(lens), 900
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(n_other, size=n, replace=False)) for n in lens] + [[]]).astype(np.int32)
+    vals = rng.integers(1, 9, size=indices.size).astype(np.float64)
+    Eo = np.zeros((n_own, ld)); Eo[:, :K] = rng.standard_normal((n_own, K)) * 1.5
+    Et = np.zeros((n_other, ld)); Et[:, :K] = rng.standard_normal((n_other, K)) * 1.5
+    for j in indices[indptr[5]:indptr[5] + 6]:  # a row with predictions of exactly -40 (and whatever the rest gives)
+        Et[j, :K] = -40.0 * Eo[5, :K] / np.sum(Eo[5, :K] ** 2)
+    npdt = np.float32 if dt == torch.float32 else np.float64
+    Eo, Et = Eo.astype(npdt).astype(np.float64), Et.astype(npdt).astype(np.float64)
+    dev = lambda a, t=dt: torch.from_numpy(np.ascontiguousarray(a)).to(be.device).to(t).contiguous()
+    ip, ix, vd, Eod, Etd = dev(indptr, torch.int64), dev(indices, torch.int32), dev(vals), dev(Eo), dev(Et)
+    want = {0: np.zeros((n_own, K)), 2: np.zeros(n_own)}
+    for i in range(n_own):
+        j = indices[indptr[i]:indptr[i + 1]]
+        y = vals[indptr[i]:indptr[i + 1]]
+        z = Et[j, :K] @ Eo[i, :K]
+        rate = np.maximum(np.logaddexp(0.0, z), 1e-300 if dt == torch.float64 else 1e-30)
+        want[0][i] = ((1.0 / (1.0 + np.exp(-z))) * y / rate) @ Et[j, :K]
+        want[2][i] = np.sum(y * np.log(rate))
+    assert np.min(Et[indices[indptr[5]:indptr[6]], :K] @ Eo[5, :K]) < -39
+    kernels = (0, 1) if 8 < K <= 16 else (0,)
+    try:
+        for lane_kernel in kernels:
+            be.lib.mu_tune_set(b"pois_lane", lane_kernel)
+            for mode in (0, 1, 2, 3):
+                shape = (n_own,) if mode == 2 else (n_own, K + 1 if mode == 3 else K)
+                out = torch.full(shape, 0.5, dtype=dt, device=be.device)
+                check(be.lib.mu_mofa_poisson_sparse_ld(_dt(Eod), mode, n_own, K, ld, _p(ip), _p(ix), _p(vd), _p(Eod),
+                                                       _p(Etd), _p(out), be._stream()))
+                got = be.to_host(out).astype(np.float64) - 0.5
+                if mode == 2:
+                    w = want[2]
+                elif mode == 3:
+                    w = np.concatenate([want[0], want[2][:, None]], axis=1)
+                else:
+                    w = want[0]
+                assert np.all(np.isfinite(got))
+                # per row: a row's terms against the row's own scale (the 0.5 the result is added to costs f32 its
+                # last bits: an absolute 1e-7 on top)
+                scale = np.maximum(np.max(np.abs(w.reshape(n_own, -1)), axis=1), 1.0)
+                err = np.max(np.abs(got - w).reshape(n_own, -1), axis=1)
+                bad = np.nonzero(err > tol * scale + (0 if dt == torch.float64 else 2e-7))[0]
+                assert bad.size == 0, (lane_kernel, mode, bad, (err / scale)[bad], [lens[i] for i in bad])
+    finally:
+        be.lib.mu_tune_set(b"pois_lane", 0)
+
+
 def _pois_dense_sweep(be, mode, Eo, Et, kap, K, blk=None):
     """mu_mofa_poisson_dense alone (no stored entries): the partial results folded in block order"""
     from muon_amd._backend import _dt, _p, check
