@@ -65,6 +65,13 @@ def _worker(rank, world, port, q):
                 "stdev": float(np.max(np.abs(stdev3 - stdev) / stdev)), "converged": bool(info3["converged"]),
                 "replicated": bool(torch.equal(comm.all_gather_rows(V3[:3].contiguous())[:3],
                                                comm.all_gather_rows(V3[:3].contiguous())[3:6]))}
+        # f64 arithmetic for f64 input (r06, tools._refine_f64): Y = X Q local, Z = X^T Y summed over the ranks, the d x w
+        # blocks replicated; the stop decisions are rank 0's
+        U4, stdev4, V4, info4 = lsi_device(be, T, n_comps=8, n_obs=n, comm=comm, return_info=True, refine_f64=True)
+        refine = {"dtype": str(V4.dtype), "bound": info4["refine_f64"]["angle_bound"], "blocks": info4["refine_f64"]["blocks"],
+                  "V": V4.numpy(), "stdev": stdev4, "U": comm.all_gather_rows(U4.contiguous()).numpy(),
+                  "replicated": bool(torch.equal(comm.all_gather_rows(V4[:3].contiguous())[:3],
+                                                 comm.all_gather_rows(V4[:3].contiguous())[3:6]))}
         rows_probe = torch.arange(14, dtype=torch.float64).reshape(7, 2) * (rank + 1)  # (7 rows, 2 ranks: chunks of 4 and 3)
         r0, r1 = comm.reduce_scatter_rows(rows_probe)
         own_ok = bool(torch.equal(rows_probe[r0:r1], 3 * torch.arange(14, dtype=torch.float64).reshape(7, 2)[r0:r1]))
@@ -110,7 +117,7 @@ def _worker(rank, world, port, q):
         if rank == 0:
             q.put({"tfidf": T.values.numpy(), "U": Uall.numpy(), "stdev": stdev, "V": V.numpy(),
                    "elbo": res["elbo"], "Z": Zall.numpy(), "W": res["W"], "iters": info["iterations"],
-                   "elbo_x": elbo_x, "modes_x": modes, "rsag_same": rsag_same, "rsqr": rsqr,
+                   "elbo_x": elbo_x, "modes_x": modes, "rsag_same": rsag_same, "rsqr": rsqr, "refine": refine,
                    "g_elbo": gres["elbo"], "g_Z": gZ.numpy(), "g_W": gres["W"], "g_r2": gres["r2"]})
     finally:
         dist.destroy_process_group()
@@ -154,6 +161,15 @@ def test_world_size_2_matches_single_process():
     assert r["halves"] and r["replicated"] and r["converged"] and r["iters"] == got["iters"], r
     assert r["angle"] < 1e-6 and r["stdev"] < 1e-6, r
     assert lsi_oracle.max_subspace_angle(got["U"], U.numpy()) < 5e-4
+    # the f64 continuation on two ranks against the same on one, and against f64 ARPACK of the same operand
+    f = got["refine"]
+    U64, stdev64, V64, i64 = lsi_device(be, T, n_comps=8, n_obs=600, return_info=True, refine_f64=True)
+    assert f["dtype"] == "torch.float64" and f["replicated"] and f["bound"] <= 1e-6 and f["blocks"] == i64["refine_f64"]["blocks"]
+    assert lsi_oracle.max_subspace_angle(f["V"], V64.numpy()) < 1e-7  # (two starts from two f32 runs, each inside its bound)
+    np.testing.assert_allclose(f["stdev"], stdev64, rtol=1e-10)
+    np.testing.assert_allclose(np.abs(f["U"]), np.abs(U64.numpy()), atol=1e-7)
+    Tsp = sp.csr_matrix((T.values.numpy().astype(np.float64), T.indices.numpy(), T.indptr.numpy()), shape=T.shape)
+    assert lsi_oracle.max_subspace_angle(f["V"], lsi_oracle.lsi(Tsp, n_comps=8)["LSI"]) < 1e-7
 
     rng = np.random.default_rng(0)
     Z = rng.standard_normal((120, 4))

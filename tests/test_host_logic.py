@@ -541,3 +541,48 @@ def test_roctx_ranges_are_balanced_and_off_by_default(monkeypatch):
     assert names == ["lsi/operands", "lsi/warm_start", "lsi/krylov", "lsi/ritz_vectors"]
     assert sum(k == "push" for k, _ in calls) == sum(k == "pop" for k, _ in calls) and _trace._depth[0] == 0
     np.testing.assert_array_equal(sd0, sd1)
+
+
+def test_f64_input_is_answered_in_f64_arithmetic():
+    """the reference runs f64 ARPACK on an f64 X (/root/reference/muon/_atac/tools.py:53).  The f32
+    Krylov process stops at the f32 floor; for f64 input it is continued in f64 (tools._refine_f64: f64 blocks, products
+    accumulated in f64, exact residuals): a 1.3 % gap - the hardest gapped case of the suite - comes out below 1e-6 rad of
+    f64 ARPACK where f32 arithmetic gives ~1e-5, singular values to 1e-9, outputs f64; f32 input keeps the f32 path."""
+    from muon_amd._atac.tools import lsi_device
+
+    X = planted_topics_csr(3000, 2500, n_topics=80, density=0.03, seed=3, dtype=np.float64)
+    T = tfidf_oracle.canonical(tfidf_oracle.tfidf(X))
+    assert T.dtype == np.float64
+    ref = lsi_oracle.lsi(T, n_comps=50)
+    ad = AnnData(T.copy())
+    ac.tl.lsi(ad, n_comps=50, backend=BE)
+    assert ad.varm["LSI"].dtype == np.float64 and ad.obsm["X_lsi"].dtype == np.float64
+    ang = lsi_oracle.max_subspace_angle(ad.varm["LSI"], ref["LSI"])
+    assert ang < 1e-6, ang
+    np.testing.assert_allclose(ad.uns["lsi"]["stdev"], ref["stdev"], rtol=1e-8)  # (the operand's VALUES stay f32: 8e-10)
+    # the embeddings: scaled like the reference's (zero mean, unit population variance), same subspace
+    np.testing.assert_allclose(ad.obsm["X_lsi"].mean(axis=0), 0, atol=1e-12)
+    np.testing.assert_allclose(ad.obsm["X_lsi"].std(axis=0), 1, rtol=1e-10)
+    assert lsi_oracle.max_subspace_angle(ad.obsm["X_lsi"] - ad.obsm["X_lsi"].mean(axis=0),
+                                         ref["X_lsi"] - ref["X_lsi"].mean(axis=0)) < 1e-5
+    # what the refinement reports, and what f32 arithmetic alone reaches on the same matrix
+    Xd = BE.upload_csr(T.indptr, T.indices, T.data, T.shape, values_dtype=np.float32)
+    _, sd32, V32, i32 = lsi_device(BE, Xd, n_comps=50, return_info=True)
+    _, sd64, V64, i64 = lsi_device(BE, Xd, n_comps=50, return_info=True, refine_f64=True)
+    assert V32.dtype == torch.float32 and V64.dtype == torch.float64 and i32["refine_f64"] is None
+    r = i64["refine_f64"]
+    assert 1 <= r["blocks"] <= 8 and r["angle_bound"] <= 1e-6 and i64["spmm"] == i32["spmm"] + 2 * r["blocks"]
+    a32 = lsi_oracle.max_subspace_angle(V32.numpy(), ref["LSI"])
+    a64 = lsi_oracle.max_subspace_angle(V64.numpy(), ref["LSI"])
+    assert a64 < 1e-7 and a64 < 0.2 * a32 and a32 < 1e-4, (a32, a64)  # (4.4e-8: what rounding the VALUES to f32 costs)
+    # a 0.16 % gap (k = 26 on the same matrix): still below 1e-6 rad, by the refinement's own bound and against ARPACK
+    ref26 = lsi_oracle.lsi(T, n_comps=26)
+    _, _, V26, i26 = lsi_device(BE, Xd, n_comps=26, return_info=True, refine_f64=True)
+    assert 1e-3 < i26["gap_rel"] < 2e-3 and i26["refine_f64"]["angle_bound"] <= 1e-6 and i26["converged"]
+    assert lsi_oracle.max_subspace_angle(V26.numpy(), ref26["LSI"]) < 1e-6
+    # unscaled embeddings: unit columns, U diag(s) = X V
+    U, sd, V, _ = lsi_device(BE, Xd, n_comps=50, scale_embeddings=False, return_info=True, refine_f64=True)
+    np.testing.assert_allclose(np.linalg.norm(U.numpy(), axis=0), 1, rtol=1e-12)
+    s = sd * np.sqrt(T.shape[0] - 1)
+    XV = T.astype(np.float32).astype(np.float64) @ V.numpy()
+    np.testing.assert_allclose(U.numpy() * s, XV, atol=1e-9 * s[0])
