@@ -537,6 +537,16 @@ int mu_mofa_tau_elbo(int dtype, int64_t D, int K, int G, const void* d_yy, const
                      const void* d_EW, const void* d_EW2, const void* d_B, const void* d_Gz,
                      const void* d_Z2, double a0, double b0, void* d_tau, void* d_ltau, double* d_elbo,
                      double* d_work, void* stream);
+/* r06, for views whose statistics are per FEATURE (a dense gaussian view with missing entries in the general engine): the
+ * expected squared residual S[d] = yy[d] - 2 <w_d> . B[d] + sum_kl Q[d][k, l] <w w^T>_d[k, l] (Q [q_rows x K^2], q_rows = D
+ * or 1 = the same block for every feature; <w w^T>[k, k] = <w_k^2>) in f64, and the node's finish for n = G x D (group,
+ * feature) pairs with their own f64 counts: a = a0 + N / 2, b = b0 + S / 2, tau = a / b, <ln tau> = psi(a) - ln b, the
+ * likelihood and tau-node terms ADDED to *d_elbo (work: mu_mofa_elbo_work_doubles).  Between the two the caller sums S and
+ * N over the ranks. */
+int mu_mofa_stats_resid(int dtype, int64_t D, int K, int64_t q_rows, const double* d_yy, const void* d_EW,
+                        const void* d_EW2, const void* d_B, const void* d_Q, double* d_S, void* stream);
+int mu_mofa_tau_finish(int dtype, int64_t n, const double* d_S, const double* d_Ngd, double a0, double b0, void* d_tau,
+                       void* d_ltau, double* d_elbo, double* d_work, void* stream);
 /* ARD precision (ard != 0: alpha[K], lalpha[K] = <ln alpha>) and sparsity level (spikeslab != 0:
  * lth[K] = <ln theta>, l1mth[K] = <ln(1 - theta)>) of one view's weights from EWh2, gamma, sig2
  * [D][K] (outputs of mu_mofa_update_w), and the ELBO terms of the W, alpha_w and theta nodes.

@@ -1343,7 +1343,7 @@ class HipBackend:
 
     mofa_poisson_lik_with_b = True  # (mode 3 of mofa_poisson_pass)
 
-    def mofa_poisson_pass(self, mode: int, E_own, E_other, kappa, X: DeviceCSR):
+    def mofa_poisson_pass(self, mode: int, E_own, E_other, kappa, X: DeviceCSR, pads: Optional[dict] = None):
         """One pass of a poisson view without anything N x D (csrc/mofa_poisson.hip, include/muon_amd.h): mode 0 ->
         a = R <W> [N, K] (E_own = <Z>, E_other = <W>, X = the view), mode 1 -> b = R^T <Z> [D, K] (E_own = <W>, E_other =
         <Z>, X = the view's transpose), mode 2 -> per-sample likelihood terms [N], mode 3 -> mode 1 with the per-feature
@@ -1356,14 +1356,24 @@ class HipBackend:
         # 9 <= K <= 12 too - 64-byte rows let the stored-entry pass read a row in one cache-line look-up (r06)
         ld = 16 if 8 < K <= 16 else next(k for k in (4, 8, 32) if k >= K)
 
-        def pad(E):
+        def pad(E, slot):
             if K == ld and E.is_contiguous():
                 return E
-            P = torch.zeros((E.shape[0], ld), dtype=E.dtype, device=E.device)
-            P[:, :K] = E
+            # `pads` (a dict the caller owns, e.g. the engine of a fit): a padded buffer per (role, shape) whose columns
+            # K .. ld - 1 are zeroed once - a pass copies the K columns in, one kernel instead of a fill and a copy.
+            # Calls are ordered on one stream and a pass has consumed its operands when the next one overwrites them;
+            # the buffers live as long as the caller (a captured iteration keeps pointing at them).
+            if pads is None:
+                P = torch.zeros((E.shape[0], ld), dtype=E.dtype, device=E.device)
+            else:
+                key = (slot, int(E.shape[0]), ld, K, E.dtype)
+                P = pads.get(key)
+                if P is None:
+                    P = pads[key] = torch.zeros((E.shape[0], ld), dtype=E.dtype, device=E.device)
+            P[:, :K].copy_(E)
             return P
 
-        E_own, E_other = pad(E_own), pad(E_other)
+        E_own, E_other = pad(E_own, "own"), pad(E_other, "other")
         blk = int(self.lib.mu_mofa_poisson_blocks_for(_dt(E_own), int(mode), K, n_own, n_other))
         nb = -(-n_other // blk)
         part = self.empty((nb, n_own) if mode == 2 else (nb, n_own, K + 1 if mode == 3 else K), E_own.dtype)
@@ -1397,6 +1407,26 @@ class HipBackend:
             check(self.lib.mu_mofa_tau_elbo(_dt(EW), D, K, G, _p(yy), _p(Ngm), _p(EW), _p(EW2), _p(B), _p(Gz),
                                             _p(Z2), float(a0), float(b0), _p(tau), _p(ltau), _p(elbo),
                                             _p(work), self._stream()))
+
+    def mofa_stats_resid(self, yy, EW, EW2, B, Q, S):
+        """S[d] = yy[d] - 2 <w_d> . B[d] + sum Q[d] * <w w^T>_d in f64 (include/muon_amd.h): yy, S f64 [D]; EW, EW2, B [D, K];
+        Q [D or 1, K^2]"""
+        D, K = EW.shape
+        assert yy.dtype == torch.float64 and S.dtype == torch.float64 and yy.is_contiguous() and S.is_contiguous()
+        assert EW.is_contiguous() and EW2.is_contiguous() and B.is_contiguous() and Q.is_contiguous()
+        assert B.shape == (D, K) and Q.shape[1] == K * K and Q.shape[0] in (1, D) and B.dtype == EW.dtype == Q.dtype
+        with self._dev_ctx():
+            check(self.lib.mu_mofa_stats_resid(_dt(EW), int(D), int(K), int(Q.shape[0]), _p(yy), _p(EW), _p(EW2), _p(B),
+                                               _p(Q), _p(S), self._stream()))
+
+    def mofa_tau_finish(self, S, Ngd, a0, b0, tau, ltau, elbo, work):
+        """tau / <ln tau> from the expected squared residuals and counts of every (group, feature) (f64, same shape as
+        tau); adds the likelihood and tau-node terms to the f64 device scalar ``elbo`` (include/muon_amd.h)."""
+        assert S.dtype == torch.float64 and Ngd.dtype == torch.float64 and S.is_contiguous() and Ngd.is_contiguous()
+        assert tau.is_contiguous() and ltau.is_contiguous() and tau.numel() == S.numel() == Ngd.numel() == ltau.numel()
+        with self._dev_ctx():
+            check(self.lib.mu_mofa_tau_finish(_dt(tau), int(S.numel()), _p(S), _p(Ngd), float(a0), float(b0), _p(tau),
+                                              _p(ltau), _p(elbo), _p(work), self._stream()))
 
     def mofa_w_elbo(self, EWh2, gamma, sig2, ard, spikeslab, a_alpha, a0, b0, th_a0, th_b0, alpha, lalpha,
                     lth, l1mth, elbo, work):

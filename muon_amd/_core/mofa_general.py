@@ -125,8 +125,8 @@ class GeneralMofaEngine:
         self.EZh2 = self.EZ2.clone()
         self.lthz = torch.full((G, K), c, dtype=torch.float64, device=self.dev)
         self.l1mthz = torch.full((G, K), c, dtype=torch.float64, device=self.dev)
+        self._elbo_work = backend.mofa_elbo_work(K) if hasattr(backend, "mofa_elbo_work") and K <= 32 else None
         if self._fused_small:
-            self._elbo_work = backend.mofa_elbo_work(K)
             self._zs = torch.zeros((G, 2, K), dtype=torch.float64, device=self.dev)
         self.elbo = []
         self._Ng_dev = self.Ng.to(self.dev)  # (resident: an iteration has no host -> device copies)
@@ -146,6 +146,7 @@ class GeneralMofaEngine:
         self._zver = 0      # state counter of the factors (the cached statistics of _gauss_stats belong to one state)
         self._gstats = {}
         self._wver = [0] * self.M  # ... and of every view's weights: b = R^T <Z> of a fused poisson view made by the ELBO
+        self._pois_pads = {}       # padded factor blocks of the poisson passes (HipBackend.mofa_poisson_pass)
         self._bnext = {}           # pass (mode 3 of mofa_poisson_pass) serves the next W update if neither has changed
 
     # -- collectives ------------------------------------------------------------------------------
@@ -358,9 +359,22 @@ class GeneralMofaEngine:
         """rows -> K^2 columns: <e e^T> with the diagonal replaced by the second moments."""
         n, K = E.shape
         P = E[:, :, None] * E[:, None, :]
-        idx = torch.arange(K, device=E.device)
-        P[:, idx, idx] = E2
+        P.diagonal(dim1=1, dim2=2).copy_(E2)  # (one strided copy: no index tensor, no gather / scatter kernels)
         return P.reshape(n, K * K)
+
+    def _z_outer(self):
+        """<z z^T> rows of ALL local samples [N, K^2] for the current factors: the W update of a fused poisson view (its
+        column sums) and the statistics of every dense gaussian view (rows times the mask) read the same block"""
+        hit = getattr(self, "_zouter", None)
+        if hit is None or hit[0] != self._zver:
+            if hit is None or not self._graph_ok:
+                hit = self._zouter = [self._zver, self._outer_moments(self.EZ, self.EZ2)]
+            else:  # (a fixed buffer, written in place: see _gauss_stats)
+                P = hit[1].view(-1, self.K, self.K)
+                torch.mul(self.EZ[:, :, None], self.EZ[:, None, :], out=P)
+                P.diagonal(dim1=1, dim2=2).copy_(self.EZ2)
+                hit[0] = self._zver
+        return hit[1]
 
     def _gauss_stats(self, m):
         """(B, Q) of a dense gaussian view for the CURRENT factors: B[g] = Y_g^T <Z_g> [D, K], Q[g] = M_g^T P_g [D, K^2]
@@ -377,7 +391,7 @@ class GeneralMofaEngine:
             return hit[1], hit[2]
         for g, (a0, b0) in enumerate(self.gslice):
             Zg = self.EZ[a0:b0]
-            P = self._outer_moments(Zg, self.EZ2[a0:b0])
+            P = self._z_outer()[a0:b0]
             torch.matmul(V.Y[a0:b0].T, Zg, out=hit[1][g])
             if V.mask is not None:
                 torch.matmul(V.mask[a0:b0].T, P, out=hit[2][g])
@@ -389,23 +403,28 @@ class GeneralMofaEngine:
     # -- one coordinate-ascent sweep -------------------------------------------------------------------
     def _update_w(self, m):
         V, Wm, K = self.views[m], self.W[m], self.K
-        Tm = torch.zeros((V.D, K * K), dtype=self.T, device=self.dev)
-        b = torch.zeros((V.D, K), dtype=self.T, device=self.dev)
+        # (the statistics are built from their first term, not added to zeros: an iteration of the poisson benchmark is
+        #  ~130 small tensor kernels at ~5 us each next to 1 ms of passes - every fill and "+=" that is not needed counts)
         if getattr(V, "fused", False):
             # Omega does not depend on the sample: T_d = kappa_d sum_n <z_n z_n^T>; b = R^T <Z> without R
-            Tm += V.kappa[:, None] * self._outer_moments(self.EZ, self.EZ2).sum(dim=0)[None, :]
+            Tm = V.kappa[:, None] * self._z_outer().sum(dim=0)[None, :]
             hit = self._bnext.get(m)
             if hit is not None and hit[0] == (self._zver, self._wver[m]):
-                b += hit[1]  # (made by the tau / ELBO pass of the iteration before, in the same sweep as its likelihood term)
+                # (made by the tau / ELBO pass of the iteration before, in the same sweep as its likelihood term; only
+                #  read below, unless the ranks add theirs up in place)
+                b = hit[1].clone() if getattr(self.comm, "world_size", 1) > 1 else hit[1]
             else:
-                b += self.be.mofa_poisson_pass(1, Wm.EW.contiguous(), self.EZ.contiguous(), V.kappa.contiguous(), V.Xt)
+                b = self.be.mofa_poisson_pass(1, Wm.EW.contiguous(), self.EZ.contiguous(), V.kappa.contiguous(), V.Xt, pads=self._pois_pads)
         elif V.stats:
             Bs, Qs = self._gauss_stats(m)
+            Tm = b = None
             for g in range(self.G):
                 tau = Wm.tau[g][:, None]
-                Tm += tau * Qs[g]
-                b += tau * Bs[g]
+                Tm = tau * Qs[g] if Tm is None else Tm.addcmul_(tau, Qs[g])
+                b = tau * Bs[g] if b is None else b.addcmul_(tau, Bs[g])
         else:
+            Tm = torch.zeros((V.D, K * K), dtype=self.T, device=self.dev)
+            b = torch.zeros((V.D, K), dtype=self.T, device=self.dev)
             for g, (a0, b0) in enumerate(self.gslice):
                 for lo, hi, Y, M in self._chunks(V, a0, b0):
                     Zc, Z2c = self.EZ[lo:hi], self.EZ2[lo:hi]
@@ -454,16 +473,22 @@ class GeneralMofaEngine:
                    + [self._rows_per_chunk(K * K)])
         # fused poisson views: a = R <W> for ALL samples at once (a sample's row depends on its own <z_n> only, which
         # changes in its own chunk, after use) and the sample-independent S
-        fused = {m: (self.be.mofa_poisson_pass(0, self.EZ.contiguous(), self.W[m].EW.contiguous(), V.kappa.contiguous(), V.X),
+        fused = {m: (self.be.mofa_poisson_pass(0, self.EZ.contiguous(), self.W[m].EW.contiguous(), V.kappa.contiguous(), V.X, pads=self._pois_pads),
                      V.kappa @ WW[m])
                  for m, V in enumerate(self.views) if getattr(V, "fused", False)}
         for g, (a0, b0) in enumerate(self.gslice):
             for lo in range(a0, b0, step):
                 hi = min(b0, lo + step)
                 Zc, Z2c = self.EZ[lo:hi], self.EZ2[lo:hi]
-                S = torch.zeros((hi - lo, K * K), dtype=self.T, device=self.dev)
-                a = torch.zeros((hi - lo, K), dtype=self.T, device=self.dev)
-                for m, V in enumerate(self.views):
+                # (views whose share is a product come first and START the sums - see _update_w; row-constant shares
+                #  and chunk-walked views add to them)
+                S = a = None
+                order = sorted(range(self.M), key=lambda m: 0 if (self.views[m].stats and m not in fused) else 1)
+                for m in order:
+                    V = self.views[m]
+                    if S is None and not (V.stats and m not in fused and V.mask is not None):
+                        S = torch.zeros((hi - lo, K * K), dtype=self.T, device=self.dev)
+                        a = torch.zeros((hi - lo, K), dtype=self.T, device=self.dev)
                     if m in fused:
                         S += fused[m][1][None, :]
                         a += fused[m][0][lo:hi]
@@ -471,6 +496,10 @@ class GeneralMofaEngine:
                     if V.stats:
                         tau = self.W[m].tau[g][:, None]
                         if V.mask is not None:
+                            if S is None:
+                                S = V.mask[lo:hi] @ (tau * WW[m])
+                                a = V.Y[lo:hi] @ (tau * self.W[m].EW)
+                                continue
                             S += V.mask[lo:hi] @ (tau * WW[m])
                         else:
                             S += (tau * WW[m]).sum(dim=0)[None, :]
@@ -525,13 +554,19 @@ class GeneralMofaEngine:
         f64 = torch.float64
         lik = torch.zeros((), dtype=f64, device=self.dev)
         for m, (V, Wm) in enumerate(zip(self.views, self.W)):
-            S = torch.zeros((G, V.D), dtype=f64, device=self.dev)
-            Ngd = torch.zeros((G, V.D), dtype=f64, device=self.dev)
-            part = torch.zeros((), dtype=f64, device=self.dev)
-            W2, Wsq = Wm.EW2, Wm.EW ** 2
+            # a stats view's expected squared residuals in one kernel per group, its node in one more (csrc/mofa_elbo.hip:
+            # ~35 tensor launches per view and iteration otherwise); the tensor forms below remain for the CPU operator set
+            fast_stats = bool(V.stats and self._elbo_work is not None and hasattr(self.be, "mofa_stats_resid")
+                              and Wm.EW.dtype == self.T)
+            if not fast_stats:
+                S = torch.zeros((G, V.D), dtype=f64, device=self.dev)
+                Ngd = torch.zeros((G, V.D), dtype=f64, device=self.dev)
+            part = torch.zeros((), dtype=f64, device=self.dev) if V.lik != "gaussian" else None
+            chunked = not (getattr(V, "fused", False) or V.stats)
+            W2, Wsq = (Wm.EW2, Wm.EW ** 2) if chunked else (None, None)
             if getattr(V, "fused", False) and getattr(self.be, "mofa_poisson_lik_with_b", False):
                 # the likelihood term and the NEXT W update's b = R^T <Z> read the same predictions: one sweep (r05)
-                out = self.be.mofa_poisson_pass(3, Wm.EW.contiguous(), self.EZ.contiguous(), V.kappa.contiguous(), V.Xt)
+                out = self.be.mofa_poisson_pass(3, Wm.EW.contiguous(), self.EZ.contiguous(), V.kappa.contiguous(), V.Xt, pads=self._pois_pads)
                 hit = self._bnext.get(m)
                 if hit is None:  # (a fixed buffer, written in place: a captured iteration finds the previous replay's b)
                     hit = self._bnext[m] = [None, torch.empty((V.D, K), dtype=self.T, device=self.dev)]
@@ -539,8 +574,14 @@ class GeneralMofaEngine:
                 hit[0] = (self._zver, self._wver[m])
                 part += out[:, K].sum(dtype=f64)
             elif getattr(V, "fused", False):
-                part += self.be.mofa_poisson_pass(2, self.EZ.contiguous(), Wm.EW.contiguous(), None, V.X).sum(dtype=f64)
-            if V.stats:
+                part += self.be.mofa_poisson_pass(2, self.EZ.contiguous(), Wm.EW.contiguous(), None, V.X, pads=self._pois_pads).sum(dtype=f64)
+            if V.stats and fast_stats:
+                Bs, Qs = self._gauss_stats(m)
+                S = torch.empty((G, V.D), dtype=f64, device=self.dev)
+                for g in range(G):
+                    self.be.mofa_stats_resid(V.yyM[g], Wm.EW, Wm.EW2, Bs[g], Qs[g], S[g])
+                Ngd = V.Ngd.clone() if self.comm.world_size > 1 else V.Ngd  # (the ranks' sum is taken in place)
+            elif V.stats:
                 Bs, Qs = self._gauss_stats(m)
                 WWm = self._outer_moments(Wm.EW, Wm.EW2)
                 for g in range(G):
@@ -568,7 +609,10 @@ class GeneralMofaEngine:
                     else:
                         t = Y * zeta - torch.nn.functional.softplus(zeta)
                         part += ((t * M) if M is not None else t).sum().to(f64)
-            if V.lik == "gaussian":
+            if V.lik == "gaussian" and fast_stats:
+                S, Ngd = self._allreduce(S, Ngd)
+                self.be.mofa_tau_finish(S, Ngd, A0, B0, Wm.tau, Wm.ltau, lik, self._elbo_work)  # (lik += the view's terms)
+            elif V.lik == "gaussian":
                 S, Ngd = self._allreduce(S, Ngd)
                 a = A0 + 0.5 * Ngd
                 b = B0 + 0.5 * S

@@ -126,6 +126,8 @@ SIGNATURES = {
     "mu_mofa_gs_update": (C.c_int, [_i32, _i64, _i32] + [_vp] * 5 + [_i32] + [_vp] * 6),
     "mu_mofa_elbo_work_doubles": (_sz, [_i32]),
     "mu_mofa_tau_elbo": (C.c_int, [_i32, _i64, _i32, _i32] + [_vp] * 7 + [_dbl, _dbl] + [_vp] * 5),
+    "mu_mofa_stats_resid": (C.c_int, [_i32, _i64, _i32, _i64] + [_vp] * 7),
+    "mu_mofa_tau_finish": (C.c_int, [_i32, _i64, _vp, _vp, _dbl, _dbl] + [_vp] * 5),
     "mu_mofa_w_elbo": (C.c_int, [_i32, _i64, _i32, _i32, _i32] + [_vp] * 3 + [_dbl] * 5 + [_vp] * 7),
     "mu_mofa_z_sums": (C.c_int, [_i32, _i64, _i64, _i32] + [_vp] * 5),
     "mu_mofa_z_elbo": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _dbl, _dbl] + [_vp] * 4),

@@ -94,6 +94,58 @@ __global__ __launch_bounds__(kET) void k_mofa_tau(int64_t D, int K, int G, const
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+// ---- the same node for a view whose statistics are per FEATURE (r06: a dense gaussian view with missing entries in
+// the general engine, csrc-side of muon_amd/_core/mofa_general.py) -------------------------------------------------------
+// With a mask the second moments of the factors do not factor out of the sum over the samples: Q[d] = sum_n M_nd <z z^T>_n
+// is a K x K block per feature (one row for all features without a mask).  Expected squared residual of feature d:
+//   S_d = yy_d - 2 <w_d> . B_d + sum_kl Q_d[k, l] <w w^T>_d[k, l],   <w w^T>[k, l] = <w_k><w_l> (k != l), <w_k^2> (k = l)
+// As tensor operations this and the node's finish below were ~35 launches of 3-8 us per view and iteration.
+template <typename T, int KP>
+__global__ __launch_bounds__(kET) void k_mofa_stats_resid(int64_t D, int K, int64_t q_rows, const double* __restrict__ yy,
+                                                          const T* __restrict__ EW, const T* __restrict__ EW2,
+                                                          const T* __restrict__ B, const T* __restrict__ Q,
+                                                          double* __restrict__ S) {
+  const int64_t d = (int64_t)blockIdx.x * kET + threadIdx.x;
+  if (d >= D) return;
+  double w[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) w[k] = (k < K) ? (double)EW[d * K + k] : 0.0;
+  const T* q = Q + (q_rows > 1 ? d : 0) * (int64_t)K * K;
+  double s = yy[d];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    if (k < K) {
+      double r = 0.0;
+#pragma unroll
+      for (int l = 0; l < KP; ++l)
+        if (l < K) r += (double)q[k * K + l] * (l == k ? (double)EW2[d * K + k] : w[k] * w[l]);
+      s += r - 2.0 * w[k] * (double)B[d * K + k];
+    }
+  }
+  S[d] = s;
+}
+
+// a = a0 + N/2, b = b0 + S/2, tau = a/b, <ln tau> = psi(a) - ln b for n = G x D (group, feature) pairs with their own
+// counts N (f64, summed over the ranks by the caller like S); the likelihood and tau-node terms into `partial`
+template <typename T>
+__global__ __launch_bounds__(kET) void k_mofa_tau_finish(int64_t n, const double* __restrict__ S,
+                                                         const double* __restrict__ Ngd, double a0, double b0,
+                                                         T* __restrict__ tau, T* __restrict__ ltau,
+                                                         double* __restrict__ partial) {
+  __shared__ double sh[kET];
+  double acc = 0.0;
+  for (int64_t id = (int64_t)blockIdx.x * kET + threadIdx.x; id < n; id += (int64_t)gridDim.x * kET) {
+    const double cnt = Ngd[id], s = S[id];
+    const double a = a0 + 0.5 * cnt, b = b0 + 0.5 * s;
+    const double t = a / b, lt = digamma_pos(a) - log(b);
+    tau[id] = (T)t;
+    ltau[id] = (T)lt;
+    acc += 0.5 * cnt * (lt - 1.8378770664093453) - 0.5 * t * s + gamma_kl(a0, b0, a, b, t, lt);  // ln 2 pi
+  }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
 // *elbo += sum of the partials, in order
 // (r05: 64 lanes take contiguous runs of the partials and the runs are added in lane order - one thread walking up to
 //  512 partials was 27 us behind a 15 us pass)
@@ -379,6 +431,50 @@ int mu_mofa_tau_elbo(int dtype, int64_t D, int K, int G, const void* d_yy, const
                           d_work, (hipStream_t)stream);
   return run_tau<double>(D, K, G, d_yy, d_Ngm, d_EW, d_EW2, d_B, d_Gz, d_Z2, a0, b0, d_tau, d_ltau, d_elbo,
                          d_work, (hipStream_t)stream);
+}
+
+int mu_mofa_stats_resid(int dtype, int64_t D, int K, int64_t q_rows, const double* d_yy, const void* d_EW,
+                        const void* d_EW2, const void* d_B, const void* d_Q, double* d_S, void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  MU_REQUIRE(K >= 1 && K <= 32, "1 <= n_factors <= 32");
+  MU_REQUIRE(D >= 0 && (q_rows == 1 || q_rows == D), "Q has one row or one per feature");
+  if (D == 0) return MU_OK;
+  MU_REQUIRE(d_yy && d_EW && d_EW2 && d_B && d_Q && d_S, "null pointer");
+  const unsigned nb = (unsigned)((D + kET - 1) / kET);
+  hipStream_t st = (hipStream_t)stream;
+#define MU_R(T_, KP_)                                                                                              \
+  hipLaunchKernelGGL((k_mofa_stats_resid<T_, KP_>), dim3(nb), dim3(kET), 0, st, D, K, q_rows, d_yy, (const T_*)d_EW, \
+                     (const T_*)d_EW2, (const T_*)d_B, (const T_*)d_Q, d_S)
+  if (dtype == MU_DTYPE_F32) {
+    if (K <= 16) MU_R(float, 16);
+    else MU_R(float, 32);
+  } else {
+    if (K <= 16) MU_R(double, 16);
+    else MU_R(double, 32);
+  }
+#undef MU_R
+  MU_CHECK_LAUNCH();
+  return MU_OK;
+}
+
+int mu_mofa_tau_finish(int dtype, int64_t n, const double* d_S, const double* d_Ngd, double a0, double b0, void* d_tau,
+                       void* d_ltau, double* d_elbo, double* d_work, void* stream) {
+  MU_REQUIRE(dtype == MU_DTYPE_F32 || dtype == MU_DTYPE_F64, "dtype must be f32 or f64");
+  MU_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return MU_OK;
+  MU_REQUIRE(d_S && d_Ngd && d_tau && d_ltau && d_elbo && d_work, "null pointer");
+  const int nb = blocks_for(n, kET);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MU_DTYPE_F32)
+    hipLaunchKernelGGL((k_mofa_tau_finish<float>), dim3(nb), dim3(kET), 0, st, n, d_S, d_Ngd, a0, b0, (float*)d_tau,
+                       (float*)d_ltau, d_work);
+  else
+    hipLaunchKernelGGL((k_mofa_tau_finish<double>), dim3(nb), dim3(kET), 0, st, n, d_S, d_Ngd, a0, b0, (double*)d_tau,
+                       (double*)d_ltau, d_work);
+  MU_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_mofa_add_partials, dim3(1), dim3(64), 0, st, nb, d_work, d_elbo);
+  MU_CHECK_LAUNCH();
+  return MU_OK;
 }
 
 int mu_mofa_w_elbo(int dtype, int64_t D, int K, int ard, int spikeslab, const void* d_EWh2,

@@ -445,6 +445,56 @@ def test_poisson_stored_entries_ragged_rows(dt, tol, K, ld):
         be.lib.mu_tune_set(b"pois_lane", 0)
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-13), (torch.float32, 2e-6)])
+@pytest.mark.parametrize("K,D,G,masked", [(1, 1, 1, True), (5, 700, 1, True), (10, 2000, 2, True), (10, 513, 3, False),
+                                          (20, 300, 2, True)])
+def test_stats_view_residual_and_tau_finish_kernels(dt, tol, K, D, G, masked):
+    """mu_mofa_stats_resid + mu_mofa_tau_finish (r06: the tau node of a dense gaussian view with missing entries in the
+    general engine, two kernels for ~35 tensor launches) against the tensor expressions they replace
+    (muon_amd/_core/mofa_general.py, the `elif V.stats` / `elif V.lik == "gaussian"` branches), in f64."""
+    import math
+
+    from muon_amd._backend import get_backend
+    from muon_amd._core.mofa_general import A0, B0, _gamma_kl
+
+    be = get_backend()
+    g = torch.Generator(device="cuda").manual_seed(K * 1000 + D)
+    r = lambda *shape: torch.randn(shape, generator=g, device="cuda", dtype=torch.float64)
+    EW = (r(D, K) * 0.7).to(dt)
+    EW2 = (EW.double() ** 2 + torch.rand((D, K), generator=g, device="cuda", dtype=torch.float64) * 0.1).to(dt)
+    S = torch.empty((G, D), dtype=torch.float64, device="cuda")
+    Ngd = torch.randint(50, 400, (G, D), generator=g, device="cuda").double()
+    yy = (r(G, D) ** 2 * 300 + 200).contiguous()
+    want_S = torch.empty_like(S)
+    idx = torch.arange(K, device="cuda")
+    WW = EW.double()[:, :, None] * EW.double()[:, None, :]
+    WW[:, idx, idx] = EW2.double()
+    WW = WW.reshape(D, K * K)
+    for gi in range(G):
+        B = (r(D, K) * 3).to(dt).contiguous()
+        A = r(D if masked else 1, K, K)
+        Q = (A @ A.transpose(1, 2) * 10).reshape(-1, K * K).to(dt).contiguous()  # (sums of outer products: symmetric, psd)
+        be.mofa_stats_resid(yy[gi], EW, EW2, B, Q, S[gi])
+        want_S[gi] = yy[gi] - 2.0 * (EW.double() * B.double()).sum(dim=1) + (Q.double() * WW).sum(dim=1)
+    assert float((S - want_S).abs().max()) <= tol * float(want_S.abs().max())
+    # the node's finish on the kernel's own S
+    tau = torch.empty((G, D), dtype=dt, device="cuda")
+    ltau = torch.empty_like(tau)
+    elbo = torch.full((), 3.25, dtype=torch.float64, device="cuda")
+    S.clamp_(min=1.0)
+    be.mofa_tau_finish(S, Ngd, A0, B0, tau, ltau, elbo, be.mofa_elbo_work(K))
+    a, b = A0 + 0.5 * Ngd, B0 + 0.5 * S
+    wt, wl = a / b, torch.digamma(a) - torch.log(b)
+    want = 3.25 + float((0.5 * Ngd * (wl - math.log(2 * math.pi)) - 0.5 * wt * S).sum()
+                        + _gamma_kl(A0, B0, a, b, wt, wl).sum())
+    assert float((tau.double() - wt).abs().max()) <= max(tol, 1e-7 if dt == torch.float32 else 0) * float(wt.abs().max())
+    assert float((ltau.double() - wl).abs().max()) <= max(tol, 1e-7 if dt == torch.float32 else 1e-12) * float(wl.abs().max())
+    assert abs(float(elbo) - want) <= 1e-11 * abs(want)
+    again = torch.full((), 3.25, dtype=torch.float64, device="cuda")
+    be.mofa_tau_finish(S, Ngd, A0, B0, tau, ltau, again, be.mofa_elbo_work(K))
+    assert float(again) == float(elbo)  # fixed-order fold
+
+
 def _pois_dense_sweep(be, mode, Eo, Et, kap, K, blk=None):
     """mu_mofa_poisson_dense alone (no stored entries): the partial results folded in block order"""
     from muon_amd._backend import _dt, _p, check
