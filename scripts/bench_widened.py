@@ -137,15 +137,17 @@ def run_mofa_ng(be, n=20000, d_dense=2000, d_sparse=20000, iters=20, sample=400,
                        "W_max_abs": float(max(np.max(np.abs(a - b)) for a, b in zip(res["W"], ref["W"])))},
             "cpu_baseline": {"value": cpu_per * 100, "unit": "s", "cores": 1, "kind": "port",
                              "sample": f"oracle on {sample} cells (densified), {len(rr)} iterations, scaled by cells"},
-            # what a FUSED tile kernel per chunk pass would do (prediction zeta = Z W^T on the matrix
-            # cores, pseudo-data transform in registers, one reduction against a K-column block): three passes over
-            # the N x D predictions, 4 N D K flops each - against the f32 matrix-core peak.  The engine's chunk
-            # passes are tensor operations over densified chunks: the small fraction is the point of the record.
+            # the poisson view's passes as tile work on the matrix cores (prediction zeta = Z W^T, the
+            # pseudo-data transform in registers, one reduction against a K-column block - since r06 that IS the kernel,
+            # k_pois_mfma): three passes over the N x D predictions of both views' size, 4 N D K flops each, against
+            # the f32 matrix-core peak.  An iteration runs two such sweeps (the likelihood shares the W update's), the
+            # stored-entry corrections, the gaussian view's statistics and ~50 small kernels.
             "roofline": (lambda fl: {"bound": "mfma", "achieved": fl / per / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                                      "frac": fl / per / 157.3e12, "traffic": None,
                                      "algorithmic_flops_per_iteration": fl,
-                                     "note": "12 N D K flops per iteration (3 chunk passes x (prediction + one reduction)), "
-                                             "f32-input MFMA peak of MI355X_MICROARCH.md"})(
+                                     "note": "12 N D K flops per iteration (3 passes x (prediction + one reduction)) against the "
+                                             "f32-input MFMA peak of MI355X_MICROARCH.md; the sweeps themselves: 0.29 / 0.32 ms "
+                                             "(profiles/r06_mofa_ng_kernel_stats.md)"})(
                 12.0 * n * (d_dense + d_sparse) * 10)}
 
 
