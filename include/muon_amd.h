@@ -526,6 +526,24 @@ int mu_mofa_poisson_sparse_ld(int dtype, int mode, int64_t n_own, int K, int ld,
                               const int32_t* d_indices, const void* d_values, const void* d_E_own, const void* d_E_other,
                               void* d_out, void* stream);
 
+/* A bernoulli view WITHOUT anything of size N x D (r06, csrc/mofa_bernoulli.hip; mofapy2's Bernoulli node with the Jaakkola
+ * bound, reached from /root/reference/muon/_core/tools.py:583-585): the data enter through R = y - 1/2 and the likelihood
+ * only (sparse products and the poisson likelihood sweep, mode 2 above), the precision Omega_nd = tanh(xi / 2) / (2 xi),
+ * xi^2 = zeta^2 + sum_k (<z_k^2><w_k^2> - <z_k>^2 <w_k>^2), depends on the two factor blocks alone.  The sweep:
+ *   out[own][c] = sum_other Omega(own, other) M_other[c],   c over the pc = K (K + 1) / 2 distinct entries of <m m^T>
+ * (own = features, other = samples, M = packed <z z^T>: the W update's T;  own = samples, other = features, M = packed
+ * <w w^T>: the Z update's S).  E / E2 [rows x K] row-major (first / second moments, stride K), M_other [n_other x ldm] from
+ * mu_mofa_pack_moments (k <= l row-major, the diagonal = second moments, zero padded; ldm = mu_mofa_jaakkola_cols(K)),
+ * 1 <= K <= 16.  Partial results for column blocks of `other_block` rows (mu_mofa_jaakkola_blocks picks it):
+ * d_part [ceil(n_other / other_block)][n_own][pc], to be added in block order.  f32 and f64 on the matrix cores. */
+int mu_mofa_jaakkola_cols(int K);
+int mu_mofa_pack_moments(int dtype, int64_t n, int K, int ldm, const void* d_E, const void* d_E2, void* d_M,
+                         void* stream);
+int64_t mu_mofa_jaakkola_blocks(int dtype, int K, int64_t n_own, int64_t n_other);
+int mu_mofa_jaakkola_sweep(int dtype, int64_t n_own, int64_t n_other, int K, int64_t other_block, const void* d_E_own,
+                           const void* d_E2_own, const void* d_E_other, const void* d_E2_other, const void* d_M_other,
+                           int ldm, void* d_part, void* stream);
+
 /* ---- MOFA+ small nodes and the ELBO, fused (tools.py:585 ent.run(): mofapy2's Tau, AlphaW, ThetaW,
  * AlphaZ node updates and calculateELBO()).  Arithmetic in f64 for both storage types; every entry
  * ADDS its ELBO terms to the device scalar *d_elbo.  d_work: mu_mofa_elbo_work_doubles(K) doubles. */

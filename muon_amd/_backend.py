@@ -213,6 +213,7 @@ class HipBackend:
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", int(device))
+        self._tri_index = {}  # (K, device) -> positions of the K x K entries in the packed upper triangle
 
     # -- plumbing -------------------------------------------------------------
     def _stream(self):
@@ -1385,6 +1386,65 @@ class HipBackend:
             check(self.lib.mu_mofa_poisson_sparse_ld(_dt(E_own), int(mode), n_own, K, ld, _p(X.indptr), _p(X.indices),
                                                      _p(X.values), _p(E_own), _p(E_other), _p(out), self._stream()))
         return out
+
+    def mofa_softplus_sweep(self, E_own, E_other, pads: Optional[dict] = None):
+        """out[own] = - sum_other ln(1 + e^zeta), zeta = <e_own> . <e_other>: the dense sweep of mofa_poisson_pass(2, ...)
+        alone (the likelihood of a bernoulli view needs it without the poisson correction over the stored entries)"""
+        n_own, K = E_own.shape
+        n_other = E_other.shape[0]
+        assert E_other.shape[1] == K and E_own.dtype == E_other.dtype and 1 <= K <= 32
+        ld = 16 if 8 < K <= 16 else next(k for k in (4, 8, 32) if k >= K)
+
+        def pad(E, slot):
+            if K == ld and E.is_contiguous():
+                return E
+            key = (slot, int(E.shape[0]), ld, K, E.dtype)
+            P = pads.get(key) if pads is not None else None
+            if P is None:
+                P = torch.zeros((E.shape[0], ld), dtype=E.dtype, device=E.device)
+                if pads is not None:
+                    pads[key] = P
+            P[:, :K].copy_(E)
+            return P
+
+        E_own, E_other = pad(E_own, "own"), pad(E_other, "other")
+        blk = int(self.lib.mu_mofa_poisson_blocks_for(_dt(E_own), 2, K, n_own, n_other))
+        nb = -(-n_other // blk)
+        part = self.empty((nb, n_own), E_own.dtype)
+        with self._dev_ctx():
+            check(self.lib.mu_mofa_poisson_dense_ld(_dt(E_own), 2, n_own, n_other, K, ld, blk, _p(E_own), _p(E_other),
+                                                    None, _p(part), self._stream()))
+            return part[0] if nb == 1 else part.sum(dim=0)
+
+    def mofa_jaakkola_sweep(self, E_own, E2_own, E_other, E2_other):
+        """The precision-weighted moment sums of a bernoulli view without anything N x D (csrc/mofa_bernoulli.hip,
+        include/muon_amd.h): out[own] = sum_other Omega(own, other) <m m^T>_other as [n_own, K, K], Omega the Jaakkola
+        precision of the pair.  E / E2: first / second moments [rows, K], K <= 16."""
+        n_own, K = E_own.shape
+        n_other = E_other.shape[0]
+        assert 1 <= K <= 16 and E_other.shape[1] == K and E_own.dtype == E_other.dtype
+        args = [t.contiguous() for t in (E_own, E2_own, E_other, E2_other)]
+        ldm = int(self.lib.mu_mofa_jaakkola_cols(K))
+        pc = K * (K + 1) // 2
+        M = self.empty((n_other, ldm), E_own.dtype)
+        blk = int(self.lib.mu_mofa_jaakkola_blocks(_dt(E_own), K, n_own, n_other))
+        nb = -(-n_other // blk)
+        part = self.empty((nb, n_own, pc), E_own.dtype)
+        with self._dev_ctx():
+            check(self.lib.mu_mofa_pack_moments(_dt(E_own), n_other, K, ldm, _p(args[2]), _p(args[3]), _p(M), self._stream()))
+            check(self.lib.mu_mofa_jaakkola_sweep(_dt(E_own), n_own, n_other, K, blk, _p(args[0]), _p(args[1]), _p(args[2]),
+                                                  _p(args[3]), _p(M), ldm, _p(part), self._stream()))
+            packed = part[0] if nb == 1 else part.sum(dim=0)  # (fixed order: deterministic)
+            idx = self._tri_index.get((K, packed.device))
+            if idx is None:
+                pos = {}
+                for k in range(K):
+                    for l in range(k, K):
+                        pos[(k, l)] = len(pos)
+                idx = torch.tensor([pos[(min(k, l), max(k, l))] for k in range(K) for l in range(K)], dtype=torch.int64,
+                                   device=packed.device)
+                self._tri_index[(K, packed.device)] = idx
+            return packed.index_select(1, idx).view(n_own, K, K)
 
     def mofa_gs_update(self, Tm, b, prior, lth, l1mth, spikeslab, E, E2, gamma, Eh2, sig2):
         """Gauss-Seidel sweep over the factors of every row with row-wise K x K statistics (include/muon_amd.h);

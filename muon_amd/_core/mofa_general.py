@@ -252,7 +252,12 @@ class GeneralMofaEngine:
         # (csrc/mofa_poisson.hip, r04)
         V.fused = bool(lik == "poisson" and V.kind == "sparse" and hasattr(be, "mofa_poisson_pass") and self.K <= 32
                        and V.X.values.dtype == T and pres.all())
-        if V.fused:
+        # a bernoulli view stored sparse with every sample present needs none either (r06, csrc/mofa_bernoulli.hip): the
+        # data enter through R = y - 1/2 and the likelihood only - sparse products - and the Jaakkola precision depends on
+        # the two factor blocks alone: one dense sweep per update
+        V.fusedb = bool(lik == "bernoulli" and V.kind == "sparse" and hasattr(be, "mofa_jaakkola_sweep")
+                        and hasattr(be, "mofa_softplus_sweep") and self.K <= 16 and V.X.values.dtype == T and pres.all())
+        if V.fused or V.fusedb:
             V.Xt = be.transpose(V.X)
         V.centred = False
         V.stats = False
@@ -362,6 +367,12 @@ class GeneralMofaEngine:
         P.diagonal(dim1=1, dim2=2).copy_(E2)  # (one strided copy: no index tensor, no gather / scatter kernels)
         return P.reshape(n, K * K)
 
+    def _times_block(self, X, E):
+        """X E for a CSR operand and a K <= 16 column block: the row-wave SpMM multiplies by 16 columns"""
+        P = torch.zeros((E.shape[0], 16), dtype=E.dtype, device=E.device)
+        P[:, :self.K] = E
+        return self.be.spmm(X, P)[:, :self.K]
+
     def _z_outer(self):
         """<z z^T> rows of ALL local samples [N, K^2] for the current factors: the W update of a fused poisson view (its
         column sums) and the statistics of every dense gaussian view (rows times the mask) read the same block"""
@@ -415,6 +426,10 @@ class GeneralMofaEngine:
                 b = hit[1].clone() if getattr(self.comm, "world_size", 1) > 1 else hit[1]
             else:
                 b = self.be.mofa_poisson_pass(1, Wm.EW.contiguous(), self.EZ.contiguous(), V.kappa.contiguous(), V.Xt, pads=self._pois_pads)
+        elif getattr(V, "fusedb", False):
+            # T_d = sum_n Omega_nd <z z^T>_n in one sweep over the factor blocks; b = (Y - 1/2)^T <Z> without Y dense
+            Tm = self.be.mofa_jaakkola_sweep(Wm.EW, Wm.EW2, self.EZ, self.EZ2).reshape(V.D, K * K)
+            b = self._times_block(V.Xt, self.EZ) - 0.5 * self.EZ.sum(dim=0)[None, :]
         elif V.stats:
             Bs, Qs = self._gauss_stats(m)
             Tm = b = None
@@ -469,13 +484,19 @@ class GeneralMofaEngine:
         az = (self.alpha_z if self.opts["ard_factors"] else torch.ones_like(self.alpha_z)).to(self.T)
         # (chunks of samples sized by the views that are walked in dense chunks: a fused poisson view needs none, and
         #  the [rows, K^2] statistics themselves bound the rest)
-        step = min([self._rows_per_chunk(v.D) for v in self.views if not getattr(v, "fused", False)]
+        step = min([self._rows_per_chunk(v.D) for v in self.views
+                    if not (getattr(v, "fused", False) or getattr(v, "fusedb", False))]
                    + [self._rows_per_chunk(K * K)])
         # fused poisson views: a = R <W> for ALL samples at once (a sample's row depends on its own <z_n> only, which
         # changes in its own chunk, after use) and the sample-independent S
         fused = {m: (self.be.mofa_poisson_pass(0, self.EZ.contiguous(), self.W[m].EW.contiguous(), V.kappa.contiguous(), V.X, pads=self._pois_pads),
                      V.kappa @ WW[m])
                  for m, V in enumerate(self.views) if getattr(V, "fused", False)}
+        # fused bernoulli views: S_n = sum_d Omega_nd <w w^T>_d for ALL samples in one sweep (a sample's row depends on
+        # its own moments only), a = (Y - 1/2) <W>
+        fusedb = {m: (self._times_block(V.X, self.W[m].EW) - 0.5 * self.W[m].EW.sum(dim=0)[None, :],
+                      self.be.mofa_jaakkola_sweep(self.EZ, self.EZ2, self.W[m].EW, self.W[m].EW2).reshape(self.N, K * K))
+                  for m, V in enumerate(self.views) if getattr(V, "fusedb", False)}
         for g, (a0, b0) in enumerate(self.gslice):
             for lo in range(a0, b0, step):
                 hi = min(b0, lo + step)
@@ -492,6 +513,10 @@ class GeneralMofaEngine:
                     if m in fused:
                         S += fused[m][1][None, :]
                         a += fused[m][0][lo:hi]
+                        continue
+                    if m in fusedb:
+                        S += fusedb[m][1][lo:hi]
+                        a += fusedb[m][0][lo:hi]
                         continue
                     if V.stats:
                         tau = self.W[m].tau[g][:, None]
@@ -562,7 +587,7 @@ class GeneralMofaEngine:
                 S = torch.zeros((G, V.D), dtype=f64, device=self.dev)
                 Ngd = torch.zeros((G, V.D), dtype=f64, device=self.dev)
             part = torch.zeros((), dtype=f64, device=self.dev) if V.lik != "gaussian" else None
-            chunked = not (getattr(V, "fused", False) or V.stats)
+            chunked = not (getattr(V, "fused", False) or getattr(V, "fusedb", False) or V.stats)
             W2, Wsq = (Wm.EW2, Wm.EW ** 2) if chunked else (None, None)
             if getattr(V, "fused", False) and getattr(self.be, "mofa_poisson_lik_with_b", False):
                 # the likelihood term and the NEXT W update's b = R^T <Z> read the same predictions: one sweep (r05)
@@ -575,6 +600,10 @@ class GeneralMofaEngine:
                 part += out[:, K].sum(dtype=f64)
             elif getattr(V, "fused", False):
                 part += self.be.mofa_poisson_pass(2, self.EZ.contiguous(), Wm.EW.contiguous(), None, V.X, pads=self._pois_pads).sum(dtype=f64)
+            elif getattr(V, "fusedb", False):
+                # sum y zeta - ln(1 + e^zeta): the stored entries through Y <W>, the rest as the poisson view's sweep
+                part += (self.EZ * self._times_block(V.X, Wm.EW)).sum(dtype=f64)
+                part += self.be.mofa_softplus_sweep(self.EZ.contiguous(), Wm.EW.contiguous(), pads=self._pois_pads).sum(dtype=f64)
             if V.stats and fast_stats:
                 Bs, Qs = self._gauss_stats(m)
                 S = torch.empty((G, V.D), dtype=f64, device=self.dev)
@@ -587,7 +616,7 @@ class GeneralMofaEngine:
                 for g in range(G):
                     S[g] = V.yyM[g] - 2.0 * (Wm.EW * Bs[g]).sum(dim=1).to(f64) + (Qs[g] * WWm).sum(dim=1).to(f64)
                 Ngd = V.Ngd.clone()
-            for g, (a0, b0) in enumerate(self.gslice if not (getattr(V, "fused", False) or V.stats) else []):
+            for g, (a0, b0) in enumerate(self.gslice if chunked else []):
                 for lo, hi, Y, M in self._chunks(V, a0, b0):
                     Zc, Z2c = self.EZ[lo:hi], self.EZ2[lo:hi]
                     zeta = Zc @ Wm.EW.T

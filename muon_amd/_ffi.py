@@ -123,6 +123,10 @@ SIGNATURES = {
     "mu_mofa_poisson_sparse": (C.c_int, [_i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_poisson_dense_ld": (C.c_int, [_i32, _i32, _i64, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mu_mofa_poisson_sparse_ld": (C.c_int, [_i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mu_mofa_jaakkola_cols": (C.c_int, [_i32]),
+    "mu_mofa_pack_moments": (C.c_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mu_mofa_jaakkola_blocks": (_i64, [_i32, _i32, _i64, _i64]),
+    "mu_mofa_jaakkola_sweep": (C.c_int, [_i32, _i64, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "mu_mofa_gs_update": (C.c_int, [_i32, _i64, _i32] + [_vp] * 5 + [_i32] + [_vp] * 6),
     "mu_mofa_elbo_work_doubles": (_sz, [_i32]),
     "mu_mofa_tau_elbo": (C.c_int, [_i32, _i64, _i32, _i32] + [_vp] * 7 + [_dbl, _dbl] + [_vp] * 5),

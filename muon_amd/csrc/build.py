@@ -11,13 +11,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["runtime.hip", "tfidf.hip", "transpose.hip", "spmm.hip", "spmm_win.hip", "spmm_narrow.hip", "spmm_ell.hip", "tpack4.hip", "dense.hip", "skinny.hip", "synth.hip", "mofa.hip", "mofa_elbo.hip", "mofa_stats.hip", "mofa_poisson.hip", "knn.hip", "wnn.hip"]
+SOURCES = ["runtime.hip", "tfidf.hip", "transpose.hip", "spmm.hip", "spmm_win.hip", "spmm_narrow.hip", "spmm_ell.hip", "tpack4.hip", "dense.hip", "skinny.hip", "synth.hip", "mofa.hip", "mofa_elbo.hip", "mofa_stats.hip", "mofa_poisson.hip", "mofa_bernoulli.hip", "knn.hip", "wnn.hip"]
 HEADERS = ["common.hpp", "sweep.hpp", os.path.join(ROOT, "include", "muon_amd.h")]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in VGPRs.  The default (AGPR form) kept the accumulators of these files'
 # loops in VGPRs BETWEEN the steps and copied them to AGPRs and back around the MFMAs of every step (k_skinny_tn: 64
 # v_accvgpr_write + 64 v_accvgpr_read per 8 MFMAs); gfx950's MFMAs take either register file.
 _VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-EXTRA = {"skinny.hip": _VGPR_FORM, "dense.hip": _VGPR_FORM, "knn.hip": _VGPR_FORM, "mofa_poisson.hip": _VGPR_FORM}
+EXTRA = {"skinny.hip": _VGPR_FORM, "dense.hip": _VGPR_FORM, "knn.hip": _VGPR_FORM, "mofa_poisson.hip": _VGPR_FORM, "mofa_bernoulli.hip": _VGPR_FORM}
 LIB = os.path.join(HERE, "libmuon_amd.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(ROOT, "include"),

@@ -258,6 +258,70 @@ def test_general_engine_on_the_gpu_matches_oracle(hip, dt, tol):
     np.testing.assert_allclose(res["Z"], ref["Z"], atol=max(tol * 10, 1e-8))
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-9), (torch.float32, 5e-3)])
+@pytest.mark.parametrize("K", [5, 10, 16])
+def test_sparse_bernoulli_view_without_dense_chunks_matches_oracle(hip, dt, tol, K):
+    """r06: a bernoulli view stored sparse is fitted without anything N x D - its
+    Jaakkola precision in one dense sweep over the factor blocks per update (csrc/mofa_bernoulli.hip, f32 and f64 on the
+    matrix cores), the data through sparse products, the likelihood through the poisson view's softplus sweep - and gives
+    what the dense restatement gives (oracle.run_general), iteration by iteration; next to a masked gaussian view and a
+    fused poisson view, two groups."""
+    from muon_amd._core.mofa_general import GeneralMofaEngine
+    from tests.test_mofa_host import _mixed_views
+
+    _, y1, y2, y3 = _mixed_views(n=400, seed=2)
+    groups = np.random.default_rng(1).integers(0, 2, 400)
+    liks = ["gaussian", "poisson", "bernoulli"]
+    ref = mofa_oracle.run_general([y1, y2, y3], liks, groups=groups, n_factors=K, n_iterations=6,
+                                  convergence_mode="slow", min_iterations=100)
+    eng = GeneralMofaEngine(hip, [y1, sp.csr_matrix(y2), sp.csr_matrix(y3)], liks, groups, K, seed=1, dtype=dt,
+                            chunk_elems=6000)
+    assert eng.views[2].fusedb and eng.views[1].fused
+    eng.run(6, "slow", min_iterations=100)
+    res = eng.results(sort_factors=False)
+    np.testing.assert_allclose(res["elbo"], ref["elbo"], rtol=tol)
+    np.testing.assert_allclose(res["Z"], ref["Z"], atol=max(tol * 10, 1e-8))
+    for a, b in zip(res["W"], ref["W"]):
+        np.testing.assert_allclose(a, b, atol=max(tol * 10, 1e-8))
+    # the same view given dense takes the chunk passes: the same fit
+    eng2 = GeneralMofaEngine(hip, [y1, sp.csr_matrix(y2), y3], liks, groups, K, seed=1, dtype=dt, chunk_elems=6000)
+    assert not eng2.views[2].fusedb
+    eng2.run(6, "slow", min_iterations=100)
+    np.testing.assert_allclose(res["elbo"], eng2.results(sort_factors=False)["elbo"], rtol=tol)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-12), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("K", [1, 3, 5, 8, 10, 12, 13, 16])
+def test_jaakkola_sweep_kernel(hip, dt, tol, K):
+    """mu_mofa_pack_moments + mu_mofa_jaakkola_sweep against the element-wise definition in numpy f64: every instantiated
+    (padded width, column tiles) pair, sizes off the 16-row tiles / the LDS stages / the workgroups, moments with zero
+    variance (xi = |zeta|) and tiny predictions (the series of tanh(xi / 2) / (2 xi))."""
+    for n_own, n_other in ((1, 1), (37, 150), (300, 517), (130, 64)):
+        rng = np.random.default_rng(K * 7 + n_own)
+        Eo = rng.standard_normal((n_own, K)) * 0.8
+        Et = rng.standard_normal((n_other, K)) * 0.6
+        Eo2 = Eo ** 2 + rng.random((n_own, K)) * 0.3
+        Et2 = Et ** 2 + rng.random((n_other, K)) * 0.2
+        Eo2[::3] = Eo[::3] ** 2  # (no variance)
+        Et[::5] *= 1e-3          # (xi ~ 1e-3 .. 1e-2)
+        Et2[::5] = Et[::5] ** 2 + 1e-6
+        npdt = np.float32 if dt == torch.float32 else np.float64
+        c = lambda a: a.astype(npdt).astype(np.float64)
+        Eo, Eo2, Et, Et2 = c(Eo), c(Eo2), c(Et), c(Et2)
+        dev = lambda a: torch.from_numpy(a).to(hip.device).to(dt)
+        got = hip.to_host(hip.mofa_jaakkola_sweep(dev(Eo), dev(Eo2), dev(Et), dev(Et2))).astype(np.float64)
+        zeta = Eo @ Et.T
+        xi = np.maximum(np.sqrt(np.maximum(zeta ** 2 + Eo2 @ Et2.T - (Eo ** 2) @ (Et ** 2).T, 0)), 1e-8)
+        Om = np.tanh(0.5 * xi) / (2 * xi)
+        P = Et[:, :, None] * Et[:, None, :]
+        i = np.arange(K)
+        P[:, i, i] = Et2
+        want = np.einsum("ot,tkl->okl", Om, P)
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want)) <= tol * max(np.max(np.abs(want)), 1e-300), (n_own, n_other)
+        assert np.array_equal(got, got.transpose(0, 2, 1))  # symmetric by construction
+
+
 def test_wrapper_fits_count_likelihoods_on_the_gpu():
     from tests.test_mofa_host import _mixed_views
 

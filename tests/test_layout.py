@@ -152,6 +152,40 @@ def test_poisson_matrix_core_sweep_isa(tmp_path):
         assert m and int(m.group(1)) <= 128, (name, m and m.group(1))
 
 
+def test_jaakkola_sweep_isa(tmp_path):
+    """k_jaakkola_sweep (csrc/mofa_bernoulli.hip, r06): 14 instances - (padded width, column tiles of the packed moments) x
+    f32 / f64 - each without spills and with its accumulators in VGPRs; the matrix-instruction count of a 16-row step is
+    OWN x (3 KP / 4 + 4 CT): the prediction and the two variance products, then one product per column tile and
+    accumulator register."""
+    import re
+    import shutil
+    import subprocess
+
+    from muon_amd.csrc import build as csrc_build
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "muon_amd", "csrc", "mofa_bernoulli.hip")
+    assert "-amdgpu-mfma-vgpr-form" in csrc_build.EXTRA["mofa_bernoulli.hip"]
+    out = tmp_path / "mofa_bernoulli.s"
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "muon_amd", "csrc"), *csrc_build.EXTRA["mofa_bernoulli.hip"], "-S",
+                           "--cuda-device-only", "-w", "-o", str(out), src])
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN[^\n:]*k_jaakkola_sweepI([fd])Li(\d+)ELi(\d+)E[^\n:]*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
+                         flags=re.S | re.M)
+    assert sorted((t, int(kp), int(ct)) for _, t, kp, ct, _ in kernels) == sorted(
+        (t, kp, ct) for t in "df" for kp, ct in ((4, 1), (8, 2), (8, 3), (12, 4), (12, 5), (16, 7), (16, 9)))
+    for name, t, kp, ct, body in kernels:
+        kp, ct = int(kp), int(ct)
+        own = 2 if (t == "f" and ct <= 5) else 1
+        assert "scratch_" not in body and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body), name
+        assert "accvgpr" not in body, name
+        op = "v_mfma_f32_16x16x4_f32" if t == "f" else "v_mfma_f64_16x16x4_f64"
+        assert len(re.findall(r"^\s*" + op + r"\b", body, flags=re.M)) == own * (3 * kp // 4 + 4 * ct), name
+
+
 def test_tpack4_isa_keeps_out_of_the_asm_owned_registers(tmp_path):
     """The fourth-generation transposition (csrc/tpack4.hip) keeps the next tile's header in v[88..91] and its 18 window
     slots in v[92..127], written by loads issued from inline asm one tile ahead: hipcc must stay below v88 (a copy or a
