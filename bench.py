@@ -23,7 +23,7 @@ the largest relative difference of the singular values go into the JSON line (`p
 secondary: the default run (c3, one GPU) also carries the two other single-GPU configurations of
 BASELINE.json as complete sub-records (ms, roofline, cpu_baseline, parity): `c2` (configs[0]/[1]) and
 `c4` (configs[3], mu.tl.mofa, f32) + `c4_f64` (the same in the reference's default precision), and
-`ingest` / `mofa_ng` / `wnn`: one measured record with parity per widened row of SURVEY 8f, `c3_api`: the
+`ingest` / `mofa_ng` / `mofa_bern` / `wnn`: one measured record with parity per widened row of SURVEY 8f, `c3_api`: the
 API path from a host matrix.
 --no-secondary skips them.
 
@@ -74,7 +74,7 @@ WORKLOADS = {  # cells = TOTAL cells for strong scaling, cells PER GPU for weak 
     "c3shard": dict(cells=125_000, peaks=200_000, scaling="weak"),
     "c2": dict(cells=10_000, peaks=30_000, scaling="weak"),
     "c4": None,  # BASELINE.json configs[3]/[4]: mu.tl.mofa, 100 ELBO iterations (scripts/bench_mofa.py)
-    "ingest": None, "mofa_ng": None, "wnn": None,  # SURVEY 8f.2 - 8f.4 (scripts/bench_widened.py)
+    "ingest": None, "mofa_ng": None, "mofa_bern": None, "wnn": None,  # SURVEY 8f.2 - 8f.4 (scripts/bench_widened.py)
     "c3_api": None,  # tfidf + lsi through the public API from a host scipy CSR (upload, fingerprints, write-back)
     "c3_rank8": None, "c5_rank8": None,  # one rank of eight, emulated on one GPU (scripts/bench_rank8.py)
     "unstructured": None, "hard": None,  # configs[2]'s shape on other spectra (scripts/bench_spectra.py)
@@ -470,7 +470,7 @@ def main():
 
     if args.workload == "c4":
         out = run_c4(args, args.steps or 100, args.warmup)
-    elif args.workload in ("ingest", "mofa_ng", "wnn", "c3_api", "c3_rank8", "c5_rank8", "unstructured", "hard"):
+    elif args.workload in ("ingest", "mofa_ng", "mofa_bern", "wnn", "c3_api", "c3_rank8", "c5_rank8", "unstructured", "hard"):
         out = run_widened(args.workload) if rank == 0 else None
     else:
         default_line = (args.workload == "c3" and world == 1 and not (args.cells or args.peaks or args.no_pack
@@ -498,7 +498,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 sec["c4_f64"] = {"error": repr(e)}
             # the widened rows, the API path and one rank of eight (configs[2] / [4] shards), seconds each
-            for name in ("ingest", "mofa_ng", "wnn", "c3_api", "c3_rank8", "c5_rank8", "unstructured", "hard"):
+            for name in ("ingest", "mofa_ng", "mofa_bern", "wnn", "c3_api", "c3_rank8", "c5_rank8", "unstructured", "hard"):
                 try:
                     torch.cuda.empty_cache()
                     sec[name] = run_widened(name)
