@@ -182,57 +182,93 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_dense(int64_t n_own, int64_
 // A wave owns kPmOwn tiles of 16 own rows (their E_own operands and accumulators stay in registers), a workgroup 256 own
 // rows; the other block is staged through the same 128-row LDS tiles as above (row stride padded where the step-3
 // reads of four row groups would meet in the same banks).  Modes and the layout of `part` as k_pois_dense.
-typedef float pm_f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kPmOwn = 4;
+// r06, later: f64 models sweep on the f64 matrix cores with the same kernel - v_mfma_f64_16x16x4_f64's C/D rows are
+// (lane >> 4) + 4 r instead of 4 (lane >> 4) + r, so the reduction index of step 3 is walked as row(j, s) of the
+// instruction's own map (PmMap<T>::row; csrc/mofa_bernoulli.hip does the same) and the transform is libm's in f64.
+template <typename T> struct PmMap;
+template <> struct PmMap<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static constexpr int OWN = 4;  // 16-row own tiles per wave
+  static __device__ __forceinline__ int row(int q, int r) { return 4 * q + r; }
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // sigmoid and softplus of a prediction; softplus in units of `unit()`, a padding row (zeta = 0) adds `pad()` units
+  static __device__ __forceinline__ void transform(float z, bool clamp, float& sig, float& sp) {
+    float a = z * -1.4426950408889634f;
+    if (clamp) a = fminf(a, 126.0f);
+    const float d = 1.0f + __builtin_amdgcn_exp2f(a);
+    sig = __builtin_amdgcn_rcpf(d);
+    sp = __builtin_amdgcn_logf(d) - a;
+  }
+  static __device__ __forceinline__ float unit() { return 0.6931471805599453f; }
+  static __device__ __forceinline__ float pad() { return 1.0f; }
+};
+template <> struct PmMap<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static constexpr int OWN = 2;
+  static __device__ __forceinline__ int row(int q, int r) { return q + 4 * r; }
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void transform(double z, bool, double& sig, double& sp) {
+    sig = pz_sigmoid(z);
+    sp = pz_softplus(z);
+  }
+  static __device__ __forceinline__ double unit() { return 1.0; }
+  static __device__ __forceinline__ double pad() { return pz_softplus(0.0); }
+};
 
-template <int KP, int MODE>
+template <typename T, int KP, int MODE>
 __global__ __launch_bounds__(kPzThreads) void k_pois_mfma(int64_t n_own, int64_t n_other, int K, int ld, int64_t other_block,
-                                                          const float* __restrict__ E_own,
-                                                          const float* __restrict__ E_other,
-                                                          const float* __restrict__ kappa, float* __restrict__ part) {
+                                                          const T* __restrict__ E_own, const T* __restrict__ E_other,
+                                                          const T* __restrict__ kappa, T* __restrict__ part) {
+  typedef PmMap<T> Mp;
+  typedef typename Mp::acc_t acc_t;
+  constexpr int kPmOwn = Mp::OWN;
   constexpr int KS = KP / 4;                                   // reduction steps of the prediction
   constexpr int LS = KP == 8 ? 12 : (KP == 16 ? 20 : KP);      // LDS row stride (dwords): 4 LS mod 64 in {16, 48}
-  __shared__ float tile[kPzTile * LS + 16];  // (+16: step 3 reads 16 columns of every row, the last row's run past it)
-  __shared__ float kap[kPzTile];
+  __shared__ T tile[kPzTile * LS + 16];  // (+16: step 3 reads 16 columns of every row, the last row's run past it)
+  __shared__ T kap[kPzTile];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lj = lane >> 4;
-  const int64_t own0 = (int64_t)blockIdx.x * kPzThreads + wave * (16 * kPmOwn);
+  const int64_t own0 = (int64_t)blockIdx.x * (64 * kPmOwn) + wave * (16 * kPmOwn);
   const int64_t o0 = (int64_t)blockIdx.y * other_block;
   const int64_t o1 = o0 + other_block < n_other ? o0 + other_block : n_other;
-  float eo[kPmOwn][KS], kown[kPmOwn], lsum[kPmOwn];
-  pm_f32x4 acc[kPmOwn];
+  T eo[kPmOwn][KS], kown[kPmOwn], lsum[kPmOwn];
+  acc_t acc[kPmOwn];
 #pragma unroll
   for (int u = 0; u < kPmOwn; ++u) {
     const int64_t row = own0 + 16 * u + li;  // (own = the tile's column = lane & 15)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) eo[u][s] = row < n_own ? E_own[row * ld + KS * lj + s] : 0.f;
-    kown[u] = ((MODE == 1 || MODE == 3) && row < n_own) ? kappa[row] : 0.f;
-    lsum[u] = 0.f;
-    acc[u] = (pm_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < KS; ++s) eo[u][s] = row < n_own ? E_own[row * ld + KS * lj + s] : (T)0;
+    kown[u] = ((MODE == 1 || MODE == 3) && row < n_own) ? kappa[row] : (T)0;
+    lsum[u] = (T)0;
+    acc[u] = (acc_t){(T)0, (T)0, (T)0, (T)0};
   }
-  if (threadIdx.x < 16) tile[kPzTile * LS + threadIdx.x] = 0.f;
+  if (threadIdx.x < 16) tile[kPzTile * LS + threadIdx.x] = (T)0;
   if (LS != KP)
     for (int i = threadIdx.x; i < kPzTile; i += kPzThreads)
-      for (int k = KP; k < LS; ++k) tile[i * LS + k] = 0.f;  // (the stride padding is read as columns >= KP too)
+      for (int k = KP; k < LS; ++k) tile[i * LS + k] = (T)0;  // (the stride padding is read as columns >= KP too)
   for (int64_t t0 = o0; t0 < o1; t0 += kPzTile) {
     const int rows = (int)(o1 - t0 < kPzTile ? o1 - t0 : kPzTile);
     __syncthreads();
     for (int i = threadIdx.x; i < kPzTile * KP; i += kPzThreads) {
       const int r = i / KP, k = i - r * KP;
-      tile[r * LS + k] = r < rows ? E_other[(t0 + r) * ld + k] : 0.f;
+      tile[r * LS + k] = r < rows ? E_other[(t0 + r) * ld + k] : (T)0;
     }
     if (MODE == 0)
-      for (int i = threadIdx.x; i < kPzTile; i += kPzThreads) kap[i] = i < rows ? kappa[t0 + i] : 0.f;
+      for (int i = threadIdx.x; i < kPzTile; i += kPzThreads) kap[i] = i < rows ? kappa[t0 + i] : (T)0;
     __syncthreads();
     for (int tt = 0; tt < rows; tt += 16) {
-      float a1[KS], b2[4], kp[4];
+      T a1[KS], b2[4], kp[4];
 #pragma unroll
       for (int s = 0; s < KS; ++s) a1[s] = tile[(tt + li) * LS + KS * lj + s];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         // (columns >= KP of B are the next row's values: finite, and output columns >= K are never stored)
-        b2[s] = MODE != 2 ? tile[(tt + 4 * lj + s) * LS + li] : 0.f;
-        kp[s] = MODE == 0 ? kap[tt + 4 * lj + s] : 0.f;
+        b2[s] = MODE != 2 ? tile[(tt + Mp::row(lj, s)) * LS + li] : (T)0;
+        kp[s] = MODE == 0 ? kap[tt + Mp::row(lj, s)] : (T)0;
       }
       // all the first products of the step, then the transform and the second product register by register across the
       // own tiles: four independent chains instead of one (0.291 -> 0.265 ms in scripts/probes/pois_mfma_bench.hip;
@@ -243,37 +279,36 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_mfma(int64_t n_own, int64_t
       // a is clamped so that 2^a stays finite (zeta < -87: sigmoid 1e-38, softplus ln2 (126 - 126) = 0); MODE 1 as
       // MODE 3, so that the two give the same b bit for bit.  A padding row has zeta = 0: it adds exactly 1 to the
       // softplus sum (2^0 = 1, log2 2 = 1), taken off after the loop instead of a select per element.
-      pm_f32x4 z[kPmOwn];
+      acc_t z[kPmOwn];
 #pragma unroll
       for (int u = 0; u < kPmOwn; ++u) {
-        z[u] = (pm_f32x4){0.f, 0.f, 0.f, 0.f};
+        z[u] = (acc_t){(T)0, (T)0, (T)0, (T)0};
 #pragma unroll
-        for (int s = 0; s < KS; ++s) z[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], eo[u][s], z[u], 0, 0, 0);
+        for (int s = 0; s < KS; ++s) z[u] = Mp::mfma(a1[s], eo[u][s], z[u]);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
         for (int u = 0; u < kPmOwn; ++u) {
-          float a = z[u][r] * -1.4426950408889634f;
-          if (MODE != 0) a = fminf(a, 126.0f);
-          const float d = 1.0f + __builtin_amdgcn_exp2f(a);
-          if (MODE == 2 || MODE == 3) lsum[u] += __builtin_amdgcn_logf(d) - a;
+          T sig, sp;
+          Mp::transform(z[u][r], MODE != 0, sig, sp);
+          if (MODE == 2 || MODE == 3) lsum[u] += sp;
           if (MODE != 2) {
-            const float rr = (MODE == 0 ? kp[r] : kown[u]) * z[u][r] - __builtin_amdgcn_rcpf(d);
-            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(rr, b2[r], acc[u], 0, 0, 0);
+            const T rr = (MODE == 0 ? kp[r] : kown[u]) * z[u][r] - sig;
+            acc[u] = Mp::mfma(rr, b2[r], acc[u]);
           }
         }
       }
     }
   }
   if (MODE == 2 || MODE == 3) {
-    // padding rows: only the last 16-row tile of the block can be partial; this lane holds rows 4 lj .. 4 lj + 3 of it
+    // padding rows: only the last 16-row tile of the block can be partial; this lane holds rows row(lj, 0 .. 3) of it
     const int rem = (int)((o1 - o0) & 15);
     int npad = 0;
     if (o1 > o0 && rem)
-      for (int r = 0; r < 4; ++r) npad += 4 * lj + r >= rem;
+      for (int r = 0; r < 4; ++r) npad += Mp::row(lj, r) >= rem;
 #pragma unroll
-    for (int u = 0; u < kPmOwn; ++u) lsum[u] = -0.6931471805599453f * (lsum[u] - (float)npad);
+    for (int u = 0; u < kPmOwn; ++u) lsum[u] = -Mp::unit() * (lsum[u] - Mp::pad() * (T)npad);
   }
   if (MODE == 2 || MODE == 3) {
 #pragma unroll
@@ -283,13 +318,13 @@ __global__ __launch_bounds__(kPzThreads) void k_pois_mfma(int64_t n_own, int64_t
     }
   }
   const int ostride = MODE == 2 ? 1 : (MODE == 3 ? K + 1 : K);
-  float* out = part + (int64_t)blockIdx.y * n_own * ostride;
+  T* out = part + (int64_t)blockIdx.y * n_own * ostride;
 #pragma unroll
   for (int u = 0; u < kPmOwn; ++u) {
     if (MODE != 2 && li < K) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {  // acc register r of lane 16 q + c: out[own = 4 q + r][k = c]
-        const int64_t row = own0 + 16 * u + 4 * lj + r;
+      for (int r = 0; r < 4; ++r) {  // acc register r of lane 16 q + c: out[own = row(q, r)][k = c]
+        const int64_t row = own0 + 16 * u + Mp::row(lj, r);
         if (row < n_own) out[row * ostride + li] = acc[u][r];
       }
     }
@@ -542,13 +577,14 @@ int pois_dense_launch(int mode, int64_t n_own, int64_t n_other, int K, int ld, i
   return MU_OK;
 }
 
-template <int KP>
+template <typename T, int KP>
 int pois_mfma_launch(int mode, int64_t n_own, int64_t n_other, int K, int ld, int64_t other_block, const void* E_own,
                      const void* E_other, const void* kappa, void* part, hipStream_t st) {
-  const dim3 grid((unsigned)((n_own + kPzThreads - 1) / kPzThreads), (unsigned)((n_other + other_block - 1) / other_block));
+  const int own_rows = 64 * PmMap<T>::OWN;
+  const dim3 grid((unsigned)((n_own + own_rows - 1) / own_rows), (unsigned)((n_other + other_block - 1) / other_block));
 #define MU_GO(MD)                                                                                                 \
-  hipLaunchKernelGGL((k_pois_mfma<KP, MD>), grid, dim3(kPzThreads), 0, st, n_own, n_other, K, ld, other_block,    \
-                     (const float*)E_own, (const float*)E_other, (const float*)kappa, (float*)part)
+  hipLaunchKernelGGL((k_pois_mfma<T, KP, MD>), grid, dim3(kPzThreads), 0, st, n_own, n_other, K, ld, other_block, \
+                     (const T*)E_own, (const T*)E_other, (const T*)kappa, (T*)part)
   if (mode == 0) MU_GO(0);
   else if (mode == 1) MU_GO(1);
   else if (mode == 2) MU_GO(2);
@@ -584,21 +620,28 @@ int pois_sparse_launch(int mode, int64_t n_own, int K, int ld, const int64_t* in
   return MU_OK;
 }
 
-template <int KP>
+template <typename T, int KP>
 const void* pois_mfma_ptr(int mode) {
-  return mode == 0 ? (const void*)k_pois_mfma<KP, 0> : mode == 1 ? (const void*)k_pois_mfma<KP, 1>
-       : mode == 2 ? (const void*)k_pois_mfma<KP, 2> : (const void*)k_pois_mfma<KP, 3>;
+  return mode == 0 ? (const void*)k_pois_mfma<T, KP, 0> : mode == 1 ? (const void*)k_pois_mfma<T, KP, 1>
+       : mode == 2 ? (const void*)k_pois_mfma<T, KP, 2> : (const void*)k_pois_mfma<T, KP, 3>;
 }
 template <typename T, int KP>
 const void* pois_dense_ptr(int mode) {
   return mode == 0 ? (const void*)k_pois_dense<T, KP, 0> : mode == 1 ? (const void*)k_pois_dense<T, KP, 1>
        : mode == 2 ? (const void*)k_pois_dense<T, KP, 2> : (const void*)k_pois_dense<T, KP, 3>;
 }
-bool pois_use_mfma(int dtype, int K) { return dtype == MU_DTYPE_F32 && K <= 16 && mu_tune_get("pois_valu") <= 0; }
+bool pois_use_mfma(int dtype, int K) { return K <= 16 && mu_tune_get("pois_valu") <= 0; }
+int pois_own_rows(int dtype, int K) {  // own rows of a workgroup of the dense sweep
+  return pois_use_mfma(dtype, K) ? 64 * (dtype == MU_DTYPE_F32 ? PmMap<float>::OWN : PmMap<double>::OWN) : kPzThreads;
+}
 const void* pois_dense_kernel(int dtype, int mode, int K) {
-  if (pois_use_mfma(dtype, K))
-    return K <= 4 ? pois_mfma_ptr<4>(mode) : K <= 8 ? pois_mfma_ptr<8>(mode) : K <= 12 ? pois_mfma_ptr<12>(mode)
-                                                                                       : pois_mfma_ptr<16>(mode);
+  if (pois_use_mfma(dtype, K)) {
+#define MU_Q(T_)                                                                                                  \
+  (K <= 4 ? pois_mfma_ptr<T_, 4>(mode) : K <= 8 ? pois_mfma_ptr<T_, 8>(mode) : K <= 12 ? pois_mfma_ptr<T_, 12>(mode) \
+                                                                                       : pois_mfma_ptr<T_, 16>(mode))
+    return dtype == MU_DTYPE_F32 ? MU_Q(float) : MU_Q(double);
+#undef MU_Q
+  }
 #define MU_P(T_)                                                                                                   \
   (K <= 4 ? pois_dense_ptr<T_, 4>(mode) : K <= 8 ? pois_dense_ptr<T_, 8>(mode) : K <= 12 ? pois_dense_ptr<T_, 12>(mode) \
    : K <= 16 ? pois_dense_ptr<T_, 16>(mode) : pois_dense_ptr<T_, 32>(mode))
@@ -620,7 +663,8 @@ int64_t mu_mofa_poisson_blocks_for(int dtype, int mode, int K, int64_t n_own, in
   if (mode < 0 || mode > 3) mode = 0;
   if (K < 1) K = 1;
   if (K > 32) K = 32;
-  const int64_t own_wgs = n_own > 0 ? (n_own + kPzThreads - 1) / kPzThreads : 1;
+  const int own_rows = pois_own_rows(dtype, K);
+  const int64_t own_wgs = n_own > 0 ? (n_own + own_rows - 1) / own_rows : 1;
   const int64_t tiles = n_other > 0 ? (n_other + kPzTile - 1) / kPzTile : 1;
   int occ = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pois_dense_kernel(dtype, mode, K), kPzThreads, 0) != hipSuccess ||
@@ -670,8 +714,10 @@ int mu_mofa_poisson_dense_ld(int dtype, int mode, int64_t n_own, int64_t n_other
   MU_REQUIRE(d_E_own && d_E_other && d_part && (mode == 2 || d_kappa), "null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (pois_use_mfma(dtype, K)) {  // the matrix-core sweep (k_pois_mfma)
-#define MU_M(KP_) pois_mfma_launch<KP_>(mode, n_own, n_other, K, ld, other_block, d_E_own, d_E_other, d_kappa, d_part, st)
-    return K <= 4 ? MU_M(4) : K <= 8 ? MU_M(8) : K <= 12 ? MU_M(12) : MU_M(16);
+#define MU_M(T_, KP_) pois_mfma_launch<T_, KP_>(mode, n_own, n_other, K, ld, other_block, d_E_own, d_E_other, d_kappa, d_part, st)
+#define MU_MK(T_) (K <= 4 ? MU_M(T_, 4) : K <= 8 ? MU_M(T_, 8) : K <= 12 ? MU_M(T_, 12) : MU_M(T_, 16))
+    return dtype == MU_DTYPE_F32 ? MU_MK(float) : MU_MK(double);
+#undef MU_MK
 #undef MU_M
   }
 #define MU_D(T_, KP_) pois_dense_launch<T_, KP_>(mode, n_own, n_other, K, ld, other_block, d_E_own, d_E_other, d_kappa, d_part, st)

@@ -117,7 +117,8 @@ def test_poisson_matrix_core_sweep_isa(tmp_path):
     (no v_accvgpr copies around every product: the file is built with -amdgpu-mfma-vgpr-form, csrc/build.py), no spills,
     no IEEE division sequence and no libm log expansion in the transform (one v_exp_f32 per prediction, one v_rcp_f32
     where the mode needs the sigmoid, one v_log_f32 where it needs the likelihood), KP / 4 + 4 matrix instructions per
-    16 x 16 tile (KP / 4 in the likelihood-only mode)."""
+    16 x 16 tile (KP / 4 in the likelihood-only mode).  f64 models: the same kernel on v_mfma_f64_16x16x4_f64 (two own
+    tiles per wave, libm in the transform)."""
     import re
     import shutil
     import subprocess
@@ -134,22 +135,25 @@ def test_poisson_matrix_core_sweep_isa(tmp_path):
                            "-I" + os.path.join(ROOT, "muon_amd", "csrc"), *csrc_build.EXTRA["mofa_poisson.hip"], "-S",
                            "--cuda-device-only", "-w", "-o", str(out), src])
     text = out.read_text()
-    kernels = re.findall(r"^(_ZN[^\n:]*k_pois_mfmaILi(\d+)ELi(\d)E[^\n:]*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
+    kernels = re.findall(r"^(_ZN[^\n:]*k_pois_mfmaI([fd])Li(\d+)ELi(\d)E[^\n:]*):[^\n]*\n(.*?)\.end_amdhsa_kernel", text,
                          flags=re.S | re.M)
-    assert len(kernels) == 16  # KP = 4, 8, 12, 16 x modes 0..3
-    tiles = 4  # kPmOwn: 16-row own tiles per wave, all in one unrolled step
-    for name, kp, mode, body in kernels:
+    assert len(kernels) == 32  # (f32, f64) x KP = 4, 8, 12, 16 x modes 0..3
+    for name, t, kp, mode, body in kernels:
         kp, mode = int(kp), int(mode)
+        tiles = 4 if t == "f" else 2  # PmMap<T>::OWN: 16-row own tiles per wave, all in one unrolled step
         assert "scratch_" not in body and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body), name
         assert "accvgpr" not in body, name
-        assert "v_div_" not in body and "v_ldexp" not in body, name
         count = lambda op: len(re.findall(r"^\s*" + op + r"\b", body, flags=re.M))
-        assert count("v_mfma_f32_16x16x4_f32") == tiles * (kp // 4 + (0 if mode == 2 else 4)), name
+        op = "v_mfma_f32_16x16x4_f32" if t == "f" else "v_mfma_f64_16x16x4_f64"
+        assert count(op) == tiles * (kp // 4 + (0 if mode == 2 else 4)), name
+        m = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
+        assert m and int(m.group(1)) <= 160, (name, m and m.group(1))
+        if t == "d":
+            continue  # (f64: libm's exp / log1p in the transform)
+        assert "v_div_" not in body and "v_ldexp" not in body, name
         assert count("v_exp_f32_e32") + count("v_exp_f32_e64") == 4 * tiles, name
         assert count("v_rcp_f32_e32") + count("v_rcp_f32_e64") == (0 if mode == 2 else 4 * tiles), name
         assert count("v_log_f32_e32") + count("v_log_f32_e64") == (4 * tiles if mode in (2, 3) else 0), name
-        m = re.search(r"\.amdhsa_next_free_vgpr (\d+)", body)
-        assert m and int(m.group(1)) <= 128, (name, m and m.group(1))
 
 
 def test_jaakkola_sweep_isa(tmp_path):
