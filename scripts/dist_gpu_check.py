@@ -60,6 +60,10 @@ angw = float(torch.linalg.matrix_norm(qb - qa @ (qa.T @ qb), ord=2))
 assert angw < 5e-5 and float(np.max(np.abs(sdw - sd) / sd)) < 1e-6, (angw, infow["bounds"])
 if rank == 0:
     print(f"warm start ({infow['warm_start']}): {infow['iterations']} expansions against {info['iterations']}, angle to the cold run {angw:.2e}")
+# f64 arithmetic for f64 input (r06, tools._refine_f64) on the row streams of the shards: the f32 process continued in f64
+# blocks, Z = X^T Y summed over the ranks in f64, the stop decisions rank 0's; against the same on one rank below
+U6, sd6, V6, info6 = lsi_device(be, T, n_comps=k, n_obs=n, comm=comm, return_info=True, refine_f64=True)
+assert V6.dtype == torch.float64 and info6["refine_f64"]["angle_bound"] <= 1e-6, info6["refine_f64"]
 if rank == 0:
     Xf = be.synth_counts(0, n, d, 50, 0.03, 0)
     Tf = tfidf_device(be, Xf, n, 3, 1e4)
@@ -74,6 +78,14 @@ if rank == 0:
     print(f"ranks {world}: tfidf max rel diff {dv:.2e}, subspace angle vs single process {ang:.2e}, stdev rel diff {ds:.2e}, "
           f"|U| max diff {du:.2e}, iterations {info['iterations']} / {inff['iterations']}")
     assert dv < 1e-6 and ang < 1e-4 and ds < 1e-5
+    U6f, sd6f, V6f, inf6 = lsi_device(be, Tf, n_comps=k, return_info=True, refine_f64=True)
+    qa, _ = torch.linalg.qr(V6)
+    qb, _ = torch.linalg.qr(V6f)
+    ang6 = float(torch.linalg.matrix_norm(qb - qa @ (qa.T @ qb), ord=2))
+    print(f"f64 continuation, ranks {world} against 1: angle {ang6:.2e} (bounds {info6['refine_f64']['angle_bound']:.1e} / "
+          f"{inf6['refine_f64']['angle_bound']:.1e}, {info6['refine_f64']['blocks']} / {inf6['refine_f64']['blocks']} blocks), "
+          f"stdev rel diff {float(np.max(np.abs(sd6 - sd6f) / sd6f)):.2e}")
+    assert ang6 < 2e-6 and float(np.max(np.abs(sd6 - sd6f) / sd6f)) < 1e-9
 
 # MOFA: two views (dense + sparse), two groups, samples sharded by rows; the sufficient statistics,
 # the factor column sums and the ELBO part of the samples are the collectives (float64 engine)
