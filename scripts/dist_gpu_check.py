@@ -116,5 +116,31 @@ if rank == 0:
     dw = max(float(np.max(np.abs(x - y))) for x, y in zip(res["W"], ref["W"]))
     print(f"mofa ranks {world}: ELBO trace max rel diff {de:.2e}, |Z| diff {dz:.2e}, |W| diff {dw:.2e}")
     assert de < 1e-9 and dz < 1e-7 and dw < 1e-7
+# the element-wise-precision engine with the views that need nothing N x D (r06): masked gaussian statistics, a fused
+# poisson view (matrix-core sweeps + stored entries), a fused bernoulli view (Jaakkola sweeps + sparse products) - T and b
+# summed over the ranks, S and a local - against the same fit in one process, f64
+from muon_amd._core.mofa_general import GeneralMofaEngine
+
+yg = y1.copy()
+yg[rng.random(yg.shape) < 0.1] = np.nan
+yp = sp.csr_matrix(rng.poisson(np.logaddexp(0, Z0 @ rng.standard_normal((400, 4)).T - 1.0)).astype(float))
+yb = sp.csr_matrix((rng.random((N, 350)) < 1 / (1 + np.exp(-(Z0 @ rng.standard_normal((350, 4)).T)))).astype(float))
+liks = ["gaussian", "poisson", "bernoulli"]
+ge = GeneralMofaEngine(be, [yg[a:b], yp[a:b], yb[a:b]], liks, groups[a:b], 6, seed=1, comm=comm, row_offset=a, n_total=N,
+                       dtype=torch.float64)
+assert ge.views[1].fused and ge.views[2].fusedb
+ge.run(8, "slow", min_iterations=100)
+gres = ge.results(sort_factors=False)
+gZ = comm.all_gather_rows(torch.from_numpy(gres["Z"]))
+if rank == 0:
+    g1 = GeneralMofaEngine(be, [yg, yp, yb], liks, groups, 6, seed=1, dtype=torch.float64)
+    g1.run(8, "slow", min_iterations=100)
+    gref = g1.results(sort_factors=False)
+    de = float(np.max(np.abs((np.asarray(gres["elbo"]) - np.asarray(gref["elbo"])) / np.asarray(gref["elbo"]))))
+    dz = float(np.max(np.abs(gZ.numpy() - gref["Z"])))
+    dw = max(float(np.max(np.abs(x - y))) for x, y in zip(gres["W"], gref["W"]))
+    print(f"general engine (masked gaussian + fused poisson + fused bernoulli) ranks {world}: ELBO trace max rel diff {de:.2e}, "
+          f"|Z| diff {dz:.2e}, |W| diff {dw:.2e}")
+    assert de < 1e-9 and dz < 1e-7 and dw < 1e-7
     print("dist gpu check ok")
 dist.barrier()
