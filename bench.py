@@ -355,6 +355,11 @@ def flatten_for_driver(out, sec):
         for pk, pv in (rec.get("parity") or {}).items():
             if isinstance(pv, (bool, int, float)):
                 cfg[f"{name}_parity_{pk}"] = pv
+        for ck, cv in (rec.get("config") or {}).items():  # (the hard spectrum continued in f64: time, verdict, bound)
+            if ck.startswith("f64_continuation_") and isinstance(cv, (bool, int, float)):
+                cfg[f"{name}_{ck}"] = cv
+                if ck in ("f64_continuation_ms_per_step", "f64_continuation_converged"):
+                    summ[f"{name}_{ck}"] = cv if not isinstance(cv, float) else float(f"{cv:.5g}")
     r8 = ((sec or {}).get("c3_rank8") or {}).get("ms_per_step")
     if r8:
         # one rank of eight against the whole matrix on one GPU: the 8-GPU speed-up BEFORE communication (an emulation

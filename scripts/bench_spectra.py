@@ -136,6 +136,16 @@ def run_hard(be, n=1_000_000, d=200_000, topics=80, k=50, sample=4_000, steps=2)
         info.update(inf)
 
     ms, _ = _timed(step, n=steps, warm=1)
+    # the same step continued in f64 arithmetic (tools._refine_f64: what `lsi` does for an f64 X) - the f32 process stops at
+    # its floor here (gap 7e-4: `converged` False); the continuation certifies the subspace by a Davis-Kahan bound
+    ref = {}
+
+    def step64():
+        T = tfidf_device(be, X, n, 3, 1e4, out=out)
+        U, sd, V, inf = lsi_device(be, T, n_comps=k, n_obs=n, return_info=True, refine_f64=True)
+        ref.update(inf)
+
+    ms64, _ = _timed(step64, n=1, warm=1)
     nnz = X.nnz
     del X, out
     torch.cuda.empty_cache()
@@ -163,7 +173,11 @@ def run_hard(be, n=1_000_000, d=200_000, topics=80, k=50, sample=4_000, steps=2)
                        "lsi_lanczos_bound": float(info.get("lanczos_bound", float("nan"))),
                        "lsi_f32_floor": float(info.get("f32_floor", float("nan"))),
                        "lanczos_bounds": [float(f"{b:.3g}") for b in info.get("bounds", [])],
-                       "warm_start": info.get("warm_start")},
+                       "warm_start": info.get("warm_start"),
+                       "f64_continuation_ms_per_step": ms64, "f64_continuation_converged": bool(ref.get("converged")),
+                       "f64_continuation_angle_bound": float(ref.get("angle_bound", float("nan"))),
+                       "f64_continuation_blocks": int((ref.get("refine_f64") or {}).get("blocks", 0)),
+                       "f64_continuation_spmm_per_step": int(ref.get("spmm", 0))},
             "parity": {"sample": f"first {sample} cells of the same generator, tfidf + lsi on the GPU against the oracle",
                        "oracle": f"scipy svds(k={topics + 2}, f64) in {t_cpu:.1f} s, then its top {k}: the whole cluster is a gapped "
                                  "problem, its leading part is exact",
