@@ -586,3 +586,37 @@ def test_f64_input_is_answered_in_f64_arithmetic():
     s = sd * np.sqrt(T.shape[0] - 1)
     XV = T.astype(np.float32).astype(np.float64) @ V.numpy()
     np.testing.assert_allclose(U.numpy() * s, XV, atol=1e-9 * s[0])
+
+
+def test_bench_line_is_flattened_for_the_driver():
+    """bench.py:flatten_for_driver: the driver keeps scalar keys of `config` and a 2 000-character
+    tail of the line - parity, the LSI figures, one value per secondary record (and the hard spectrum's f64 continuation)
+    must be flat scalars under `config`, and a compact `summary` the LAST key of the line."""
+    import importlib.util
+    import json
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = {"metric": "cells/sec", "value": 3.5e6, "ms_per_step": 284.9, "roofline": {"frac": 0.1731, "avg_launch_ms": 36.48},
+           "config": {"workload": "c3", "lsi": {"spmm_per_step": 5, "converged": True, "angle_bound": 2e-5}},
+           "parity": {"tfidf_pattern_identical": True, "tfidf_values_max_rel": 4.4e-7, "lsi_angle_rad": 4.2e-6,
+                      "lsi_stdev_max_rel": 6e-7, "sample": "text is not a scalar"}}
+    sec = {"c2": {"value": 1.06e6, "unit": "cells/s", "ms_per_step": 9.38, "roofline": {"frac": 0.096}},
+           "mofa_ng": {"value": 0.1779, "unit": "s", "roofline": {"frac": 0.1887}, "parity": {"elbo_max_rel": 1.5e-15, "oracle": "x"}},
+           "c3_rank8": {"value": 43.4, "unit": "ms", "ms_per_step": 43.4},
+           "hard": {"value": 2.26e6, "unit": "cells/s", "ms_per_step": 443.1,
+                    "config": {"workload": "hard", "f64_continuation_ms_per_step": 1057.9, "f64_continuation_converged": True,
+                               "f64_continuation_angle_bound": 3.1e-7, "f64_continuation_blocks": 4}},
+           "wnn": {"error": "RuntimeError('x')"}}
+    bench.flatten_for_driver(out, sec)
+    cfg = out["config"]
+    assert cfg["lsi_spmm_per_step"] == 5 and cfg["lsi_converged"] is True and cfg["parity_lsi_angle_rad"] == 4.2e-6
+    assert cfg["c2_ms_per_step"] == 9.38 and cfg["mofa_ng_value"] == 0.1779 and cfg["mofa_ng_parity_elbo_max_rel"] == 1.5e-15
+    assert cfg["hard_ms_per_step"] == 443.1 and cfg["hard_f64_continuation_converged"] is True
+    assert cfg["hard_f64_continuation_angle_bound"] == 3.1e-7 and "wnn_error" in cfg
+    assert cfg["speedup_8gpu_before_comm_emulated"] == round(284.9 / 43.4, 3)
+    assert "mofa_ng_parity_oracle" not in cfg  # (strings stay in the sub-record)
+    assert list(out)[-1] == "summary" and out["summary"]["hard_f64_continuation_converged"] is True
+    assert len(json.dumps(out["summary"], separators=(",", ":"))) < 1900
