@@ -272,25 +272,35 @@ def _refine_f64(backend, comm, X, Xt, V0, k, n_obs, scale_embeddings, angle_goal
             G += A[main:].T @ B[main:]
         return G
 
-    def orth(Z):
-        """CholeskyQR2 in f64; None if the block has (numerically) no new direction"""
-        for _ in range(2):
+    def orth(Z, scale=None):
+        """Orthonormal basis of the block's span in f64 (Gram, eigen-decomposition on the host, a second pass for the
+        rounding of the first).  Directions without independent content - a converged Ritz vector adds nothing to the
+        next block, and a Krylov space that has reached the dimension of the matrix has none left: deflation - are
+        dropped: squared lengths below 1e-13 of the block's largest, or below 1e-20 of ``scale``, the squared length its
+        columns had BEFORE they were projected against the basis (what is left of such a direction is rounding, and as
+        much of it lies along the basis as across it: normalising it would put a vector into the basis that is not
+        orthogonal to it).  None if nothing is left."""
+        for it in range(2):
             G = backend.to_host(tn(Z, Z))
             G = 0.5 * (G + G.T)
-            dg = np.diag(G)
-            if not np.all(np.isfinite(G)) or dg.min() <= 1e-28 * max(dg.max(), 1e-300):
+            if not np.all(np.isfinite(G)):
                 return None
-            try:
-                L = np.linalg.cholesky(G)
-            except np.linalg.LinAlgError:
+            mu, E = np.linalg.eigh(G)
+            # (the Gram's own eigenvalues are good to ~1e-16 of its largest: squared lengths below 1e-13 of it are not
+            #  told apart from rounding, whatever the block's history)
+            floor_ = max(float(mu[-1]), 0.0) * 1e-13
+            if it == 0 and scale is not None:
+                floor_ = max(floor_, float(scale) * 1e-20)
+            keep = mu > floor_
+            if mu[-1] <= 0 or not keep.any():
                 return None
-            Z = Z @ backend.to_device(np.ascontiguousarray(np.linalg.inv(L).T), np.float64)
+            S = E[:, keep] / np.sqrt(mu[keep])
+            Z = Z @ backend.to_device(np.ascontiguousarray(S), np.float64)
         return Z
 
     Q = orth(V0.to(f64))
     if Q is None:
         raise _RedoOnHost("f64 refinement: the f32 Ritz block is rank deficient")
-    w = Q.shape[1]
     Qs, Ys, Zs = [], [], []
     T = np.zeros((0, 0))
     hist = []
@@ -305,12 +315,14 @@ def _refine_f64(backend, comm, X, Xt, V0, k, n_obs, scale_embeddings, angle_goal
         Qs.append(Q)
         Ys.append(Y)
         Zs.append(Z)
-        # T = K^T A K: the new block row and column (Z is summed over the ranks already: nothing to reduce)
-        Tn = np.zeros(((m + 1) * w, (m + 1) * w))
-        Tn[:m * w, :m * w] = T
-        col = backend.to_host(torch.cat([tn(Qi, Z) for Qi in Qs], dim=0))  # [(m + 1) w, w]
-        Tn[:, m * w:] = col
-        Tn[m * w:, :] = col.T
+        # T = K^T A K: the new block row and column (Z is summed over the ranks already: nothing to reduce; blocks may
+        # have lost columns to deflation: offsets by their widths)
+        col = backend.to_host(torch.cat([tn(Qi, Z) for Qi in Qs], dim=0))  # [columns so far, this block's]
+        tot, wm = col.shape
+        Tn = np.zeros((tot, tot))
+        Tn[:tot - wm, :tot - wm] = T
+        Tn[:, tot - wm:] = col
+        Tn[tot - wm:, :] = col.T
         T = 0.5 * (Tn + Tn.T)
         lam, Cm = np.linalg.eigh(T)
         order = np.argsort(lam)[::-1]
@@ -331,7 +343,7 @@ def _refine_f64(backend, comm, X, Xt, V0, k, n_obs, scale_embeddings, angle_goal
         for _ in range(2):
             for Qi in Qs:
                 Zn -= Qi @ tn(Qi, Zn)
-        Q = orth(Zn)
+        Q = orth(Zn, scale=float(torch.max((Z * Z).sum(dim=0))))
         dead = Q is None
         if world > 1:
             dead = comm.agree(dead)
@@ -924,10 +936,13 @@ def _lsi_device(
     refined = None
     if refine_f64:
         mark("lsi/refine_f64")
-        ncol = min(w, C_all.shape[1])  # the Ritz block the f32 run ends with: top-k and what it kept beside them
-        Cb = np.zeros((C_all.shape[0], w))
-        Cb[:, :ncol] = C_all[:, :ncol]
-        U, s, V, refined = _refine_f64(backend, comm, X, Xt, combine(Qs, Cb)[0][:, :ncol], k, n_obs, scale_embeddings)
+        # the Ritz vectors the f32 run ends with: the top k and what its restarts keep beside them (at least one more:
+        # the continuation's gap estimate; n_comps beyond the block width makes this several blocks' worth of columns)
+        # (every column of the start is a column of every f64 product: the multiple of 32 that holds k and at least
+        #  eight more - with one or two spare columns the continuation crawls: k = 63 of 64 took 8 blocks to 3e-6)
+        ncol = min(C_all.shape[1], max(32, 32 * (-(-(k + 8) // 32))))
+        V0 = first_columns(combine(Qs, np.ascontiguousarray(C_all[:, :ncol])), ncol)
+        U, s, V, refined = _refine_f64(backend, comm, X, Xt, V0, k, n_obs, scale_embeddings)
         if refined["angle_bound"] <= 1e-4:
             converged = True
 

@@ -416,6 +416,17 @@ def test_f64_input_is_answered_in_f64_arithmetic(hip):
         np.testing.assert_allclose(ad.uns["lsi"]["stdev"], ref["stdev"], rtol=1e-8)
         np.testing.assert_allclose(ad.obsm["X_lsi"].mean(axis=0), 0, atol=1e-11)
         np.testing.assert_allclose(ad.obsm["X_lsi"].std(axis=0), 1, rtol=1e-9)
+    # more components than the block width (the continuation starts from every Ritz vector the f32 run kept) and a
+    # Krylov space that reaches the matrix dimension (deflation): tests/test_host_logic.py has the anatomy
+    X2 = planted_topics_csr(1500, 900, n_topics=30, density=0.05, seed=3, dtype=np.float64)
+    T2 = tfidf_oracle.canonical(tfidf_oracle.tfidf(X2))
+    for k in (63, 70):
+        ref2 = lsi_oracle.lsi(T2, n_comps=k)
+        ad = AnnData(T2.copy())
+        ac.tl.lsi(ad, n_comps=k)
+        assert ad.varm["LSI"].shape == (900, k) and ad.varm["LSI"].dtype == np.float64
+        assert lsi_oracle.max_subspace_angle(ad.varm["LSI"], ref2["LSI"]) < 1e-6
+        np.testing.assert_allclose(ad.uns["lsi"]["stdev"], ref2["stdev"], rtol=1e-8)
     # the same operand with and without the continuation: what it costs and what it buys
     Xd = hip.upload_csr(T.indptr, T.indices, T.data, T.shape, values_dtype=np.float32)
     ref = lsi_oracle.lsi(T, n_comps=50)

@@ -588,6 +588,27 @@ def test_f64_input_is_answered_in_f64_arithmetic():
     np.testing.assert_allclose(U.numpy() * s, XV, atol=1e-9 * s[0])
 
 
+@pytest.mark.parametrize("k", [5, 63, 70, 100])
+def test_f64_continuation_with_wide_starts_and_an_exhausted_krylov_space(k):
+    """tools._refine_f64 beyond the comfortable case: more components than the block width (the start block is every Ritz
+    vector the f32 run kept: 193 columns here, several blocks' worth), and a Krylov space that reaches the dimension of
+    the matrix (900 columns: the fifth block has 128 directions left of 193 - deflation must drop the rest, normalised
+    rounding is not orthogonal to the basis).  Against f64 ARPACK of the f64 operand."""
+    from muon_amd._atac.tools import lsi_device
+
+    X = planted_topics_csr(1500, 900, n_topics=30, density=0.05, seed=3, dtype=np.float64)
+    T = tfidf_oracle.canonical(tfidf_oracle.tfidf(X))
+    ref = lsi_oracle.lsi(T, n_comps=k)
+    Xd = BE.upload_csr(T.indptr, T.indices, T.data, T.shape, values_dtype=np.float32)
+    U, sd, V, info = lsi_device(BE, Xd, n_comps=k, return_info=True, refine_f64=True)
+    r = info["refine_f64"]
+    assert V.shape == (900, k) and V.dtype == torch.float64 and U.shape == (1500, k)
+    assert r["angle_bound"] <= 1e-6 and info["converged"], r
+    assert lsi_oracle.max_subspace_angle(V.numpy(), ref["LSI"]) < 1e-6
+    np.testing.assert_allclose(sd, ref["stdev"], rtol=1e-8)
+    assert np.abs(V.numpy().T @ V.numpy() - np.eye(k)).max() < 1e-10
+
+
 def test_bench_line_is_flattened_for_the_driver():
     """bench.py:flatten_for_driver: the driver keeps scalar keys of `config` and a 2 000-character
     tail of the line - parity, the LSI figures, one value per secondary record (and the hard spectrum's f64 continuation)
