@@ -322,6 +322,61 @@ def test_jaakkola_sweep_kernel(hip, dt, tol, K):
         assert np.array_equal(got, got.transpose(0, 2, 1))  # symmetric by construction
 
 
+@pytest.mark.parametrize("shape", [(5, 3, 2, 1), (17, 33, 1, 1), (40, 16, 16, 2), (130, 257, 7, 3)])
+def test_sparse_bernoulli_view_edge_shapes(hip, shape):
+    """the fused bernoulli path at shapes below every tile of its kernels (a handful of samples / features, one factor,
+    several groups, a feature without a single one): f64 against the dense restatement to rounding, f32 inside its bar"""
+    from muon_amd._core.mofa_general import GeneralMofaEngine
+
+    N, D, K, G = shape
+    rng = np.random.default_rng(N + D)
+    Z = rng.standard_normal((N, 3))
+    y = (rng.random((N, D)) < 1 / (1 + np.exp(-(Z @ rng.standard_normal((D, 3)).T)))).astype(float)
+    y[:, 0] = 0
+    groups = np.sort(np.concatenate([np.arange(G), rng.integers(0, G, N - G)]))
+    ref = mofa_oracle.run_general([y], ["bernoulli"], groups=groups, n_factors=K, n_iterations=5, convergence_mode="slow",
+                                  min_iterations=100)
+    for dt, tol in ((torch.float64, 1e-11), (torch.float32, 5e-3)):
+        eng = GeneralMofaEngine(hip, [sp.csr_matrix(y)], ["bernoulli"], groups, K, seed=1, dtype=dt)
+        assert eng.views[0].fusedb
+        eng.run(5, "slow", min_iterations=100)
+        res = eng.results(sort_factors=False)
+        np.testing.assert_allclose(res["elbo"], ref["elbo"], rtol=tol)
+        np.testing.assert_allclose(res["Z"], ref["Z"], atol=max(10 * tol, 1e-9))
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float64, 1e-11), (torch.float32, 3e-5)])
+def test_poisson_passes_edge_shapes(dt, tol):
+    """mofa_poisson_pass (matrix-core sweep + stored entries, every padded width) at shapes of one or a few rows on either
+    side, against the element-wise definition: nothing reads past a block, padded lanes add nothing"""
+    from muon_amd._backend import get_backend
+
+    be = get_backend()
+    rng = np.random.default_rng(0)
+    for K in (1, 2, 9, 12, 16, 17, 32):
+        for N, D in ((1, 1), (2, 5), (3, 1), (1, 40), (65, 2), (16, 16)):
+            Z = rng.standard_normal((N, K)) * 0.7
+            W = rng.standard_normal((D, K)) * 0.5
+            Y = sp.csr_matrix(rng.poisson(np.logaddexp(0, Z @ W.T)).astype(np.float64))
+            Y.sort_indices()
+            kappa = 0.25 + 0.17 * np.asarray(Y.max(axis=0).todense()).ravel()
+            zeta = Z @ W.T
+            r = np.maximum(np.logaddexp(0, zeta), 1e-300)
+            Yd = Y.toarray()
+            R = kappa[None, :] * zeta - 1.0 / (1.0 + np.exp(-zeta)) * (1.0 - Yd / r)
+            want = (R @ W, R.T @ Z, (Yd * np.log(r) - r).sum(axis=1))
+            X = be.upload_csr(Y.indptr, Y.indices, Y.data, Y.shape, values_dtype=np.float64)
+            X = X.with_values(X.values.to(dt))
+            Xt = be.transpose(X)
+            Zd, Wd, kd = (torch.from_numpy(a).to(be.device).to(dt).contiguous() for a in (Z, W, kappa))
+            got = (be.mofa_poisson_pass(0, Zd, Wd, kd, X), be.mofa_poisson_pass(1, Wd, Zd, kd, Xt),
+                   be.mofa_poisson_pass(2, Zd, Wd, None, X))
+            for mode, (g, w) in enumerate(zip(got, want)):
+                g = be.to_host(g).astype(np.float64)
+                assert g.shape == w.shape and np.all(np.isfinite(g)), (K, N, D, mode)
+                assert np.max(np.abs(g - w)) <= tol * max(np.max(np.abs(w)), 1e-30), (K, N, D, mode)
+
+
 def test_wrapper_fits_count_likelihoods_on_the_gpu():
     from tests.test_mofa_host import _mixed_views
 
